@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the kmap hot path on MI355X.
+
+Metric (BASELINE.json): Hamming pairs/s of the sampled-k-mer all-pairs matrix at N = 50 k, k = 8
+(config C3).  One "step" = one pass of the Hamming-matrix kernel over the whole batch of sampled
+k-mers: N x N ordered pairs written as uint8 into HBM; hashes/labels are resident in HBM before
+the timed region.  value = pairs processed by all ranks / max-over-ranks wall time.
+
+Multi-GPU (--gpus G, launched by torch.distributed.run, one rank per GPU): the matrix is sharded
+by row blocks, every rank holds all N hashes, no data-path collective.  Weak scaling:
+N_total = 50 000 * sqrt(G) (rounded to 16) so that every GPU keeps 2.5e9 pairs per step.
+
+Extra objects on the JSON line: `roofline` (HIP-event kernel time vs the 8 TB/s HBM peak, algorithmic
+bytes = rows*N + 5N) and `cpu_baseline` (the CPU oracle's OpenMP matrix kernel on a bounded row
+sample of the same workload; a reported baseline, not the target).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290 GB/s
+K = 8
+N_BASE = 50_000
+CONSEQ_LENS = [8, 8]    # two full-length motif labels + noise label 2 (synthetic C3 sample)
+
+
+def synth_sample(n, seed):
+    """Sampled k-mers as scan_motif hands them over: hashes expanded by counts (duplicates allowed --
+    k=8 has only 32 896 revcom-merged k-mers), labels grouped 0,1,noise."""
+    rng = np.random.default_rng(seed)
+    n_motif = n // 2
+    kh = np.concatenate([rng.integers(0, 4 ** K, size=n_motif // 2, dtype=np.uint64),
+                         rng.integers(0, 4 ** K, size=n_motif - n_motif // 2, dtype=np.uint64),
+                         rng.integers(0, 4 ** K, size=n - n_motif, dtype=np.uint64)]).astype(np.uint32)
+    lab = np.concatenate([np.zeros(n_motif // 2), np.ones(n_motif - n_motif // 2), np.full(n - n_motif, 2)]).astype(np.int32)
+    return kh, lab
+
+
+def cpu_baseline(kh, lab, target_s=12.0):
+    """Oracle (CPU restatement, OpenMP) timed on a bounded row sample of the same N."""
+    from oracle import oracle as O
+    L = O.lib()
+    n = len(kh)
+    kh64 = np.ascontiguousarray(kh, np.uint64)
+    cl = np.ascontiguousarray(CONSEQ_LENS, np.int32)
+    cores = os.cpu_count() or 1
+    rows = min(n, 2048)
+    out = np.empty((rows, n), np.uint8)
+    L.ko_hamdist_rows(kh64, lab, n, K, cl, len(cl), 0, rows, out)          # warm-up (thread pool, page faults)
+    done, t0 = 0, time.perf_counter()
+    while True:                                                            # row blocks round-robin over the matrix
+        r0 = done % max(n - rows + 1, 1)
+        L.ko_hamdist_rows(kh64, lab, n, K, cl, len(cl), r0, rows, out)
+        done += rows
+        dt = time.perf_counter() - t0
+        if dt >= target_s:
+            break
+    rows2 = done
+    return {"value": rows2 * n / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{rows2} of {n} rows x {n} cols (oracle ko_hamdist_rows, OpenMP, {dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+    from kmap_amd import _ffi
+    from kmap_amd.hamdist import hamdist_matrix_dev, pitch_for
+    torch.cuda.set_device(local_rank)
+    _ffi.check(_ffi.lib().kmap_set_device(local_rank))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- workload (weak scaling: constant pairs per GPU) ----
+    n = int(round(N_BASE * math.sqrt(world) / 16)) * 16
+    rows_per = (n + world - 1) // world
+    row0 = rank * rows_per
+    nrows = max(0, min(rows_per, n - row0))
+    kh, lab = synth_sample(n, seed=2)
+    ld = pitch_for(n)
+    kh_d, lab_d = _ffi.DeviceBuffer.from_numpy(kh), _ffi.DeviceBuffer.from_numpy(lab)
+    out_d = _ffi.DeviceBuffer(max(nrows, 1) * ld)
+
+    def step():
+        hamdist_matrix_dev(kh_d.ptr, lab_d.ptr, n, K, CONSEQ_LENS, out_d.ptr, ld, row0=row0, nrows=nrows)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        _ffi.sync()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev0, ev1 = _ffi.Event(), _ffi.Event()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_ms(ev1) / args.steps
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    # spot-check the timed output against the oracle (a wrong fast kernel is not a result)
+    from oracle import oracle as O
+    chk_rows = min(nrows, 8)
+    if chk_rows:
+        got = out_d.to_numpy(np.uint8, (chk_rows, ld))[:, :n]
+        want = np.empty((chk_rows, n), np.uint8)
+        O.lib().ko_hamdist_rows(np.ascontiguousarray(kh, np.uint64), lab, n, K, np.ascontiguousarray(CONSEQ_LENS, np.int32),
+                                len(CONSEQ_LENS), row0, chk_rows, want)
+        assert np.array_equal(got, want), "timed kernel output differs from the oracle"
+
+    if rank == 0:
+        pairs_total = float(n) * float(n)
+        algo_bytes = nrows * n + 5 * n          # u8 out + u32 hashes + u8 group ids, per launch on this rank
+        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        line = {
+            "metric": "hamming_pairs_per_s", "value": pairs_total * args.steps / wall, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"C3 Hamming stage: all-pairs Hamming matrix of N={n} sampled 8-mers "
+                                   f"(u32 hashes, labels 0/1/noise), uint8 out, row-sharded over {world} GPU(s)",
+                       "n_kmers": n, "k": K, "rows_per_gpu": rows_per, "pairs_per_gpu_per_step": float(nrows) * n},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "hamdist_matrix_kernel<u32>",
+                         "kernel_ms": kern_ms, "algorithmic_bytes": algo_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(kh, lab)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,204 @@
+/*
+ * kmap_hip.h -- C ABI of libkmap_hip.so: the MI355X (gfx950) implementation of kmap's
+ * data-parallel hot path.  Plain pointers and sizes only; no torch / numpy types.
+ *
+ * The reference (chengl7-lab/kmap) has no FFI layer: its de-facto operator API is the set of
+ * numpy-in/numpy-out Python functions whose bodies launch Taichi kernels.
+ * Every entry point below names the reference operator + kernel it replaces
+ * (file:line relative to the reference's src/kmap/).  kmap_amd/_ffi.py is the ctypes binding;
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (KMAP_E_*); kmap_last_error() returns a
+ *     thread-local message.
+ *   - `*_dev` pointers are device (HBM) pointers; plain names are host pointers.  Host-pointer
+ *     entry points are blocking.  Device-pointer entry points are asynchronous on `stream`
+ *     (a hipStream_t passed as void*, NULL = default stream) unless stated otherwise.
+ *   - the caller allocates every output (like the reference: np.empty then kernel); the library
+ *     returns heap memory only behind opaque handles.
+ *   - hashes are uint32 for k < 16 and uint64 for 16 <= k < 32, invalid hash = all ones,
+ *     counts int32 / int64 (kmer_count.py:351-370).  k >= 32 or k <= 0 -> KMAP_E_INVAL.
+ */
+#ifndef KMAP_HIP_H
+#define KMAP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMAP_OK 0
+#define KMAP_E_INVAL (-1)   /* bad argument (k range, null pointer, size) */
+#define KMAP_E_HIP (-2)     /* HIP runtime error (message has hipGetErrorString) */
+#define KMAP_E_NOMEM (-3)   /* device allocation failed */
+#define KMAP_E_UNSUP (-4)   /* valid request this build cannot serve */
+#define KMAP_E_STATE (-5)   /* handle used out of order */
+
+/* ---- library / device -------------------------------------------------------------------- */
+int kmap_version(void);                       /* 1000*major + minor */
+const char *kmap_last_error(void);
+int kmap_device_count(int *n);
+int kmap_set_device(int dev);
+int kmap_get_device(int *dev);
+/* arch name of the current device, e.g. "gfx950:sramecc+:xnack-" */
+int kmap_device_arch(char *buf, int buflen);
+
+/* raw device memory, so a ctypes caller can keep data resident between calls */
+int kmap_malloc(void **dev_ptr, size_t bytes);
+int kmap_free(void *dev_ptr);
+int kmap_memset(void *dev_ptr, int value, size_t bytes, void *stream);
+int kmap_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes, void *stream);
+int kmap_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes, void *stream);
+int kmap_memcpy_d2d(void *dev_dst, const void *dev_src, size_t bytes, void *stream);
+/* pitched device->host copy: `rows` rows of `width` bytes, device pitch `dpitch`, dense host */
+int kmap_memcpy2d_d2h(void *host_dst, size_t hpitch, const void *dev_src, size_t dpitch, size_t width, size_t rows,
+                      void *stream);
+int kmap_stream_sync(void *stream);
+int kmap_stream_create(void **stream);
+int kmap_stream_destroy(void *stream);
+/* HIP-event timing on the stream the kernels run on (bench.py's roofline leg) */
+int kmap_event_create(void **ev);
+int kmap_event_destroy(void *ev);
+int kmap_event_record(void *ev, void *stream);
+int kmap_event_elapsed_ms(void *ev_start, void *ev_stop, float *ms); /* synchronises ev_stop */
+
+/* ---- k-mer hashing: comp_kmer_hash_taichi kmer_count.py:449-473, kernels taichi_core.py:3-61
+ * hash at every array index; invalid if the window touches a 255 byte or passes the end. */
+int kmap_hash_kmers_u32_dev(const uint8_t *seq_dev, int64_t n, int k, uint32_t *out_dev, void *stream);
+int kmap_hash_kmers_u64_dev(const uint8_t *seq_dev, int64_t n, int k, uint64_t *out_dev, void *stream);
+int kmap_hash_kmers_u32(const uint8_t *seq, int64_t n, int k, uint32_t *out);
+int kmap_hash_kmers_u64(const uint8_t *seq, int64_t n, int k, uint64_t *out);
+
+/* ---- per-read de-duplication: remove_duplicate_hash_per_seq kmer_count.py:743-760
+ * borders: (n_seq,2) int64 [start, end); keeps the first occurrence of each value per read. */
+int kmap_dedupe_per_read_u32_dev(uint32_t *hash_dev, int64_t n, const int64_t *borders_dev, int64_t n_seq,
+                                 void *stream);
+int kmap_dedupe_per_read_u64_dev(uint64_t *hash_dev, int64_t n, const int64_t *borders_dev, int64_t n_seq,
+                                 void *stream);
+int kmap_dedupe_per_read_u32(uint32_t *hash, int64_t n, const int64_t *borders, int64_t n_seq);
+int kmap_dedupe_per_read_u64(uint64_t *hash, int64_t n, const int64_t *borders, int64_t n_seq);
+
+/* ---- reverse complement: get_revcom_hash_arr kmer_count.py:613-623, taichi_core.py:181-224 */
+int kmap_revcom_u32_dev(const uint32_t *in_dev, int64_t n, int k, uint32_t *out_dev, void *stream);
+int kmap_revcom_u64_dev(const uint64_t *in_dev, int64_t n, int k, uint64_t *out_dev, void *stream);
+int kmap_revcom_u32(const uint32_t *in, int64_t n, int k, uint32_t *out);
+int kmap_revcom_u64(const uint64_t *in, int64_t n, int k, uint64_t *out);
+
+/* ---- Hamming 1-vs-N: cal_hamming_dist / _head / _tail kmer_count.py:494-577,
+ * kernels taichi_core.py:63-177.  dist = #nonzero 2-bit groups of ((h >> shift_bits) ^ cons) over
+ * the low `clen` groups.  full: shift 0, clen k; head: shift 2(k-clen); tail: shift 0. */
+int kmap_hamdist_1vN_u32_dev(const uint32_t *h_dev, int64_t n, uint32_t cons, int shift_bits, int clen,
+                             uint8_t *out_dev, void *stream);
+int kmap_hamdist_1vN_u64_dev(const uint64_t *h_dev, int64_t n, uint64_t cons, int shift_bits, int clen,
+                             uint8_t *out_dev, void *stream);
+int kmap_hamdist_1vN_u32(const uint32_t *h, int64_t n, uint32_t cons, int shift_bits, int clen, uint8_t *out);
+int kmap_hamdist_1vN_u64(const uint64_t *h, int64_t n, uint64_t cons, int shift_bits, int clen, uint8_t *out);
+
+/* ---- masking: mask_input kmer_count.py:580-610 (one kmer_len, several consensuses).
+ * In place on the uint8 sequence array; hashes are taken from the array as it is on entry. */
+int kmap_mask_hamball_dev(uint8_t *seq_dev, int64_t n, int k, const uint64_t *cons, const int32_t *radius,
+                          int n_cons, void *stream);                       /* cons/radius: host arrays */
+int kmap_mask_hamball(uint8_t *seq, int64_t n, int k, const uint64_t *cons, const int32_t *radius, int n_cons);
+
+/* ---- counting: count_uniq_hash kmer_count.py:476-491 (+ remove_duplicate..., merge_revcom
+ * kmer_count.py:643-685) fused on device.  Two-call pattern: *_run returns the number of unique
+ * k-mers, *_fetch copies them out (uniq ascending like np.unique; after merge_revcom in the
+ * reference's order).  The counts object owns device memory; free it with kmap_counts_destroy. */
+typedef struct kmap_counts kmap_counts;
+int kmap_counts_create(kmap_counts **c);
+int kmap_counts_destroy(kmap_counts *c);
+/* from the sequence array (hash + optional per-read dedupe + count + optional revcom merge) */
+int kmap_counts_run_seq_dev(kmap_counts *c, const uint8_t *seq_dev, int64_t n, const int64_t *borders_dev,
+                            int64_t n_seq, int k, int dedupe_per_read, int merge_revcom, int64_t *n_uniq,
+                            void *stream);
+/* from a materialised hash array (drop-in for count_uniq_hash; invalid hashes dropped) */
+int kmap_counts_run_hashes_dev(kmap_counts *c, const void *hash_dev, int64_t n, int k, int merge_revcom,
+                               int64_t *n_uniq, void *stream);
+/* uniq_out: uint32[n_uniq] (k<16) or uint64[n_uniq]; cnt_out: int32 (k<16) or int64 */
+int kmap_counts_fetch(kmap_counts *c, void *uniq_out, void *cnt_out);
+int kmap_counts_total(kmap_counts *c, int64_t *total);          /* sum of counts */
+/* Hamming-ball mass of candidates over the counted k-mers: find_motif motif_discovery.py:666-673 */
+int kmap_counts_hamball_mass(kmap_counts *c, const uint64_t *cands, int n_cand, int radius, int revcom,
+                             double *mass_out);
+
+/* ---- motif occurrence scan: get_motif_occurence motif_discovery.py:1422-1477.
+ * For every read and one consensus: positions p in the reference's slice [0 : len-k+1] whose
+ * min(fwd, revcom) distance is <= radius AND equals the read's minimum.  Two-call: run returns the
+ * total number of hits; fetch writes per-read hit counts (int32[n_seq]), min distance (int8[n_seq],
+ * -1 = none) and the concatenated positions (int32[total], read order, ascending per read). */
+typedef struct kmap_scan kmap_scan;
+int kmap_scan_create(kmap_scan **s);
+int kmap_scan_destroy(kmap_scan *s);
+int kmap_scan_run_dev(kmap_scan *s, const uint8_t *seq_dev, int64_t n, const int64_t *borders_dev, int64_t n_seq,
+                      int k, uint64_t cons, int radius, int revcom, int64_t *total_hits, void *stream);
+int kmap_scan_fetch(kmap_scan *s, int32_t *hits_per_read, int8_t *min_dist, int32_t *positions);
+
+/* ---- all-pairs Hamming matrix: cal_samp_kmer_hamdist_mat motif_discovery.py:759-808
+ * (one launch instead of n_uniq launches + Python block expansion).  kh: N hashes (already
+ * expanded by counts), label: N int32; pairs sharing label l with clen[l] < k are compared on the
+ * first clen[l] bases only.  Writes rows [row0, row0+nrows) as uint8 with leading dimension ld
+ * (ld % 16 == 0 and a 16-byte aligned out_dev give the fast path). */
+int kmap_hamdist_matrix_u32_dev(const uint32_t *kh_dev, const int32_t *label_dev, int64_t n, int k,
+                                const int32_t *clen, int n_lab, int64_t row0, int64_t nrows, uint8_t *out_dev,
+                                int64_t ld, void *stream);                 /* clen: host array */
+int kmap_hamdist_matrix_u64_dev(const uint64_t *kh_dev, const int32_t *label_dev, int64_t n, int k,
+                                const int32_t *clen, int n_lab, int64_t row0, int64_t nrows, uint8_t *out_dev,
+                                int64_t ld, void *stream);
+/* host convenience: dense n x n uint8 out */
+int kmap_hamdist_matrix_u8(const uint64_t *kh, const int32_t *label, int64_t n, int k, const int32_t *clen,
+                           int n_lab, uint8_t *out);
+
+/* ---- kNN smoothing: knn_smooth visualization.py:90-109, kernel taichi_core.py:227-249
+ * integer form: sums[i,j] = sum_{a in nb[i], b in nb[j]} D[a,b]  (exact; S = f32(sums)/n_nb/n_nb),
+ * diagonal forced to 0.  D: uint8 rows [0,n) with leading dimension ldd; nb: int32 [n, n_nb];
+ * writes uint16 rows [row0,row0+nrows) with leading dimension lds. */
+int kmap_knn_sums_u8_dev(const uint8_t *D_dev, int64_t ldd, const int32_t *nb_dev, int64_t n, int n_nb,
+                         int64_t row0, int64_t nrows, uint16_t *sums_dev, int64_t lds, void *stream);
+/* generic float form in the reference's summation order (any distance matrix) */
+int kmap_knn_smooth_f32(const float *D, const int32_t *nb, int64_t n, int n_nb, float *S_out);
+
+/* ---- embedding operators (drop-in L3): visualization.py:131-176,235-256, taichi_core.py:252-326 */
+int kmap_ld_prob_mat_f32(const float *ld_2xn, int64_t n, float *q_out_nxn);          /* incl. clip */
+int kmap_cross_entropy_f32(const float *p_nxn, const float *q_nxn, int64_t n, float *loss_out);
+int kmap_gradient_loss_f32(const float *p_nxn, const float *q_nxn, const float *ld_2xn, int64_t n,
+                           float *grad_out_2xn);                                       /* incl. x4 */
+
+/* ---- device-resident embedding loop: umap visualization.py:270-326 ------------------------
+ * The session owns the high-dimensional probabilities for rows [row0,row0+nrows) of the N x N
+ * problem (either a float matrix, or uint16 neighbour sums + a LUT of (n_nb^2 * k + 1) floats
+ * computed on the host with the reference's numpy expression chain), the 2 x N coordinates,
+ * n_best snapshots and the scalar loop state.  One `step` = one reference iteration:
+ * q -> loss -> best-list insert -> early-stop test -> gradient -> update -> jitter. */
+typedef struct kmap_embed kmap_embed;
+#define KMAP_EMBED_FAST 0      /* wavefront-parallel row sums (order differs from the reference) */
+#define KMAP_EMBED_SEQ 1       /* one lane per row, j ascending, no FMA: the reference's f32 order */
+int kmap_embed_create(kmap_embed **e, int64_t n, int64_t row0, int64_t nrows, int n_best, float learning_rate,
+                      int mode);
+int kmap_embed_destroy(kmap_embed *e);
+int kmap_embed_set_prob_f32(kmap_embed *e, const float *p_rows_dev, int64_t ld);       /* device rows */
+int kmap_embed_set_prob_lut(kmap_embed *e, const uint16_t *sums_rows_dev, int64_t ld, const float *lut,
+                            int lut_len);                                               /* lut: host */
+/* init: 2 x N coordinates, n_best placeholder snapshots (n_best x 2 x N), host arrays */
+int kmap_embed_set_coords(kmap_embed *e, const float *coords_2xn, const float *placeholders);
+/* jitter normals N(0, 0.01) pre-drawn from the host RNG stream, consumed in order */
+int kmap_embed_set_jitter(kmap_embed *e, const float *normals, int n_normals);
+/* external (e.g. torch-allocated) buffers for multi-GPU: grads of the local rows are written to
+ * grad_dev (2 x N, local rows filled, rest 0) and loss partial to loss_dev (double[1]) by
+ * `kmap_embed_forces`; after the all-reduce the caller runs `kmap_embed_apply`. */
+int kmap_embed_forces(kmap_embed *e, float *grad_dev_2xn, double *loss_dev, void *stream);
+int kmap_embed_apply(kmap_embed *e, const float *grad_dev_2xn, const double *loss_dev, void *stream);
+/* single-GPU convenience: n_iter iterations of forces+apply on `stream` */
+int kmap_embed_step(kmap_embed *e, int n_iter, void *stream);
+/* loop state: iterations done, stopped flag, last loss, best loss, jitter normals consumed */
+int kmap_embed_state(kmap_embed *e, int64_t *iters, int *stopped, float *last_loss, float *best_loss,
+                     int *jitter_used, void *stream);
+int kmap_embed_get_coords(kmap_embed *e, float *coords_2xn, void *stream);      /* current iterate */
+int kmap_embed_get_best(kmap_embed *e, float *coords_2xn, void *stream);        /* lowest-loss snapshot */
+int kmap_embed_get_losses(kmap_embed *e, float *losses, int64_t max_n, int64_t *n_out, void *stream);
+void *kmap_embed_coords_dev(kmap_embed *e);                                      /* device ptr (2 x N f32) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMAP_HIP_H */

@@ -1,0 +1,398 @@
+// counts.hip -- k-mer counting on device: count_uniq_hash (kmer_count.py:476-491) fused with
+// remove_duplicate_hash_per_seq (:743-760) and merge_revcom (:643-685), the Hamming-ball mass
+// of find_motif (motif_discovery.py:666-673) and the per-read motif occurrence scan
+// (motif_discovery.py:1422-1477).
+//
+// Counting uses a direct-address histogram of 4^k uint32 bins in HBM for k <= 16 (MI355X has
+// 288 GB: even the 16 GiB table of k = 16 is resident), followed by an order-preserving
+// compaction that applies the reverse-complement merge on the fly.  A uint32 bin wraps exactly
+// like the reference's int64 -> int32 cast of np.unique counts.
+#include "common.h"
+
+int kmap_hash_launch_u32(const uint8_t *seq, int64_t n, int k, uint32_t *out, void *stream);
+int kmap_hash_launch_u64(const uint8_t *seq, int64_t n, int k, uint64_t *out, void *stream);
+
+namespace {
+
+constexpr int BLK = 256;
+static inline unsigned grid_for(int64_t n, int64_t per_block) {
+    int64_t g = (n + per_block - 1) / per_block;
+    return (unsigned)(g < 1 ? 1 : g);
+}
+
+// ---- histogram ----------------------------------------------------------------------------------
+template <typename H>
+__global__ __launch_bounds__(BLK) void hist_kernel(const H *__restrict__ h, int64_t n, uint32_t *__restrict__ bins) {
+    const int64_t stride = (int64_t)gridDim.x * BLK;
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
+        const H v = h[i];
+        if (v != (H)~(H)0) atomicAdd(&bins[(uint64_t)v], 1u);
+    }
+}
+
+// ---- order-preserving compaction with optional revcom merge ------------------------------------
+constexpr int CT_PER_THREAD = 8;
+constexpr int CT_TILE = BLK * CT_PER_THREAD;   // bins per block
+
+__device__ __forceinline__ uint64_t rc_bits(uint64_t x, int k) { return revcom_hash(x, k); }
+
+// keep/emit decision for bin x (see merge_revcom, kmer_count.py:643-685): returns true if an
+// entry is emitted; key/cnt are the emitted values.
+__device__ __forceinline__ bool bin_entry(const uint32_t *__restrict__ bins, uint64_t x, int k, int merge, uint64_t &key,
+                                          uint32_t &cnt) {
+    const uint32_t c = bins[x];
+    if (c == 0) return false;
+    key = x;
+    cnt = c;
+    if (!merge) return true;
+    const uint64_t r = rc_bits(x, k);
+    if (r == x) {   // palindrome: its own partner, the reference adds the count to itself
+        cnt = c + c;
+        return true;
+    }
+    const uint32_t cr = bins[r];
+    if (cr > 0 && x > r) return false;   // higher member of a present pair is deleted
+    key = (x > r) ? r : x;               // partner absent and x > rc(x): replaced in place, not re-sorted
+    cnt = c + cr;
+    return true;
+}
+
+__global__ __launch_bounds__(BLK) void compact_count_kernel(const uint32_t *__restrict__ bins, uint64_t n_bins, int k,
+                                                            int merge, uint32_t *__restrict__ block_counts) {
+    __shared__ uint32_t wsum[BLK / 64];
+    const uint64_t x0 = ((uint64_t)blockIdx.x * BLK + threadIdx.x) * CT_PER_THREAD;
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < CT_PER_THREAD; ++j) {
+        uint64_t key;
+        uint32_t cnt;
+        if (x0 + j < n_bins) m += bin_entry(bins, x0 + j, k, merge, key, cnt);
+    }
+    for (int o = 32; o > 0; o >>= 1) m += __shfl_down(m, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of n uint32 values into uint64 offsets by ONE block (n up to a few million);
+// total written to *total
+__global__ __launch_bounds__(1024) void scan_single_block_kernel(const uint32_t *__restrict__ in, int64_t n,
+                                                                 uint64_t *__restrict__ out,
+                                                                 uint64_t *__restrict__ total) {
+    __shared__ uint64_t part[1024];
+    const int t = threadIdx.x;
+    const int64_t chunk = (n + 1023) / 1024;
+    const int64_t lo = (int64_t)t * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+    uint64_t s = 0;
+    for (int64_t i = lo; i < hi; ++i) s += in[i];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan
+        uint64_t v = (t >= o) ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint64_t run = (t == 0) ? 0 : part[t - 1];
+    for (int64_t i = lo; i < hi; ++i) {
+        out[i] = run;
+        run += in[i];
+    }
+    if (t == 1023) *total = part[1023];
+}
+
+template <typename H>
+__global__ __launch_bounds__(BLK) void compact_write_kernel(const uint32_t *__restrict__ bins, uint64_t n_bins, int k,
+                                                            int merge, const uint64_t *__restrict__ block_off,
+                                                            H *__restrict__ uniq, uint32_t *__restrict__ cnt_out) {
+    __shared__ uint32_t wsum[BLK / 64];
+    const uint64_t x0 = ((uint64_t)blockIdx.x * BLK + threadIdx.x) * CT_PER_THREAD;
+    uint64_t keys[CT_PER_THREAD];
+    uint32_t cnts[CT_PER_THREAD];
+    uint32_t flags = 0, m = 0;
+#pragma unroll
+    for (int j = 0; j < CT_PER_THREAD; ++j) {
+        if (x0 + j < n_bins && bin_entry(bins, x0 + j, k, merge, keys[j], cnts[j])) {
+            flags |= 1u << j;
+            ++m;
+        }
+    }
+    // exclusive scan of m across the block: wave scan + wave sums
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = m;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    uint64_t pos = block_off[blockIdx.x] + woff + (inc - m);
+#pragma unroll
+    for (int j = 0; j < CT_PER_THREAD; ++j) {
+        if (flags & (1u << j)) {
+            uniq[pos] = (H)keys[j];
+            cnt_out[pos] = cnts[j];
+            ++pos;
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLK) void sum_counts_kernel(const uint32_t *__restrict__ cnt, int64_t n, int as_signed,
+                                                         unsigned long long *__restrict__ total) {
+    // the reference sums int32 counts as Python ints (find_motif :648): sign-extend for k < 16
+    long long s = 0;
+    const int64_t stride = (int64_t)gridDim.x * BLK;
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += stride)
+        s += as_signed ? (long long)(int32_t)cnt[i] : (long long)cnt[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(total, (unsigned long long)s);
+}
+
+// ---- Hamming-ball mass -----------------------------------------------------------------------
+struct CandTab {
+    uint64_t fwd[16];
+    uint64_t rc[16];
+    int n;
+};
+template <typename H>
+__global__ __launch_bounds__(BLK) void mass_kernel(const H *__restrict__ uniq, const uint32_t *__restrict__ cnt, int64_t n,
+                                                   int k, CandTab t, int radius, int revcom, int as_signed,
+                                                   unsigned long long *__restrict__ mass) {
+    long long acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0;
+    const uint64_t m = low_mask<uint64_t>(k);
+    const int64_t stride = (int64_t)gridDim.x * BLK;
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
+        const uint64_t u = (uint64_t)uniq[i];
+        const long long w = as_signed ? (long long)(int32_t)cnt[i] : (long long)cnt[i];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (c < t.n) {
+                int d = popc2((u ^ t.fwd[c]) & m);
+                if (revcom) {
+                    int d2 = popc2((u ^ t.rc[c]) & m);
+                    d = d2 < d ? d2 : d;
+                }
+                if (d <= radius) acc[c] += w;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        if (c < t.n) {   // wave-uniform
+            long long s = acc[c];
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+            if ((threadIdx.x & 63) == 0 && s != 0) atomicAdd(&mass[c], (unsigned long long)s);
+        }
+    }
+}
+
+static uint64_t host_revcom(uint64_t h, int k, int narrow) {
+    // same arithmetic as the device helper (u32 wrap for k < 16)
+    if (narrow) {
+        uint32_t mask = (uint32_t)((1ull << (2 * k)) - 1), com = mask - (uint32_t)h, r = com & 3u;
+        for (int i = 0; i < k - 1; ++i) { r <<= 2; com >>= 2; r += com & 3u; }
+        return r;
+    }
+    uint64_t mask = (k >= 32) ? ~0ull : ((1ull << (2 * k)) - 1), com = mask - h, r = com & 3u;
+    for (int i = 0; i < k - 1; ++i) { r <<= 2; com >>= 2; r += com & 3u; }
+    return r;
+}
+
+}  // namespace
+
+struct kmap_counts {
+    int k = 0;
+    int narrow = 1;          // hash dtype uint32 (k < 16)
+    int64_t n_uniq = 0;
+    void *uniq = nullptr;    // H[n_uniq]
+    uint32_t *cnt = nullptr; // uint32[n_uniq]
+    size_t cap = 0;          // entries allocated
+    uint32_t *bins = nullptr;
+    size_t bins_cap = 0;     // bins allocated
+};
+
+namespace {
+
+int ensure_bins(kmap_counts *c, size_t n_bins) {
+    if (c->bins_cap < n_bins) {
+        if (c->bins) KMAP_CHECK_HIP(hipFree(c->bins));
+        c->bins = nullptr;
+        c->bins_cap = 0;
+        hipError_t e = hipMalloc((void **)&c->bins, n_bins * 4);
+        if (e != hipSuccess) {
+            kmap_set_error("counts: cannot allocate %zu-bin histogram (%.1f GiB): %s", n_bins, n_bins * 4.0 / (1 << 30),
+                           hipGetErrorString(e));
+            return KMAP_E_NOMEM;
+        }
+        c->bins_cap = n_bins;
+    }
+    return KMAP_OK;
+}
+
+template <typename H>
+int run_hashes(kmap_counts *c, const H *hash_dev, int64_t n, int k, int merge, int64_t *n_uniq, hipStream_t st) {
+    KMAP_REQUIRE(k <= 16, "counts: k=%d > 16 is not supported by the direct-histogram path of this build", k);
+    const size_t n_bins = (size_t)1 << (2 * k);
+    KMAP_TRY(ensure_bins(c, n_bins));
+    KMAP_CHECK_HIP(hipMemsetAsync(c->bins, 0, n_bins * 4, st));
+    if (n > 0) {
+        int64_t g = (n + BLK - 1) / BLK;
+        if (g > 256 * 32) g = 256 * 32;
+        hist_kernel<H><<<(unsigned)g, BLK, 0, st>>>(hash_dev, n, c->bins);
+    }
+    const unsigned nb = grid_for((int64_t)n_bins, CT_TILE);
+    uint32_t *bc = nullptr;
+    uint64_t *boff = nullptr;
+    KMAP_TRY(kmap_scratch((void **)&bc, (size_t)nb * 4, st, KMAP_SLOT_A));
+    KMAP_TRY(kmap_scratch((void **)&boff, ((size_t)nb + 1) * 8, st, KMAP_SLOT_B));
+    compact_count_kernel<<<nb, BLK, 0, st>>>(c->bins, n_bins, k, merge, bc);
+    scan_single_block_kernel<<<1, 1024, 0, st>>>(bc, nb, boff, boff + nb);
+    uint64_t total = 0;
+    KMAP_CHECK_HIP(hipMemcpyAsync(&total, boff + nb, 8, hipMemcpyDeviceToHost, st));
+    KMAP_CHECK_HIP(hipStreamSynchronize(st));
+    if (c->cap < total || !c->uniq) {
+        if (c->uniq) KMAP_CHECK_HIP(hipFree(c->uniq));
+        if (c->cnt) KMAP_CHECK_HIP(hipFree(c->cnt));
+        c->uniq = nullptr;
+        c->cnt = nullptr;
+        c->cap = 0;
+        const size_t cap = total ? total : 1;
+        KMAP_CHECK_HIP(hipMalloc(&c->uniq, cap * 8));
+        KMAP_CHECK_HIP(hipMalloc((void **)&c->cnt, cap * 4));
+        c->cap = cap;
+    }
+    if (total) compact_write_kernel<H><<<nb, BLK, 0, st>>>(c->bins, n_bins, k, merge, boff, (H *)c->uniq, c->cnt);
+    KMAP_CHECK_HIP(hipGetLastError());
+    c->k = k;
+    c->narrow = (k < 16);
+    c->n_uniq = (int64_t)total;
+    if (n_uniq) *n_uniq = (int64_t)total;
+    return KMAP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kmap_counts_create(kmap_counts **c) {
+    KMAP_REQUIRE(c, "counts_create: null");
+    *c = new kmap_counts();
+    return KMAP_OK;
+}
+int kmap_counts_destroy(kmap_counts *c) {
+    if (!c) return KMAP_OK;
+    if (c->uniq) (void)hipFree(c->uniq);
+    if (c->cnt) (void)hipFree(c->cnt);
+    if (c->bins) (void)hipFree(c->bins);
+    delete c;
+    return KMAP_OK;
+}
+
+int kmap_counts_run_hashes_dev(kmap_counts *c, const void *hash_dev, int64_t n, int k, int merge_revcom, int64_t *n_uniq,
+                               void *stream) {
+    KMAP_REQUIRE(c, "counts_run_hashes: null handle");
+    KMAP_REQUIRE(k > 0 && k < 32, "counts_run_hashes: k=%d out of range", k);
+    KMAP_REQUIRE(n >= 0 && (n == 0 || hash_dev), "counts_run_hashes: bad input");
+    if (k < 16) return run_hashes<uint32_t>(c, (const uint32_t *)hash_dev, n, k, merge_revcom, n_uniq, as_stream(stream));
+    return run_hashes<uint64_t>(c, (const uint64_t *)hash_dev, n, k, merge_revcom, n_uniq, as_stream(stream));
+}
+
+int kmap_counts_run_seq_dev(kmap_counts *c, const uint8_t *seq_dev, int64_t n, const int64_t *borders_dev, int64_t n_seq,
+                            int k, int dedupe_per_read, int merge_revcom, int64_t *n_uniq, void *stream) {
+    KMAP_REQUIRE(c, "counts_run_seq: null handle");
+    KMAP_REQUIRE(k > 0 && k < 32, "counts_run_seq: k=%d out of range", k);
+    KMAP_REQUIRE(n >= 0 && (n == 0 || seq_dev), "counts_run_seq: bad input");
+    KMAP_REQUIRE(!dedupe_per_read || n_seq == 0 || borders_dev, "counts_run_seq: dedupe needs borders");
+    hipStream_t st = as_stream(stream);
+    const size_t hb = (k < 16) ? 4 : 8;
+    void *hash = nullptr;
+    hipError_t e = hipMalloc(&hash, (size_t)(n ? n : 1) * hb);
+    if (e != hipSuccess) {
+        kmap_set_error("counts_run_seq: hash scratch of %zu bytes: %s", (size_t)n * hb, hipGetErrorString(e));
+        return KMAP_E_NOMEM;
+    }
+    int rc;
+    if (k < 16) {
+        rc = kmap_hash_launch_u32(seq_dev, n, k, (uint32_t *)hash, stream);
+        if (rc == KMAP_OK && dedupe_per_read) rc = kmap_dedupe_per_read_u32_dev((uint32_t *)hash, n, borders_dev, n_seq, stream);
+        if (rc == KMAP_OK) rc = run_hashes<uint32_t>(c, (const uint32_t *)hash, n, k, merge_revcom, n_uniq, st);
+    } else {
+        rc = kmap_hash_launch_u64(seq_dev, n, k, (uint64_t *)hash, stream);
+        if (rc == KMAP_OK && dedupe_per_read) rc = kmap_dedupe_per_read_u64_dev((uint64_t *)hash, n, borders_dev, n_seq, stream);
+        if (rc == KMAP_OK) rc = run_hashes<uint64_t>(c, (const uint64_t *)hash, n, k, merge_revcom, n_uniq, st);
+    }
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(hash);
+    return rc;
+}
+
+int kmap_counts_fetch(kmap_counts *c, void *uniq_out, void *cnt_out) {
+    KMAP_REQUIRE(c && c->k > 0, "counts_fetch: nothing counted yet");
+    if (c->n_uniq == 0) return KMAP_OK;
+    KMAP_REQUIRE(uniq_out && cnt_out, "counts_fetch: null output");
+    const size_t n = (size_t)c->n_uniq;
+    KMAP_CHECK_HIP(hipMemcpy(uniq_out, c->uniq, n * (c->narrow ? 4 : 8), hipMemcpyDeviceToHost));
+    if (c->narrow) {
+        KMAP_CHECK_HIP(hipMemcpy(cnt_out, c->cnt, n * 4, hipMemcpyDeviceToHost));   // uint32 bits == int32 wrap
+    } else {
+        uint32_t *tmp = (uint32_t *)malloc(n * 4);
+        KMAP_REQUIRE(tmp, "counts_fetch: host malloc");
+        hipError_t e = hipMemcpy(tmp, c->cnt, n * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            for (size_t i = 0; i < n; ++i) ((int64_t *)cnt_out)[i] = (int64_t)tmp[i];
+        free(tmp);
+        KMAP_CHECK_HIP(e);
+    }
+    return KMAP_OK;
+}
+
+int kmap_counts_total(kmap_counts *c, int64_t *total) {
+    KMAP_REQUIRE(c && c->k > 0 && total, "counts_total: nothing counted yet");
+    *total = 0;
+    if (c->n_uniq == 0) return KMAP_OK;
+    DevBuf t;
+    KMAP_TRY(t.alloc(8));
+    KMAP_CHECK_HIP(hipMemset(t.p, 0, 8));
+    int64_t g = (c->n_uniq + BLK - 1) / BLK;
+    if (g > 4096) g = 4096;
+    sum_counts_kernel<<<(unsigned)g, BLK>>>(c->cnt, c->n_uniq, c->narrow, t.as<unsigned long long>());
+    KMAP_CHECK_HIP(hipMemcpy(total, t.p, 8, hipMemcpyDeviceToHost));
+    return KMAP_OK;
+}
+
+int kmap_counts_hamball_mass(kmap_counts *c, const uint64_t *cands, int n_cand, int radius, int revcom, double *mass_out) {
+    KMAP_REQUIRE(c && c->k > 0, "hamball_mass: nothing counted yet");
+    KMAP_REQUIRE(n_cand >= 0 && (n_cand == 0 || (cands && mass_out)), "hamball_mass: null pointer");
+    DevBuf m;
+    KMAP_TRY(m.alloc(16 * 8));
+    for (int c0 = 0; c0 < n_cand; c0 += 16) {
+        CandTab t;
+        t.n = (n_cand - c0 < 16) ? n_cand - c0 : 16;
+        for (int i = 0; i < t.n; ++i) {
+            t.fwd[i] = cands[c0 + i];
+            t.rc[i] = host_revcom(cands[c0 + i], c->k, c->narrow);
+        }
+        KMAP_CHECK_HIP(hipMemset(m.p, 0, 16 * 8));
+        if (c->n_uniq > 0) {
+            int64_t g = (c->n_uniq + BLK - 1) / BLK;
+            if (g > 2048) g = 2048;
+            if (c->narrow)
+                mass_kernel<uint32_t><<<(unsigned)g, BLK>>>((const uint32_t *)c->uniq, c->cnt, c->n_uniq, c->k, t, radius,
+                                                            revcom, 1, m.as<unsigned long long>());
+            else
+                mass_kernel<uint64_t><<<(unsigned)g, BLK>>>((const uint64_t *)c->uniq, c->cnt, c->n_uniq, c->k, t, radius,
+                                                            revcom, 0, m.as<unsigned long long>());
+            KMAP_CHECK_HIP(hipGetLastError());
+        }
+        long long host[16];
+        KMAP_CHECK_HIP(hipMemcpy(host, m.p, 16 * 8, hipMemcpyDeviceToHost));
+        for (int i = 0; i < t.n; ++i) mass_out[c0 + i] = (double)host[i];
+    }
+    return KMAP_OK;
+}
+
+}  // extern "C"

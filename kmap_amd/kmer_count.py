@@ -1,0 +1,418 @@
+"""Host side of the k-mer counting path: the reference's operator interface
+(/root/reference/src/kmap/kmer_count.py) re-exposed over the HIP C ABI.
+
+Function names, argument meaning and error behaviour follow the reference so that its callers
+(and tests written against it) run unchanged; every array operator launches a hand-written
+gfx950 kernel through kmap_amd._ffi -- there is no numpy/CPU implementation of the kernels here.
+Host-only pieces (dtype rules, scalar hash helpers, FASTA encoding, TOML/CSV contracts) are plain
+Python like the reference's.
+"""
+import ctypes as C
+import gzip
+import pickle
+from dataclasses import dataclass, fields
+from importlib.resources import files
+from pathlib import Path
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, ptr
+
+# file-name contract of the result directory (reference kmer_count.py:26-53)
+FileNameDict = {
+    "default_config_file": "default_config.toml",
+    "config_file": "config.toml",
+    "default_motif_def_file": "default_motif_def_table.csv",
+    "motif_def_file": "motif_def_table.csv",
+    "processed_fasta_file": "input.bin.pkl",
+    "processed_fasta_seqboarder_file": "input.seqboarder.bin.pkl",
+    "motif_pos_density_file": "motif_pos_density.np.pkl",
+    "motif_pos_density_plot_dir": "motif_pos_density",
+    "kmer_count_dir": "kmer_count",
+    "conseq_similarity_dir": "conseq_similarity",
+    "co_occur_dir": "co_occurence",
+    "co_occur_dist_mat_file": "co_occurence_motif_dist_mat.tsv",
+    "co_occur_dist_data_file": "co_occurence_motif_dist_data.txt",
+    "co_occur_mat_file": "co_occurence_mat.tsv",
+    "co_occur_mat_norm_file": "co_occurence_mat.norm.tsv",
+    "co_occur_network_fig": "co_occur_network.pdf",
+    "motif_occurence_file": "final.motif_occurence.csv",
+    "hamball_dir": "hamming_balls",
+    "candidate_conseq_file": "candidate_conseq.csv",
+    "final_conseq_file": "final_conseq.txt",
+    "final_conseq_info_file": "final_conseq.info.csv",
+    "sample_kmer_pkl_file": "sample_kmers.pkl",
+    "sample_kmer_txt_file": "sample_kmers.tsv",
+    "sample_kmer_hamdist_mat_file": "sample_kmer_hamdist_mat.pkl",
+    "ld_data_file": "low_dim_data.tsv",
+    "ld_fig_file_stem": "ld_data",
+}
+
+MISSING_VAL = 255
+_BASES = "ACGT"
+_ENC = np.full(256, MISSING_VAL, dtype=np.uint8)
+for _i, _b in enumerate(_BASES):
+    _ENC[ord(_b)] = _i
+
+
+# ---- dtype rules (reference kmer_count.py:351-370) ----------------------------------------------
+def get_cnt_dtype(kmer_len: int):
+    return np.int32 if kmer_len < 16 else np.int64
+
+
+def get_hash_dtype(kmer_len):
+    if 0 < kmer_len < 16:
+        return np.uint32
+    elif kmer_len < 32:
+        return np.uint64
+    raise Exception(f"max_kmer_len=31, kmer_len={kmer_len} is greater the maximum value.")
+
+
+def get_invalid_hash(dtype):
+    return dtype(np.iinfo(dtype).max)
+
+
+# ---- scalar helpers (reference kmer_count.py:238-268,416-446,626-640) ---------------------------
+def kmer2hash(kmer: str) -> np.uint64:
+    assert len(kmer) < 32, "kmer should be shorted than 32 bases"
+    kh = 0
+    for base in kmer:
+        kh = (kh << 2) | _BASES.index(base)
+    return np.uint64(kh)
+
+
+def hash2kmer(hashkey, k: int) -> str:
+    hk = int(hashkey)
+    return "".join(_BASES[(hk >> (2 * (k - 1 - i))) & 3] for i in range(k))
+
+
+def revcom_hash(in_hash, kmer_len: int):
+    dt = get_hash_dtype(kmer_len)
+    com = ((1 << (2 * kmer_len)) - 1 - int(in_hash)) % (1 << (8 * np.dtype(dt).itemsize))
+    out = 0
+    for _ in range(kmer_len):
+        out = (out << 2) | (com & 3)
+        com >>= 2
+    return dt(out)
+
+
+def reverse_complement(seq):
+    return seq[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+def arr2dna(dna_np_arr: np.ndarray) -> str:
+    lut = np.full(256, ord("?"), np.uint8)
+    lut[:4] = np.frombuffer(b"ACGT", np.uint8)
+    lut[MISSING_VAL] = ord("N")
+    return lut[np.asarray(dna_np_arr, np.uint8)].tobytes().decode()
+
+
+def dna2arr(dna_str, dtype=np.uint8, append_missing_val_flag=True) -> np.ndarray:
+    """A/C/G/T -> 0..3, anything else -> 255, optional trailing 255 separator (upper case expected)."""
+    codes = _ENC[np.frombuffer(dna_str.encode("latin-1"), dtype=np.uint8)].astype(dtype)
+    if append_missing_val_flag:
+        codes = np.append(codes, dtype(MISSING_VAL))
+    return codes
+
+
+# ---- array operators: HIP kernels ------------------------------------------------------------
+def _as_hash(a, kmer_len):
+    dt = get_hash_dtype(kmer_len)
+    a = np.asarray(a)
+    if a.dtype != dt:
+        a = a.astype(dt)
+    return np.ascontiguousarray(a), dt
+
+
+def comp_kmer_hash(seq_np_arr: np.ndarray, kmer_len: int) -> np.ndarray:
+    """k-mer hash at every array index (reference comp_kmer_hash_taichi, kmer_count.py:449-473)."""
+    dt = get_hash_dtype(kmer_len)
+    seq = np.ascontiguousarray(seq_np_arr, dtype=np.uint8)
+    out = np.empty(len(seq), dtype=dt)
+    fn = _ffi.lib().kmap_hash_kmers_u32 if dt == np.uint32 else _ffi.lib().kmap_hash_kmers_u64
+    check(fn(ptr(seq), len(seq), kmer_len, ptr(out)))
+    return out
+
+
+comp_kmer_hash_taichi = comp_kmer_hash   # the reference's name for the same operator
+
+
+def remove_duplicate_hash_per_seq(hash_arr: np.ndarray, boarder_mat: np.ndarray, invalid_hash=None) -> np.ndarray:
+    """In place: per read keep the first occurrence of each hash (reference kmer_count.py:743-760)."""
+    assert boarder_mat.shape[1] == 2
+    assert hash_arr.dtype in (np.uint32, np.uint64) and hash_arr.flags.c_contiguous
+    b = np.ascontiguousarray(boarder_mat, dtype=np.int64)
+    fn = _ffi.lib().kmap_dedupe_per_read_u32 if hash_arr.dtype == np.uint32 else _ffi.lib().kmap_dedupe_per_read_u64
+    check(fn(ptr(hash_arr), len(hash_arr), ptr(b), len(b)))
+    return hash_arr
+
+
+class DeviceCounts:
+    """Owns a kmap_counts handle: unique k-mers + counts resident in HBM."""
+
+    def __init__(self):
+        h = _ffi.vp()
+        check(_ffi.lib().kmap_counts_create(C.byref(h)))
+        self._h = h.value
+        self.k = 0
+        self.n_uniq = 0
+
+    def run_hashes(self, hash_dev_ptr, n, k, merge_revcom, stream=None):
+        nu = _ffi.i64(0)
+        check(_ffi.lib().kmap_counts_run_hashes_dev(self._h, hash_dev_ptr, n, k, int(merge_revcom), C.byref(nu), stream))
+        self.k, self.n_uniq = k, nu.value
+        return self.n_uniq
+
+    def run_seq(self, seq_dev_ptr, n, borders_dev_ptr, n_seq, k, dedupe, merge_revcom, stream=None):
+        nu = _ffi.i64(0)
+        check(_ffi.lib().kmap_counts_run_seq_dev(self._h, seq_dev_ptr, n, borders_dev_ptr, n_seq, k, int(dedupe),
+                                                 int(merge_revcom), C.byref(nu), stream))
+        self.k, self.n_uniq = k, nu.value
+        return self.n_uniq
+
+    def fetch(self):
+        u = np.empty(self.n_uniq, get_hash_dtype(self.k))
+        c = np.empty(self.n_uniq, get_cnt_dtype(self.k))
+        check(_ffi.lib().kmap_counts_fetch(self._h, ptr(u), ptr(c)))
+        return u, c
+
+    def total(self):
+        t = _ffi.i64(0)
+        check(_ffi.lib().kmap_counts_total(self._h, C.byref(t)))
+        return t.value
+
+    def hamball_mass(self, cands, radius, revcom=True):
+        cands = np.ascontiguousarray(cands, dtype=np.uint64)
+        out = np.zeros(len(cands), np.float64)
+        check(_ffi.lib().kmap_counts_hamball_mass(self._h, ptr(cands), len(cands), int(radius), int(revcom), ptr(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            _ffi.lib().kmap_counts_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def count_uniq_hash(hash_arr: np.ndarray, kmer_len):
+    """Sorted unique hashes + counts, invalid hash dropped (reference kmer_count.py:476-491)."""
+    h, dt = _as_hash(hash_arr, kmer_len)
+    dev = _ffi.DeviceBuffer.from_numpy(h)
+    dc = DeviceCounts()
+    try:
+        dc.run_hashes(dev.ptr, len(h), kmer_len, merge_revcom=False)
+        return dc.fetch()
+    finally:
+        dc.close()
+        dev.free()
+
+
+def _ham(kh_arr, consensus_kh, kmer_len, shift_bits, clen):
+    h, dt = _as_hash(kh_arr, kmer_len)
+    out = np.empty(len(h), dtype=np.uint8)
+    fn = _ffi.lib().kmap_hamdist_1vN_u32 if dt == np.uint32 else _ffi.lib().kmap_hamdist_1vN_u64
+    check(fn(ptr(h), len(h), int(dt(consensus_kh)), shift_bits, clen, ptr(out)))
+    return out
+
+
+def cal_hamming_dist(kh_arr: np.ndarray, consensus_kh, kmer_len: int) -> np.ndarray:
+    """Hamming distance of every hash to one consensus (reference kmer_count.py:494-515)."""
+    return _ham(kh_arr, consensus_kh, kmer_len, 0, kmer_len)
+
+
+def cal_hamming_dist_head(kh_arr, consensus_kh, kmer_len: int, consensus_len: int) -> np.ndarray:
+    """Consensus (<= k bases) against the first consensus_len bases (reference kmer_count.py:518-546)."""
+    assert consensus_len <= kmer_len
+    return _ham(kh_arr, consensus_kh, kmer_len, 2 * (kmer_len - consensus_len), consensus_len)
+
+
+def cal_hamming_dist_tail(kh_arr, consensus_kh, kmer_len: int, consensus_len: int) -> np.ndarray:
+    """Consensus against the last consensus_len bases (reference kmer_count.py:549-577)."""
+    assert consensus_len <= kmer_len
+    return _ham(kh_arr, consensus_kh, kmer_len, 0, consensus_len)
+
+
+def mask_input(seq_np_arr: np.ndarray, kmer_len: int, consensus_kh_arr, max_hamball_dist_arr):
+    """In place: overwrite every occurrence of the consensuses' Hamming balls with 255
+    (reference kmer_count.py:580-610)."""
+    assert seq_np_arr.dtype == np.uint8 and seq_np_arr.flags.c_contiguous
+    cons = np.ascontiguousarray(consensus_kh_arr, dtype=np.uint64)
+    rad = np.ascontiguousarray(max_hamball_dist_arr, dtype=np.int32)
+    assert len(cons) == len(rad)
+    check(_ffi.lib().kmap_mask_hamball(ptr(seq_np_arr), len(seq_np_arr), kmer_len, ptr(cons), ptr(rad), len(cons)))
+    return seq_np_arr
+
+
+def get_revcom_hash_arr(in_hash_arr: np.ndarray, kmer_len: int) -> np.ndarray:
+    """Reverse-complement hash of every entry (reference kmer_count.py:613-623)."""
+    h, dt = _as_hash(in_hash_arr, kmer_len)
+    out = np.empty_like(h)
+    fn = _ffi.lib().kmap_revcom_u32 if dt == np.uint32 else _ffi.lib().kmap_revcom_u64
+    check(fn(ptr(h), len(h), kmer_len, ptr(out)))
+    return out
+
+
+def merge_revcom(uniq_kmer_hash_arr: np.ndarray, uniq_kh_cnt_arr: np.ndarray, kmer_len: int,
+                 keep_lower_hash_flag=True) -> Tuple:
+    """Sum the counts of reverse-complement pairs and keep one key per pair (reference
+    kmer_count.py:643-685, including: palindromes double, a kept key whose partner is absent is
+    replaced in place without re-sorting).  Like the reference: revcom on device, set logic in numpy.
+    (The fused device path -- DeviceCounts.run_seq(..., merge_revcom=True) -- does the same in bin space.)"""
+    kh = np.asarray(uniq_kmer_hash_arr)
+    cnt = np.asarray(uniq_kh_cnt_arr)
+    rc = get_revcom_hash_arr(kh, kmer_len).astype(kh.dtype)
+    pos = np.searchsorted(kh, rc)
+    pos_c = np.minimum(pos, max(len(kh) - 1, 0))
+    has_partner = (kh[pos_c] == rc) if len(kh) else np.zeros(0, bool)
+    merged = cnt + np.where(has_partner, cnt[pos_c], 0).astype(cnt.dtype)
+    worse = (kh > rc) if keep_lower_hash_flag else (kh < rc)
+    keep = ~(has_partner & worse)
+    out_kh = np.where(worse, rc, kh)[keep]
+    return out_kh, merged[keep]
+
+
+def mask_ham_ball(seq_np_arr: np.ndarray, motif_def_dict: dict, consensus_seq_list: List[str],
+                  max_ham_dist_list: List[int] = ()) -> np.ndarray:
+    """Mask user-supplied consensus Hamming balls, grouped by length (reference kmer_count.py:688-723)."""
+    lens = [len(s) for s in consensus_seq_list]
+    if len(max_ham_dist_list) == 0:
+        max_ham_dist_list = [motif_def_dict[n].max_ham_dist for n in lens]
+    assert len(max_ham_dist_list) == len(consensus_seq_list)
+    for k in sorted(set(lens)):
+        sel = [i for i, n in enumerate(lens) if n == k]
+        seq_np_arr = mask_input(seq_np_arr, k, np.array([kmer2hash(consensus_seq_list[i]) for i in sel]),
+                                np.array([max_ham_dist_list[i] for i in sel]))
+    return seq_np_arr
+
+
+# ---- motif definition table + config (reference kmer_count.py:104-136,221-235,726-740) -----------
+@dataclass
+class MotifDef:
+    kmer_len: int
+    p_uniform: float
+    max_ham_dist: int
+    ratio_mu: float
+    ratio_std: float
+    ratio_cutoff: float
+
+    @classmethod
+    def get_field_names(cls):
+        return ",".join(f.name for f in fields(cls))
+
+    def __str__(self):
+        return ",".join(str(getattr(self, f.name)) for f in fields(self))
+
+
+def init_motif_def_dict(motif_def_file, p_value_cutoff=1e-10) -> dict:
+    import pandas as pd
+    from scipy.stats import norm
+    table = {"p_value_cutoff": p_value_cutoff}
+    for _, row in pd.read_csv(motif_def_file).iterrows():
+        k = int(row["kmer_len"])
+        cutoff = norm.ppf(1 - p_value_cutoff, loc=row["ratio_mu"], scale=row["ratio_std"])
+        table[k] = MotifDef(k, row["p_uniform"], int(row["max_ham_dist"]), row["ratio_mu"], row["ratio_std"], cutoff)
+    return table
+
+
+def _pkg_file(name):
+    return files(__package__).joinpath(name)
+
+
+def read_default_config_file(debug=False):
+    from ._toml import load_toml
+    cfg = load_toml(_pkg_file(FileNameDict["default_config_file"]))
+    if debug:
+        print(cfg)
+    return cfg
+
+
+def gen_motif_def_dict(config_dict: dict, debug=False) -> Dict:
+    src = config_dict["motif_discovery"]["motif_def_file"]
+    cutoff = config_dict["motif_discovery"]["p_value_cutoff"]
+    if src == "default":
+        table = init_motif_def_dict(_pkg_file(FileNameDict["default_motif_def_file"]), p_value_cutoff=cutoff)
+    else:
+        assert Path(src).exists()
+        table = init_motif_def_dict(src, p_value_cutoff=cutoff)
+    if debug:
+        print(table)
+    return table
+
+
+# ---- FASTA -> uint8 array contract (reference kmer_count.py:182-218,308-347) ---------------------
+def _iter_fasta_records(file_name):
+    opener = gzip.open if str(file_name).endswith(".gz") else open
+    with opener(file_name, "rt") as fh:
+        header, chunks = None, []
+        for line in fh:
+            if line.startswith(">"):
+                if header is not None:
+                    yield header, "".join(chunks)
+                header, chunks = line[1:].strip(), []
+            elif header is not None:
+                chunks.append("".join(line.split()))
+        if header is not None:
+            yield header, "".join(chunks)
+
+
+def read_dnaseq_file(file_name, file_type="fasta"):
+    """Yield one uint8 array (with trailing 255 separator) per FASTA record, sequence upper-cased."""
+    assert file_type == "fasta"
+    for _, seq in _iter_fasta_records(file_name):
+        yield dna2arr(seq.upper(), append_missing_val_flag=True)
+
+
+def encode_fasta(fasta_file):
+    """Whole file -> (uint8 array with 255 separators, (n_seq,2) int64 [start, end-of-read))."""
+    parts = list(read_dnaseq_file(fasta_file))
+    lens = np.array([len(p) for p in parts], dtype=np.int64)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64) if len(parts) else np.zeros(0, np.int64)
+    arr = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+    return arr, np.stack([starts, starts + lens - 1], axis=1).astype(int) if len(parts) else np.zeros((0, 2), int)
+
+
+def proc_input(input_fasta_file: str, res_dir=".", out_bin_file_name: str = "input.bin.pkl",
+               out_boarder_bin_file_name: str = "input.seqboarder.bin.pkl", debug=True):
+    assert Path(input_fasta_file).exists()
+    assert Path(res_dir).exists()
+    assert out_bin_file_name.endswith(".pkl")
+    arr, borders = encode_fasta(input_fasta_file)
+    out = Path(res_dir) / out_bin_file_name
+    if debug:
+        print(f"Convert input file={input_fasta_file} into binary file {out}. buffer_size={len(arr) / 2 ** 30}GB.")
+    with open(out, "wb") as fh:
+        pickle.dump(arr, fh)
+    with open(Path(res_dir) / out_boarder_bin_file_name, "wb") as fh:
+        pickle.dump(borders, fh)
+    print(f"input binary file {out} generated.\n")
+
+
+def _preproc(fasta_file: str, res_dir=".", debug=False):
+    """`kmap preproc` (reference kmer_count.py:139-179): config.toml, motif_def_table.csv, input pickles."""
+    from ._toml import dump_toml, load_toml
+    assert Path(fasta_file).exists()
+    Path(res_dir).mkdir(exist_ok=True)
+    cfg_path = Path(res_dir) / FileNameDict["config_file"]
+    had_cfg = cfg_path.exists()
+    cfg = load_toml(cfg_path) if had_cfg else read_default_config_file(debug=debug)
+    if not had_cfg or cfg["general"].get("input_fasta_file") is None:
+        cfg["general"]["input_fasta_file"] = fasta_file
+        cfg["general"]["res_dir"] = res_dir
+        dump_toml(cfg, cfg_path)
+    table = gen_motif_def_dict(cfg, debug=debug)
+    ks = sorted(k for k in table if isinstance(k, int))
+    with open(Path(res_dir) / FileNameDict["motif_def_file"], "w+") as fh:
+        fh.write(MotifDef.get_field_names() + "\n")
+        for k in ks:
+            fh.write(str(table[k]) + "\n")
+    proc_input(cfg["general"]["input_fasta_file"], cfg["general"]["res_dir"],
+               out_bin_file_name=FileNameDict["processed_fasta_file"],
+               out_boarder_bin_file_name=FileNameDict["processed_fasta_seqboarder_file"], debug=debug)
+    return cfg, table
