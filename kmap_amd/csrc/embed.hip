@@ -1,0 +1,781 @@
+// embed.hip -- kNN smoothing and the 2-D embedding loop (reference visualization.py:90-326,
+// kernels taichi_core.py:227-326), device resident.
+//
+//  * knn sums   : sums[i,j] = sum_{a in nb[i], b in nb[j]} D[a,b] as exact integers (u16), computed as
+//                 A*D*A^T in two factored steps through LDS (20+20 reads per pair instead of 400).
+//  * forces     : one pass over the rows a GPU owns: q_ij, clip, cross-entropy partial (j > i),
+//                 T_ij = q/(1-q)*(p-q), g_i = sum_j T_ij (y_i - y_j).  p comes either from an f32 matrix
+//                 or from LUT[sums[i,j]] (the LUT holds the reference's numpy-evaluated
+//                 exp(-sigmoid(s/n_nb/n_nb)/0.5) for every possible integer sum).
+//       FAST mode: a wave sweeps 4 rows at a time, lanes over columns, DPP/shuffle reduction.
+//       SEQ  mode: one lane per row, j ascending, IEEE f32 without FMA == the reference's arithmetic.
+//  * apply      : loss -> best-list insert (bisect.insort_right) -> early-stop test -> y += -(4 g) lr
+//                 -> add_jitter (as written in the reference: only points 0 and 1 are ever touched),
+//                 all on device; the host only pre-draws the jitter normals from numpy's RNG stream.
+//
+// Everything float here is compiled with -ffp-contract=off and no fast-math: the per-pair values are
+// bit-identical to numpy's f32 scalar arithmetic; FAST mode differs from the reference only in the
+// order of the row sums.
+#include <math.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr int BLK = 256;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// =================================================================================================
+// kNN sums
+// =================================================================================================
+constexpr int KNN_TPB = 1024;
+constexpr int KNN_CHUNK_MAX = 65536;   // u16 entries of one row staged in LDS (128 KiB of the 160 KiB)
+
+__global__ void transpose_nb_kernel(const int32_t *__restrict__ nb, int64_t n, int n_nb, int32_t *__restrict__ nbT) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * n_nb) return;
+    const int64_t i = t / n_nb;
+    const int a = (int)(t % n_nb);
+    nbT[(int64_t)a * n + i] = nb[t];
+}
+
+// one block per output row i (grid-stride); dynamic LDS: chunk u16 entries
+__global__ __launch_bounds__(KNN_TPB) void knn_sums_kernel(const uint8_t *__restrict__ D, int64_t ldd,
+                                                            const int32_t *__restrict__ nb,
+                                                            const int32_t *__restrict__ nbT, int64_t n, int n_nb,
+                                                            int64_t row0, int64_t nrows, uint16_t *__restrict__ T,
+                                                            int64_t ldt, int chunk) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t M[];
+    const int tid = threadIdx.x;
+    for (int64_t lr = blockIdx.x; lr < nrows; lr += gridDim.x) {
+        const int64_t i = row0 + lr;
+        uint16_t *Trow = T + lr * ldt;
+        for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+            const int64_t cend = (c0 + chunk < n) ? c0 + chunk : n;
+            // ---- step 1: M[b - c0] = sum_a D[nb[i][a], b] ----
+            for (int64_t b = c0 + (int64_t)tid * 16; b < cend; b += (int64_t)KNN_TPB * 16) {
+                uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};   // 16-bit fields: bytes 0,2 / 1,3 of each dword
+                if (b + 16 <= n) {
+                    for (int a = 0; a < n_nb; ++a) {
+                        const int64_t r = nb[i * n_nb + a];   // block-uniform -> scalar load
+                        const u32x4 w = *reinterpret_cast<const u32x4 *>(D + r * ldd + b);
+                        lo[0] += w.x & 0x00FF00FFu; hi[0] += (w.x >> 8) & 0x00FF00FFu;
+                        lo[1] += w.y & 0x00FF00FFu; hi[1] += (w.y >> 8) & 0x00FF00FFu;
+                        lo[2] += w.z & 0x00FF00FFu; hi[2] += (w.z >> 8) & 0x00FF00FFu;
+                        lo[3] += w.w & 0x00FF00FFu; hi[3] += (w.w >> 8) & 0x00FF00FFu;
+                    }
+                } else {   // ragged right edge: byte loads
+                    for (int a = 0; a < n_nb; ++a) {
+                        const int64_t r = nb[i * n_nb + a];
+                        for (int c = 0; c < 16 && b + c < n; ++c) {
+                            const uint32_t v = D[r * ldd + b + c];
+                            const int d = c >> 2, f = c & 3;
+                            if (f & 1) hi[d] += v << (8 * (f & 2));
+                            else lo[d] += v << (8 * (f & 2));
+                        }
+                    }
+                }
+                uint32_t o[8];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    o[2 * d] = (lo[d] & 0xFFFFu) | (hi[d] << 16);
+                    o[2 * d + 1] = (lo[d] >> 16) | (hi[d] & 0xFFFF0000u);
+                }
+                u32x4 *dst = reinterpret_cast<u32x4 *>(M + (b - c0));
+                dst[0] = u32x4{o[0], o[1], o[2], o[3]};
+                dst[1] = u32x4{o[4], o[5], o[6], o[7]};
+            }
+            __syncthreads();
+            // ---- step 2: T[i,j] (+)= sum_{b in nb[j] within chunk} M[b - c0] ----
+            for (int64_t j = tid; j < n; j += KNN_TPB) {
+                uint32_t s = 0;
+                for (int a = 0; a < n_nb; ++a) {
+                    const int64_t b = nbT[(int64_t)a * n + j];
+                    if (b >= c0 && b < cend) s += M[b - c0];
+                }
+                if (c0 > 0) s += Trow[j];
+                if (cend == n && j == i) s = 0;   // diagonal forced to 0 (visualization.py:103,107)
+                Trow[j] = (uint16_t)s;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// generic float smoothing in the reference's summation order (taichi_core.py:227-249):
+// thread per (i,j), i<j: 400 gathers ii-outer/jj-inner, /n_nb twice; mirrored; diagonal 0
+__global__ __launch_bounds__(BLK) void knn_smooth_f32_kernel(const float *__restrict__ D, const int32_t *__restrict__ nb,
+                                                             int64_t n, int n_nb, float *__restrict__ S) {
+    const int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    if (t >= n * n) return;
+    const int64_t i = t / n, j = t % n;
+    if (i == j) { S[t] = 0.0f; return; }
+    if (i > j) return;
+    float s = 0.0f;
+    for (int ii = 0; ii < n_nb; ++ii) {
+        const int64_t r = nb[i * n_nb + ii];
+        for (int jj = 0; jj < n_nb; ++jj) s += D[r * n + nb[j * n_nb + jj]];
+    }
+    s = s / (float)n_nb;
+    s = s / (float)n_nb;
+    S[i * n + j] = s;
+    S[j * n + i] = s;
+}
+
+// =================================================================================================
+// per-pair arithmetic shared by all force kernels (IEEE f32, numpy scalar order)
+// =================================================================================================
+struct Pair {
+    float q, t, ce;
+};
+__device__ __forceinline__ float q_of(float dx, float dy) {
+    const float d2 = dx * dx + dy * dy;              // (dx*dx) + (dy*dy), no FMA (taichi_core.py:254)
+    float q = 1.0f / (1.0f + d2);                    // :255
+    q = fminf(q, 0.999f);                            // np.minimum(prob, 1 - 1e-3)   visualization.py:254
+    q = fmaxf(q, 0.001f);                            // np.maximum(prob, 1e-3)       visualization.py:255
+    return q;
+}
+__device__ __forceinline__ float t_of(float p, float q) {
+    return (q / (1.0f - q)) * (p - q);               // visualization.py:132-134
+}
+template <bool EXACT_LOG>
+__device__ __forceinline__ float ce_of(float p, float q) {
+    // taichi_core.py:279-303: eps = 1e-10 branches (q is already clipped to [1e-3, 1-1e-3])
+    const float eps = 1e-10f;
+    const float lq = EXACT_LOG ? logf(q) : __logf(q);
+    const float l1q = EXACT_LOG ? logf(1.0f - q) : __logf(1.0f - q);
+    if (p < eps) return -l1q;
+    if (p > 1.0f - eps) return -lq;
+    return -p * lq - (1.0f - p) * l1q;
+}
+
+// probability source: f32 rows, or u16 sums + LUT (LUT copy in LDS)
+struct ProbSrc {
+    const float *pf;        // [nrows x ld] or null
+    const uint16_t *ps;     // [nrows x ld] or null
+    const float *lut;       // device LUT
+    int64_t ld;
+    int lut_len;
+};
+
+// =================================================================================================
+// FAST forces: a wave owns RPW rows at a time and sweeps the columns
+// =================================================================================================
+constexpr int F_RPW = 4;          // rows per wave
+constexpr int F_WAVES = 4;        // waves per block
+constexpr int F_CPL = 8;          // columns per lane per step (16 B of u16 sums / 32 B of f32)
+constexpr int F_LUT_LDS = 12416;  // floats of LUT cached in LDS (n_nb^2*k+1 <= 400*31+1 = 12401)
+
+template <bool LUTSRC>
+__global__ __launch_bounds__(KMAP_WAVE *F_WAVES) void forces_fast_kernel(ProbSrc src, const float *__restrict__ Y,
+                                                                          int64_t n, int64_t row0, int64_t nrows,
+                                                                          float *__restrict__ G,
+                                                                          double *__restrict__ loss_part) {
+    __shared__ float lut_s[LUTSRC ? F_LUT_LDS : 1];
+    __shared__ double wloss[F_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (LUTSRC) {
+        for (int t = threadIdx.x; t < src.lut_len && t < F_LUT_LDS; t += blockDim.x) lut_s[t] = src.lut[t];
+        __syncthreads();
+    }
+    const float *X = Y, *Yy = Y + n;
+    double wave_loss = 0.0;
+    const int64_t rbase = ((int64_t)blockIdx.x * F_WAVES + wave) * F_RPW;
+    if (rbase < nrows) {
+        float xi[F_RPW], yi[F_RPW], gx[F_RPW], gy[F_RPW];
+        int64_t gi[F_RPW];
+#pragma unroll
+        for (int r = 0; r < F_RPW; ++r) {
+            const int64_t lr = (rbase + r < nrows) ? rbase + r : nrows - 1;   // clamp: duplicates are discarded below
+            gi[r] = row0 + lr;
+            xi[r] = X[gi[r]];
+            yi[r] = Yy[gi[r]];
+            gx[r] = gy[r] = 0.0f;
+        }
+        float ce_acc = 0.0f;
+        for (int64_t j0 = (int64_t)lane * F_CPL; j0 < n; j0 += (int64_t)KMAP_WAVE * F_CPL) {
+            float xj[F_CPL], yj[F_CPL];
+            const bool fullc = (j0 + F_CPL <= n);
+#pragma unroll
+            for (int c = 0; c < F_CPL; ++c) {
+                const int64_t j = fullc ? j0 + c : ((j0 + c < n) ? j0 + c : n - 1);
+                xj[c] = X[j];
+                yj[c] = Yy[j];
+            }
+            float ce_step = 0.0f;
+#pragma unroll
+            for (int r = 0; r < F_RPW; ++r) {
+                const int64_t lr = (rbase + r < nrows) ? rbase + r : nrows - 1;
+                float p[F_CPL];
+                if (LUTSRC) {
+                    const uint16_t *row = src.ps + lr * src.ld + j0;
+                    if (fullc && (src.ld % 8 == 0)) {
+                        const u32x4 w = *reinterpret_cast<const u32x4 *>(row);
+                        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                        for (int c = 0; c < F_CPL; ++c) p[c] = lut_s[(ws[c >> 1] >> (16 * (c & 1))) & 0xFFFFu];
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < F_CPL; ++c) p[c] = (j0 + c < n) ? lut_s[row[c]] : 0.0f;
+                    }
+                } else {
+                    const float *row = src.pf + lr * src.ld + j0;
+#pragma unroll
+                    for (int c = 0; c < F_CPL; ++c) p[c] = (j0 + c < n) ? row[c] : 0.0f;
+                }
+#pragma unroll
+                for (int c = 0; c < F_CPL; ++c) {
+                    const int64_t j = j0 + c;
+                    const float dx = xi[r] - xj[c], dy = yi[r] - yj[c];
+                    const float q = q_of(dx, dy);
+                    const float t = t_of(p[c], q);
+                    const bool live = (j < n) && (j != gi[r]);
+                    gx[r] += live ? t * dx : 0.0f;
+                    gy[r] += live ? t * dy : 0.0f;
+                    const float ce = ce_of<false>(p[c], q);
+                    ce_step += (live && j > gi[r] && (rbase + r < nrows)) ? ce : 0.0f;
+                }
+            }
+            ce_acc += ce_step;
+            if ((j0 / ((int64_t)KMAP_WAVE * F_CPL)) % 16 == 15) {   // flush the f32 partial into f64 regularly
+                wave_loss += (double)ce_acc;
+                ce_acc = 0.0f;
+            }
+        }
+        wave_loss += (double)ce_acc;
+        // wave reduction of the 2*RPW row sums and the loss
+#pragma unroll
+        for (int r = 0; r < F_RPW; ++r) {
+            for (int o = 32; o > 0; o >>= 1) {
+                gx[r] += __shfl_down(gx[r], o);
+                gy[r] += __shfl_down(gy[r], o);
+            }
+            if (lane == 0 && rbase + r < nrows) {
+                G[gi[r]] = gx[r];
+                G[n + gi[r]] = gy[r];
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) wave_loss += __shfl_down(wave_loss, o);
+    }
+    if (lane == 0) wloss[wave] = wave_loss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < F_WAVES; ++w) s += wloss[w];
+        loss_part[blockIdx.x] = s;
+    }
+}
+
+// =================================================================================================
+// SEQ forces: one lane per row, j ascending -- the reference's summation order
+// (taichi_core.py:305-326: ret_val += diff[i,j] * (y[k,i] - y[k,j]), j != i)
+// =================================================================================================
+template <bool LUTSRC>
+__global__ __launch_bounds__(KMAP_WAVE) void forces_seq_kernel(ProbSrc src, const float *__restrict__ Y, int64_t n,
+                                                               int64_t row0, int64_t nrows, float *__restrict__ G,
+                                                               double *__restrict__ loss_part) {
+    __shared__ float lut_s[LUTSRC ? F_LUT_LDS : 1];
+    if (LUTSRC) {
+        for (int t = threadIdx.x; t < src.lut_len && t < F_LUT_LDS; t += blockDim.x) lut_s[t] = src.lut[t];
+        __syncthreads();
+    }
+    const int64_t lr = (int64_t)blockIdx.x * KMAP_WAVE + threadIdx.x;
+    const bool valid = lr < nrows;
+    const int64_t lrc = valid ? lr : nrows - 1;
+    const int64_t i = row0 + lrc;
+    const float *X = Y, *Yy = Y + n;
+    const float xi = X[i], yi = Yy[i];
+    float gx = 0.0f, gy = 0.0f, ce_acc = 0.0f;
+    double loss = 0.0;
+    for (int64_t j = 0; j < n; ++j) {
+        const float xj = X[j], yj = Yy[j];   // wave-uniform address -> scalar loads
+        float p;
+        if (LUTSRC) p = lut_s[src.ps[lrc * src.ld + j]];
+        else p = src.pf[lrc * src.ld + j];
+        const float dx = xi - xj, dy = yi - yj;
+        const float q = q_of(dx, dy);
+        const float t = t_of(p, q);
+        if (j != i) {
+            gx = gx + t * dx;   // product rounded, then added (-ffp-contract=off)
+            gy = gy + t * dy;
+            if (j > i) ce_acc += ce_of<false>(p, q);
+        }
+        if ((j & 127) == 127) {
+            loss += (double)ce_acc;
+            ce_acc = 0.0f;
+        }
+    }
+    loss += (double)ce_acc;
+    if (valid) {
+        G[i] = gx;
+        G[n + i] = gy;
+    } else {
+        loss = 0.0;
+    }
+    for (int o = 32; o > 0; o >>= 1) loss += __shfl_down(loss, o);
+    if (threadIdx.x == 0) loss_part[blockIdx.x] = loss;
+}
+
+// deterministic reduction of the per-block loss partials into loss_out[0]
+__global__ __launch_bounds__(1024) void reduce_loss_kernel(const double *__restrict__ part, int n_part,
+                                                           double *__restrict__ loss_out) {
+    __shared__ double sh[1024];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n_part; i += 1024) s += part[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_out[0] = sh[0];
+}
+
+// =================================================================================================
+// loop state + apply
+// =================================================================================================
+constexpr int MAX_BEST = 64;
+struct LoopState {
+    long long iters;        // reference iterations executed (loss evaluations)
+    int stopped;            // early stop reached (visualization.py:310-311)
+    int jitter_used;        // normals consumed from the pre-drawn stream
+    int n_best;
+    float prev_loss;        // `loss` of the reference loop (inf before the first iteration)
+    float last_loss;
+    float best_loss[MAX_BEST];   // ascending (bisect.insort_right order)
+    int best_slot[MAX_BEST];     // snapshot buffer holding that entry
+};
+
+__global__ __launch_bounds__(BLK) void apply_kernel(LoopState *__restrict__ states, int cur, float *__restrict__ Y,
+                                                    const float *__restrict__ G, const double *__restrict__ loss_sum,
+                                                    float *__restrict__ snaps, int64_t n, float lr,
+                                                    const double *__restrict__ normals, int n_normals,
+                                                    float *__restrict__ loss_log, int64_t loss_log_cap) {
+    const LoopState st = states[cur];   // every block reads the same, already complete state
+    const int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
+    if (st.stopped) {
+        if (leader) states[cur ^ 1] = st;
+        return;
+    }
+    const float loss = (float)(2.0 * loss_sum[0]);   // np.sum(ce) * 2 (visualization.py:176)
+    const int nb = st.n_best;
+    const bool insert = loss < st.best_loss[nb - 1];                    // :303 (false for NaN)
+    const bool stop = fabsf(st.prev_loss - loss) < 1e-7f * fabsf(loss); // :310
+    const int slot = st.best_slot[nb - 1];
+    const bool special = (idx == 0 || idx == 1 || idx == n || idx == n + 1);   // owned by the leader (jitter)
+    if (idx < 2 * n && !special) {
+        const float y = Y[idx];
+        if (insert) snaps[(int64_t)slot * 2 * n + idx] = y;             // snapshot of the iterate that produced `loss`
+        if (!stop) {
+            const float g = 4.0f * G[idx];                              // gradient_loss_taichi returns 4.0 * ret (:145)
+            Y[idx] = y + (-g * lr);                                     // ld_data += (-grad_loss * learning_rate) (:316)
+        }
+    }
+    if (!leader) return;
+    LoopState ns = st;
+    ns.iters = st.iters + 1;
+    ns.last_loss = loss;
+    if (st.iters < loss_log_cap) loss_log[st.iters] = loss;
+    if (insert) {   // best_res_list[:-1] then bisect.insort_right by loss (:304-308)
+        int pos = 0;
+        while (pos < nb - 1 && !(st.best_loss[pos] > loss)) ++pos;
+        for (int t = nb - 1; t > pos; --t) {
+            ns.best_loss[t] = st.best_loss[t - 1];
+            ns.best_slot[t] = st.best_slot[t - 1];
+        }
+        ns.best_loss[pos] = loss;
+        ns.best_slot[pos] = slot;
+    }
+    if (insert)
+        for (int d = 0; d < 2 && d < n; ++d)
+            for (int c = 0; c < 2; ++c) snaps[(int64_t)slot * 2 * n + (int64_t)c * n + d] = Y[(int64_t)c * n + d];
+    if (stop) {
+        ns.stopped = 1;
+    } else {
+        ns.prev_loss = loss;
+        // update + add_jitter for points 0 and 1 (visualization.py:179-196 indexes the 2 x N array as N x 2,
+        // so `ld_data[:, d]` is the (x_d, y_d) pair of point d)
+        for (int d = 0; d < 2 && d < n; ++d) {
+            float v[2];
+            for (int c = 0; c < 2; ++c) {
+                const int64_t id = (int64_t)c * n + d;
+                const float g = 4.0f * G[id];
+                v[c] = Y[id] + (-g * lr);
+            }
+            const int lo_i = (v[1] < v[0]) ? 1 : 0;                     // argsort of two values (stable)
+            const float diff = v[1 - lo_i] - v[lo_i];                   // np.diff of the sorted pair
+            if (diff < 0.1f) {
+                const double nrm = (ns.jitter_used < n_normals) ? normals[ns.jitter_used] : 0.0;
+                ns.jitter_used += 1;
+                v[lo_i] = (float)((double)v[lo_i] + nrm);               // f32 array element += f64 draw
+            }
+            for (int c = 0; c < 2; ++c) Y[(int64_t)c * n + d] = v[c];
+        }
+    }
+    states[cur ^ 1] = ns;
+}
+
+}  // namespace
+
+// =================================================================================================
+// session object
+// =================================================================================================
+struct kmap_embed {
+    int64_t n = 0, row0 = 0, nrows = 0;
+    int n_best = 10, mode = KMAP_EMBED_FAST;
+    float lr = 0.01f;
+    ProbSrc src{};
+    float *lut_dev = nullptr;
+    float *Y = nullptr, *G = nullptr, *snaps = nullptr, *loss_log = nullptr;
+    double *loss_part = nullptr, *loss_sum = nullptr, *normals = nullptr;
+    int n_normals = 0, n_part = 0;
+    int64_t loss_log_cap = 1 << 16;
+    LoopState *states = nullptr;
+    int cur = 0;
+    bool have_prob = false, have_coords = false;
+};
+
+namespace {
+int n_force_blocks(const kmap_embed *e) {
+    if (e->mode == KMAP_EMBED_SEQ) return (int)((e->nrows + KMAP_WAVE - 1) / KMAP_WAVE);
+    return (int)((e->nrows + F_RPW * F_WAVES - 1) / (F_RPW * F_WAVES));
+}
+}  // namespace
+
+extern "C" {
+
+int kmap_knn_sums_u8_dev(const uint8_t *D_dev, int64_t ldd, const int32_t *nb_dev, int64_t n, int n_nb, int64_t row0,
+                         int64_t nrows, uint16_t *sums_dev, int64_t lds, void *stream) {
+    KMAP_REQUIRE(n >= 0 && nrows >= 0 && row0 >= 0 && row0 + nrows <= n, "knn_sums: bad row range");
+    KMAP_REQUIRE(n_nb > 0 && n_nb <= 256, "knn_sums: n_nb=%d out of range", n_nb);
+    KMAP_REQUIRE(ldd >= n && lds >= n, "knn_sums: leading dimension < n");
+    KMAP_REQUIRE(ldd % 16 == 0 && ((uintptr_t)D_dev % 16) == 0, "knn_sums: D must be 16-byte aligned with ldd %% 16 == 0");
+    if (n == 0 || nrows == 0) return KMAP_OK;
+    KMAP_REQUIRE(D_dev && nb_dev && sums_dev, "knn_sums: null pointer");
+    hipStream_t st = as_stream(stream);
+    int32_t *nbT = nullptr;
+    KMAP_TRY(kmap_scratch((void **)&nbT, (size_t)n * n_nb * 4, st, KMAP_SLOT_D));
+    transpose_nb_kernel<<<(unsigned)((n * n_nb + 255) / 256), 256, 0, st>>>(nb_dev, n, n_nb, nbT);
+    int64_t chunk = (n + 15) & ~(int64_t)15;
+    if (chunk > KNN_CHUNK_MAX) chunk = KNN_CHUNK_MAX;
+    const size_t lds_bytes = (size_t)chunk * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)knn_sums_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           KNN_CHUNK_MAX * 2));
+        attr_set = true;
+    }
+    int64_t grid = nrows < 2048 ? nrows : 2048;
+    knn_sums_kernel<<<(unsigned)grid, KNN_TPB, lds_bytes, st>>>(D_dev, ldd, nb_dev, nbT, n, n_nb, row0, nrows, sums_dev,
+                                                                lds, (int)chunk);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+
+int kmap_knn_smooth_f32(const float *D, const int32_t *nb, int64_t n, int n_nb, float *S_out) {
+    KMAP_REQUIRE(n >= 0 && n_nb > 0, "knn_smooth_f32: bad sizes");
+    if (n == 0) return KMAP_OK;
+    KMAP_REQUIRE(D && nb && S_out, "knn_smooth_f32: null pointer");
+    DevBuf dD, dnb, dS;
+    KMAP_TRY(dD.alloc((size_t)n * n * 4));
+    KMAP_TRY(dnb.alloc((size_t)n * n_nb * 4));
+    KMAP_TRY(dS.alloc((size_t)n * n * 4));
+    KMAP_CHECK_HIP(hipMemcpy(dD.p, D, (size_t)n * n * 4, hipMemcpyHostToDevice));
+    KMAP_CHECK_HIP(hipMemcpy(dnb.p, nb, (size_t)n * n_nb * 4, hipMemcpyHostToDevice));
+    knn_smooth_f32_kernel<<<(unsigned)((n * n + BLK - 1) / BLK), BLK>>>(dD.as<float>(), dnb.as<int32_t>(), n, n_nb,
+                                                                         dS.as<float>());
+    KMAP_CHECK_HIP(hipGetLastError());
+    KMAP_CHECK_HIP(hipMemcpy(S_out, dS.p, (size_t)n * n * 4, hipMemcpyDeviceToHost));
+    return KMAP_OK;
+}
+
+// ---- session ---------------------------------------------------------------------------------
+int kmap_embed_create(kmap_embed **out, int64_t n, int64_t row0, int64_t nrows, int n_best, float learning_rate,
+                      int mode) {
+    KMAP_REQUIRE(out, "embed_create: null");
+    KMAP_REQUIRE(n > 0 && row0 >= 0 && nrows >= 0 && row0 + nrows <= n, "embed_create: bad row range");
+    KMAP_REQUIRE(n_best > 0 && n_best <= MAX_BEST, "embed_create: n_best must be in [1,%d]", MAX_BEST);
+    KMAP_REQUIRE(mode == KMAP_EMBED_FAST || mode == KMAP_EMBED_SEQ, "embed_create: unknown mode %d", mode);
+    kmap_embed *e = new kmap_embed();
+    e->n = n; e->row0 = row0; e->nrows = nrows; e->n_best = n_best; e->lr = learning_rate; e->mode = mode;
+    e->n_part = n_force_blocks(e) > 0 ? n_force_blocks(e) : 1;
+    hipError_t err = hipSuccess;
+    auto A = [&](void **p, size_t b) { if (err == hipSuccess) err = hipMalloc(p, b ? b : 16); };
+    A((void **)&e->Y, (size_t)2 * n * 4);
+    A((void **)&e->G, (size_t)2 * n * 4);
+    A((void **)&e->snaps, (size_t)n_best * 2 * n * 4);
+    A((void **)&e->loss_log, (size_t)e->loss_log_cap * 4);
+    A((void **)&e->loss_part, (size_t)e->n_part * 8);
+    A((void **)&e->loss_sum, 8);
+    A((void **)&e->states, 2 * sizeof(LoopState));
+    A((void **)&e->lut_dev, F_LUT_LDS * 4);
+    if (err != hipSuccess) {
+        kmap_set_error("embed_create: %s", hipGetErrorString(err));
+        kmap_embed_destroy(e);
+        return KMAP_E_NOMEM;
+    }
+    LoopState s0;
+    memset(&s0, 0, sizeof s0);
+    s0.n_best = n_best;
+    s0.prev_loss = INFINITY;
+    s0.last_loss = INFINITY;
+    for (int b = 0; b < MAX_BEST; ++b) {
+        s0.best_loss[b] = INFINITY;
+        s0.best_slot[b] = b;
+    }
+    KMAP_CHECK_HIP(hipMemcpy(&e->states[0], &s0, sizeof s0, hipMemcpyHostToDevice));
+    KMAP_CHECK_HIP(hipMemcpy(&e->states[1], &s0, sizeof s0, hipMemcpyHostToDevice));
+    KMAP_CHECK_HIP(hipMemset(e->G, 0, (size_t)2 * n * 4));
+    *out = e;
+    return KMAP_OK;
+}
+
+int kmap_embed_destroy(kmap_embed *e) {
+    if (!e) return KMAP_OK;
+    void *ptrs[] = {e->Y, e->G, e->snaps, e->loss_log, e->loss_part, e->loss_sum, e->states, e->lut_dev, e->normals};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete e;
+    return KMAP_OK;
+}
+
+int kmap_embed_set_prob_f32(kmap_embed *e, const float *p_rows_dev, int64_t ld) {
+    KMAP_REQUIRE(e && p_rows_dev && ld >= e->n, "embed_set_prob_f32: bad arguments");
+    e->src = ProbSrc{p_rows_dev, nullptr, nullptr, ld, 0};
+    e->have_prob = true;
+    return KMAP_OK;
+}
+
+int kmap_embed_set_prob_lut(kmap_embed *e, const uint16_t *sums_rows_dev, int64_t ld, const float *lut, int lut_len) {
+    KMAP_REQUIRE(e && sums_rows_dev && lut && ld >= e->n, "embed_set_prob_lut: bad arguments");
+    KMAP_REQUIRE(lut_len > 0 && lut_len <= F_LUT_LDS, "embed_set_prob_lut: lut_len=%d exceeds %d", lut_len, F_LUT_LDS);
+    KMAP_CHECK_HIP(hipMemcpy(e->lut_dev, lut, (size_t)lut_len * 4, hipMemcpyHostToDevice));
+    e->src = ProbSrc{nullptr, sums_rows_dev, e->lut_dev, ld, lut_len};
+    e->have_prob = true;
+    return KMAP_OK;
+}
+
+int kmap_embed_set_coords(kmap_embed *e, const float *coords_2xn, const float *placeholders) {
+    KMAP_REQUIRE(e && coords_2xn, "embed_set_coords: null");
+    KMAP_CHECK_HIP(hipMemcpy(e->Y, coords_2xn, (size_t)2 * e->n * 4, hipMemcpyHostToDevice));
+    if (placeholders)
+        KMAP_CHECK_HIP(hipMemcpy(e->snaps, placeholders, (size_t)e->n_best * 2 * e->n * 4, hipMemcpyHostToDevice));
+    else
+        KMAP_CHECK_HIP(hipMemset(e->snaps, 0, (size_t)e->n_best * 2 * e->n * 4));
+    e->have_coords = true;
+    return KMAP_OK;
+}
+
+int kmap_embed_set_jitter(kmap_embed *e, const double *normals, int n_normals) {
+    KMAP_REQUIRE(e && n_normals >= 0 && (n_normals == 0 || normals), "embed_set_jitter: bad arguments");
+    KMAP_CHECK_HIP(hipDeviceSynchronize());
+    if (e->normals) KMAP_CHECK_HIP(hipFree(e->normals));
+    e->normals = nullptr;
+    e->n_normals = 0;
+    if (n_normals) {
+        KMAP_CHECK_HIP(hipMalloc((void **)&e->normals, (size_t)n_normals * 8));
+        KMAP_CHECK_HIP(hipMemcpy(e->normals, normals, (size_t)n_normals * 8, hipMemcpyHostToDevice));
+        e->n_normals = n_normals;
+    }
+    return KMAP_OK;
+}
+
+int kmap_embed_forces(kmap_embed *e, float *grad_dev_2xn, double *loss_dev, void *stream) {
+    KMAP_REQUIRE(e && e->have_prob && e->have_coords, "embed_forces: probabilities/coordinates not set");
+    hipStream_t st = as_stream(stream);
+    float *G = grad_dev_2xn ? grad_dev_2xn : e->G;
+    double *L = loss_dev ? loss_dev : e->loss_sum;
+    const int nblk = n_force_blocks(e);
+    if (nblk == 0) {
+        KMAP_CHECK_HIP(hipMemsetAsync(L, 0, 8, st));
+        return KMAP_OK;
+    }
+    const bool lut = e->src.ps != nullptr;
+    if (e->mode == KMAP_EMBED_SEQ) {
+        if (lut) forces_seq_kernel<true><<<nblk, KMAP_WAVE, 0, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
+        else forces_seq_kernel<false><<<nblk, KMAP_WAVE, 0, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
+    } else {
+        if (lut) forces_fast_kernel<true><<<nblk, KMAP_WAVE * F_WAVES, 0, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
+        else forces_fast_kernel<false><<<nblk, KMAP_WAVE * F_WAVES, 0, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
+    }
+    reduce_loss_kernel<<<1, 1024, 0, st>>>(e->loss_part, nblk, L);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+
+int kmap_embed_apply(kmap_embed *e, const float *grad_dev_2xn, const double *loss_dev, void *stream) {
+    KMAP_REQUIRE(e && e->have_coords, "embed_apply: coordinates not set");
+    hipStream_t st = as_stream(stream);
+    const float *G = grad_dev_2xn ? grad_dev_2xn : e->G;
+    const double *L = loss_dev ? loss_dev : e->loss_sum;
+    const unsigned grid = (unsigned)((2 * e->n + BLK - 1) / BLK);
+    apply_kernel<<<grid, BLK, 0, st>>>(e->states, e->cur, e->Y, G, L, e->snaps, e->n, e->lr, e->normals, e->n_normals,
+                                       e->loss_log, e->loss_log_cap);
+    KMAP_CHECK_HIP(hipGetLastError());
+    e->cur ^= 1;
+    return KMAP_OK;
+}
+
+int kmap_embed_step(kmap_embed *e, int n_iter, void *stream) {
+    KMAP_REQUIRE(e && e->row0 == 0 && e->nrows == e->n, "embed_step: single-GPU convenience needs all rows local");
+    for (int it = 0; it < n_iter; ++it) {
+        KMAP_TRY(kmap_embed_forces(e, nullptr, nullptr, stream));
+        KMAP_TRY(kmap_embed_apply(e, nullptr, nullptr, stream));
+    }
+    return KMAP_OK;
+}
+
+int kmap_embed_state(kmap_embed *e, int64_t *iters, int *stopped, float *last_loss, float *best_loss, int *jitter_used,
+                     void *stream) {
+    KMAP_REQUIRE(e, "embed_state: null");
+    KMAP_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+    LoopState s;
+    KMAP_CHECK_HIP(hipMemcpy(&s, &e->states[e->cur], sizeof s, hipMemcpyDeviceToHost));
+    if (iters) *iters = s.iters;
+    if (stopped) *stopped = s.stopped;
+    if (last_loss) *last_loss = s.last_loss;
+    if (best_loss) *best_loss = s.best_loss[0];
+    if (jitter_used) *jitter_used = s.jitter_used;
+    return KMAP_OK;
+}
+
+int kmap_embed_get_coords(kmap_embed *e, float *coords_2xn, void *stream) {
+    KMAP_REQUIRE(e && coords_2xn, "embed_get_coords: null");
+    KMAP_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+    KMAP_CHECK_HIP(hipMemcpy(coords_2xn, e->Y, (size_t)2 * e->n * 4, hipMemcpyDeviceToHost));
+    return KMAP_OK;
+}
+
+int kmap_embed_get_best(kmap_embed *e, float *coords_2xn, void *stream) {
+    KMAP_REQUIRE(e && coords_2xn, "embed_get_best: null");
+    KMAP_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+    LoopState s;
+    KMAP_CHECK_HIP(hipMemcpy(&s, &e->states[e->cur], sizeof s, hipMemcpyDeviceToHost));
+    KMAP_CHECK_HIP(hipMemcpy(coords_2xn, e->snaps + (size_t)s.best_slot[0] * 2 * e->n, (size_t)2 * e->n * 4,
+                             hipMemcpyDeviceToHost));   // best_res_list[0][1] (visualization.py:325)
+    return KMAP_OK;
+}
+
+int kmap_embed_get_losses(kmap_embed *e, float *losses, int64_t max_n, int64_t *n_out, void *stream) {
+    KMAP_REQUIRE(e && n_out, "embed_get_losses: null");
+    KMAP_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+    LoopState s;
+    KMAP_CHECK_HIP(hipMemcpy(&s, &e->states[e->cur], sizeof s, hipMemcpyDeviceToHost));
+    int64_t m = s.iters < e->loss_log_cap ? s.iters : e->loss_log_cap;
+    if (m > max_n) m = max_n;
+    if (m > 0 && losses) KMAP_CHECK_HIP(hipMemcpy(losses, e->loss_log, (size_t)m * 4, hipMemcpyDeviceToHost));
+    *n_out = m;
+    return KMAP_OK;
+}
+
+void *kmap_embed_coords_dev(kmap_embed *e) { return e ? (void *)e->Y : nullptr; }
+
+// ---- drop-in L3 float operators (host pointers, blocking) -----------------------------------------
+}  // extern "C"
+
+namespace {
+__global__ __launch_bounds__(BLK) void ld_prob_kernel(const float *__restrict__ Y, int64_t n, float *__restrict__ Q) {
+    const int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    if (t >= n * n) return;
+    const int64_t i = t / n, j = t % n;
+    // np.ones then the kernel fills i != j; clip applies to the diagonal's 1.0 too (visualization.py:251-255)
+    Q[t] = (i == j) ? 0.999f : q_of(Y[i] - Y[j], Y[n + i] - Y[n + j]);
+}
+__global__ __launch_bounds__(BLK) void ce_rows_kernel(const float *__restrict__ P, const float *__restrict__ Q, int64_t n,
+                                                      double *__restrict__ part) {
+    __shared__ double sh[BLK];
+    double s = 0.0;
+    const int64_t i = blockIdx.x;
+    for (int64_t j = i + 1 + threadIdx.x; j < n; j += BLK) {
+        float q = Q[i * n + j];
+        const float eps = 1e-10f;
+        q = (q < eps) ? eps : ((q > 1.0f - eps) ? 1.0f - eps : q);   // taichi_core.py:283-288
+        s += (double)ce_of<true>(P[i * n + j], q);
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = BLK / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[i] = sh[0];
+}
+__global__ __launch_bounds__(KMAP_WAVE) void grad_rows_kernel(const float *__restrict__ P, const float *__restrict__ Q,
+                                                              const float *__restrict__ Y, int64_t n,
+                                                              float *__restrict__ G) {
+    const int64_t i = (int64_t)blockIdx.x * KMAP_WAVE + threadIdx.x;
+    if (i >= n) return;
+    const float xi = Y[i], yi = Y[n + i];
+    float gx = 0.0f, gy = 0.0f;
+    for (int64_t j = 0; j < n; ++j) {
+        if (j == i) continue;
+        const float t = t_of(P[i * n + j], Q[i * n + j]);
+        gx = gx + t * (xi - Y[j]);
+        gy = gy + t * (yi - Y[n + j]);
+    }
+    G[i] = 4.0f * gx;
+    G[n + i] = 4.0f * gy;
+}
+}  // namespace
+
+extern "C" {
+
+int kmap_ld_prob_mat_f32(const float *ld_2xn, int64_t n, float *q_out_nxn) {
+    KMAP_REQUIRE(n >= 0, "ld_prob_mat: n<0");
+    if (n == 0) return KMAP_OK;
+    KMAP_REQUIRE(ld_2xn && q_out_nxn, "ld_prob_mat: null pointer");
+    DevBuf dy, dq;
+    KMAP_TRY(dy.alloc((size_t)2 * n * 4));
+    KMAP_TRY(dq.alloc((size_t)n * n * 4));
+    KMAP_CHECK_HIP(hipMemcpy(dy.p, ld_2xn, (size_t)2 * n * 4, hipMemcpyHostToDevice));
+    ld_prob_kernel<<<(unsigned)((n * n + BLK - 1) / BLK), BLK>>>(dy.as<float>(), n, dq.as<float>());
+    KMAP_CHECK_HIP(hipGetLastError());
+    KMAP_CHECK_HIP(hipMemcpy(q_out_nxn, dq.p, (size_t)n * n * 4, hipMemcpyDeviceToHost));
+    return KMAP_OK;
+}
+
+int kmap_cross_entropy_f32(const float *p_nxn, const float *q_nxn, int64_t n, float *loss_out) {
+    KMAP_REQUIRE(n >= 0 && loss_out, "cross_entropy: bad arguments");
+    *loss_out = 0.0f;
+    if (n == 0) return KMAP_OK;
+    KMAP_REQUIRE(p_nxn && q_nxn, "cross_entropy: null pointer");
+    DevBuf dp, dq, dpart, dsum;
+    KMAP_TRY(dp.alloc((size_t)n * n * 4));
+    KMAP_TRY(dq.alloc((size_t)n * n * 4));
+    KMAP_TRY(dpart.alloc((size_t)n * 8));
+    KMAP_TRY(dsum.alloc(8));
+    KMAP_CHECK_HIP(hipMemcpy(dp.p, p_nxn, (size_t)n * n * 4, hipMemcpyHostToDevice));
+    KMAP_CHECK_HIP(hipMemcpy(dq.p, q_nxn, (size_t)n * n * 4, hipMemcpyHostToDevice));
+    ce_rows_kernel<<<(unsigned)n, BLK>>>(dp.as<float>(), dq.as<float>(), n, dpart.as<double>());
+    reduce_loss_kernel<<<1, 1024>>>(dpart.as<double>(), (int)n, dsum.as<double>());
+    KMAP_CHECK_HIP(hipGetLastError());
+    double s = 0.0;
+    KMAP_CHECK_HIP(hipMemcpy(&s, dsum.p, 8, hipMemcpyDeviceToHost));
+    *loss_out = (float)(2.0 * s);
+    return KMAP_OK;
+}
+
+int kmap_gradient_loss_f32(const float *p_nxn, const float *q_nxn, const float *ld_2xn, int64_t n, float *grad_out_2xn) {
+    KMAP_REQUIRE(n >= 0, "gradient_loss: n<0");
+    if (n == 0) return KMAP_OK;
+    KMAP_REQUIRE(p_nxn && q_nxn && ld_2xn && grad_out_2xn, "gradient_loss: null pointer");
+    DevBuf dp, dq, dy, dg;
+    KMAP_TRY(dp.alloc((size_t)n * n * 4));
+    KMAP_TRY(dq.alloc((size_t)n * n * 4));
+    KMAP_TRY(dy.alloc((size_t)2 * n * 4));
+    KMAP_TRY(dg.alloc((size_t)2 * n * 4));
+    KMAP_CHECK_HIP(hipMemcpy(dp.p, p_nxn, (size_t)n * n * 4, hipMemcpyHostToDevice));
+    KMAP_CHECK_HIP(hipMemcpy(dq.p, q_nxn, (size_t)n * n * 4, hipMemcpyHostToDevice));
+    KMAP_CHECK_HIP(hipMemcpy(dy.p, ld_2xn, (size_t)2 * n * 4, hipMemcpyHostToDevice));
+    grad_rows_kernel<<<(unsigned)((n + KMAP_WAVE - 1) / KMAP_WAVE), KMAP_WAVE>>>(dp.as<float>(), dq.as<float>(),
+                                                                                 dy.as<float>(), n, dg.as<float>());
+    KMAP_CHECK_HIP(hipGetLastError());
+    KMAP_CHECK_HIP(hipMemcpy(grad_out_2xn, dg.p, (size_t)2 * n * 4, hipMemcpyDeviceToHost));
+    return KMAP_OK;
+}
+
+}  // extern "C"

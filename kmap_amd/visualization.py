@@ -1,0 +1,399 @@
+"""Host side of the embedding path: the reference's visualization.py interface
+(/root/reference/src/kmap/visualization.py) over the HIP C ABI.
+
+`kmap()` / `umap()` / `knn_smooth()` keep the reference's names, arguments and RNG protocol
+(np.random.seed, init draw, n_best placeholder draws, jitter draws in stream order); the
+arithmetic runs in kmap_amd/csrc/embed.hip with all state resident in HBM.  No CPU fallback.
+"""
+import ctypes as C
+import pickle
+from pathlib import Path
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, ptr
+from .hamdist import hamdist_matrix_dev, pitch_for
+from .kmer_count import FileNameDict, get_hash_dtype
+
+EMBED_FAST, EMBED_SEQ = 0, 1
+
+
+def default_mode():
+    """SEQ (the reference's f32 summation order; reproduces its trajectories) unless KMAP_EMBED_MODE=fast.
+    FAST sums each row wavefront-parallel: same per-pair values, different rounding of the row sums, and the
+    gradient-descent dynamics amplify that difference over hundreds of iterations (measured: 1e-3 relative
+    on the loss after 200 iterations at N=96) -- statistically equivalent embeddings, not the same digits."""
+    import os
+    return EMBED_FAST if os.environ.get("KMAP_EMBED_MODE", "seq").lower() == "fast" else EMBED_SEQ
+
+
+_LUT_CAP = 12416          # floats of LUT the force kernels cache in LDS (embed.hip F_LUT_LDS)
+_JITTER_CHUNK = 4096      # normals pre-drawn per refill
+_SEGMENT = 256            # iterations between host polls of the device loop state
+
+
+# ---- smoothing ------------------------------------------------------------------------------------
+def _pad_cols(a, ld):
+    if a.shape[1] == ld and a.flags.c_contiguous:
+        return a
+    out = np.zeros((a.shape[0], ld), a.dtype)
+    out[:, :a.shape[1]] = a
+    return out
+
+
+def _is_small_int_matrix(m):
+    return np.issubdtype(m.dtype, np.integer) and m.size > 0 and m.min() >= 0 and m.max() <= 255
+
+
+def knn_sums_dev(D_dev_ptr, ldd, nb, n, n_nb, row0=0, nrows=None, stream=None):
+    """Device: integer neighbour sums of rows [row0,row0+nrows) -> DeviceBuffer of uint16 [nrows x lds]."""
+    nrows = n - row0 if nrows is None else nrows
+    lds = (n + 127) & ~127
+    nb_d = _ffi.DeviceBuffer.from_numpy(np.ascontiguousarray(nb, np.int32))
+    sums_d = _ffi.DeviceBuffer(max(nrows, 1) * lds * 2)
+    check(_ffi.lib().kmap_knn_sums_u8_dev(D_dev_ptr, ldd, nb_d.ptr, n, n_nb, row0, nrows, sums_d.ptr, lds, stream))
+    _ffi.sync(stream)
+    nb_d.free()
+    return sums_d, lds
+
+
+def knn_smooth(dist_mat: np.ndarray, n_neighbour: int, neighbor_inds_mat=None) -> np.ndarray:
+    """Smoothed distance matrix, float32 (reference visualization.py:90-109).
+    neighbor_inds_mat: optional (N, n_neighbour) indices to use instead of np.argpartition's choice
+    (its tie order depends on numpy version / CPU ISA; tests inject the reference's matrix)."""
+    n = len(dist_mat)
+    if neighbor_inds_mat is None:
+        neighbor_inds_mat = np.argpartition(dist_mat, n_neighbour, axis=1)[:, :n_neighbour]
+    nb = np.ascontiguousarray(neighbor_inds_mat, np.int32)
+    if _is_small_int_matrix(dist_mat):
+        ldd = pitch_for(n)
+        D_d = _ffi.DeviceBuffer.from_numpy(_pad_cols(np.ascontiguousarray(dist_mat, np.uint8), ldd))
+        sums_d, lds = knn_sums_dev(D_d.ptr, ldd, nb, n, n_neighbour)
+        sums = sums_d.to_numpy(np.uint16, (n, lds))[:, :n]
+        D_d.free()
+        sums_d.free()
+        # exact integer sums -> f32, then the two f32 divisions of the kernel (taichi_core.py:236)
+        return (sums.astype(np.float32) / np.float32(n_neighbour)) / np.float32(n_neighbour)
+    D = np.ascontiguousarray(dist_mat, np.float32)
+    S = np.empty((n, n), np.float32)
+    check(_ffi.lib().kmap_knn_smooth_f32(ptr(D), ptr(nb), n, n_neighbour, ptr(S)))
+    return S
+
+
+def sigmoid(dist_mat, max_val=16.0, change_point=10.0, scale_factor=3.0):
+    """reference visualization.py:199-212 (numpy expression, evaluated on the host)."""
+    assert max_val > change_point > 0
+    assert scale_factor > 0
+    return max_val / (1 + np.exp(-scale_factor * (dist_mat - change_point)))
+
+
+def hd_prob_lut(kmer_len, n_neighbour, max_sum):
+    """p for every possible integer neighbour sum s: exp(-sigmoid(f32(s)/n_nb/n_nb)/0.5) as float32,
+    evaluated by numpy with the reference's own expression chain (visualization.py:262,289)."""
+    s = np.arange(max_sum + 1, dtype=np.float32)
+    S = (s / np.float32(n_neighbour)) / np.float32(n_neighbour)
+    T = sigmoid(S, 16.0, change_point=kmer_len / 2, scale_factor=0.2 * kmer_len - 0.2)
+    return np.exp(-T / 0.5).astype("float32")
+
+
+# ---- L3 operators ------------------------------------------------------------------------------------
+def cal_ld_prob_mat_taichi(ld_data: np.ndarray, iter_mat=None):
+    """q matrix incl. the [1e-3, 1-1e-3] clip (reference visualization.py:235-256)."""
+    assert ld_data.shape[0] == 2 and ld_data.dtype == np.float32
+    n = ld_data.shape[1]
+    q = np.empty((n, n), np.float32)
+    check(_ffi.lib().kmap_ld_prob_mat_f32(ptr(np.ascontiguousarray(ld_data)), n, ptr(q)))
+    return q
+
+
+def cross_entropy_taichi(hd_prob_mat, ld_prob_mat, iter_mat=None):
+    """2 * sum_{i<j} CE (reference visualization.py:162-176); float64 accumulation on device."""
+    assert hd_prob_mat.dtype == np.float32 and ld_prob_mat.dtype == np.float32
+    out = C.c_float(0)
+    check(_ffi.lib().kmap_cross_entropy_f32(ptr(np.ascontiguousarray(hd_prob_mat)), ptr(np.ascontiguousarray(ld_prob_mat)),
+                                            len(hd_prob_mat), C.byref(out)))
+    return np.float32(out.value)
+
+
+def gradient_loss_taichi(hd_prob_mat, ld_prob_mat, ld_data, debug=False):
+    """4 * row sums of q/(1-q)*(p-q)*(y_i-y_j), sequential f32 (reference visualization.py:131-145)."""
+    assert ld_data.dtype == np.float32 and len(ld_data) == 2
+    n = len(hd_prob_mat)
+    g = np.empty((2, n), np.float32)
+    check(_ffi.lib().kmap_gradient_loss_f32(ptr(np.ascontiguousarray(hd_prob_mat, np.float32)),
+                                            ptr(np.ascontiguousarray(ld_prob_mat, np.float32)),
+                                            ptr(np.ascontiguousarray(ld_data)), n, ptr(g)))
+    return g
+
+
+# ---- device-resident loop ------------------------------------------------------------------------------
+class EmbedSession:
+    """Owns a kmap_embed handle (coordinates, probabilities, snapshots and loop state in HBM)."""
+
+    def __init__(self, n, n_best=10, learning_rate=0.01, mode=EMBED_FAST, row0=0, nrows=None):
+        h = _ffi.vp()
+        nrows = n - row0 if nrows is None else nrows
+        check(_ffi.lib().kmap_embed_create(C.byref(h), n, row0, nrows, n_best, learning_rate, mode))
+        self._h, self.n, self.n_best = h.value, n, n_best
+        self._keep = []
+
+    def set_prob_f32(self, p_dev, ld):
+        self._keep.append(p_dev)
+        check(_ffi.lib().kmap_embed_set_prob_f32(self._h, p_dev.ptr, ld))
+
+    def set_prob_lut(self, sums_dev, ld, lut):
+        self._keep.append(sums_dev)
+        lut = np.ascontiguousarray(lut, np.float32)
+        check(_ffi.lib().kmap_embed_set_prob_lut(self._h, sums_dev.ptr, ld, ptr(lut), len(lut)))
+
+    def set_coords(self, coords, placeholders=None):
+        coords = np.ascontiguousarray(coords, np.float32)
+        ph = None if placeholders is None else np.ascontiguousarray(placeholders, np.float32)
+        check(_ffi.lib().kmap_embed_set_coords(self._h, ptr(coords), ptr(ph)))
+
+    def set_jitter(self, normals):
+        normals = np.ascontiguousarray(normals, np.float64)
+        check(_ffi.lib().kmap_embed_set_jitter(self._h, ptr(normals), len(normals)))
+
+    def step(self, n_iter, stream=None):
+        check(_ffi.lib().kmap_embed_step(self._h, n_iter, stream))
+
+    def forces(self, grad_ptr=None, loss_ptr=None, stream=None):
+        check(_ffi.lib().kmap_embed_forces(self._h, grad_ptr, loss_ptr, stream))
+
+    def apply(self, grad_ptr=None, loss_ptr=None, stream=None):
+        check(_ffi.lib().kmap_embed_apply(self._h, grad_ptr, loss_ptr, stream))
+
+    def state(self, stream=None):
+        it, st, ll, bl, ju = _ffi.i64(0), _ffi.i32(0), _ffi.f32(0), _ffi.f32(0), _ffi.i32(0)
+        check(_ffi.lib().kmap_embed_state(self._h, C.byref(it), C.byref(st), C.byref(ll), C.byref(bl), C.byref(ju), stream))
+        return {"iters": it.value, "stopped": bool(st.value), "last_loss": ll.value, "best_loss": bl.value,
+                "jitter_used": ju.value}
+
+    def coords(self, stream=None):
+        out = np.empty((2, self.n), np.float32)
+        check(_ffi.lib().kmap_embed_get_coords(self._h, ptr(out), stream))
+        return out
+
+    def best(self, stream=None):
+        out = np.empty((2, self.n), np.float32)
+        check(_ffi.lib().kmap_embed_get_best(self._h, ptr(out), stream))
+        return out
+
+    def losses(self, max_n=1 << 16, stream=None):
+        out = np.empty(max_n, np.float32)
+        m = _ffi.i64(0)
+        check(_ffi.lib().kmap_embed_get_losses(self._h, ptr(out), max_n, C.byref(m), stream))
+        return out[:m.value].copy()
+
+    def coords_dev_ptr(self):
+        return _ffi.lib().kmap_embed_coords_dev(self._h)
+
+    def close(self):
+        if self._h:
+            _ffi.lib().kmap_embed_destroy(self._h)
+            self._h = None
+        for b in self._keep:
+            b.free()
+        self._keep = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _init_draws(n_data, n_best_result, random_seed):
+    """RNG protocol of the reference's umap (visualization.py:281,292-293)."""
+    np.random.seed(random_seed)
+    ld_data = np.random.randn(2, n_data).astype("float32")
+    placeholders = np.stack([np.random.randn(2, n_data).astype("float32") for _ in range(n_best_result)]) \
+        if n_best_result > 0 else np.zeros((0, 2, n_data), np.float32)
+    return ld_data, placeholders
+
+
+def _run_loop(sess, n_max_iter, step_fn=None, debug=False, trace=None):
+    """Drive the device loop in segments; jitter normals are pre-drawn from numpy's global stream in
+    order, and the stream is left exactly where the reference would leave it (one draw per jitter hit)."""
+    rng_state = np.random.get_state()
+    pool = np.zeros(0, np.float64)
+    info = sess.state()
+    while info["iters"] < n_max_iter and not info["stopped"]:
+        seg = min(_SEGMENT, n_max_iter - info["iters"])
+        if len(pool) - info["jitter_used"] < 2 * seg:
+            pool = np.concatenate([pool, np.random.normal(0, 0.01, _JITTER_CHUNK)])
+            sess.set_jitter(pool)
+        if step_fn is None:
+            sess.step(seg)
+        else:
+            step_fn(seg)
+        info = sess.state()
+        if debug:
+            print(f"i_iter= {info['iters']} loss= {info['last_loss']}")
+    np.random.set_state(rng_state)
+    if info["jitter_used"]:
+        np.random.normal(0, 0.01, info["jitter_used"])
+    if trace is not None:
+        trace["losses"] = sess.losses()
+        trace["state"] = info
+        trace["last_coords"] = sess.coords()
+    return info
+
+
+def umap(hd_dist_mat: np.ndarray, n_max_iter=2500, learning_rate=0.01, n_best_result=10, random_seed=None, debug=True,
+         mode=None, trace=None) -> np.ndarray:
+    """Drop-in for the reference's umap (visualization.py:270-326): transformed distance matrix in,
+    lowest-loss 2 x N embedding out.  mode=EMBED_SEQ reproduces the reference's f32 summation order."""
+    n = len(hd_dist_mat)
+    mode = default_mode() if mode is None else mode
+    ld_data, placeholders = _init_draws(n, n_best_result, random_seed)
+    hd_prob_mat = np.exp(-hd_dist_mat / 0.5).astype("float32")          # sigma0 = 0.5 (:284,289)
+    if n_max_iter <= 0 or n == 0:
+        return placeholders[0] if len(placeholders) else ld_data
+    ld = (n + 63) & ~63
+    p_dev = _ffi.DeviceBuffer.from_numpy(_pad_cols(hd_prob_mat, ld))
+    sess = EmbedSession(n, n_best_result, learning_rate, mode)
+    try:
+        sess.set_prob_f32(p_dev, ld)
+        sess.set_coords(ld_data, placeholders)
+        _run_loop(sess, n_max_iter, debug=debug, trace=trace)
+        return sess.best()
+    finally:
+        sess.close()
+
+
+def kmap(hamdist_mat: np.ndarray, kmer_len: int, n_neighbour=20, n_max_iter=2500, learning_rate=0.01, n_best_result=10,
+         random_seed=None, debug=True, mode=None, neighbor_inds_mat=None, trace=None) -> np.ndarray:
+    """Drop-in for the reference's kmap (visualization.py:259-267).  Integer distance matrices (the
+    Hamming matrices scan_motif writes) stay on the device end to end: uint8 D -> uint16 neighbour sums
+    -> LUT probabilities -> embedding loop; other matrices go through the float operators."""
+    n = len(hamdist_mat)
+    mode = default_mode() if mode is None else mode
+    if _is_small_int_matrix(hamdist_mat) and n_neighbour * n_neighbour * int(hamdist_mat.max()) + 1 <= _LUT_CAP \
+            and n_max_iter > 0:
+        if neighbor_inds_mat is None:
+            neighbor_inds_mat = np.argpartition(hamdist_mat, n_neighbour, axis=1)[:, :n_neighbour]   # :100
+        ldd = pitch_for(n)
+        D_d = _ffi.DeviceBuffer.from_numpy(_pad_cols(np.ascontiguousarray(hamdist_mat, np.uint8), ldd))
+        sums_d, lds = knn_sums_dev(D_d.ptr, ldd, neighbor_inds_mat, n, n_neighbour)
+        D_d.free()
+        print("distance smoothing finished.")
+        lut = hd_prob_lut(kmer_len, n_neighbour, n_neighbour * n_neighbour * int(hamdist_mat.max()))
+        ld_data, placeholders = _init_draws(n, n_best_result, random_seed)
+        sess = EmbedSession(n, n_best_result, learning_rate, mode)
+        try:
+            sess.set_prob_lut(sums_d, lds, lut)
+            sess.set_coords(ld_data, placeholders)
+            _run_loop(sess, n_max_iter, debug=debug, trace=trace)
+            out = sess.best()
+        finally:
+            sess.close()
+        print("optimization finished.")
+        return out
+    trans = knn_smooth(hamdist_mat, n_neighbour, neighbor_inds_mat)
+    trans = sigmoid(trans, 16.0, change_point=kmer_len / 2, scale_factor=0.2 * kmer_len - 0.2)
+    print("distance smoothing finished.")
+    out = umap(trans, n_max_iter=n_max_iter, learning_rate=learning_rate, n_best_result=n_best_result,
+               random_seed=random_seed, debug=debug, mode=mode, trace=trace)
+    print("optimization finished.")
+    return out
+
+
+def device_knn_indices_note():
+    return ("neighbour selection uses numpy.argpartition on the host for drop-in fidelity; its tie order is "
+            "numpy/ISA specific (SURVEY.md hard part 1)")
+
+
+def kmap_from_kmers(samp_kh, samp_cnts, samp_label, conseq_list, kmer_len, n_neighbour=20, n_max_iter=2500,
+                    learning_rate=0.01, n_best_result=10, random_seed=None, debug=False, mode=None,
+                    neighbor_inds_mat=None, trace=None):
+    """Hot path used by visualize_kmers when sample_kmers.pkl is available: the Hamming matrix is computed
+    on the device from the sampled hashes (never materialised as int64 on the host)."""
+    mode = default_mode() if mode is None else mode
+    kh = np.repeat(np.asarray(samp_kh), samp_cnts).astype(get_hash_dtype(kmer_len))
+    lab = np.repeat(np.asarray(samp_label), samp_cnts).astype(np.int32)
+    n = len(kh)
+    lens = [len(c) for c in conseq_list]
+    ldd = pitch_for(n)
+    kh_d, lab_d = _ffi.DeviceBuffer.from_numpy(kh), _ffi.DeviceBuffer.from_numpy(lab)
+    D_d = _ffi.DeviceBuffer(n * ldd)
+    hamdist_matrix_dev(kh_d.ptr, lab_d.ptr, n, kmer_len, lens, D_d.ptr, ldd)
+    if neighbor_inds_mat is None:
+        # drop-in neighbour choice: numpy argpartition on int64 rows, streamed back in row blocks
+        nbs = []
+        blk = max(1, min(n, (64 << 20) // max(n, 1)))
+        for r0 in range(0, n, blk):
+            r1 = min(n, r0 + blk)
+            rows = np.empty((r1 - r0, n), np.uint8)
+            check(_ffi.lib().kmap_memcpy2d_d2h(ptr(rows), n, D_d.ptr + r0 * ldd, ldd, n, r1 - r0, None))
+            nbs.append(np.argpartition(rows.astype(np.int64), n_neighbour, axis=1)[:, :n_neighbour])
+        neighbor_inds_mat = np.concatenate(nbs)
+    sums_d, lds = knn_sums_dev(D_d.ptr, ldd, neighbor_inds_mat, n, n_neighbour)
+    for b in (D_d, kh_d, lab_d):
+        b.free()
+    lut = hd_prob_lut(kmer_len, n_neighbour, n_neighbour * n_neighbour * kmer_len)
+    ld_data, placeholders = _init_draws(n, n_best_result, random_seed)
+    sess = EmbedSession(n, n_best_result, learning_rate, mode)
+    try:
+        sess.set_prob_lut(sums_d, lds, lut)
+        sess.set_coords(ld_data, placeholders)
+        _run_loop(sess, n_max_iter, debug=debug, trace=trace)
+        return sess.best(), lab
+    finally:
+        sess.close()
+
+
+# ---- `kmap visualize_kmers` --------------------------------------------------------------------------
+def _visualize_kmers(res_dir: str, debug=False, mode=None):
+    """reference visualization.py:36-87: config.toml + sample_kmer_hamdist_mat.pkl -> low_dim_data.tsv"""
+    from ._toml import load_toml
+    cfg_path = Path(res_dir) / FileNameDict["config_file"]
+    assert cfg_path.exists()
+    cfg = load_toml(cfg_path)
+    if not debug:
+        debug = cfg["general"]["debug"]
+    vz = cfg["visualization"]
+    random_seed = vz["random_seed"]
+    if random_seed == "default":
+        random_seed = None
+    else:
+        assert isinstance(random_seed, (int, float))
+    with open(Path(res_dir) / FileNameDict["sample_kmer_hamdist_mat_file"], "rb") as fh:
+        kmer_len, hamdist_mat, label_arr = pickle.load(fh)
+    if hamdist_mat is None:
+        # compact hand-off written by scan_motif above the int64-matrix size threshold
+        with open(Path(res_dir) / FileNameDict["sample_kmer_pkl_file"], "rb") as fh:
+            samp_kh, samp_cnts, samp_label, conseq_list = pickle.load(fh)
+        ld_data, _ = kmap_from_kmers(samp_kh, samp_cnts, samp_label, conseq_list, kmer_len, n_neighbour=vz["n_neighbour"],
+                                     n_max_iter=vz["n_max_iter"], learning_rate=vz["learning_rate"],
+                                     n_best_result=vz["n_best_result"], random_seed=random_seed, debug=debug, mode=mode)
+    else:
+        ld_data = kmap(hamdist_mat, kmer_len, n_neighbour=vz["n_neighbour"], n_max_iter=vz["n_max_iter"],
+                       learning_rate=vz["learning_rate"], n_best_result=vz["n_best_result"], random_seed=random_seed,
+                       debug=debug, mode=mode)
+    lines = ["x\ty\tlabel"]
+    for x, y, label in zip(ld_data[0], ld_data[1], label_arr):
+        lines.append(f"{x:3.3f}\t{y:3.3f}\t{int(label)}")
+    with open(Path(res_dir) / FileNameDict["ld_data_file"], "w+") as fh:
+        fh.write("\n".join(lines) + "\n")
+    print("Dimensionality reduction finished. Low dimensional embeddings generated.")
+    if vz.get("gen_fig_flag"):
+        print("gen_fig_flag: plotting is outside the GPU hot path of kmap_amd; low_dim_data.tsv holds the embedding.")
+    return ld_data
+
+
+def smoke_embed():
+    """Tiny end-to-end embedding on cuda:0 checked against the CPU oracle (used by __graft_entry__.smoke)."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(1)
+    n, k = 96, 8
+    kh = rng.integers(0, 4 ** k, size=n, dtype=np.uint64)
+    D = O.hamdist_matrix_u8(kh, np.zeros(n, np.int32), k, [k]).astype(np.int64)
+    nb = np.argpartition(D, 20, axis=1)[:, :20]
+    tr_o, tr_g = {}, {}
+    want = O.kmap(D, k, n_max_iter=15, random_seed=3, nb=nb, trace=tr_o)
+    got = kmap(D, k, n_max_iter=15, random_seed=3, debug=False, mode=EMBED_SEQ, neighbor_inds_mat=nb, trace=tr_g)
+    assert np.allclose(tr_g["losses"], np.array(tr_o["losses"], np.float32), rtol=2e-6), "embedding loss mismatch"
+    assert np.allclose(got, want, atol=1e-5), "embedding coordinates mismatch"

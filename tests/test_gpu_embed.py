@@ -1,0 +1,199 @@
+"""GPU parity of the smoothing + embedding path against golden traces produced by the reference
+and against the CPU oracle.  Integer neighbour sums: bit-exact.  Float path tolerances are stated
+per test (north star: 1e-5 abs on coordinates at a fixed seed)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def V():
+    import kmap_amd.visualization as vz
+    return vz
+
+
+def test_knn_smooth_golden(V, golden):
+    e, s = golden("embed_ops.npz"), golden("scan_testfa.npz")
+    S = V.knn_smooth(s["hamdist_mat_u8"].astype(np.int64), int(e["n_nb"]), neighbor_inds_mat=e["nb"])
+    assert S.dtype == np.float32
+    np.testing.assert_array_equal(S, e["S"])                       # integer sums are exact in f32
+    S2 = V.knn_smooth(e["small_D"], 4, neighbor_inds_mat=e["small_nb"])
+    np.testing.assert_array_equal(S2, e["small_S"])
+    # reference's own test shape (kmap_tests.py:579-612): vs an f64 triple loop within 1e-4
+    D, nb = e["small_D"].astype(float), e["small_nb"]
+    ref = np.array([[D[np.ix_(nb[i], nb[j])].sum() / 16 if i != j else 0 for j in range(10)] for i in range(10)])
+    assert np.all(np.abs(S2 - ref) < 1e-4)
+
+
+def test_knn_smooth_float_matrix_vs_oracle(V):
+    from oracle import oracle as O
+    rng = np.random.default_rng(4)
+    for n, n_nb in ((37, 5), (200, 20)):
+        x = rng.standard_normal((n, 3))
+        D = np.sqrt(((x[:, None] - x[None]) ** 2).sum(-1))          # a Euclidean (non-integer) matrix
+        nb = np.argpartition(D, n_nb, axis=1)[:, :n_nb]
+        np.testing.assert_array_equal(V.knn_smooth(D, n_nb, neighbor_inds_mat=nb), O.knn_smooth(D, n_nb, nb=nb))
+
+
+def test_knn_sums_chunked_rows_vs_oracle(V):
+    """N above one LDS chunk is exercised with a row range (multi-GPU decomposition) at moderate N."""
+    from oracle import oracle as O
+    from kmap_amd import _ffi
+    from kmap_amd.hamdist import pitch_for
+    rng = np.random.default_rng(9)
+    n, k, n_nb = 3000, 12, 20
+    kh = rng.integers(0, 4 ** k, size=n, dtype=np.uint64)
+    D = O.hamdist_matrix_u8(kh, np.zeros(n, np.int32), k, [k])
+    nb = np.argpartition(D.astype(np.int64), n_nb, axis=1)[:, :n_nb]
+    ldd = pitch_for(n)
+    Dp = np.zeros((n, ldd), np.uint8)
+    Dp[:, :n] = D
+    D_d = _ffi.DeviceBuffer.from_numpy(Dp)
+    rows = slice(1000, 1700)
+    sums_d, lds = V.knn_sums_dev(D_d.ptr, ldd, nb, n, n_nb, row0=rows.start, nrows=rows.stop - rows.start)
+    got = sums_d.to_numpy(np.uint16, (rows.stop - rows.start, lds))[:, :n]
+    A = np.zeros((n, n), np.int32)
+    np.add.at(A, (np.repeat(np.arange(n), n_nb), nb.ravel()), 1)
+    want = (A[rows] @ D.astype(np.int32)) @ A.T
+    want[np.arange(rows.stop - rows.start), np.arange(rows.start, rows.stop)] = 0
+    np.testing.assert_array_equal(got, want)
+
+
+def test_lut_matches_golden_hd_prob(V, golden):
+    e = golden("embed_ops.npz")
+    k, n_nb = int(e["kmer_len"]), int(e["n_nb"])
+    lut = V.hd_prob_lut(k, n_nb, n_nb * n_nb * k)
+    sums = np.rint(e["S"].astype(np.float64) * n_nb * n_nb).astype(np.int64)
+    # numpy's f32 exp may differ by an ulp between the CPU that made the fixture and this one
+    np.testing.assert_allclose(lut[sums], e["hd_prob"], rtol=2e-6, atol=1e-45)
+
+
+def test_embed_ops_golden(V, golden):
+    e = golden("embed_ops.npz")
+    np.testing.assert_array_equal(V.cal_ld_prob_mat_taichi(e["op_ld"]), e["op_q"])          # IEEE ops only
+    np.testing.assert_array_equal(V.gradient_loss_taichi(e["op_p"], e["op_q"], e["op_ld"]), e["op_grad"])
+    np.testing.assert_allclose(V.cross_entropy_taichi(e["op_p"], e["op_q"]), e["op_loss"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["n96", "n300"])
+def test_umap_trace_seq_mode(V, golden, tag):
+    """SEQ mode = the reference's arithmetic: per-iteration losses (rtol 2e-6: device log vs numpy log),
+    coordinates after the last iteration and the returned best snapshot within 1e-5 abs."""
+    u = golden(f"umap_{tag}.npz")
+    tr = {}
+    final = V.kmap(u["D"].astype(np.int64), int(u["kmer_len"]), n_max_iter=int(u["n_iter"]), random_seed=int(u["seed"]),
+                   debug=False, mode=V.EMBED_SEQ, neighbor_inds_mat=u["nb"], trace=tr)
+    assert len(tr["losses"]) == len(u["losses"])
+    np.testing.assert_allclose(tr["losses"], u["losses"], rtol=2e-6)
+    assert tr["state"]["jitter_used"] == int(u["jitter_hits"].sum())
+    np.testing.assert_allclose(tr["last_coords"], u["coords"][-1], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(final, u["final"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["n96", "n300"])
+def test_umap_trace_fast_mode(V, golden, tag):
+    """FAST mode (wavefront-parallel row sums) computes the same per-pair values but rounds the row sums
+    differently; gradient descent amplifies that, so it is pinned step-wise: the first iterations agree with
+    the reference trace to f32 round-off and the run ends at a loss as low as the reference's (within 10 %)."""
+    u = golden(f"umap_{tag}.npz")
+    tr = {}
+    V.kmap(u["D"].astype(np.int64), int(u["kmer_len"]), n_max_iter=int(u["n_iter"]), random_seed=int(u["seed"]),
+           debug=False, mode=V.EMBED_FAST, neighbor_inds_mat=u["nb"], trace=tr)
+    np.testing.assert_allclose(tr["losses"][:3], u["losses"][:3], rtol=2e-6)
+    assert tr["losses"].min() <= u["losses"].min() * 1.10          # reaches an equally good optimum
+    assert tr["losses"][-1] < 0.5 * tr["losses"][0]
+
+
+def test_fast_and_seq_forces_agree_per_step(V, golden):
+    """One force evaluation from identical coordinates: FAST vs SEQ gradients agree to f32 summation
+    round-off (1e-5 relative to the gradient scale) and the losses to 1e-6 relative."""
+    from kmap_amd import _ffi
+    u = golden("umap_n300.npz")
+    n, k, n_nb = 300, int(u["kmer_len"]), 20
+    D = u["D"]
+    from kmap_amd.hamdist import pitch_for
+    ldd = pitch_for(n)
+    Dp = np.zeros((n, ldd), np.uint8)
+    Dp[:, :n] = D
+    lut = V.hd_prob_lut(k, n_nb, n_nb * n_nb * int(D.max()))
+    outs = {}
+    for mode in (V.EMBED_SEQ, V.EMBED_FAST):
+        D_d = _ffi.DeviceBuffer.from_numpy(Dp)
+        sums_d, lds = V.knn_sums_dev(D_d.ptr, ldd, u["nb"], n, n_nb)
+        sess = V.EmbedSession(n, 10, 0.01, mode)
+        sess.set_prob_lut(sums_d, lds, lut)
+        sess.set_coords(u["coords"][10])
+        g_d, l_d = _ffi.DeviceBuffer(2 * n * 4), _ffi.DeviceBuffer(8)
+        g_d.zero()
+        sess.forces(g_d.ptr, l_d.ptr)
+        _ffi.sync()
+        outs[mode] = (g_d.to_numpy(np.float32, (2, n)), l_d.to_numpy(np.float64, (1,))[0])
+        sess.close()
+        D_d.free()
+    (gs, ls), (gf, lf) = outs[V.EMBED_SEQ], outs[V.EMBED_FAST]
+    assert abs(ls - lf) <= 1e-6 * abs(ls)
+    np.testing.assert_allclose(gf, gs, rtol=0, atol=1e-5 * np.abs(gs).max())
+
+
+def test_umap_dropin_float_matrix_path(V, golden):
+    """umap(hd_dist_mat) with an f32 matrix equals the LUT path on the same data (same kernels, other source)."""
+    u, e = golden("umap_n96.npz"), golden("embed_ops.npz")
+    k = int(u["kmer_len"])
+    S = V.knn_smooth(u["D"].astype(np.int64), 20, neighbor_inds_mat=u["nb"])
+    T = V.sigmoid(S, 16.0, change_point=k / 2, scale_factor=0.2 * k - 0.2)
+    a = V.umap(T, n_max_iter=50, random_seed=11, debug=False, mode=V.EMBED_SEQ)
+    b = V.kmap(u["D"].astype(np.int64), k, n_max_iter=50, random_seed=11, debug=False, mode=V.EMBED_SEQ,
+               neighbor_inds_mat=u["nb"])
+    np.testing.assert_array_equal(a, b)
+
+
+def test_rng_stream_left_like_reference(V, golden):
+    """After kmap() numpy's global RNG is where the reference leaves it: seed, init + n_best draws, then one
+    normal per jitter hit."""
+    u = golden("umap_n96.npz")
+    V.kmap(u["D"].astype(np.int64), int(u["kmer_len"]), n_max_iter=int(u["n_iter"]), random_seed=int(u["seed"]),
+           debug=False, mode=V.EMBED_SEQ, neighbor_inds_mat=u["nb"])
+    got = np.random.random()
+    np.random.seed(int(u["seed"]))
+    np.random.randn(2, 96)
+    for _ in range(10):
+        np.random.randn(2, 96)
+    hits = int(u["jitter_hits"].sum())
+    if hits:
+        np.random.normal(0, 0.01, hits)
+    assert got == np.random.random()
+
+
+def test_early_stop_and_zero_iters(V):
+    rng = np.random.default_rng(2)
+    D = rng.integers(0, 9, size=(40, 40))
+    D = np.triu(D, 1)
+    D = D + D.T
+    out0 = V.kmap(D, 8, n_neighbour=5, n_max_iter=0, random_seed=5, debug=False)
+    np.random.seed(5)
+    np.random.randn(2, 40)
+    np.testing.assert_array_equal(out0, np.random.randn(2, 40).astype("float32"))   # first placeholder (reference :293,325)
+    tr = {}
+    V.kmap(D, 8, n_neighbour=5, n_max_iter=3, random_seed=5, debug=False, trace=tr)
+    assert len(tr["losses"]) == 3 and tr["state"]["iters"] == 3
+
+
+def test_fast_vs_seq_at_default_size(V):
+    """N = 5000 (the reference's default n_total_sample), k = 8: FAST tracks SEQ's loss curve (see default_mode() for why trajectories are not compared digit by digit); the loss decreases; best snapshot has the lowest logged loss."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(12)
+    n, k = 5000, 8
+    kh = rng.integers(0, 4 ** k, size=n, dtype=np.uint64)
+    lab = np.sort(rng.integers(0, 3, size=n)).astype(np.int32)
+    ta, tb = {}, {}
+    a, _ = V.kmap_from_kmers(kh, np.ones(n, int), lab, ["ACGTACGT", "ACGTAC"], k, n_max_iter=30, random_seed=7,
+                             mode=V.EMBED_SEQ, trace=ta)
+    b, _ = V.kmap_from_kmers(kh, np.ones(n, int), lab, ["ACGTACGT", "ACGTAC"], k, n_max_iter=30, random_seed=7,
+                             mode=V.EMBED_FAST, trace=tb)
+    np.testing.assert_allclose(tb["losses"][:2], ta["losses"][:2], rtol=2e-6)
+    print("N=5000 fast-vs-seq: max rel loss diff over 30 iterations =", np.abs(tb["losses"] / ta["losses"] - 1).max(),
+          " max |dcoord| =", np.abs(ta["last_coords"] - tb["last_coords"]).max())
+    np.testing.assert_allclose(tb["losses"], ta["losses"], rtol=5e-2)
+    assert ta["losses"][-1] < ta["losses"][0] and tb["losses"][-1] < tb["losses"][0]
+    assert ta["state"]["best_loss"] == ta["losses"].min()
