@@ -115,6 +115,9 @@ int kmap_counts_run_seq_dev(kmap_counts *c, const uint8_t *seq_dev, int64_t n, c
 /* from a materialised hash array (drop-in for count_uniq_hash; invalid hashes dropped) */
 int kmap_counts_run_hashes_dev(kmap_counts *c, const void *hash_dev, int64_t n, int k, int merge_revcom,
                                int64_t *n_uniq, void *stream);
+/* load counts computed earlier (e.g. from kmer_count/k{k}.pkl, find_motif motif_discovery.py:621-624):
+ * uniq uint32/uint64 by k, cnt int32/int64 by k, host arrays */
+int kmap_counts_load(kmap_counts *c, const void *uniq, const void *cnt, int64_t n_uniq, int k);
 /* uniq_out: uint32[n_uniq] (k<16) or uint64[n_uniq]; cnt_out: int32 (k<16) or int64 */
 int kmap_counts_fetch(kmap_counts *c, void *uniq_out, void *cnt_out);
 int kmap_counts_total(kmap_counts *c, int64_t *total);          /* sum of counts */
@@ -133,6 +136,15 @@ int kmap_scan_destroy(kmap_scan *s);
 int kmap_scan_run_dev(kmap_scan *s, const uint8_t *seq_dev, int64_t n, const int64_t *borders_dev, int64_t n_seq,
                       int k, uint64_t cons, int radius, int revcom, int64_t *total_hits, void *stream);
 int kmap_scan_fetch(kmap_scan *s, int32_t *hits_per_read, int8_t *min_dist, int32_t *positions);
+
+/* host-side writer of the occurrence table (gen_motif_occurence_file motif_discovery.py:1396-1419):
+ * rows "seq_ind;loc,loc;...;seq_len" for every read with at least one hit; per consensus c the arrays
+ * hits[c] (int32[n_seq]) and pos[c] (int32, concatenated in read order, already subsampled/sorted).
+ * header is written verbatim as the first line.  Native because the reference's per-read Python
+ * formatting dominates at 10^7 reads. */
+int kmap_write_occurrence_csv(const char *path, const char *header, int64_t n_seq, int n_cons,
+                              const int32_t *const *hits, const int32_t *const *pos, const int64_t *read_len,
+                              int64_t *rows_written);
 
 /* ---- all-pairs Hamming matrix: cal_samp_kmer_hamdist_mat motif_discovery.py:759-808
  * (one launch instead of n_uniq launches + Python block expansion).  kh: N hashes (already

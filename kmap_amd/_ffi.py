@@ -60,6 +60,7 @@ _SIGS = {
     "kmap_counts_destroy": (i32, [vp]),
     "kmap_counts_run_seq_dev": (i32, [vp, vp, i64, vp, i64, i32, i32, i32, P(i64), vp]),
     "kmap_counts_run_hashes_dev": (i32, [vp, vp, i64, i32, i32, P(i64), vp]),
+    "kmap_counts_load": (i32, [vp, vp, vp, i64, i32]),
     "kmap_counts_fetch": (i32, [vp, vp, vp]),
     "kmap_counts_total": (i32, [vp, P(i64)]),
     "kmap_counts_hamball_mass": (i32, [vp, vp, i32, i32, i32, vp]),
@@ -67,6 +68,7 @@ _SIGS = {
     "kmap_scan_destroy": (i32, [vp]),
     "kmap_scan_run_dev": (i32, [vp, vp, i64, vp, i64, i32, u64, i32, i32, P(i64), vp]),
     "kmap_scan_fetch": (i32, [vp, vp, vp, vp]),
+    "kmap_write_occurrence_csv": (i32, [C.c_char_p, C.c_char_p, i64, i32, vp, vp, vp, P(i64)]),
     "kmap_hamdist_matrix_u32_dev": (i32, [vp, vp, i64, i32, vp, i32, i64, i64, vp, i64, vp]),
     "kmap_hamdist_matrix_u64_dev": (i32, [vp, vp, i64, i32, vp, i32, i64, i64, vp, i64, vp]),
     "kmap_hamdist_matrix_u8": (i32, [vp, vp, i64, i32, vp, i32, vp]),

@@ -1,0 +1,46 @@
+"""`kmap` command line: the three verbs of the reference's CLI that sit on the GPU hot path
+(reference cli.py:9-36, kmer_count.py:70-101, motif_discovery.py:29-53, visualization.py:18-33),
+with the same option names.  The reference's reporting verbs (ex_hamball, draw_logo, align_conseq,
+extract_motif_locations, check_motif_co_occurence, plot_network) are out of scope here."""
+import click
+
+from . import __version__
+
+
+@click.group()
+def cli():
+    """KMAP on MI355X: k-mer counting, motif scan and 2-D k-mer embedding (HIP kernels)."""
+
+
+def display_paper_info():
+    print()
+    print(f"kmap_amd {__version__} -- MI355X/gfx950 implementation of the kmap hot path")
+    print("method: KMAP, Fu et al., bioRxiv 2024, doi:10.1101/2024.04.12.589197")
+    print()
+
+
+@cli.command(name="preproc")
+@click.option("--fasta_file", type=str, required=True, help="Input fasta file")
+@click.option("--res_dir", type=str, default=".", required=False, help="Result directory for storing all outputs")
+@click.option("--gpu_mode", type=bool, default=True, required=False, help="kept for CLI compatibility (always GPU)")
+@click.option("--debug", type=bool, default=False, required=False, help="display debug information.")
+def preproc(fasta_file, res_dir=".", gpu_mode=True, debug=False):
+    from .kmer_count import _preproc
+    _preproc(fasta_file, res_dir, debug)
+
+
+@cli.command(name="scan_motif")
+@click.option("--res_dir", type=str, required=True, help="Result directory for storing all outputs")
+@click.option("--gpu_mode", type=bool, default=True, required=False, help="kept for CLI compatibility (always GPU)")
+@click.option("--debug", type=bool, default=False, required=False, help="display debug information.")
+def scan_motif(res_dir, gpu_mode=True, debug=False):
+    from .motif_discovery import _scan_motif
+    _scan_motif(res_dir, debug)
+
+
+@cli.command(name="visualize_kmers")
+@click.option("--res_dir", type=str, required=True, help="Result directory for storing all outputs")
+@click.option("--debug", type=bool, default=False, required=False, help="display debug information.")
+def visualize_kmers(res_dir, debug=False):
+    from .visualization import _visualize_kmers
+    _visualize_kmers(res_dir, debug)

@@ -8,6 +8,7 @@
 // compaction that applies the reverse-complement merge on the fly.  A uint32 bin wraps exactly
 // like the reference's int64 -> int32 cast of np.unique counts.
 #include "common.h"
+#include "scan_util.h"
 
 int kmap_hash_launch_u32(const uint8_t *seq, int64_t n, int k, uint32_t *out, void *stream);
 int kmap_hash_launch_u64(const uint8_t *seq, int64_t n, int k, uint64_t *out, void *stream);
@@ -72,33 +73,6 @@ __global__ __launch_bounds__(BLK) void compact_count_kernel(const uint32_t *__re
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
-// exclusive scan of n uint32 values into uint64 offsets by ONE block (n up to a few million);
-// total written to *total
-__global__ __launch_bounds__(1024) void scan_single_block_kernel(const uint32_t *__restrict__ in, int64_t n,
-                                                                 uint64_t *__restrict__ out,
-                                                                 uint64_t *__restrict__ total) {
-    __shared__ uint64_t part[1024];
-    const int t = threadIdx.x;
-    const int64_t chunk = (n + 1023) / 1024;
-    const int64_t lo = (int64_t)t * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
-    uint64_t s = 0;
-    for (int64_t i = lo; i < hi; ++i) s += in[i];
-    part[t] = s;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan
-        uint64_t v = (t >= o) ? part[t - o] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    uint64_t run = (t == 0) ? 0 : part[t - 1];
-    for (int64_t i = lo; i < hi; ++i) {
-        out[i] = run;
-        run += in[i];
-    }
-    if (t == 1023) *total = part[1023];
 }
 
 template <typename H>
@@ -328,6 +302,38 @@ int kmap_counts_run_seq_dev(kmap_counts *c, const uint8_t *seq_dev, int64_t n, c
     (void)hipStreamSynchronize(st);
     (void)hipFree(hash);
     return rc;
+}
+
+int kmap_counts_load(kmap_counts *c, const void *uniq, const void *cnt, int64_t n_uniq, int k) {
+    KMAP_REQUIRE(c && k > 0 && k < 32 && n_uniq >= 0, "counts_load: bad arguments");
+    KMAP_REQUIRE(n_uniq == 0 || (uniq && cnt), "counts_load: null pointer");
+    const int narrow = (k < 16);
+    if (c->cap < (size_t)n_uniq || !c->uniq) {
+        if (c->uniq) KMAP_CHECK_HIP(hipFree(c->uniq));
+        if (c->cnt) KMAP_CHECK_HIP(hipFree(c->cnt));
+        c->uniq = nullptr; c->cnt = nullptr; c->cap = 0;
+        const size_t cap = n_uniq ? (size_t)n_uniq : 1;
+        KMAP_CHECK_HIP(hipMalloc(&c->uniq, cap * 8));
+        KMAP_CHECK_HIP(hipMalloc((void **)&c->cnt, cap * 4));
+        c->cap = cap;
+    }
+    if (n_uniq) {
+        KMAP_CHECK_HIP(hipMemcpy(c->uniq, uniq, (size_t)n_uniq * (narrow ? 4 : 8), hipMemcpyHostToDevice));
+        if (narrow) {
+            KMAP_CHECK_HIP(hipMemcpy(c->cnt, cnt, (size_t)n_uniq * 4, hipMemcpyHostToDevice));
+        } else {   // int64 counts are kept as uint32 on the device (see header: < 2^32 per k-mer)
+            uint32_t *tmp = (uint32_t *)malloc((size_t)n_uniq * 4);
+            KMAP_REQUIRE(tmp, "counts_load: host malloc");
+            for (int64_t i = 0; i < n_uniq; ++i) tmp[i] = (uint32_t)((const int64_t *)cnt)[i];
+            hipError_t e = hipMemcpy(c->cnt, tmp, (size_t)n_uniq * 4, hipMemcpyHostToDevice);
+            free(tmp);
+            KMAP_CHECK_HIP(e);
+        }
+    }
+    c->k = k;
+    c->narrow = narrow;
+    c->n_uniq = n_uniq;
+    return KMAP_OK;
 }
 
 int kmap_counts_fetch(kmap_counts *c, void *uniq_out, void *cnt_out) {

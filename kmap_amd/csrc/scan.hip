@@ -1,0 +1,184 @@
+// scan.hip -- per-read motif occurrence scan ("Hamming-ball scan over reads", BASELINE config 5).
+// Replaces get_motif_occurence (reference motif_discovery.py:1422-1477), which per read and per
+// consensus launches one hash kernel + two Hamming kernels from Python.  Here: one wave per read,
+// hash windows rolled from the uint8 array (1 B per position), min(fwd, revcom) distance, wave-min of
+// the hits, ballot-ordered compaction of the positions at the read's minimum distance.
+//
+// Roofline: HBM-bound, 1 B per array position + sparse hit output.
+#include "common.h"
+#include "scan_util.h"
+
+namespace {
+
+constexpr int SC_WAVES = 4;
+
+// number of candidate positions = len(hash_arr[0 : L-k+1]) with Python slice semantics (negative stop wraps)
+__device__ __forceinline__ int64_t slice_stop(int64_t L, int k) {
+    int64_t stop = L - k + 1;
+    if (stop < 0) {
+        stop += L;
+        if (stop < 0) stop = 0;
+    }
+    return stop > L ? L : stop;
+}
+
+// min(fwd, rc) Hamming distance of the k-mer starting at read[p] (invalid window = all ones, compared as is)
+__device__ __forceinline__ int window_dist(const uint8_t *__restrict__ read, int64_t L, int64_t p, int k, uint64_t m,
+                                           uint64_t cons, uint64_t rcc, int revcom) {
+    uint64_t h = 0;
+    bool bad = (p + k > L);
+    for (int i = 0; i < k; ++i) {
+        const uint32_t b = (p + i < L) ? read[p + i] : 255u;
+        bad |= (b == 255u);
+        h = (h << 2) + b;
+    }
+    h = bad ? m : (h & m);
+    int d = popc2((h ^ cons) & m);
+    if (revcom) {
+        const int d2 = popc2((h ^ rcc) & m);
+        d = d2 < d ? d2 : d;
+    }
+    return d;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(KMAP_WAVE *SC_WAVES) void scan_kernel(const uint8_t *__restrict__ seq, int64_t n,
+                                                                    const int64_t *__restrict__ borders, int64_t n_seq,
+                                                                    int k, uint64_t cons, uint64_t rcc, int radius,
+                                                                    int revcom, int32_t *__restrict__ hits,
+                                                                    int8_t *__restrict__ min_dist,
+                                                                    const uint64_t *__restrict__ offs,
+                                                                    int32_t *__restrict__ pos_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * SC_WAVES + (threadIdx.x >> 6);
+    if (s >= n_seq) return;
+    int64_t st = borders[2 * s], en = borders[2 * s + 1];
+    if (st < 0) st = 0;
+    if (en > n) en = n;
+    const int64_t L = en > st ? en - st : 0;
+    const uint8_t *read = seq + st;
+    const int64_t stop = slice_stop(L, k);
+    const uint64_t m = low_mask<uint64_t>(k);
+    int best;
+    if (!WRITE) {
+        best = 1 << 30;
+        for (int64_t p = lane; p < stop; p += 64) {
+            const int d = window_dist(read, L, p, k, m, cons, rcc, revcom);
+            if (d <= radius && d < best) best = d;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const int v = __shfl_xor(best, o);
+            best = v < best ? v : best;
+        }
+    } else {
+        best = min_dist[s];
+        if (best < 0) return;
+    }
+    int count = 0;
+    uint64_t base = WRITE ? offs[s] : 0;
+    if (best <= radius) {
+        for (int64_t p0 = 0; p0 < stop; p0 += 64) {
+            const int64_t p = p0 + lane;
+            const bool hit = (p < stop) && (window_dist(read, L, p, k, m, cons, rcc, revcom) == best);
+            const unsigned long long mask = __ballot(hit);
+            if (WRITE && hit) pos_out[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)p;
+            const int c = __popcll(mask);
+            count += c;
+            base += c;
+        }
+    }
+    if (!WRITE && lane == 0) {
+        hits[s] = count;
+        min_dist[s] = (int8_t)((best <= radius) ? best : -1);
+    }
+}
+
+}  // namespace
+
+struct kmap_scan {
+    int64_t n_seq = 0, total = 0, cap_seq = 0, cap_pos = 0;
+    int32_t *hits = nullptr;
+    int8_t *mind = nullptr;
+    uint64_t *offs = nullptr;
+    int32_t *pos = nullptr;
+};
+
+extern "C" {
+
+int kmap_scan_create(kmap_scan **s) {
+    KMAP_REQUIRE(s, "scan_create: null");
+    *s = new kmap_scan();
+    return KMAP_OK;
+}
+int kmap_scan_destroy(kmap_scan *s) {
+    if (!s) return KMAP_OK;
+    void *ptrs[] = {s->hits, s->mind, s->offs, s->pos};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete s;
+    return KMAP_OK;
+}
+
+int kmap_scan_run_dev(kmap_scan *s, const uint8_t *seq_dev, int64_t n, const int64_t *borders_dev, int64_t n_seq, int k,
+                      uint64_t cons, int radius, int revcom, int64_t *total_hits, void *stream) {
+    KMAP_REQUIRE(s, "scan_run: null handle");
+    KMAP_REQUIRE(k > 0 && k < 32, "scan_run: k=%d out of range", k);
+    KMAP_REQUIRE(n >= 0 && n_seq >= 0 && radius >= 0, "scan_run: negative size");
+    s->n_seq = n_seq;
+    s->total = 0;
+    if (total_hits) *total_hits = 0;
+    if (n_seq == 0) return KMAP_OK;
+    KMAP_REQUIRE(seq_dev && borders_dev, "scan_run: null pointer");
+    hipStream_t st = as_stream(stream);
+    if (s->cap_seq < n_seq) {
+        void *ptrs[] = {s->hits, s->mind, s->offs};
+        for (void *p : ptrs)
+            if (p) KMAP_CHECK_HIP(hipFree(p));
+        s->hits = nullptr; s->mind = nullptr; s->offs = nullptr; s->cap_seq = 0;
+        KMAP_CHECK_HIP(hipMalloc((void **)&s->hits, (size_t)n_seq * 4));
+        KMAP_CHECK_HIP(hipMalloc((void **)&s->mind, (size_t)n_seq));
+        KMAP_CHECK_HIP(hipMalloc((void **)&s->offs, ((size_t)n_seq + 1) * 8));
+        s->cap_seq = n_seq;
+    }
+    const uint64_t m = low_mask<uint64_t>(k);
+    const uint64_t c = cons & m;
+    // reverse complement on the host (same arithmetic as revcom_hash; u32 wrap for k < 16 is moot: c < 4^k)
+    uint64_t com = m - c, rcc = com & 3u;
+    for (int i = 0; i < k - 1; ++i) { rcc <<= 2; com >>= 2; rcc += com & 3u; }
+    const unsigned grid = (unsigned)((n_seq + SC_WAVES - 1) / SC_WAVES);
+    scan_kernel<false><<<grid, KMAP_WAVE * SC_WAVES, 0, st>>>(seq_dev, n, borders_dev, n_seq, k, c, rcc, radius, revcom,
+                                                              s->hits, s->mind, nullptr, nullptr);
+    scan_single_block_kernel<<<1, 1024, 0, st>>>(reinterpret_cast<const uint32_t *>(s->hits), n_seq, s->offs,
+                                                 s->offs + n_seq);
+    uint64_t total = 0;
+    KMAP_CHECK_HIP(hipMemcpyAsync(&total, s->offs + n_seq, 8, hipMemcpyDeviceToHost, st));
+    KMAP_CHECK_HIP(hipStreamSynchronize(st));
+    if (s->cap_pos < (int64_t)total || !s->pos) {
+        if (s->pos) KMAP_CHECK_HIP(hipFree(s->pos));
+        s->pos = nullptr;
+        s->cap_pos = 0;
+        const size_t cap = total ? (size_t)total : 1;
+        KMAP_CHECK_HIP(hipMalloc((void **)&s->pos, cap * 4));
+        s->cap_pos = (int64_t)cap;
+    }
+    if (total)
+        scan_kernel<true><<<grid, KMAP_WAVE * SC_WAVES, 0, st>>>(seq_dev, n, borders_dev, n_seq, k, c, rcc, radius, revcom,
+                                                                 s->hits, s->mind, s->offs, s->pos);
+    KMAP_CHECK_HIP(hipGetLastError());
+    s->total = (int64_t)total;
+    if (total_hits) *total_hits = (int64_t)total;
+    return KMAP_OK;
+}
+
+int kmap_scan_fetch(kmap_scan *s, int32_t *hits_per_read, int8_t *min_dist, int32_t *positions) {
+    KMAP_REQUIRE(s, "scan_fetch: null handle");
+    KMAP_CHECK_HIP(hipDeviceSynchronize());
+    if (s->n_seq) {
+        if (hits_per_read) KMAP_CHECK_HIP(hipMemcpy(hits_per_read, s->hits, (size_t)s->n_seq * 4, hipMemcpyDeviceToHost));
+        if (min_dist) KMAP_CHECK_HIP(hipMemcpy(min_dist, s->mind, (size_t)s->n_seq, hipMemcpyDeviceToHost));
+    }
+    if (s->total && positions) KMAP_CHECK_HIP(hipMemcpy(positions, s->pos, (size_t)s->total * 4, hipMemcpyDeviceToHost));
+    return KMAP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,464 @@
+"""Host side of `kmap scan_motif`: the orchestration of the reference's motif_discovery.py
+(/root/reference/src/kmap/motif_discovery.py) with every array stage on the GPU.
+
+The sequence array and read borders are uploaded once (DeviceSeq); per k the fused device path does
+hash -> per-read dedupe -> histogram count -> revcom merge, Hamming-ball mass, masking and the
+occurrence scan without round-tripping hashes through the host.  File contracts (candidate_conseq.csv,
+final_conseq*.{txt,csv}, *.motif_occurence.csv, k{k}.pkl, sample_kmers.{pkl,tsv},
+sample_kmer_hamdist_mat.pkl) and the caching rules of the reference are kept.  Plot / report branches
+(position density, co-occurrence, logos, consensus alignment) are outside this package's scope and are
+skipped with a notice.
+"""
+import ctypes as C
+import pickle
+import warnings
+from pathlib import Path
+from typing import List
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, ptr
+from .hamdist import _convert_to_block_arr, cal_samp_kmer_hamdist_mat  # noqa: F401  (re-exported, reference names)
+from .kmer_count import (DeviceCounts, FileNameDict, cal_hamming_dist_head, cal_hamming_dist_tail, encode_fasta,
+                         gen_motif_def_dict, get_cnt_dtype, get_hash_dtype, get_revcom_hash_arr, hash2kmer, kmer2hash,
+                         mask_ham_ball, revcom_hash, reverse_complement)
+
+# int64 N x N pickle is kept up to this many sampled k-mers (2 GiB); above it scan_motif writes the compact
+# hand-off [kmer_len, None, label_arr] and visualize_kmers recomputes the matrix on the device
+DENSE_PKL_MAX_N = 16384
+
+
+def write_lines(str_list: List, outfile):
+    with open(outfile, "w+") as fh:
+        for line in str_list:
+            fh.write(line + "\n")
+
+
+# ---- device-resident sequence array ----------------------------------------------------------------
+class DeviceSeq:
+    """uint8 sequence array (+ pristine copy) and (n_seq, 2) borders in HBM."""
+
+    def __init__(self, seq_np_arr, boarder_mat):
+        seq = np.ascontiguousarray(seq_np_arr, dtype=np.uint8)
+        self.n = len(seq)
+        self.borders_host = np.ascontiguousarray(boarder_mat, dtype=np.int64).reshape(-1, 2)
+        self.n_seq = len(self.borders_host)
+        self.orig = _ffi.DeviceBuffer.from_numpy(seq)
+        self.work = _ffi.DeviceBuffer(max(self.n, 1))
+        self.borders = _ffi.DeviceBuffer.from_numpy(self.borders_host)
+        self.read_len = (self.borders_host[:, 1] - self.borders_host[:, 0]).astype(np.int64)
+        self.reset()
+        self._scan = None
+
+    def reset(self):
+        check(_ffi.lib().kmap_memcpy_d2d(self.work.ptr, self.orig.ptr, self.n, None))
+
+    def count(self, dc: DeviceCounts, k, dedupe, merge_revcom, use_work=True):
+        src = self.work if use_work else self.orig
+        return dc.run_seq(src.ptr, self.n, self.borders.ptr, self.n_seq, k, dedupe, merge_revcom)
+
+    def mask(self, k, consensus_kh_arr, max_ham_dist_arr):
+        cons = np.ascontiguousarray(consensus_kh_arr, dtype=np.uint64)
+        rad = np.ascontiguousarray(max_ham_dist_arr, dtype=np.int32)
+        check(_ffi.lib().kmap_mask_hamball_dev(self.work.ptr, self.n, k, ptr(cons), ptr(rad), len(cons), None))
+
+    def download(self):
+        return self.work.to_numpy(np.uint8, (self.n,))
+
+    def scan(self, k, consensus_kh, radius, revcom):
+        """positions at each read's minimum hit distance (original, unmasked reads):
+        returns (hits_per_read int32[n_seq], positions int32[total])."""
+        if self._scan is None:
+            h = _ffi.vp()
+            check(_ffi.lib().kmap_scan_create(C.byref(h)))
+            self._scan = h.value
+        tot = _ffi.i64(0)
+        check(_ffi.lib().kmap_scan_run_dev(self._scan, self.orig.ptr, self.n, self.borders.ptr, self.n_seq, k,
+                                           int(consensus_kh), int(radius), int(revcom), C.byref(tot), None))
+        hits = np.empty(self.n_seq, np.int32)
+        mind = np.empty(self.n_seq, np.int8)
+        pos = np.empty(tot.value, np.int32)
+        check(_ffi.lib().kmap_scan_fetch(self._scan, ptr(hits), ptr(mind), ptr(pos)))
+        return hits, pos
+
+    def close(self):
+        if self._scan:
+            _ffi.lib().kmap_scan_destroy(self._scan)
+            self._scan = None
+        for b in (self.orig, self.work, self.borders):
+            b.free()
+
+
+# ---- consensus merging (reference motif_discovery.py:533-591) -------------------------------------
+def merge_consensus_seqs(conseq_list: List[str]) -> List[str]:
+    """A candidate of length L survives (as its (L-1)-mer relative) only if candidates of length L-1 and L-2
+    overlap it (or its reverse complement) up to a one-base shift; everything it covers is then dropped."""
+
+    def covers(long_kmer, short_kmer):
+        return short_kmer[:-1] in long_kmer or short_kmer[1:] in long_kmer
+
+    pending = sorted(conseq_list, key=len, reverse=True)
+    finals = []
+    while pending:
+        cur = pending[0]
+        rc = reverse_complement(cur)
+
+        def related(s):
+            return covers(cur, s) or covers(rc, s)
+
+        one = next((s for s in pending if len(s) == len(cur) - 1 and related(s)), None)
+        two = next((s for s in pending if len(s) == len(cur) - 2 and related(s)), None)
+        if one and two:
+            finals.append(one)
+            pending = [s for s in pending if not related(s)]
+        else:
+            pending = pending[1:]
+    return finals
+
+
+# ---- find_motif (reference motif_discovery.py:594-702) -----------------------------------------------
+def _wrap_total(total, k):
+    """`sum(uniq_kh_cnt_arr)` in the reference accumulates numpy scalars of the count dtype: int32 wrap for k<16."""
+    return int(np.array(total, dtype=np.int64).astype(get_cnt_dtype(k)))
+
+
+def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_std, ratio_cutoff, top_k=5, n_trial=10,
+               merge_revcom_mode=True, rep_mode=False, save_kmer_cnt_flag=True, kmer_cnt_pkl_file: Path = None,
+               boarder_pkl_file: Path = None, debug=False, dev_seq: DeviceSeq = None) -> dict:
+    """Greedy motif discovery for one k.  Drop-in signature; `dev_seq` (optional) is an already uploaded
+    DeviceSeq whose working copy is masked in place (then seq_np_arr is not touched)."""
+    from scipy.stats import norm
+    if boarder_pkl_file:
+        assert Path(boarder_pkl_file).exists()
+    own = dev_seq is None
+    if own:
+        with open(boarder_pkl_file, "rb") as fh:
+            boarder_mat = pickle.load(fh)
+        dev_seq = DeviceSeq(seq_np_arr, boarder_mat)
+    dc = DeviceCounts()
+    try:
+        cached = save_kmer_cnt_flag and kmer_cnt_pkl_file and Path(kmer_cnt_pkl_file).exists()
+        if cached:
+            with open(Path(kmer_cnt_pkl_file), "rb") as fh:
+                k_pkl, uniq_kh_arr, uniq_kh_cnt_arr = pickle.load(fh)
+            assert kmer_len == k_pkl
+            u = np.ascontiguousarray(uniq_kh_arr, get_hash_dtype(kmer_len))
+            c = np.ascontiguousarray(uniq_kh_cnt_arr, get_cnt_dtype(kmer_len))
+            check(_ffi.lib().kmap_counts_load(dc._h, ptr(u), ptr(c), len(u), kmer_len))
+            dc.k, dc.n_uniq = kmer_len, len(u)
+        else:
+            dev_seq.count(dc, kmer_len, dedupe=not rep_mode, merge_revcom=merge_revcom_mode)   # first round
+            uniq_kh_arr, uniq_kh_cnt_arr = dc.fetch()
+        if save_kmer_cnt_flag and kmer_cnt_pkl_file and not Path(kmer_cnt_pkl_file).exists():
+            with open(kmer_cnt_pkl_file, "wb") as fh:
+                pickle.dump([kmer_len, uniq_kh_arr, uniq_kh_cnt_arr], fh)
+        n_total_kmer = _wrap_total(dc.total(), kmer_len)   # first round only (:648)
+
+        res = {}
+        for i_trial in range(n_trial):
+            if top_k > len(uniq_kh_cnt_arr):
+                if debug:
+                    print(f"There are only {len(uniq_kh_cnt_arr)} kmers, while top_k={top_k}.")
+                break
+            top_k_inds = np.array(np.argpartition(uniq_kh_cnt_arr, -top_k)[-top_k:])   # same numpy call -> same ties
+            if len(top_k_inds) == 0:
+                break
+            hamball_cnt_arr = dc.hamball_mass(uniq_kh_arr[top_k_inds], max_ham_dist, merge_revcom_mode)
+            if debug:
+                print(f"{i_trial= }")
+            best = int(np.argmax(hamball_cnt_arr))
+            consensus_kh = uniq_kh_arr[top_k_inds[best]]
+            hamball_proportion = (hamball_cnt_arr[best] + 0.0) / n_total_kmer
+            hamball_ratio = hamball_proportion / p_unif
+            if not hamball_ratio > ratio_cutoff:
+                break
+            res[consensus_kh] = (hamball_proportion, hamball_ratio,
+                                 norm.logsf(hamball_ratio, loc=ratio_mu, scale=ratio_std) / np.log(10))
+            cons = [consensus_kh, revcom_hash(consensus_kh, kmer_len)] if merge_revcom_mode else [consensus_kh]
+            dev_seq.mask(kmer_len, np.array(cons), np.array([max_ham_dist] * len(cons)))
+            dev_seq.count(dc, kmer_len, dedupe=False, merge_revcom=merge_revcom_mode)   # later rounds: no dedupe (:695)
+            uniq_kh_arr, uniq_kh_cnt_arr = dc.fetch()
+        if own:
+            seq_np_arr[:] = dev_seq.download()   # the reference mutates its argument
+        return res
+    finally:
+        dc.close()
+        if own:
+            dev_seq.close()
+
+
+# ---- motif occurrence (reference motif_discovery.py:1396-1477) -------------------------------------------
+def scan_motif_occurence(dev_seq: DeviceSeq, conseq_list, motif_def_dict, revcom_mode=True):
+    """Per consensus: (hits_per_read int32[n_seq], positions int32[sum]) after the reference's >20-hit random
+    subsample (np.random.choice in read order, then consensus order -- the reference's draw order)."""
+    per = []
+    for conseq in conseq_list:
+        k = len(conseq)
+        hits, pos = dev_seq.scan(k, kmer2hash(conseq), motif_def_dict[k].max_ham_dist, revcom_mode)
+        per.append([hits, pos])
+    big = [(int(r), c) for c, (hits, _) in enumerate(per) for r in np.nonzero(hits > 20)[0]]
+    if big:
+        offs = [np.concatenate([[0], np.cumsum(h, dtype=np.int64)]) for h, _ in per]
+        keep = [np.ones(len(p), bool) for _, p in per]
+        newhits = [h.copy() for h, _ in per]
+        for r, c in sorted(big):
+            lo, hi = offs[c][r], offs[c][r + 1]
+            locs = per[c][1][lo:hi]
+            idx = np.random.choice(len(locs), 20, replace=False)        # :1468
+            sel = np.zeros(len(locs), bool)
+            sel[idx] = True                                             # np.sort(locs[idx]): locs ascending already
+            keep[c][lo:hi] = sel
+            newhits[c][r] = 20
+        per = [[newhits[c], per[c][1][keep[c]]] for c in range(len(per))]
+    return per
+
+
+def gen_motif_occurence_file(conseq_list: List[str], motif_def_dict: dict, input_fasta_file, output_file, revcom_mode=True,
+                             dev_seq: DeviceSeq = None):
+    """seq_ind;loc,loc;...;seq_len for every read with a hit.  With `dev_seq` the resident read array is
+    scanned (it is the encoding of the same FASTA); otherwise the FASTA is encoded and uploaded here."""
+    own = dev_seq is None
+    if own:
+        assert Path(input_fasta_file).exists()
+        arr, borders = encode_fasta(str(input_fasta_file))
+        dev_seq = DeviceSeq(arr, borders)
+    try:
+        per = scan_motif_occurence(dev_seq, conseq_list, motif_def_dict, revcom_mode)
+        header = "seq_ind;" + ";".join(f"motif_{i}_{c}" for i, c in enumerate(conseq_list)) + ";seq_len"
+        n_cons = len(conseq_list)
+        hits_ptrs = (C.c_void_p * max(n_cons, 1))(*[h.ctypes.data for h, _ in per])
+        pos_keep = [np.ascontiguousarray(p, np.int32) if len(p) else np.zeros(1, np.int32) for _, p in per]
+        pos_ptrs = (C.c_void_p * max(n_cons, 1))(*[p.ctypes.data for p in pos_keep])
+        rows = _ffi.i64(0)
+        check(_ffi.lib().kmap_write_occurrence_csv(str(output_file).encode(), header.encode(), dev_seq.n_seq, n_cons,
+                                                   hits_ptrs, pos_ptrs, ptr(dev_seq.read_len), C.byref(rows)))
+        return per
+    finally:
+        if own:
+            dev_seq.close()
+
+
+def get_motif_seq_num(per, motif_index):
+    """(reads with the motif, total occurrences) -- what the reference parses back out of the CSV (:1345-1393)."""
+    hits = per[motif_index][0]
+    return int(np.count_nonzero(hits)), int(hits.sum())
+
+
+# ---- sampling (reference motif_discovery.py:812-921) -------------------------------------------------------
+def sample_disp_kmer(conseq_list: List[str], kmer_len: int, motif_def_dict: dict, kmer_count_dir: Path, n_total_sample=5000,
+                     n_motif_kmer=2500, revcom_mode=True):
+    conseq_list = [s for s in conseq_list if 2 < len(s) <= kmer_len]
+    assert len(conseq_list) > 0
+    assert all(len(a) >= len(b) for a, b in zip(conseq_list, conseq_list[1:]))
+    with open(Path(kmer_count_dir) / f"k{kmer_len}.pkl", "rb") as fh:
+        res_list = pickle.load(fh)
+    assert res_list[0] == kmer_len
+    uniq_kh_arr, uniq_kh_cnt_arr = res_list[1], res_list[2]
+
+    sampling_flag = True
+    if n_total_sample > sum(uniq_kh_cnt_arr):
+        warnings.warn(f"The number of samples n_sample={n_total_sample} is larger than the original "
+                      f"data n_seq={sum(uniq_kh_cnt_arr)}, process and return original data.")
+        sampling_flag = False
+
+    n_conseq, n_uniq = len(conseq_list), len(uniq_kh_arr)
+    ham_dist_mat = np.zeros((n_conseq, n_uniq), dtype=int)
+    rc_flag_mat = np.zeros((n_conseq, n_uniq), dtype=bool)
+    for i, conseq in enumerate(conseq_list):
+        conseq_kh = kmer2hash(conseq)
+        dist_arr = cal_hamming_dist_head(uniq_kh_arr, conseq_kh, kmer_len, len(conseq))
+        if revcom_mode:
+            rc_conseq_kh = revcom_hash(conseq_kh, len(conseq))
+            assert conseq_kh <= rc_conseq_kh
+            rc_dist_arr = cal_hamming_dist_tail(uniq_kh_arr, rc_conseq_kh, kmer_len, len(conseq))
+            rc_flag_mat[i] = rc_dist_arr < dist_arr
+            dist_arr = np.minimum(dist_arr, rc_dist_arr)
+        ham_dist_mat[i] = dist_arr
+    for i, conseq in enumerate(conseq_list):
+        ham_dist_mat[i][ham_dist_mat[i] > motif_def_dict[len(conseq)].max_ham_dist] = kmer_len
+    min_dist_arr = np.min(ham_dist_mat, axis=0)
+    label_arr = np.argmin(ham_dist_mat, axis=0)
+    label_arr[min_dist_arr > motif_def_dict[kmer_len].max_ham_dist] = n_conseq
+
+    if revcom_mode:   # align Hamming-ball members with their consensus
+        for i in range(n_conseq):
+            members = np.where(label_arr == i)[0]
+            flip = members[rc_flag_mat[i][members]]
+            if len(flip):
+                uniq_kh_arr[flip] = get_revcom_hash_arr(uniq_kh_arr[flip], kmer_len)
+    if not sampling_flag:
+        return uniq_kh_arr, uniq_kh_cnt_arr, label_arr, conseq_list
+
+    sample_cnt_arr = np.bincount(label_arr, weights=uniq_kh_cnt_arr)
+    motif_weights = sample_cnt_arr[:-1] / sum(sample_cnt_arr[:-1])
+    sample_cnt_arr[:-1] = np.around(n_motif_kmer * motif_weights)
+    sample_cnt_arr[-1] = n_total_sample - sum(sample_cnt_arr[0:-1])
+    sample_cnt_arr = sample_cnt_arr.astype(int)
+    assert len(sample_cnt_arr) == n_conseq + 1
+
+    samp_inds, samp_cnts = [], []
+    for c in range(n_conseq + 1):
+        c_inds = np.where(label_arr == c)[0]
+        ws = uniq_kh_cnt_arr[c_inds]
+        ws = ws / sum(ws)
+        tmpcnts = np.random.multinomial(sample_cnt_arr[c], ws, size=1).squeeze()   # global legacy RNG, as the reference
+        samp_inds.append(c_inds[tmpcnts > 0])
+        samp_cnts.append(tmpcnts[tmpcnts > 0])
+    samp_inds = np.concatenate(samp_inds)
+    samp_cnts = np.concatenate(samp_cnts)
+    return uniq_kh_arr[samp_inds], samp_cnts, label_arr[samp_inds], conseq_list
+
+
+# ---- `kmap scan_motif` (reference motif_discovery.py:187-486) ------------------------------------------------
+def _scan_motif(res_dir: str, debug=False):
+    from ._toml import load_toml
+    res = Path(res_dir)
+    config_file_path = res / FileNameDict["config_file"]
+    motif_def_file_path = res / FileNameDict["motif_def_file"]
+    proc_fasta_file_path = res / FileNameDict["processed_fasta_file"]
+    assert config_file_path.exists()
+    assert motif_def_file_path.exists()
+    assert proc_fasta_file_path.exists()
+
+    config_dict = load_toml(config_file_path)
+    motif_def_dict = gen_motif_def_dict(config_dict, debug=debug)
+    md = config_dict["motif_discovery"]
+    min_k, max_k = config_dict["kmer_count"]["min_k"], config_dict["kmer_count"]["max_k"]
+    revcom_mode = config_dict["kmer_count"]["revcom_mode"]
+    rep_mode = config_dict["general"]["repetitive_mode"]
+
+    with open(proc_fasta_file_path, "rb") as fh:
+        seq_np_arr = pickle.load(fh)
+    boarder_pkl_file = res / FileNameDict["processed_fasta_seqboarder_file"]
+    with open(boarder_pkl_file, "rb") as fh:
+        boarder_mat = pickle.load(fh)
+    n_all_seq = len(boarder_mat)
+
+    # the occurrence scans read the ORIGINAL reads (the reference re-parses the FASTA for them)
+    scan_seq = DeviceSeq(seq_np_arr, boarder_mat)
+    if md["noise_kmer_file"] != "None":
+        assert Path(md["noise_kmer_file"]).exists()
+        with open(Path(md["noise_kmer_file"]), "r") as fh:
+            noise = [ln.strip() for ln in fh if ln.strip()]
+        if noise:
+            seq_np_arr = mask_ham_ball(seq_np_arr, motif_def_dict, noise, [0 for _ in noise])
+    count_seq = DeviceSeq(seq_np_arr, boarder_mat) if md["noise_kmer_file"] != "None" else scan_seq
+
+    top_k, n_trial = md["top_k"], md["n_trial"]
+    save_kmer_cnt_flag = md["save_kmer_cnt_flag"]
+    input_fasta_file = Path(config_dict["general"]["input_fasta_file"])
+    candidate_conseq_list = []
+    if save_kmer_cnt_flag:
+        (res / FileNameDict["kmer_count_dir"]).mkdir(exist_ok=True)
+
+    candidate_conseq_file = res / FileNameDict["candidate_conseq_file"]
+    if candidate_conseq_file.exists():
+        print(f"{candidate_conseq_file} already exist, re-use it.")
+    else:
+        occ_flag = md["store_conseq_occur_info_flag"]
+        head = "kmer_len,conseq_hash,conseq,conseq_rc,hamball_proportion,hamball_ratio,log10_p_value"
+        if occ_flag:
+            head += ",n_motif_reads,n_all_reads,motif_reads_prop,motif_occurrence,motif_occurrence_per_motif_read"
+        lines = [head]
+        for kmer_len in range(min_k, max_k + 1):
+            count_seq.reset()
+            d = motif_def_dict[kmer_len]
+            kmer_cnt_file = res / FileNameDict["kmer_count_dir"] / f"k{kmer_len}.pkl"
+            consensus_kh_dict = find_motif(None, kmer_len, d.max_ham_dist, d.p_uniform, d.ratio_mu, d.ratio_std,
+                                           d.ratio_cutoff, top_k, n_trial, revcom_mode, rep_mode,
+                                           save_kmer_cnt_flag=save_kmer_cnt_flag, kmer_cnt_pkl_file=kmer_cnt_file,
+                                           boarder_pkl_file=boarder_pkl_file, debug=debug, dev_seq=count_seq)
+            tmp_list = [hash2kmer(kh, kmer_len) for kh in consensus_kh_dict]
+            per = None
+            if occ_flag:
+                occ_file = res / FileNameDict["kmer_count_dir"] / f"k{kmer_len}.motif_occurence.csv"
+                per = gen_motif_occurence_file(tmp_list, motif_def_dict, input_fasta_file, occ_file, revcom_mode,
+                                               dev_seq=scan_seq)
+            for i, kmer_seq in enumerate(tmp_list):
+                kh = kmer2hash(kmer_seq)
+                prop, ratio, log10_p = consensus_kh_dict[get_hash_dtype(kmer_len)(kh)]
+                row = (f"{kmer_len},{kh},{kmer_seq},{reverse_complement(kmer_seq)},{prop:0.8f},"
+                       f"{ratio:0.4f},{log10_p:0.4f}")
+                if occ_flag:
+                    n_motif_seq, n_occ = get_motif_seq_num(per, i)
+                    row += (f",{n_motif_seq},{n_all_seq},{float(n_motif_seq) / n_all_seq:0.4f},{n_occ},"
+                            f"{float(n_occ) / n_motif_seq:0.2f}")
+                lines.append(row)
+                candidate_conseq_list.append(kmer_seq)
+        print(f"kmer counting finished for k={min_k}...{max_k}. Candidate consensus sequences generated.")
+        write_lines(lines, candidate_conseq_file)
+
+    final_conseq_file = res / FileNameDict["final_conseq_file"]
+    if final_conseq_file.exists():
+        with open(final_conseq_file, "r") as fh:
+            final_conseq_list = fh.read().splitlines()
+        print(f"{final_conseq_file} already exist, re-use it.")
+    else:
+        final_conseq_list = merge_consensus_seqs(candidate_conseq_list)
+        write_lines(final_conseq_list, final_conseq_file)
+
+    final_conseq_info_file = res / FileNameDict["final_conseq_info_file"]
+    if final_conseq_info_file.exists():
+        print(f"{final_conseq_info_file} already exist, re-use it.")
+    else:
+        with open(final_conseq_file, "r") as fh:
+            final_conseq_list = fh.read().splitlines()
+        with open(candidate_conseq_file, "r") as fh:
+            cand_lines = fh.read().splitlines()
+        cols = cand_lines[0].split(",")
+        cols[1], cols[0] = cols[0], "motif_id"
+        info = [",".join(cols)]
+        motif_ind = 0
+        for conseq in final_conseq_list:
+            for line in cand_lines:
+                if "," + conseq + "," in line:
+                    el = line.split(",")
+                    el[1], el[0] = el[0], str(motif_ind)
+                    motif_ind += 1
+                    info.append(",".join(el))
+        write_lines(info, final_conseq_info_file)
+        print("Final consensus sequences generated.")
+
+    occurence_file = res / FileNameDict["motif_occurence_file"]
+    gen_motif_occurence_file(final_conseq_list, motif_def_dict, input_fasta_file, occurence_file, revcom_mode,
+                             dev_seq=scan_seq)
+
+    for flag in ("motif_pos_density_flag", "motif_co_occurence_flag", "gen_hamball_flag"):
+        if md.get(flag):
+            print(f"{flag}: plot/report branch is outside kmap_amd's GPU hot path, skipped.")
+
+    sample_kmer_pkl_file = res / FileNameDict["sample_kmer_pkl_file"]
+    if md["sample_kmer_flag"] and not save_kmer_cnt_flag:
+        print(f"kmers cannot be sampled when {save_kmer_cnt_flag=}, skip kmer sampling!")
+    if sample_kmer_pkl_file.exists():
+        print(f"sample kmer file {sample_kmer_pkl_file} exists, skip sampling!")
+    elif md["sample_kmer_flag"] and save_kmer_cnt_flag:
+        n_total_sample, n_motif_sample = md["n_total_sample"], md["n_motif_sample"]
+        kmer_len = max([len(conseq) for conseq in final_conseq_list])   # ValueError if no motif, like the reference
+        samp_kh_arr, samp_cnts, samp_label_arr, conseq_list = sample_disp_kmer(
+            final_conseq_list, kmer_len, motif_def_dict, kmer_count_dir=res / FileNameDict["kmer_count_dir"],
+            n_total_sample=n_total_sample, n_motif_kmer=n_motif_sample, revcom_mode=revcom_mode)
+        with open(sample_kmer_pkl_file, "wb") as fh:
+            pickle.dump([samp_kh_arr, samp_cnts, samp_label_arr, conseq_list], fh)
+        kmers = np.array([hash2kmer(kh, kmer_len) for kh in samp_kh_arr])
+        with open(res / FileNameDict["sample_kmer_txt_file"], "w+") as fh:
+            for kmer, cnt, label in zip(kmers, samp_cnts, samp_label_arr):
+                fh.write(f"{kmer}\t{label}\n" * int(cnt))
+        print(f"kmers are sampled for visualization. {kmer_len= }, {n_total_sample= }, {n_motif_sample= }")
+
+        label_arr = _convert_to_block_arr(samp_label_arr, samp_cnts)
+        if len(label_arr) <= DENSE_PKL_MAX_N:
+            hamdist_mat = cal_samp_kmer_hamdist_mat(samp_kh_arr, samp_cnts, samp_label_arr, conseq_list, kmer_len,
+                                                    uniq_dist_flag=False)
+        else:
+            hamdist_mat = None   # compact hand-off; visualize_kmers recomputes the matrix on the device
+            print(f"N={len(label_arr)} > {DENSE_PKL_MAX_N}: int64 matrix not materialised (compact hand-off).")
+        with open(res / FileNameDict["sample_kmer_hamdist_mat_file"], "wb") as fh:
+            pickle.dump([kmer_len, hamdist_mat, label_arr], fh)
+        print("Hamming distance matrix of sampled kmers are generated.")
+
+    if count_seq is not scan_seq:
+        count_seq.close()
+    scan_seq.close()
+    print("All tasks of scan motif finished.")

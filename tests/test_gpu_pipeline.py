@@ -1,0 +1,155 @@
+"""GPU end-to-end parity on the reference's own tests/test.fa (config C1): preproc -> scan_motif ->
+visualize_kmers through kmap_amd must reproduce the files the reference wrote (tests/golden/scan_testfa*)."""
+import pickle
+import shutil
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+def _lines(p):
+    with open(p) as fh:
+        return fh.read().splitlines()
+
+
+@pytest.fixture(scope="module")
+def run_dir(tmp_path_factory):
+    from kmap_amd._toml import dump_toml, load_toml
+    from kmap_amd.kmer_count import _preproc
+    from kmap_amd.motif_discovery import _scan_motif
+    tmp = tmp_path_factory.mktemp("c1")
+    fa = tmp / "test.fa"
+    shutil.copyfile(GOLD / "test.fa", fa)
+    res = tmp / "res"
+    res.mkdir()
+    cfg = load_toml(GOLD / "scan_testfa" / "config.toml")          # the config the reference run used
+    cfg["general"]["input_fasta_file"] = str(fa)
+    cfg["general"]["res_dir"] = str(res)
+    dump_toml(cfg, res / "config.toml")
+    _preproc(str(fa), str(res))
+    np.random.seed(123)                                              # gen_golden.py seeds the same way
+    _scan_motif(str(res))
+    return res
+
+
+def test_preproc_arrays(run_dir, golden):
+    s = golden("scan_testfa.npz")
+    with open(run_dir / "input.bin.pkl", "rb") as fh:
+        seq = pickle.load(fh)
+    with open(run_dir / "input.seqboarder.bin.pkl", "rb") as fh:
+        borders = pickle.load(fh)
+    assert seq.dtype == np.uint8 and borders.dtype == s["borders"].dtype
+    np.testing.assert_array_equal(seq, s["seq"])
+    np.testing.assert_array_equal(borders, s["borders"])
+    assert _lines(run_dir / "motif_def_table.csv") == _lines(GOLD / "scan_testfa" / "motif_def_table.csv")
+
+
+@pytest.mark.parametrize("k", range(6, 13))
+def test_kmer_count_pickles(run_dir, golden, k):
+    s = golden("scan_testfa.npz")
+    with open(run_dir / "kmer_count" / f"k{k}.pkl", "rb") as fh:
+        kk, u, c = pickle.load(fh)
+    assert kk == k and u.dtype == s[f"k{k}_uniq"].dtype and c.dtype == s[f"k{k}_cnt"].dtype
+    np.testing.assert_array_equal(u, s[f"k{k}_uniq"])
+    np.testing.assert_array_equal(c, s[f"k{k}_cnt"])
+
+
+@pytest.mark.parametrize("name", ["candidate_conseq.csv", "final_conseq.txt", "final_conseq.info.csv",
+                                  "final.motif_occurence.csv", "sample_kmers.tsv"])
+def test_text_outputs_identical(run_dir, name):
+    assert _lines(run_dir / name) == _lines(GOLD / "scan_testfa" / name)
+
+
+@pytest.mark.parametrize("k", [8, 10])
+def test_per_k_occurrence_files(run_dir, k):
+    assert _lines(run_dir / "kmer_count" / f"k{k}.motif_occurence.csv") == _lines(GOLD / "scan_testfa" / f"k{k}.motif_occurence.csv")
+
+
+def test_readme_two_final_motifs(run_dir):
+    assert len(_lines(run_dir / "final_conseq.txt")) == 2          # reference README.md:105
+
+
+def test_sample_and_matrix_pickles(run_dir, golden):
+    s = golden("scan_testfa.npz")
+    with open(run_dir / "sample_kmers.pkl", "rb") as fh:
+        kh, cnts, lab, conseqs = pickle.load(fh)
+    np.testing.assert_array_equal(kh, s["samp_kh"])
+    np.testing.assert_array_equal(cnts, s["samp_cnts"])
+    np.testing.assert_array_equal(lab, s["samp_label"])
+    assert conseqs == [str(c) for c in s["samp_conseqs"]]
+    with open(run_dir / "sample_kmer_hamdist_mat.pkl", "rb") as fh:
+        klen, mat, labels = pickle.load(fh)
+    assert klen == int(s["hamdist_kmer_len"]) and mat.dtype == np.int64
+    np.testing.assert_array_equal(mat, s["hamdist_mat_u8"])
+    np.testing.assert_array_equal(labels, s["hamdist_label"])
+
+
+def test_find_motif_dropin_signature(run_dir, golden, motif_defs):
+    """find_motif with the reference's numpy-in signature (mutates its argument like the reference)."""
+    from kmap_amd.motif_discovery import find_motif
+    s, f = golden("scan_testfa.npz"), golden("find_motif_testfa.npz")
+    for k, rep in ((8, 0), (10, 0), (8, 1)):
+        d = motif_defs[k]
+        seq = s["seq"].copy()
+        r = find_motif(seq, k, d.max_ham_dist, d.p_uniform, d.ratio_mu, d.ratio_std, d.ratio_cutoff, top_k=5, n_trial=10,
+                       merge_revcom_mode=True, rep_mode=bool(rep), save_kmer_cnt_flag=False, kmer_cnt_pkl_file=None,
+                       boarder_pkl_file=run_dir / "input.seqboarder.bin.pkl")
+        tag = f"k{k}_rep{rep}"
+        assert [int(x) for x in r] == [int(x) for x in f[f"{tag}_kh"]]
+        np.testing.assert_allclose(np.array([list(v) for v in r.values()]).reshape(-1, 3), f[f"{tag}_vals"], rtol=1e-12)
+        if len(r):
+            assert not np.array_equal(seq, s["seq"])                # masked in place
+
+
+def test_occurrence_scan_vs_oracle_with_subsample(motif_defs):
+    """Low-complexity reads with > 20 hits at the minimum distance exercise the reference's random subsample
+    (np.random.choice order) -- compared with the oracle's restatement under the same seed."""
+    from kmap_amd.motif_discovery import DeviceSeq, gen_motif_occurence_file
+    from oracle import oracle as O
+    import tempfile
+    rng = np.random.default_rng(8)
+    reads = ["A" * 60, "ACGT" * 12, "".join(rng.choice(list("ACGT"), 80)), "AAAAAAAC" * 6, "ACG", "", "TTTTTTTTTTTTTTTTTTTTTTTTTTTTTT",
+             "".join(rng.choice(list("ACGTN"), 70))]
+    arrs = [O.dna2arr(r) for r in reads]
+    seq = np.concatenate(arrs)
+    lens = np.array([len(a) for a in arrs])
+    st = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    borders = np.stack([st, st + lens - 1], 1).astype(np.int64)
+    conseqs = ["AAAAAA", "ACGTACGT", "TTTTTTTTTTTT"]
+    r_of = {k: d.max_ham_dist for k, d in motif_defs.items()}
+    with tempfile.TemporaryDirectory() as td:
+        ds = DeviceSeq(seq, borders)
+        np.random.seed(77)
+        gen_motif_occurence_file(conseqs, motif_defs, None, Path(td) / "occ.csv", True, dev_seq=ds)
+        ds.close()
+        got = _lines(Path(td) / "occ.csv")
+    np.random.seed(77)
+    want = O.motif_occurence_lines(seq, borders, conseqs, r_of, True, np.random)
+    assert got == want
+
+
+def test_visualize_kmers_c1(run_dir, golden):
+    """visualize_kmers on the C1 result directory: low_dim_data.tsv equals the golden trace's best snapshot
+    printed with the reference's %3.3f format (the file contract is 1e-3 granular)."""
+    from kmap_amd._toml import dump_toml, load_toml
+    from kmap_amd.visualization import _visualize_kmers
+    u = golden("umap_n300.npz")
+    cfg = load_toml(run_dir / "config.toml")
+    assert cfg["visualization"]["random_seed"] == int(u["seed"]) and cfg["visualization"]["n_max_iter"] == int(u["n_iter"])
+    ld = _visualize_kmers(str(run_dir))
+    # np.argpartition on this host may pick other tie members than on the host that made the fixture, so the
+    # strict comparison is only made when the neighbour choice coincides
+    with open(run_dir / "sample_kmer_hamdist_mat.pkl", "rb") as fh:
+        _, mat, labels = pickle.load(fh)
+    rows = _lines(run_dir / "low_dim_data.tsv")
+    assert rows[0] == "x\ty\tlabel" and len(rows) == 301
+    assert [int(r.split("\t")[2]) for r in rows[1:]] == [int(x) for x in labels]
+    if np.array_equal(np.argpartition(mat, 20, axis=1)[:, :20], u["nb"]):
+        np.testing.assert_allclose(ld, u["final"], rtol=0, atol=1e-5)
+        want = [f"{x:3.3f}\t{y:3.3f}\t{int(l)}" for x, y, l in zip(u["final"][0], u["final"][1], labels)]
+        mism = sum(a != b for a, b in zip(rows[1:], want))
+        assert mism <= 3    # a coordinate within 1e-5 of a rounding boundary may print differently
