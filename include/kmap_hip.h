@@ -198,8 +198,9 @@ int kmap_embed_set_coords(kmap_embed *e, const float *coords_2xn, const float *p
 int kmap_embed_set_jitter(kmap_embed *e, const double *normals, int n_normals);
 /* external (e.g. torch-allocated) buffers for multi-GPU: grads of the local rows are written to
  * grad_dev (2 x N, local rows filled, rest 0) and loss partial to loss_dev (double[1]) by
- * `kmap_embed_forces` (entries of other rows are NOT touched: zero the buffer once); after the
- * all-reduce the caller runs `kmap_embed_apply`.  NULL pointers select the session's own buffers. */
+ * `kmap_embed_forces` (entries of other rows are NOT touched: zero the buffer before every call,
+ * an in-place all-reduce leaves the other ranks' rows behind); after the all-reduce the caller runs
+ * `kmap_embed_apply`.  NULL pointers select the session's own buffers. */
 int kmap_embed_forces(kmap_embed *e, float *grad_dev_2xn, double *loss_dev, void *stream);
 int kmap_embed_apply(kmap_embed *e, const float *grad_dev_2xn, const double *loss_dev, void *stream);
 /* single-GPU convenience: n_iter iterations of forces+apply on `stream` */

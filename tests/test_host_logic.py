@@ -1,0 +1,148 @@
+"""CPU tests of the host-side logic and of the C-ABI library surface (no GPU compute calls)."""
+import ctypes
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+GOLD = ROOT / "tests" / "golden"
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from kmap_amd import _ffi
+    if not _ffi.LIB_PATH.exists():
+        from kmap_amd.build import build
+        build()
+    return _ffi.LIB_PATH
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    """Every function declared in include/kmap_hip.h is exported by libkmap_hip.so and bound in _ffi."""
+    from kmap_amd import _ffi
+    header = (ROOT / "include" / "kmap_hip.h").read_text()
+    declared = set(re.findall(r"\b(kmap_[A-Za-z0-9_]+)\s*\(", header))
+    lib = ctypes.CDLL(str(built_lib))
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, f"declared but not exported: {missing}"
+    unbound = sorted(declared - set(_ffi.exported_symbols()))
+    assert not unbound, f"declared but not bound in _ffi: {unbound}"
+    assert set(_ffi.exported_symbols()) <= declared
+    _ffi.lib()
+    assert _ffi.lib().kmap_version() >= 1
+
+
+def test_no_fallback_when_library_missing(tmp_path, monkeypatch):
+    from kmap_amd import _ffi
+    monkeypatch.setattr(_ffi, "_lib", None)
+    monkeypatch.setattr(_ffi, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(_ffi.KmapError):
+        _ffi.lib()
+
+
+def test_product_never_imports_oracle():
+    for py in (ROOT / "kmap_amd").rglob("*.py"):
+        src = py.read_text()
+        if py.name == "visualization.py":
+            src = src.split("def smoke_embed")[0]           # the smoke check is the one sanctioned use
+        assert "oracle" not in src, f"{py} references the oracle"
+
+
+def test_dtype_rules_and_scalar_helpers(golden):
+    import kmap_amd.kmer_count as K
+    assert K.get_hash_dtype(15) == np.uint32 and K.get_hash_dtype(16) == np.uint64 and K.get_hash_dtype(31) == np.uint64
+    assert K.get_cnt_dtype(15) == np.int32 and K.get_cnt_dtype(16) == np.int64
+    with pytest.raises(Exception):
+        K.get_hash_dtype(32)
+    assert K.get_invalid_hash(np.uint32) == 0xFFFFFFFF
+    g = golden("ops.npz")
+    for s, h, rc in zip(g["kmer_strs"], g["kmer_hashes"], g["kmer_rc_hashes"]):
+        s = str(s)
+        assert int(K.kmer2hash(s)) == int(h) and K.hash2kmer(h, len(s)) == s
+        assert int(K.revcom_hash(h, len(s))) == int(rc)
+        assert K.hash2kmer(rc, len(s)) == K.reverse_complement(s)
+    assert K.arr2dna(K.dna2arr("ACGTNacgt")) == "ACGTNNNNNN"           # lower case is not mapped (callers upper-case)
+
+
+def test_fasta_encoding_matches_reference_arrays(golden, tmp_path):
+    import kmap_amd.kmer_count as K
+    s = golden("scan_testfa.npz")
+    arr, borders = K.encode_fasta(str(GOLD / "test.fa"))
+    np.testing.assert_array_equal(arr, s["seq"])
+    np.testing.assert_array_equal(borders, s["borders"])
+    # multi-line records, lower case, N, blank lines, gz
+    fa = tmp_path / "m.fa"
+    fa.write_text(">r1 desc\nacgt\nNNAC\n\n>r2\nTTTT\n>empty\n>r3\nAC GT\n")
+    a2, b2 = K.encode_fasta(str(fa))
+    assert K.arr2dna(a2) == "ACGTNNACN" + "TTTTN" + "N" + "ACGTN"
+    np.testing.assert_array_equal(b2, [[0, 8], [9, 13], [14, 14], [15, 19]])
+    import gzip
+    with gzip.open(tmp_path / "m.fa.gz", "wt") as fh:
+        fh.write(fa.read_text())
+    a3, b3 = K.encode_fasta(str(tmp_path / "m.fa.gz"))
+    np.testing.assert_array_equal(a2, a3)
+
+
+def test_merge_consensus_seqs_golden(golden):
+    from kmap_amd.motif_discovery import merge_consensus_seqs
+    g = golden("ops.npz")
+    assert merge_consensus_seqs([str(x) for x in g["mcs_in"]]) == [str(x) for x in g["mcs_out"]] == ["CGTACGT", "CTAGGGG"]
+    cands = [ln.split(",")[2] for ln in (GOLD / "scan_testfa" / "candidate_conseq.csv").read_text().splitlines()[1:]]
+    assert merge_consensus_seqs(cands) == (GOLD / "scan_testfa" / "final_conseq.txt").read_text().splitlines()
+    assert merge_consensus_seqs([]) == []
+
+
+def test_motif_def_table_and_config(golden, tmp_path):
+    import kmap_amd.kmer_count as K
+    from kmap_amd._toml import dump_toml, load_toml
+    cfg = K.read_default_config_file()
+    ref_cfg = load_toml(GOLD / "scan_testfa" / "config.toml")
+    for sec in ref_cfg:                                               # same sections and keys as the reference's config
+        assert set(ref_cfg[sec]) - {"input_fasta_file"} <= set(cfg[sec]) | {"input_fasta_file"}
+    assert cfg["kmer_count"] == {"min_k": 6, "max_k": 16, "revcom_mode": True}
+    assert cfg["visualization"]["n_max_iter"] == 2500 and cfg["motif_discovery"]["n_total_sample"] == 5000
+    dump_toml(cfg, tmp_path / "c.toml")
+    assert load_toml(tmp_path / "c.toml") == cfg
+    table = K.gen_motif_def_dict(cfg)
+    g = golden("ops.npz")
+    for k, cut in zip(g["mdef_k"], g["mdef_cutoff"]):
+        np.testing.assert_allclose(table[int(k)].ratio_cutoff, cut, rtol=1e-12, equal_nan=True)
+    assert table[8].max_ham_dist == 2 and table[14].max_ham_dist == 5
+
+
+def test_cli_verbs_and_options():
+    from click.testing import CliRunner
+    from kmap_amd.cli import cli
+    r = CliRunner().invoke(cli, ["--help"])
+    assert r.exit_code == 0
+    for verb in ("preproc", "scan_motif", "visualize_kmers"):
+        assert verb in r.output
+        h = CliRunner().invoke(cli, [verb, "--help"])
+        assert h.exit_code == 0 and "--res_dir" in h.output
+    assert "--fasta_file" in CliRunner().invoke(cli, ["preproc", "--help"]).output
+
+
+def test_row_partition():
+    from kmap_amd.distributed import row_partition
+    for n, w in ((10, 3), (50000, 8), (7, 8), (0, 2), (200000, 8)):
+        parts = [row_partition(n, w, r) for r in range(w)]
+        assert parts[0][0] == 0 and sum(p[1] for p in parts) == n
+        for (a0, an), (b0, _) in zip(parts, parts[1:]):
+            assert a0 + an == b0
+        assert max(p[1] for p in parts) - min(p[1] for p in parts) <= 1
+
+
+def test_lut_expression_matches_matrix_expression(golden):
+    """The LUT of all integer sums equals the reference's matrix expression evaluated entry-wise (same numpy)."""
+    from kmap_amd.visualization import hd_prob_lut, sigmoid
+    e = golden("embed_ops.npz")
+    k, n_nb = int(e["kmer_len"]), int(e["n_nb"])
+    S = e["S"]
+    T = sigmoid(S, 16.0, change_point=k / 2, scale_factor=0.2 * k - 0.2)
+    p_mat = np.exp(-T / 0.5).astype("float32")
+    sums = np.rint(S.astype(np.float64) * n_nb * n_nb).astype(np.int64)
+    np.testing.assert_array_equal(hd_prob_lut(k, n_nb, n_nb * n_nb * k)[sums], p_mat)
