@@ -167,6 +167,12 @@ int kmap_hamdist_matrix_u8(const uint64_t *kh, const int32_t *label, int64_t n, 
  * writes uint16 rows [row0,row0+nrows) with leading dimension lds. */
 int kmap_knn_sums_u8_dev(const uint8_t *D_dev, int64_t ldd, const int32_t *nb_dev, int64_t n, int n_nb,
                          int64_t row0, int64_t nrows, uint16_t *sums_dev, int64_t lds, void *stream);
+/* deterministic device k-NN selection for rows [row0,row0+nrows): the n_nb smallest entries of each row of D,
+ * ties broken by the lowest column index (self included, like the reference's argpartition over the full row).
+ * The reference uses np.argpartition (visualization.py:100) whose choice among ties is numpy/ISA specific; this
+ * rule is used where the int64 matrix is never materialised on the host (N > 16384).  nb_out: int32 [nrows, n_nb]. */
+int kmap_knn_select_u8_dev(const uint8_t *D_dev, int64_t ldd, int64_t n, int n_nb, int64_t row0, int64_t nrows,
+                           int32_t *nb_out_dev, void *stream);
 /* generic float form in the reference's summation order (any distance matrix) */
 int kmap_knn_smooth_f32(const float *D, const int32_t *nb, int64_t n, int n_nb, float *S_out);
 

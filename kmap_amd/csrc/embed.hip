@@ -105,6 +105,51 @@ __global__ __launch_bounds__(KNN_TPB) void knn_sums_kernel(const uint8_t *__rest
     }
 }
 
+// k-NN selection on uint8 rows: wave per row.  Pass 1 histograms the row's values (LDS, 256 bins per wave);
+// the threshold value t is where the cumulative count reaches n_nb; pass 2 walks the row in index order and
+// takes every entry < t plus the first (n_nb - count_lt) entries == t (ballot-ordered compaction).
+constexpr int SEL_WAVES = 4;
+__global__ __launch_bounds__(KMAP_WAVE *SEL_WAVES) void knn_select_kernel(const uint8_t *__restrict__ D, int64_t ldd,
+                                                                           int64_t n, int n_nb, int64_t row0, int64_t nrows,
+                                                                           int32_t *__restrict__ nb) {
+    __shared__ uint32_t hist[SEL_WAVES][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t lr = (int64_t)blockIdx.x * SEL_WAVES + wave;
+    if (lr >= nrows) return;
+    uint32_t *h = hist[wave];
+    for (int b = lane; b < 256; b += 64) h[b] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const uint8_t *row = D + (row0 + lr) * ldd;
+    for (int64_t j = lane; j < n; j += 64) atomicAdd(&h[row[j]], 1u);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    // threshold (every lane computes the same scalar walk)
+    uint32_t below = 0;
+    int t = 0;
+    for (; t < 256; ++t) {
+        const uint32_t c = h[t];
+        if (below + c >= (uint32_t)n_nb) break;
+        below += c;
+    }
+    uint32_t quota_eq = (uint32_t)n_nb - below;   // entries == t still to take (n >= n_nb guaranteed by the host)
+    uint32_t written = 0;
+    int32_t *out = nb + lr * n_nb;
+    for (int64_t j0 = 0; j0 < n && written < (uint32_t)n_nb; j0 += 64) {
+        const int64_t j = j0 + lane;
+        const int v = (j < n) ? (int)row[j] : 256;
+        const unsigned long long m_lt = __ballot(v < t);
+        const unsigned long long m_eq = __ballot(v == t);
+        const unsigned long long lanebit = 1ull << lane, lower = lanebit - 1ull;
+        const uint32_t n_lt = (uint32_t)__popcll(m_lt);
+        if (v < t) out[written + (uint32_t)__popcll(m_lt & lower)] = (int32_t)j;
+        const uint32_t rank_eq = (uint32_t)__popcll(m_eq & lower);
+        if (v == t && rank_eq < quota_eq) out[written + n_lt + rank_eq] = (int32_t)j;   // lt and eq slots interleave per chunk
+        const uint32_t take_eq = (uint32_t)__popcll(m_eq) < quota_eq ? (uint32_t)__popcll(m_eq) : quota_eq;
+        quota_eq -= take_eq;
+        written += n_lt + take_eq;
+    }
+}
+
 // generic float smoothing in the reference's summation order (taichi_core.py:227-249):
 // thread per (i,j), i<j: 400 gathers ii-outer/jj-inner, /n_nb twice; mirrored; diagonal 0
 __global__ __launch_bounds__(BLK) void knn_smooth_f32_kernel(const float *__restrict__ D, const int32_t *__restrict__ nb,
@@ -143,13 +188,14 @@ __device__ __forceinline__ float t_of(float p, float q) {
 }
 template <bool EXACT_LOG>
 __device__ __forceinline__ float ce_of(float p, float q) {
-    // taichi_core.py:279-303: eps = 1e-10 branches (q is already clipped to [1e-3, 1-1e-3])
+    // taichi_core.py:279-303: eps = 1e-10 branches (q is already clipped to [1e-3, 1-1e-3]); branch-free.
+    // !EXACT_LOG: v_log_f32 (log2, 1 ulp) * ln2 -- arguments lie in [1e-3, 0.999], no denormal handling needed.
     const float eps = 1e-10f;
-    const float lq = EXACT_LOG ? logf(q) : __logf(q);
-    const float l1q = EXACT_LOG ? logf(1.0f - q) : __logf(1.0f - q);
-    if (p < eps) return -l1q;
-    if (p > 1.0f - eps) return -lq;
-    return -p * lq - (1.0f - p) * l1q;
+    const float lq = EXACT_LOG ? logf(q) : __builtin_amdgcn_logf(q) * 0.69314718f;
+    const float l1q = EXACT_LOG ? logf(1.0f - q) : __builtin_amdgcn_logf(1.0f - q) * 0.69314718f;
+    const float full = -p * lq - (1.0f - p) * l1q;
+    const float hi = (p > 1.0f - eps) ? -lq : full;
+    return (p < eps) ? -l1q : hi;
 }
 
 // probability source: f32 rows, or u16 sums + LUT (LUT copy in LDS)
@@ -162,19 +208,52 @@ struct ProbSrc {
 };
 
 // =================================================================================================
-// FAST forces: a wave owns RPW rows at a time and sweeps the columns
+// FAST forces: a wave owns F_RPW rows at a time and sweeps the columns, 8 columns per lane per step.
+// Not bit-pinned (row sums are reduced wavefront-parallel), so the per-pair math uses v_rcp_f32 /
+// v_log_f32 and explicit FMAs: ~25 VALU + 4 transcendental issues per pair instead of ~96.
+//   q   = clamp(1/(1+d2)),  t = q/(1-q)*(p-q),  g += t*(y_i-y_j)
+//   ce  = -(p*ln q + (1-p)*ln(1-q)) = -ln2 * (log2(1-q) + p*(log2 q - log2(1-q)))   (eps branches of the
+//         reference change ce by < 1e-9 relative and are dropped here; SEQ mode keeps them)
+// The diagonal needs no predicate for the gradient (dx = dy = 0 -> t*0 = 0); the loss takes j > i only.
 // =================================================================================================
-constexpr int F_RPW = 4;          // rows per wave
-constexpr int F_WAVES = 4;        // waves per block
+constexpr int F_RPW = 2;          // rows per wave
+constexpr int F_WAVES = 8;        // waves per block
 constexpr int F_CPL = 8;          // columns per lane per step (16 B of u16 sums / 32 B of f32)
 constexpr int F_LUT_LDS = 12416;  // floats of LUT cached in LDS (n_nb^2*k+1 <= 400*31+1 = 12401)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool GUARD>
+__device__ __forceinline__ void fast_pairs(const float (&p)[F_CPL], const float (&xj)[F_CPL], const float (&yj)[F_CPL],
+                                           float xi, float yi, int64_t gi, int64_t j0, int64_t n, float &gx, float &gy,
+                                           float &ce2) {
+#pragma unroll
+    for (int c = 0; c < F_CPL; ++c) {
+        const float dx = xi - xj[c], dy = yi - yj[c];
+        const float s = 1.0f + __builtin_fmaf(dx, dx, dy * dy);
+        float q = __builtin_amdgcn_rcpf(s);
+        q = __builtin_fminf(__builtin_fmaxf(q, 0.001f), 0.999f);
+        const float omq = 1.0f - q;
+        float t = (q * __builtin_amdgcn_rcpf(omq)) * (p[c] - q);
+        const float lq = __builtin_amdgcn_logf(q), l1 = __builtin_amdgcn_logf(omq);   // log2
+        float e = __builtin_fmaf(p[c], lq - l1, l1);
+        const int64_t j = j0 + c;
+        if (GUARD) {
+            const bool in = j < n;
+            t = in ? t : 0.0f;
+            e = in ? e : 0.0f;
+        }
+        gx = __builtin_fmaf(t, dx, gx);
+        gy = __builtin_fmaf(t, dy, gy);
+        ce2 += (j > gi) ? e : 0.0f;
+    }
+}
 
 template <bool LUTSRC>
 __global__ __launch_bounds__(KMAP_WAVE *F_WAVES) void forces_fast_kernel(ProbSrc src, const float *__restrict__ Y,
                                                                           int64_t n, int64_t row0, int64_t nrows,
                                                                           float *__restrict__ G,
                                                                           double *__restrict__ loss_part) {
-    __shared__ float lut_s[LUTSRC ? F_LUT_LDS : 1];
+    extern __shared__ __attribute__((aligned(16))) float lut_s[];   // lut_len floats (dynamic: sized by the launch)
     __shared__ double wloss[F_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (LUTSRC) {
@@ -186,33 +265,40 @@ __global__ __launch_bounds__(KMAP_WAVE *F_WAVES) void forces_fast_kernel(ProbSrc
     const int64_t rbase = ((int64_t)blockIdx.x * F_WAVES + wave) * F_RPW;
     if (rbase < nrows) {
         float xi[F_RPW], yi[F_RPW], gx[F_RPW], gy[F_RPW];
-        int64_t gi[F_RPW];
+        int64_t gi[F_RPW], lrow[F_RPW];
 #pragma unroll
         for (int r = 0; r < F_RPW; ++r) {
-            const int64_t lr = (rbase + r < nrows) ? rbase + r : nrows - 1;   // clamp: duplicates are discarded below
-            gi[r] = row0 + lr;
+            lrow[r] = (rbase + r < nrows) ? rbase + r : nrows - 1;   // clamped duplicate rows are discarded below
+            gi[r] = row0 + lrow[r];
             xi[r] = X[gi[r]];
             yi[r] = Yy[gi[r]];
             gx[r] = gy[r] = 0.0f;
         }
-        float ce_acc = 0.0f;
-        for (int64_t j0 = (int64_t)lane * F_CPL; j0 < n; j0 += (int64_t)KMAP_WAVE * F_CPL) {
+        const bool vec_ok = (src.ld % 8 == 0) && (n % 4 == 0 || true);
+        float ce2 = 0.0f;   // log2 units, f32 partial flushed into f64 every 16 steps
+        int step = 0;
+        for (int64_t j0 = (int64_t)lane * F_CPL; j0 < n; j0 += (int64_t)KMAP_WAVE * F_CPL, ++step) {
+            const bool full = (j0 + F_CPL <= n);
             float xj[F_CPL], yj[F_CPL];
-            const bool fullc = (j0 + F_CPL <= n);
+            if (full && (n % 4 == 0)) {   // 16-byte aligned coordinate rows
+                const f32x4 a0 = *reinterpret_cast<const f32x4 *>(X + j0), a1 = *reinterpret_cast<const f32x4 *>(X + j0 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4 *>(Yy + j0), b1 = *reinterpret_cast<const f32x4 *>(Yy + j0 + 4);
+                xj[0] = a0.x; xj[1] = a0.y; xj[2] = a0.z; xj[3] = a0.w; xj[4] = a1.x; xj[5] = a1.y; xj[6] = a1.z; xj[7] = a1.w;
+                yj[0] = b0.x; yj[1] = b0.y; yj[2] = b0.z; yj[3] = b0.w; yj[4] = b1.x; yj[5] = b1.y; yj[6] = b1.z; yj[7] = b1.w;
+            } else {
 #pragma unroll
-            for (int c = 0; c < F_CPL; ++c) {
-                const int64_t j = fullc ? j0 + c : ((j0 + c < n) ? j0 + c : n - 1);
-                xj[c] = X[j];
-                yj[c] = Yy[j];
+                for (int c = 0; c < F_CPL; ++c) {
+                    const int64_t j = (j0 + c < n) ? j0 + c : n - 1;
+                    xj[c] = X[j];
+                    yj[c] = Yy[j];
+                }
             }
-            float ce_step = 0.0f;
 #pragma unroll
             for (int r = 0; r < F_RPW; ++r) {
-                const int64_t lr = (rbase + r < nrows) ? rbase + r : nrows - 1;
                 float p[F_CPL];
                 if (LUTSRC) {
-                    const uint16_t *row = src.ps + lr * src.ld + j0;
-                    if (fullc && (src.ld % 8 == 0)) {
+                    const uint16_t *row = src.ps + lrow[r] * src.ld + j0;
+                    if (full && vec_ok) {
                         const u32x4 w = *reinterpret_cast<const u32x4 *>(row);
                         const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
@@ -222,31 +308,22 @@ __global__ __launch_bounds__(KMAP_WAVE *F_WAVES) void forces_fast_kernel(ProbSrc
                         for (int c = 0; c < F_CPL; ++c) p[c] = (j0 + c < n) ? lut_s[row[c]] : 0.0f;
                     }
                 } else {
-                    const float *row = src.pf + lr * src.ld + j0;
+                    const float *row = src.pf + lrow[r] * src.ld + j0;
 #pragma unroll
                     for (int c = 0; c < F_CPL; ++c) p[c] = (j0 + c < n) ? row[c] : 0.0f;
                 }
-#pragma unroll
-                for (int c = 0; c < F_CPL; ++c) {
-                    const int64_t j = j0 + c;
-                    const float dx = xi[r] - xj[c], dy = yi[r] - yj[c];
-                    const float q = q_of(dx, dy);
-                    const float t = t_of(p[c], q);
-                    const bool live = (j < n) && (j != gi[r]);
-                    gx[r] += live ? t * dx : 0.0f;
-                    gy[r] += live ? t * dy : 0.0f;
-                    const float ce = ce_of<false>(p[c], q);
-                    ce_step += (live && j > gi[r] && (rbase + r < nrows)) ? ce : 0.0f;
-                }
+                float e = 0.0f;
+                if (full) fast_pairs<false>(p, xj, yj, xi[r], yi[r], gi[r], j0, n, gx[r], gy[r], e);
+                else fast_pairs<true>(p, xj, yj, xi[r], yi[r], gi[r], j0, n, gx[r], gy[r], e);
+                ce2 += (rbase + r < nrows) ? e : 0.0f;
             }
-            ce_acc += ce_step;
-            if ((j0 / ((int64_t)KMAP_WAVE * F_CPL)) % 16 == 15) {   // flush the f32 partial into f64 regularly
-                wave_loss += (double)ce_acc;
-                ce_acc = 0.0f;
+            if ((step & 15) == 15) {
+                wave_loss += (double)ce2;
+                ce2 = 0.0f;
             }
         }
-        wave_loss += (double)ce_acc;
-        // wave reduction of the 2*RPW row sums and the loss
+        wave_loss += (double)ce2;
+        wave_loss *= -0.6931471805599453;   // log2 -> -ln
 #pragma unroll
         for (int r = 0; r < F_RPW; ++r) {
             for (int o = 32; o > 0; o >>= 1) {
@@ -271,13 +348,14 @@ __global__ __launch_bounds__(KMAP_WAVE *F_WAVES) void forces_fast_kernel(ProbSrc
 
 // =================================================================================================
 // SEQ forces: one lane per row, j ascending -- the reference's summation order
-// (taichi_core.py:305-326: ret_val += diff[i,j] * (y[k,i] - y[k,j]), j != i)
+// (taichi_core.py:305-326: ret_val += diff[i,j] * (y[k,i] - y[k,j]), j != i).  IEEE f32, no FMA.
+// The 8 terms of a column group are evaluated independently (ILP), then added in order.
 // =================================================================================================
 template <bool LUTSRC>
 __global__ __launch_bounds__(KMAP_WAVE) void forces_seq_kernel(ProbSrc src, const float *__restrict__ Y, int64_t n,
                                                                int64_t row0, int64_t nrows, float *__restrict__ G,
                                                                double *__restrict__ loss_part) {
-    __shared__ float lut_s[LUTSRC ? F_LUT_LDS : 1];
+    extern __shared__ __attribute__((aligned(16))) float lut_s[];
     if (LUTSRC) {
         for (int t = threadIdx.x; t < src.lut_len && t < F_LUT_LDS; t += blockDim.x) lut_s[t] = src.lut[t];
         __syncthreads();
@@ -290,8 +368,65 @@ __global__ __launch_bounds__(KMAP_WAVE) void forces_seq_kernel(ProbSrc src, cons
     const float xi = X[i], yi = Yy[i];
     float gx = 0.0f, gy = 0.0f, ce_acc = 0.0f;
     double loss = 0.0;
-    for (int64_t j = 0; j < n; ++j) {
-        const float xj = X[j], yj = Yy[j];   // wave-uniform address -> scalar loads
+    constexpr int U = 8;
+    const bool vec_ok = LUTSRC && (src.ld % 8 == 0);
+    int64_t j0 = 0;
+    for (; j0 + U <= n; j0 += U) {
+        float p[U], tx[U], ty[U], ce[U];
+        if (LUTSRC) {
+            const uint16_t *row = src.ps + lrc * src.ld + j0;
+            if (vec_ok) {
+                const u32x4 w = *reinterpret_cast<const u32x4 *>(row);
+                const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int c = 0; c < U; ++c) p[c] = lut_s[(ws[c >> 1] >> (16 * (c & 1))) & 0xFFFFu];
+            } else {
+#pragma unroll
+                for (int c = 0; c < U; ++c) p[c] = lut_s[row[c]];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < U; ++c) p[c] = src.pf[lrc * src.ld + j0 + c];
+        }
+        float xs[U], ys[U];
+        if ((n & 3) == 0) {   // 16-byte aligned rows: wave-uniform vector loads -> s_load_dwordx4
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(X + j0), a1 = *reinterpret_cast<const f32x4 *>(X + j0 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(Yy + j0), b1 = *reinterpret_cast<const f32x4 *>(Yy + j0 + 4);
+            xs[0] = a0.x; xs[1] = a0.y; xs[2] = a0.z; xs[3] = a0.w; xs[4] = a1.x; xs[5] = a1.y; xs[6] = a1.z; xs[7] = a1.w;
+            ys[0] = b0.x; ys[1] = b0.y; ys[2] = b0.z; ys[3] = b0.w; ys[4] = b1.x; ys[5] = b1.y; ys[6] = b1.z; ys[7] = b1.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < U; ++c) {
+                xs[c] = X[j0 + c];
+                ys[c] = Yy[j0 + c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < U; ++c) {
+            const float xj = xs[c], yj = ys[c];
+            const float dx = xi - xj, dy = yi - yj;
+            const float q = q_of(dx, dy);
+            const float t = t_of(p[c], q);
+            tx[c] = t * dx;                                  // products rounded on their own (-ffp-contract=off)
+            ty[c] = t * dy;
+            ce[c] = ce_of<false>(p[c], q);
+        }
+#pragma unroll
+        for (int c = 0; c < U; ++c) {                        // ordered accumulation: j ascending
+            const int64_t j = j0 + c;
+            if (j != i) {
+                gx = gx + tx[c];
+                gy = gy + ty[c];
+                if (j > i) ce_acc += ce[c];
+            }
+        }
+        if ((j0 & 127) == 120) {
+            loss += (double)ce_acc;
+            ce_acc = 0.0f;
+        }
+    }
+    for (int64_t j = j0; j < n; ++j) {
+        const float xj = X[j], yj = Yy[j];
         float p;
         if (LUTSRC) p = lut_s[src.ps[lrc * src.ld + j]];
         else p = src.pf[lrc * src.ld + j];
@@ -299,13 +434,9 @@ __global__ __launch_bounds__(KMAP_WAVE) void forces_seq_kernel(ProbSrc src, cons
         const float q = q_of(dx, dy);
         const float t = t_of(p, q);
         if (j != i) {
-            gx = gx + t * dx;   // product rounded, then added (-ffp-contract=off)
+            gx = gx + t * dx;
             gy = gy + t * dy;
             if (j > i) ce_acc += ce_of<false>(p, q);
-        }
-        if ((j & 127) == 127) {
-            loss += (double)ce_acc;
-            ce_acc = 0.0f;
         }
     }
     loss += (double)ce_acc;
@@ -476,6 +607,18 @@ int kmap_knn_sums_u8_dev(const uint8_t *D_dev, int64_t ldd, const int32_t *nb_de
     return KMAP_OK;
 }
 
+int kmap_knn_select_u8_dev(const uint8_t *D_dev, int64_t ldd, int64_t n, int n_nb, int64_t row0, int64_t nrows,
+                           int32_t *nb_out_dev, void *stream) {
+    KMAP_REQUIRE(n >= 0 && nrows >= 0 && row0 >= 0 && row0 + nrows <= n && ldd >= n, "knn_select: bad sizes");
+    KMAP_REQUIRE(n_nb > 0 && n_nb <= n, "knn_select: n_nb=%d must be in [1, n]", n_nb);
+    if (nrows == 0) return KMAP_OK;
+    KMAP_REQUIRE(D_dev && nb_out_dev, "knn_select: null pointer");
+    knn_select_kernel<<<(unsigned)((nrows + SEL_WAVES - 1) / SEL_WAVES), KMAP_WAVE * SEL_WAVES, 0, as_stream(stream)>>>(
+        D_dev, ldd, n, n_nb, row0, nrows, nb_out_dev);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+
 int kmap_knn_smooth_f32(const float *D, const int32_t *nb, int64_t n, int n_nb, float *S_out) {
     KMAP_REQUIRE(n >= 0 && n_nb > 0, "knn_smooth_f32: bad sizes");
     if (n == 0) return KMAP_OK;
@@ -595,12 +738,13 @@ int kmap_embed_forces(kmap_embed *e, float *grad_dev_2xn, double *loss_dev, void
         return KMAP_OK;
     }
     const bool lut = e->src.ps != nullptr;
+    const size_t lds = lut ? (((size_t)e->src.lut_len * 4 + 15) & ~(size_t)15) : 16;
     if (e->mode == KMAP_EMBED_SEQ) {
-        if (lut) forces_seq_kernel<true><<<nblk, KMAP_WAVE, 0, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
-        else forces_seq_kernel<false><<<nblk, KMAP_WAVE, 0, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
+        if (lut) forces_seq_kernel<true><<<nblk, KMAP_WAVE, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
+        else forces_seq_kernel<false><<<nblk, KMAP_WAVE, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
     } else {
-        if (lut) forces_fast_kernel<true><<<nblk, KMAP_WAVE * F_WAVES, 0, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
-        else forces_fast_kernel<false><<<nblk, KMAP_WAVE * F_WAVES, 0, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
+        if (lut) forces_fast_kernel<true><<<nblk, KMAP_WAVE * F_WAVES, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
+        else forces_fast_kernel<false><<<nblk, KMAP_WAVE * F_WAVES, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
     }
     reduce_loss_kernel<<<1, 1024, 0, st>>>(e->loss_part, nblk, L);
     KMAP_CHECK_HIP(hipGetLastError());

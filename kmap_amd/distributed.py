@@ -69,15 +69,21 @@ def kmap_from_kmers_distributed(samp_kh, samp_cnts, samp_label, conseq_list, kme
     # full D on every GPU (N^2 bytes; 40 GB at N = 200 k fits the 288 GB part): neighbour rows are arbitrary
     D_d = _ffi.DeviceBuffer(n * ldd)
     hamdist_matrix_dev(kh_d.ptr, lab_d.ptr, n, kmer_len, lens, D_d.ptr, ldd)
-    # neighbour choice for the local rows on the host (numpy argpartition, drop-in), then all-gather
-    rows = np.empty((max(nrows, 1), n), np.uint8)
-    if nrows:
-        check(_ffi.lib().kmap_memcpy2d_d2h(ptr(rows), n, D_d.ptr + row0 * ldd, ldd, n, nrows, None))
-    nb_local = np.argpartition(rows[:nrows].astype(np.int64), n_neighbour, axis=1)[:, :n_neighbour].astype(np.int32)
-    parts = [None] * world
-    dist.all_gather_object(parts, nb_local)
-    nb = np.concatenate(parts)
+    if vz.knn_mode(n) == "device":
+        # every rank selects all rows on its own GPU (N x 20 ints; cheaper than gathering them)
+        nb = vz.knn_select_dev(D_d.ptr, ldd, n, n_neighbour)
+    else:
+        # drop-in neighbour choice for the local rows on the host (numpy argpartition), then all-gather
+        rows = np.empty((max(nrows, 1), n), np.uint8)
+        if nrows:
+            check(_ffi.lib().kmap_memcpy2d_d2h(ptr(rows), n, D_d.ptr + row0 * ldd, ldd, n, nrows, None))
+        nb_local = np.argpartition(rows[:nrows].astype(np.int64), n_neighbour, axis=1)[:, :n_neighbour].astype(np.int32)
+        parts = [None] * world
+        dist.all_gather_object(parts, nb_local)
+        nb = np.concatenate(parts)
     sums_d, lds = vz.knn_sums_dev(D_d.ptr, ldd, nb, n, n_neighbour, row0=row0, nrows=nrows)
+    if isinstance(nb, _ffi.DeviceBuffer):
+        nb.free()
     for b in (D_d, kh_d, lab_d):
         b.free()
     lut = vz.hd_prob_lut(kmer_len, n_neighbour, n_neighbour * n_neighbour * kmer_len)

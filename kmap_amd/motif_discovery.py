@@ -28,6 +28,22 @@ from .kmer_count import (DeviceCounts, FileNameDict, cal_hamming_dist_head, cal_
 # hand-off [kmer_len, None, label_arr] and visualize_kmers recomputes the matrix on the device
 DENSE_PKL_MAX_N = 16384
 
+STAGE_TIMES = {}   # cumulative wall-clock per stage of the last runs (tools/e2e.py, bench.py report it)
+
+
+class _stage:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        import time
+        self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        import time
+        _ffi.sync()
+        STAGE_TIMES[self.name] = STAGE_TIMES.get(self.name, 0.0) + time.perf_counter() - self.t0
+
 
 def write_lines(str_list: List, outfile):
     with open(outfile, "w+") as fh:
@@ -328,15 +344,17 @@ def _scan_motif(res_dir: str, debug=False):
     revcom_mode = config_dict["kmer_count"]["revcom_mode"]
     rep_mode = config_dict["general"]["repetitive_mode"]
 
-    with open(proc_fasta_file_path, "rb") as fh:
-        seq_np_arr = pickle.load(fh)
-    boarder_pkl_file = res / FileNameDict["processed_fasta_seqboarder_file"]
-    with open(boarder_pkl_file, "rb") as fh:
-        boarder_mat = pickle.load(fh)
+    with _stage("load_inputs"):
+        with open(proc_fasta_file_path, "rb") as fh:
+            seq_np_arr = pickle.load(fh)
+        boarder_pkl_file = res / FileNameDict["processed_fasta_seqboarder_file"]
+        with open(boarder_pkl_file, "rb") as fh:
+            boarder_mat = pickle.load(fh)
     n_all_seq = len(boarder_mat)
 
     # the occurrence scans read the ORIGINAL reads (the reference re-parses the FASTA for them)
-    scan_seq = DeviceSeq(seq_np_arr, boarder_mat)
+    with _stage("upload"):
+        scan_seq = DeviceSeq(seq_np_arr, boarder_mat)
     if md["noise_kmer_file"] != "None":
         assert Path(md["noise_kmer_file"]).exists()
         with open(Path(md["noise_kmer_file"]), "r") as fh:
@@ -365,16 +383,18 @@ def _scan_motif(res_dir: str, debug=False):
             count_seq.reset()
             d = motif_def_dict[kmer_len]
             kmer_cnt_file = res / FileNameDict["kmer_count_dir"] / f"k{kmer_len}.pkl"
-            consensus_kh_dict = find_motif(None, kmer_len, d.max_ham_dist, d.p_uniform, d.ratio_mu, d.ratio_std,
-                                           d.ratio_cutoff, top_k, n_trial, revcom_mode, rep_mode,
-                                           save_kmer_cnt_flag=save_kmer_cnt_flag, kmer_cnt_pkl_file=kmer_cnt_file,
-                                           boarder_pkl_file=boarder_pkl_file, debug=debug, dev_seq=count_seq)
+            with _stage("find_motif"):
+                consensus_kh_dict = find_motif(None, kmer_len, d.max_ham_dist, d.p_uniform, d.ratio_mu, d.ratio_std,
+                                               d.ratio_cutoff, top_k, n_trial, revcom_mode, rep_mode,
+                                               save_kmer_cnt_flag=save_kmer_cnt_flag, kmer_cnt_pkl_file=kmer_cnt_file,
+                                               boarder_pkl_file=boarder_pkl_file, debug=debug, dev_seq=count_seq)
             tmp_list = [hash2kmer(kh, kmer_len) for kh in consensus_kh_dict]
             per = None
             if occ_flag:
                 occ_file = res / FileNameDict["kmer_count_dir"] / f"k{kmer_len}.motif_occurence.csv"
-                per = gen_motif_occurence_file(tmp_list, motif_def_dict, input_fasta_file, occ_file, revcom_mode,
-                                               dev_seq=scan_seq)
+                with _stage("occurrence_per_k"):
+                    per = gen_motif_occurence_file(tmp_list, motif_def_dict, input_fasta_file, occ_file, revcom_mode,
+                                                   dev_seq=scan_seq)
             for i, kmer_seq in enumerate(tmp_list):
                 kh = kmer2hash(kmer_seq)
                 prop, ratio, log10_p = consensus_kh_dict[get_hash_dtype(kmer_len)(kh)]
@@ -421,8 +441,9 @@ def _scan_motif(res_dir: str, debug=False):
         print("Final consensus sequences generated.")
 
     occurence_file = res / FileNameDict["motif_occurence_file"]
-    gen_motif_occurence_file(final_conseq_list, motif_def_dict, input_fasta_file, occurence_file, revcom_mode,
-                             dev_seq=scan_seq)
+    with _stage("occurrence_final"):
+        gen_motif_occurence_file(final_conseq_list, motif_def_dict, input_fasta_file, occurence_file, revcom_mode,
+                                 dev_seq=scan_seq)
 
     for flag in ("motif_pos_density_flag", "motif_co_occurence_flag", "gen_hamball_flag"):
         if md.get(flag):
@@ -436,9 +457,10 @@ def _scan_motif(res_dir: str, debug=False):
     elif md["sample_kmer_flag"] and save_kmer_cnt_flag:
         n_total_sample, n_motif_sample = md["n_total_sample"], md["n_motif_sample"]
         kmer_len = max([len(conseq) for conseq in final_conseq_list])   # ValueError if no motif, like the reference
-        samp_kh_arr, samp_cnts, samp_label_arr, conseq_list = sample_disp_kmer(
-            final_conseq_list, kmer_len, motif_def_dict, kmer_count_dir=res / FileNameDict["kmer_count_dir"],
-            n_total_sample=n_total_sample, n_motif_kmer=n_motif_sample, revcom_mode=revcom_mode)
+        with _stage("sample_kmers"):
+            samp_kh_arr, samp_cnts, samp_label_arr, conseq_list = sample_disp_kmer(
+                final_conseq_list, kmer_len, motif_def_dict, kmer_count_dir=res / FileNameDict["kmer_count_dir"],
+                n_total_sample=n_total_sample, n_motif_kmer=n_motif_sample, revcom_mode=revcom_mode)
         with open(sample_kmer_pkl_file, "wb") as fh:
             pickle.dump([samp_kh_arr, samp_cnts, samp_label_arr, conseq_list], fh)
         kmers = np.array([hash2kmer(kh, kmer_len) for kh in samp_kh_arr])
@@ -449,13 +471,15 @@ def _scan_motif(res_dir: str, debug=False):
 
         label_arr = _convert_to_block_arr(samp_label_arr, samp_cnts)
         if len(label_arr) <= DENSE_PKL_MAX_N:
-            hamdist_mat = cal_samp_kmer_hamdist_mat(samp_kh_arr, samp_cnts, samp_label_arr, conseq_list, kmer_len,
-                                                    uniq_dist_flag=False)
+            with _stage("hamdist_matrix_int64"):
+                hamdist_mat = cal_samp_kmer_hamdist_mat(samp_kh_arr, samp_cnts, samp_label_arr, conseq_list, kmer_len,
+                                                        uniq_dist_flag=False)
         else:
             hamdist_mat = None   # compact hand-off; visualize_kmers recomputes the matrix on the device
             print(f"N={len(label_arr)} > {DENSE_PKL_MAX_N}: int64 matrix not materialised (compact hand-off).")
-        with open(res / FileNameDict["sample_kmer_hamdist_mat_file"], "wb") as fh:
-            pickle.dump([kmer_len, hamdist_mat, label_arr], fh)
+        with _stage("write_hamdist_pkl"):
+            with open(res / FileNameDict["sample_kmer_hamdist_mat_file"], "wb") as fh:
+                pickle.dump([kmer_len, hamdist_mat, label_arr], fh)
         print("Hamming distance matrix of sampled kmers are generated.")
 
     if count_seq is not scan_seq:

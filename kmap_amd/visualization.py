@@ -28,6 +28,43 @@ def default_mode():
     return EMBED_FAST if os.environ.get("KMAP_EMBED_MODE", "seq").lower() == "fast" else EMBED_SEQ
 
 
+STAGE_TIMES = {}          # cumulative wall-clock per stage (tools/e2e.py, bench.py report it)
+
+
+class _stage:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        import time
+        self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        import time
+        _ffi.sync()
+        STAGE_TIMES[self.name] = STAGE_TIMES.get(self.name, 0.0) + time.perf_counter() - self.t0
+
+
+def knn_mode(n):
+    """'numpy' (the reference's np.argpartition on int64 rows: drop-in, tie order numpy/ISA specific) up to the size where
+    scan_motif still writes the int64 matrix; 'device' (smallest distance, then lowest index) above it, where the
+    reference cannot run and 2.5e9+ int64 entries would have to be streamed through the host.  KMAP_KNN overrides."""
+    import os
+    from .motif_discovery import DENSE_PKL_MAX_N
+    forced = os.environ.get("KMAP_KNN", "").lower()
+    if forced in ("numpy", "device"):
+        return forced
+    return "numpy" if n <= DENSE_PKL_MAX_N else "device"
+
+
+def knn_select_dev(D_dev_ptr, ldd, n, n_nb, row0=0, nrows=None, stream=None):
+    """Device k-NN selection -> (DeviceBuffer int32 [nrows, n_nb])."""
+    nrows = n - row0 if nrows is None else nrows
+    nb_d = _ffi.DeviceBuffer(max(nrows, 1) * n_nb * 4)
+    check(_ffi.lib().kmap_knn_select_u8_dev(D_dev_ptr, ldd, n, n_nb, row0, nrows, nb_d.ptr, stream))
+    return nb_d
+
+
 _LUT_CAP = 12416          # floats of LUT the force kernels cache in LDS (embed.hip F_LUT_LDS)
 _JITTER_CHUNK = 4096      # normals pre-drawn per refill
 _SEGMENT = 256            # iterations between host polls of the device loop state
@@ -50,11 +87,13 @@ def knn_sums_dev(D_dev_ptr, ldd, nb, n, n_nb, row0=0, nrows=None, stream=None):
     """Device: integer neighbour sums of rows [row0,row0+nrows) -> DeviceBuffer of uint16 [nrows x lds]."""
     nrows = n - row0 if nrows is None else nrows
     lds = (n + 127) & ~127
-    nb_d = _ffi.DeviceBuffer.from_numpy(np.ascontiguousarray(nb, np.int32))
+    own = not isinstance(nb, _ffi.DeviceBuffer)
+    nb_d = _ffi.DeviceBuffer.from_numpy(np.ascontiguousarray(nb, np.int32)) if own else nb
     sums_d = _ffi.DeviceBuffer(max(nrows, 1) * lds * 2)
     check(_ffi.lib().kmap_knn_sums_u8_dev(D_dev_ptr, ldd, nb_d.ptr, n, n_nb, row0, nrows, sums_d.ptr, lds, stream))
     _ffi.sync(stream)
-    nb_d.free()
+    if own:
+        nb_d.free()
     return sums_d, lds
 
 
@@ -317,20 +356,27 @@ def kmap_from_kmers(samp_kh, samp_cnts, samp_label, conseq_list, kmer_len, n_nei
     n = len(kh)
     lens = [len(c) for c in conseq_list]
     ldd = pitch_for(n)
-    kh_d, lab_d = _ffi.DeviceBuffer.from_numpy(kh), _ffi.DeviceBuffer.from_numpy(lab)
-    D_d = _ffi.DeviceBuffer(n * ldd)
-    hamdist_matrix_dev(kh_d.ptr, lab_d.ptr, n, kmer_len, lens, D_d.ptr, ldd)
-    if neighbor_inds_mat is None:
-        # drop-in neighbour choice: numpy argpartition on int64 rows, streamed back in row blocks
-        nbs = []
-        blk = max(1, min(n, (64 << 20) // max(n, 1)))
-        for r0 in range(0, n, blk):
-            r1 = min(n, r0 + blk)
-            rows = np.empty((r1 - r0, n), np.uint8)
-            check(_ffi.lib().kmap_memcpy2d_d2h(ptr(rows), n, D_d.ptr + r0 * ldd, ldd, n, r1 - r0, None))
-            nbs.append(np.argpartition(rows.astype(np.int64), n_neighbour, axis=1)[:, :n_neighbour])
-        neighbor_inds_mat = np.concatenate(nbs)
-    sums_d, lds = knn_sums_dev(D_d.ptr, ldd, neighbor_inds_mat, n, n_neighbour)
+    with _stage("hamdist_matrix"):
+        kh_d, lab_d = _ffi.DeviceBuffer.from_numpy(kh), _ffi.DeviceBuffer.from_numpy(lab)
+        D_d = _ffi.DeviceBuffer(n * ldd)
+        hamdist_matrix_dev(kh_d.ptr, lab_d.ptr, n, kmer_len, lens, D_d.ptr, ldd)
+    with _stage("knn_select"):
+        if neighbor_inds_mat is None and knn_mode(n) == "device":
+            neighbor_inds_mat = knn_select_dev(D_d.ptr, ldd, n, n_neighbour)
+        elif neighbor_inds_mat is None:
+            # drop-in neighbour choice: numpy argpartition on int64 rows, streamed back in row blocks
+            nbs = []
+            blk = max(1, min(n, (64 << 20) // max(n, 1)))
+            for r0 in range(0, n, blk):
+                r1 = min(n, r0 + blk)
+                rows = np.empty((r1 - r0, n), np.uint8)
+                check(_ffi.lib().kmap_memcpy2d_d2h(ptr(rows), n, D_d.ptr + r0 * ldd, ldd, n, r1 - r0, None))
+                nbs.append(np.argpartition(rows.astype(np.int64), n_neighbour, axis=1)[:, :n_neighbour])
+            neighbor_inds_mat = np.concatenate(nbs)
+    with _stage("knn_sums"):
+        sums_d, lds = knn_sums_dev(D_d.ptr, ldd, neighbor_inds_mat, n, n_neighbour)
+    if isinstance(neighbor_inds_mat, _ffi.DeviceBuffer):
+        neighbor_inds_mat.free()
     for b in (D_d, kh_d, lab_d):
         b.free()
     lut = hd_prob_lut(kmer_len, n_neighbour, n_neighbour * n_neighbour * kmer_len)
@@ -339,7 +385,8 @@ def kmap_from_kmers(samp_kh, samp_cnts, samp_label, conseq_list, kmer_len, n_nei
     try:
         sess.set_prob_lut(sums_d, lds, lut)
         sess.set_coords(ld_data, placeholders)
-        _run_loop(sess, n_max_iter, debug=debug, trace=trace)
+        with _stage("embed_loop"):
+            _run_loop(sess, n_max_iter, debug=debug, trace=trace)
         return sess.best(), lab
     finally:
         sess.close()

@@ -60,6 +60,28 @@ def test_knn_sums_chunked_rows_vs_oracle(V):
     np.testing.assert_array_equal(got, want)
 
 
+def test_device_knn_selection_vs_oracle_rule(V):
+    """Device k-NN selection (smallest distance, then lowest index) == stable argsort, as sets per row."""
+    from oracle import oracle as O
+    from kmap_amd import _ffi
+    from kmap_amd.hamdist import pitch_for
+    rng = np.random.default_rng(17)
+    for n, k, n_nb in ((65, 8, 20), (1000, 8, 20), (3001, 14, 7), (200, 31, 200)):
+        kh = rng.integers(0, 4 ** k, size=n, dtype=np.uint64)
+        kh[:: 7] = kh[0]                                   # duplicates: distance-0 ties beyond the diagonal
+        D = O.hamdist_matrix_u8(kh, np.zeros(n, np.int32), k, [k])
+        ldd = pitch_for(n)
+        Dp = np.zeros((n, ldd), np.uint8)
+        Dp[:, :n] = D
+        D_d = _ffi.DeviceBuffer.from_numpy(Dp)
+        r0, nr = (n // 3, n - n // 3) if n > 100 else (0, n)
+        nb_d = V.knn_select_dev(D_d.ptr, ldd, n, n_nb, row0=r0, nrows=nr)
+        _ffi.sync()
+        got = np.sort(nb_d.to_numpy(np.int32, (nr, n_nb)), axis=1)
+        want = np.sort(O.knn_select_stable(D, n_nb)[r0:r0 + nr], axis=1)
+        np.testing.assert_array_equal(got, want)
+
+
 def test_lut_matches_golden_hd_prob(V, golden):
     e = golden("embed_ops.npz")
     k, n_nb = int(e["kmer_len"]), int(e["n_nb"])
