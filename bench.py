@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e", default="C3", choices=["none", "C2", "C3"],
+                    help="also time scan_motif + visualize_kmers end to end on this synthetic config (rank 0, N=1 only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -158,6 +160,18 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(kh, lab)
+        if world == 1 and args.e2e != "none":
+            # the other half of BASELINE.json's metric: end-to-end wall time on a clean res_dir (synthetic reads are
+            # generated and written outside the timed stages; scan_motif loads them from the pickles like the reference)
+            from kmap_amd.e2e import run_e2e
+            del out_d
+            line["e2e"] = {}
+            for mode in ("fast", "seq"):
+                r = run_e2e(args.e2e, mode)
+                line["e2e"][mode] = {"scan_motif_s": r["times"]["scan_motif_s"], "visualize_kmers_s": r["times"]["visualize_kmers_s"],
+                                     "e2e_s": r["times"]["e2e_s"], "final_conseq": r["final_conseq"], "stages": r["stages"]}
+            line["e2e"]["workload"] = (f"{args.e2e}: {r['n_reads']} x {r['read_len']} bp synthetic reads, k={r['k_range'][0]}..{r['k_range'][1]}, "
+                                       f"N={r['n_total']} sampled k-mers, {r['iters']} iterations, 1 GPU; seq = reference summation order, fast = wavefront sums")
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -31,6 +31,41 @@ __global__ __launch_bounds__(BLK) void hist_kernel(const H *__restrict__ h, int6
     }
 }
 
+// LDS-privatised histogram for small tables: a block owns HL_BINS consecutive bins of the pass's range in LDS,
+// streams the whole hash array (grid-stride, 16-byte loads) and counts only hashes of that range with LDS atomics;
+// one flush of the non-zero LDS bins per block at the end.  4^k / HL_BINS passes re-read the hash array (4 B per
+// position per pass), which beats ~20 G scattered device-scope atomics per second up to ~8 passes (k <= 9).
+constexpr int HL_BINS = 32768;      // 128 KiB of uint32 per block (one block per CU)
+constexpr int HL_TPB = 1024;
+__global__ __launch_bounds__(HL_TPB) void hist_lds_kernel(const uint32_t *__restrict__ h, int64_t n, uint32_t bin0,
+                                                          uint32_t *__restrict__ bins) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lb[];
+    for (int b = threadIdx.x; b < HL_BINS; b += HL_TPB) lb[b] = 0;
+    __syncthreads();
+    typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+    const int64_t n4 = n / 4;
+    const int64_t stride = (int64_t)gridDim.x * HL_TPB;
+    const u32x4v *h4 = reinterpret_cast<const u32x4v *>(h);
+    for (int64_t i = (int64_t)blockIdx.x * HL_TPB + threadIdx.x; i < n4; i += stride) {
+        const u32x4v v = h4[i];
+        const uint32_t a = v.x - bin0, b = v.y - bin0, c = v.z - bin0, d = v.w - bin0;   // invalid (all ones) never lands in range
+        if (a < (uint32_t)HL_BINS) atomicAdd(&lb[a], 1u);
+        if (b < (uint32_t)HL_BINS) atomicAdd(&lb[b], 1u);
+        if (c < (uint32_t)HL_BINS) atomicAdd(&lb[c], 1u);
+        if (d < (uint32_t)HL_BINS) atomicAdd(&lb[d], 1u);
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += HL_TPB) {
+            const uint32_t a = h[i] - bin0;
+            if (a < (uint32_t)HL_BINS) atomicAdd(&lb[a], 1u);
+        }
+    __syncthreads();
+    for (int b = threadIdx.x; b < HL_BINS; b += HL_TPB) {
+        const uint32_t c = lb[b];
+        if (c) atomicAdd(&bins[bin0 + b], c);
+    }
+}
+
 // ---- order-preserving compaction with optional revcom merge ------------------------------------
 constexpr int CT_PER_THREAD = 8;
 constexpr int CT_TILE = BLK * CT_PER_THREAD;   // bins per block
@@ -214,9 +249,22 @@ int run_hashes(kmap_counts *c, const H *hash_dev, int64_t n, int k, int merge, i
     KMAP_TRY(ensure_bins(c, n_bins));
     KMAP_CHECK_HIP(hipMemsetAsync(c->bins, 0, n_bins * 4, st));
     if (n > 0) {
-        int64_t g = (n + BLK - 1) / BLK;
-        if (g > 256 * 32) g = 256 * 32;
-        hist_kernel<H><<<(unsigned)g, BLK, 0, st>>>(hash_dev, n, c->bins);
+        const size_t passes = (n_bins + HL_BINS - 1) / HL_BINS;
+        if (sizeof(H) == 4 && passes <= 8 && n >= (1 << 20) && ((uintptr_t)hash_dev % 16) == 0) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)hist_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   HL_BINS * 4));
+                attr_set = true;
+            }
+            for (size_t p = 0; p < passes; ++p)
+                hist_lds_kernel<<<256, HL_TPB, HL_BINS * 4, st>>>((const uint32_t *)hash_dev, n, (uint32_t)(p * HL_BINS),
+                                                                 c->bins);
+        } else {
+            int64_t g = (n + BLK - 1) / BLK;
+            if (g > 256 * 32) g = 256 * 32;
+            hist_kernel<H><<<(unsigned)g, BLK, 0, st>>>(hash_dev, n, c->bins);
+        }
     }
     const unsigned nb = grid_for((int64_t)n_bins, CT_TILE);
     uint32_t *bc = nullptr;
@@ -224,7 +272,7 @@ int run_hashes(kmap_counts *c, const H *hash_dev, int64_t n, int k, int merge, i
     KMAP_TRY(kmap_scratch((void **)&bc, (size_t)nb * 4, st, KMAP_SLOT_A));
     KMAP_TRY(kmap_scratch((void **)&boff, ((size_t)nb + 1) * 8, st, KMAP_SLOT_B));
     compact_count_kernel<<<nb, BLK, 0, st>>>(c->bins, n_bins, k, merge, bc);
-    scan_single_block_kernel<<<1, 1024, 0, st>>>(bc, nb, boff, boff + nb);
+    KMAP_TRY(exclusive_scan_u32(bc, nb, boff, st));
     uint64_t total = 0;
     KMAP_CHECK_HIP(hipMemcpyAsync(&total, boff + nb, 8, hipMemcpyDeviceToHost, st));
     KMAP_CHECK_HIP(hipStreamSynchronize(st));

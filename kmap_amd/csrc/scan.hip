@@ -148,8 +148,7 @@ int kmap_scan_run_dev(kmap_scan *s, const uint8_t *seq_dev, int64_t n, const int
     const unsigned grid = (unsigned)((n_seq + SC_WAVES - 1) / SC_WAVES);
     scan_kernel<false><<<grid, KMAP_WAVE * SC_WAVES, 0, st>>>(seq_dev, n, borders_dev, n_seq, k, c, rcc, radius, revcom,
                                                               s->hits, s->mind, nullptr, nullptr);
-    scan_single_block_kernel<<<1, 1024, 0, st>>>(reinterpret_cast<const uint32_t *>(s->hits), n_seq, s->offs,
-                                                 s->offs + n_seq);
+    KMAP_TRY(exclusive_scan_u32(reinterpret_cast<const uint32_t *>(s->hits), n_seq, s->offs, st));
     uint64_t total = 0;
     KMAP_CHECK_HIP(hipMemcpyAsync(&total, s->offs + n_seq, 8, hipMemcpyDeviceToHost, st));
     KMAP_CHECK_HIP(hipStreamSynchronize(st));

@@ -1,0 +1,65 @@
+"""End-to-end `scan_motif` + `visualize_kmers` on seeded synthetic reads (BASELINE configs), with per-stage timers.
+Used by tools/e2e.py and by bench.py's `e2e` leg.  Plot-only flags are off (BASELINE.md prescribes that for both
+sides); k range 6..9 so that the longest final consensus is an 8-mer (the configs' "k = 8");
+np.random.seed(123) before scan_motif; visualization.random_seed = 7."""
+import os
+import shutil
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+CONFIGS = {
+    "C1s": dict(n_reads=2000, read_len=60, seed=9, n_total=300, n_motif=150, iters=100),
+    "C2": dict(n_reads=100_000, read_len=150, seed=1, n_total=5000, n_motif=2500, iters=2500),
+    "C3": dict(n_reads=10_000_000, read_len=150, seed=2, n_total=50_000, n_motif=25_000, iters=2500),
+}
+
+
+def run_e2e(config="C2", mode="seq", min_k=6, max_k=9, iters=None, keep=False, quiet=True):
+    import contextlib
+    import io
+    from . import motif_discovery as md, synth, visualization as vz
+    c = CONFIGS[config]
+    prev_mode = os.environ.get("KMAP_EMBED_MODE")
+    os.environ["KMAP_EMBED_MODE"] = mode
+    md.STAGE_TIMES.clear()
+    vz.STAGE_TIMES.clear()
+    t = {}
+    t0 = time.perf_counter()
+    seq, borders = synth.synth_reads(c["n_reads"], c["read_len"], c["seed"])
+    t["synth_s"] = time.perf_counter() - t0
+    res = Path(tempfile.mkdtemp(prefix=f"kmap_{config}_"))
+    over = {"kmer_count": {"min_k": min_k, "max_k": max_k},
+            "motif_discovery": {"motif_pos_density_flag": False, "motif_co_occurence_flag": False, "gen_hamball_flag": False,
+                                "n_total_sample": c["n_total"], "n_motif_sample": c["n_motif"]},
+            "visualization": {"gen_fig_flag": False, "random_seed": 7, "n_max_iter": iters or c["iters"]}}
+    t0 = time.perf_counter()
+    synth.write_res_dir(res, seq, borders, over)
+    t["write_inputs_s"] = time.perf_counter() - t0
+    del seq, borders
+    sink = io.StringIO() if quiet else None
+    try:
+        with (contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext()):
+            np.random.seed(123)
+            t0 = time.perf_counter()
+            md._scan_motif(str(res))
+            t["scan_motif_s"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            vz._visualize_kmers(str(res))
+            t["visualize_kmers_s"] = time.perf_counter() - t0
+        t["e2e_s"] = t["scan_motif_s"] + t["visualize_kmers_s"]
+        finals = (res / "final_conseq.txt").read_text().split()
+        rows = (res / "low_dim_data.tsv").read_text().splitlines()
+        stages = dict(md.STAGE_TIMES)
+        stages.update({"viz_" + k: v for k, v in vz.STAGE_TIMES.items()})
+        return {"config": config, "mode": mode, **c, "k_range": [min_k, max_k], "final_conseq": finals,
+                "n_embedded": len(rows) - 1, "times": t, "stages": stages}
+    finally:
+        if prev_mode is None:
+            os.environ.pop("KMAP_EMBED_MODE", None)
+        else:
+            os.environ["KMAP_EMBED_MODE"] = prev_mode
+        if not keep:
+            shutil.rmtree(res, ignore_errors=True)
