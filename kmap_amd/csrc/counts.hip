@@ -331,12 +331,8 @@ int kmap_counts_run_seq_dev(kmap_counts *c, const uint8_t *seq_dev, int64_t n, c
     KMAP_REQUIRE(!dedupe_per_read || n_seq == 0 || borders_dev, "counts_run_seq: dedupe needs borders");
     hipStream_t st = as_stream(stream);
     const size_t hb = (k < 16) ? 4 : 8;
-    void *hash = nullptr;
-    hipError_t e = hipMalloc(&hash, (size_t)(n ? n : 1) * hb);
-    if (e != hipSuccess) {
-        kmap_set_error("counts_run_seq: hash scratch of %zu bytes: %s", (size_t)n * hb, hipGetErrorString(e));
-        return KMAP_E_NOMEM;
-    }
+    void *hash = nullptr;   // cached arena buffer: 4-8 B per position, reused across k and rounds
+    KMAP_TRY(kmap_scratch(&hash, (size_t)(n ? n : 1) * hb, st, KMAP_SLOT_HASH));
     int rc;
     if (k < 16) {
         rc = kmap_hash_launch_u32(seq_dev, n, k, (uint32_t *)hash, stream);
@@ -347,8 +343,6 @@ int kmap_counts_run_seq_dev(kmap_counts *c, const uint8_t *seq_dev, int64_t n, c
         if (rc == KMAP_OK && dedupe_per_read) rc = kmap_dedupe_per_read_u64_dev((uint64_t *)hash, n, borders_dev, n_seq, stream);
         if (rc == KMAP_OK) rc = run_hashes<uint64_t>(c, (const uint64_t *)hash, n, k, merge_revcom, n_uniq, st);
     }
-    (void)hipStreamSynchronize(st);
-    (void)hipFree(hash);
     return rc;
 }
 
