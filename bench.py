@@ -90,12 +90,19 @@ def main():
     import torch
     from kmap_amd import _ffi
     from kmap_amd.hamdist import hamdist_matrix_dev, pitch_for
-    torch.cuda.set_device(local_rank)
-    _ffi.check(_ffi.lib().kmap_set_device(local_rank))
+    # KMAP_BENCH_BACKEND=gloo + KMAP_BENCH_SAME_GPU=1 rehearse the multi-rank path on a one-GPU box (timing collectives
+    # over gloo, every rank on GPU 0); the real runs use one GPU per rank and RCCL ("nccl").
+    backend = os.environ.get("KMAP_BENCH_BACKEND", "nccl")
+    dev = 0 if os.environ.get("KMAP_BENCH_SAME_GPU") else local_rank
+    torch.cuda.set_device(dev)
+    _ffi.check(_ffi.lib().kmap_set_device(dev))
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
 
     # ---- workload (weak scaling: constant pairs per GPU) ----
     n = int(round(N_BASE * math.sqrt(world) / 16)) * 16

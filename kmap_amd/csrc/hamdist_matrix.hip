@@ -8,8 +8,9 @@
 // (+N gid bytes).  Per output byte the VALU does xor / lshr / or3 / bcnt / lshl_or.
 //
 // Mapping (wave64): a lane owns 16 consecutive columns -> one 16-byte store per row; a wave owns
-// 1024 consecutive columns x 64 rows; the row's hash is wave-uniform (v_readlane from a register
-// that holds the 64 row hashes of the wave), the 16 column hashes live in VGPRs for all 64 rows.
+// 1024 consecutive columns x 8 rows (short-lived waves keep the chip's stores close to memory order:
+// 8 rows/wave 5.83 TB/s, 16: 5.45, 64: 4.95 at N = 50k); the row's hash is wave-uniform (v_readlane from a
+// register holding the wave's row hashes), the 16 column hashes live in VGPRs for all rows of the wave.
 #include <stdlib.h>
 
 #include "common.h"
@@ -18,8 +19,8 @@ namespace {
 
 constexpr int COLS_PER_LANE = 16;
 constexpr int COLS_PER_WAVE = COLS_PER_LANE * KMAP_WAVE;   // 1024
-constexpr int ROWS_PER_WAVE = 64;
-constexpr int WAVES_PER_BLOCK = 4;
+constexpr int ROWS_PER_WAVE = 8;    // default (<= 64: row hashes live in one register per lane); see sweep in DESIGN.md
+constexpr int WAVES_PER_BLOCK = 8;   // max; launch uses wpb <= this
 
 // gid[i] = 0 for "compare all k bases"; g > 0 = index+1 of a consensus shorter than k:
 // pairs with equal non-zero gid are compared on the first clen bases, i.e. (a^b) >> gshift[g].
@@ -105,11 +106,12 @@ __device__ __forceinline__ void run_rows(const H (&b)[COLS_PER_LANE], const uint
 template <typename H, bool NT>
 __global__ __launch_bounds__(KMAP_WAVE *WAVES_PER_BLOCK) void hamdist_matrix_kernel(
     const H *__restrict__ kh, const uint8_t *__restrict__ gid, ByteTab gshift, int64_t n, H mask,
-    int64_t row0, int64_t nrows, uint8_t *__restrict__ out, int64_t ld, int vec_ok) {
+    int64_t row0, int64_t nrows, uint8_t *__restrict__ out, int64_t ld, int vec_ok, int rpw, int row_major, int wpb) {
     const int lane = threadIdx.x & (KMAP_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t col0 = (int64_t)blockIdx.x * COLS_PER_WAVE + (int64_t)lane * COLS_PER_LANE;
-    const int64_t rbase = ((int64_t)blockIdx.y * WAVES_PER_BLOCK + wave) * ROWS_PER_WAVE;
+    const unsigned bx = row_major ? blockIdx.y : blockIdx.x, by = row_major ? blockIdx.x : blockIdx.y;
+    const int64_t col0 = (int64_t)bx * COLS_PER_WAVE + (int64_t)lane * COLS_PER_LANE;
+    const int64_t rbase = ((int64_t)by * wpb + wave) * rpw;
     if (rbase >= nrows) return;   // wave-uniform
 
     // ---- the wave's 64 row hashes: one coalesced load, then v_readlane per row ----
@@ -118,14 +120,14 @@ __global__ __launch_bounds__(KMAP_WAVE *WAVES_PER_BLOCK) void hamdist_matrix_ker
     const H arow = rvalid ? (H)(kh[myrow] & mask) : (H)0;
     const uint32_t grow = rvalid ? (uint32_t)gid[myrow] : 0u;
     const uint32_t srow = gshift.v[grow];
-    const int rcount = (int)((nrows - rbase < ROWS_PER_WAVE) ? (nrows - rbase) : ROWS_PER_WAVE);
+    const int rcount = (int)((nrows - rbase < rpw) ? (nrows - rbase) : rpw);
     uint8_t *orow = out + rbase * ld + col0;
 
     // ---- the lane's 16 column hashes + group ids ----
     H b[COLS_PER_LANE];
     uint32_t gcol[COLS_PER_LANE / 4];
     // whole wave on the aligned interior? (wave-uniform: the last lane's columns are in range)
-    const int64_t wave_col_end = (int64_t)blockIdx.x * COLS_PER_WAVE + COLS_PER_WAVE;
+    const int64_t wave_col_end = (int64_t)bx * COLS_PER_WAVE + COLS_PER_WAVE;
     if (vec_ok && wave_col_end <= n) {
         constexpr int HV = 16 / sizeof(H);   // hashes per 16-byte load
         const u32x4 *src = reinterpret_cast<const u32x4 *>(kh + col0);
@@ -190,18 +192,22 @@ int launch_matrix(const H *kh_dev, const int32_t *label_dev, int64_t n, int k, c
     build_gid_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(label_dev, n, lab2gid, n_lab, gid);
 
     const int vec_ok = ((uintptr_t)kh_dev % 16 == 0) && ((uintptr_t)out_dev % 16 == 0) && (ld % 16 == 0);
-    dim3 grid((unsigned)((n + COLS_PER_WAVE - 1) / COLS_PER_WAVE),
-              (unsigned)((nrows + ROWS_PER_WAVE * WAVES_PER_BLOCK - 1) / (ROWS_PER_WAVE * WAVES_PER_BLOCK)));
+    static const int rpw = [] { const char *e = getenv("KMAP_HAMDIST_RPW"); int v = e ? atoi(e) : ROWS_PER_WAVE; return (v >= 1 && v <= 64) ? v : ROWS_PER_WAVE; }();
+    static const int row_major = [] { const char *e = getenv("KMAP_HAMDIST_ROWMAJOR"); return e ? atoi(e) : 0; }();
+    const unsigned gx = (unsigned)((n + COLS_PER_WAVE - 1) / COLS_PER_WAVE);
+    static const int wpb = [] { const char *e = getenv("KMAP_HAMDIST_WPB"); int v = e ? atoi(e) : 2; return (v >= 1 && v <= WAVES_PER_BLOCK) ? v : 2; }();
+    const unsigned gy = (unsigned)((nrows + (int64_t)rpw * wpb - 1) / ((int64_t)rpw * wpb));
+    dim3 grid = row_major ? dim3(gy, gx) : dim3(gx, gy);
     KMAP_REQUIRE(grid.y <= 65535u, "hamdist_matrix: nrows too large for one launch (%lld)", (long long)nrows);
     // non-temporal stores by default (write-once streaming output: 5.02 vs 4.77 TB/s measured at N=50k);
     // KMAP_HAMDIST_NT=0 switches back to default-policy stores for A/B runs
     static const bool nt = !(getenv("KMAP_HAMDIST_NT") && getenv("KMAP_HAMDIST_NT")[0] == '0');
     if (nt)
-        hamdist_matrix_kernel<H, true><<<grid, dim3(KMAP_WAVE * WAVES_PER_BLOCK), 0, st>>>(
-            kh_dev, gid, gshift, n, low_mask<H>(k), row0, nrows, out_dev, ld, vec_ok);
+        hamdist_matrix_kernel<H, true><<<grid, dim3(KMAP_WAVE * wpb), 0, st>>>(
+            kh_dev, gid, gshift, n, low_mask<H>(k), row0, nrows, out_dev, ld, vec_ok, rpw, row_major, wpb);
     else
-        hamdist_matrix_kernel<H, false><<<grid, dim3(KMAP_WAVE * WAVES_PER_BLOCK), 0, st>>>(
-            kh_dev, gid, gshift, n, low_mask<H>(k), row0, nrows, out_dev, ld, vec_ok);
+        hamdist_matrix_kernel<H, false><<<grid, dim3(KMAP_WAVE * wpb), 0, st>>>(
+            kh_dev, gid, gshift, n, low_mask<H>(k), row0, nrows, out_dev, ld, vec_ok, rpw, row_major, wpb);
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;
 }
