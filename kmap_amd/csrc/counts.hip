@@ -213,16 +213,7 @@ static uint64_t host_revcom(uint64_t h, int k, int narrow) {
 
 }  // namespace
 
-struct kmap_counts {
-    int k = 0;
-    int narrow = 1;          // hash dtype uint32 (k < 16)
-    int64_t n_uniq = 0;
-    void *uniq = nullptr;    // H[n_uniq]
-    uint32_t *cnt = nullptr; // uint32[n_uniq]
-    size_t cap = 0;          // entries allocated
-    uint32_t *bins = nullptr;
-    size_t bins_cap = 0;     // bins allocated
-};
+#include "counts_internal.h"
 
 namespace {
 
@@ -244,7 +235,10 @@ int ensure_bins(kmap_counts *c, size_t n_bins) {
 
 template <typename H>
 int run_hashes(kmap_counts *c, const H *hash_dev, int64_t n, int k, int merge, int64_t *n_uniq, hipStream_t st) {
-    KMAP_REQUIRE(k <= 16, "counts: k=%d > 16 is not supported by the direct-histogram path of this build", k);
+    if (k > 16) {
+        if constexpr (sizeof(H) == 8) return kmap_counts_sort_path(c, (const uint64_t *)hash_dev, n, k, merge, n_uniq, st);
+        KMAP_REQUIRE(false, "counts: k=%d needs uint64 hashes", k);
+    }
     const size_t n_bins = (size_t)1 << (2 * k);
     KMAP_TRY(ensure_bins(c, n_bins));
     KMAP_CHECK_HIP(hipMemsetAsync(c->bins, 0, n_bins * 4, st));

@@ -1,0 +1,19 @@
+// counts_internal.h -- the counts handle shared by counts.hip (histogram path) and counts_sort.hip (k >= 17)
+#pragma once
+#include "common.h"
+
+struct kmap_counts {
+    int k = 0;
+    int narrow = 1;          // hash dtype uint32 (k < 16)
+    int64_t n_uniq = 0;
+    void *uniq = nullptr;    // H[n_uniq]
+    uint32_t *cnt = nullptr; // uint32[n_uniq]
+    size_t cap = 0;          // entries allocated
+    uint32_t *bins = nullptr;
+    size_t bins_cap = 0;     // bins allocated
+};
+
+
+// k >= 17: sort + run-length encode + revcom merge (counts_sort.hip)
+int kmap_counts_sort_path(kmap_counts *c, const uint64_t *hash_dev, int64_t n, int k, int merge, int64_t *n_uniq,
+                          hipStream_t st);

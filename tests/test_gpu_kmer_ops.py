@@ -54,7 +54,7 @@ def test_hash_count_golden(K, golden, k):
     g = golden("ops.npz")
     h = K.comp_kmer_hash(g["nseq_arr"], k)
     np.testing.assert_array_equal(h, g[f"nseq_hash_k{k}"])
-    if k <= 16:
+    if True:   # k <= 16: histogram path; k >= 17: sort + run-length path
         u, c = K.count_uniq_hash(h, k)
         np.testing.assert_array_equal(u, g[f"nseq_uniq_k{k}"])
         np.testing.assert_array_equal(c, g[f"nseq_cnt_k{k}"])
@@ -176,6 +176,27 @@ def test_counts_testfa_golden(K, golden, k, rep):
     cands = mu[np.argsort(mn)[-5:]]
     np.testing.assert_array_equal(dc.hamball_mass(cands, 2, True), O.hamball_mass(mu, mn, k, cands, 2, True))
     np.testing.assert_array_equal(dc.hamball_mass(cands, 1, False), O.hamball_mass(mu, mn, k, cands, 1, False))
+    dc.close()
+
+
+def test_counts_large_k_sort_path_vs_oracle(K, O):
+    """17 <= k < 32 (sort + run-length encode + binary-search revcom merge), with and without per-read dedupe."""
+    rng = np.random.default_rng(23)
+    seq, borders = synth_reads(rng, 3000, 40, 160)
+    seq[5000:5400] = np.tile(np.array([0, 1], np.uint8), 200)          # low complexity: duplicates + revcom partners
+    from kmap_amd import _ffi
+    seq_d, bor_d = _ffi.DeviceBuffer.from_numpy(seq), _ffi.DeviceBuffer.from_numpy(borders)
+    dc = K.DeviceCounts()
+    for k in (17, 20, 31):
+        for dedupe, merge in ((True, True), (False, True), (False, False)):
+            dc.run_seq(seq_d.ptr, len(seq), bor_d.ptr, len(borders), k, dedupe=dedupe, merge_revcom=merge)
+            u, c = dc.fetch()
+            ou, oc = O.count_kmers(seq, borders, k, rep_mode=not dedupe, revcom_mode=merge)
+            np.testing.assert_array_equal(u, ou)
+            np.testing.assert_array_equal(c, oc)
+            assert u.dtype == np.uint64 and c.dtype == np.int64 and dc.total() == int(oc.sum())
+    cands = u[:3]
+    np.testing.assert_array_equal(dc.hamball_mass(cands, 8, True), O.hamball_mass(u, c, 31, cands, 8, True))
     dc.close()
 
 

@@ -132,6 +132,35 @@ def test_occurrence_scan_vs_oracle_with_subsample(motif_defs):
     assert got == want
 
 
+def test_c5_shape_scan_and_count_vs_oracle(motif_defs):
+    """Config C5 shape at test size: k = 14, max_ham_dist = 5 ball scan over 300 bp reads + counting at k = 14 / 16."""
+    from kmap_amd import synth
+    from kmap_amd.kmer_count import DeviceCounts, kmer2hash
+    from kmap_amd.motif_discovery import DeviceSeq
+    from oracle import oracle as O
+    import ctypes as C
+    seq, borders = synth.synth_reads(3000, 300, 3, motifs=("AGGACCTACGTACA", "AATCGATAGC"))
+    seq[::997] = 255                                                     # a few N bases inside reads
+    ds = DeviceSeq(seq, borders)
+    hits, pos = ds.scan(14, kmer2hash("AGGACCTACGTACA"), motif_defs[14].max_ham_dist, True)
+    buf, md, off = np.empty(400, np.int32), C.c_int(0), 0
+    for i, (st, en) in enumerate(borders):
+        m = O.lib().ko_scan_read(np.ascontiguousarray(seq[st:en]), en - st, 14, int(kmer2hash("AGGACCTACGTACA")), 5, 1, buf, C.byref(md))
+        assert hits[i] == m
+        np.testing.assert_array_equal(pos[off:off + m], buf[:m])
+        off += m
+    assert off == len(pos) and np.count_nonzero(hits) > 1000
+    dc = DeviceCounts()
+    for k in (14, 16):
+        ds.count(dc, k, dedupe=True, merge_revcom=True)
+        u, c = dc.fetch()
+        ou, oc = O.count_kmers(seq, borders, k, rep_mode=False, revcom_mode=True)
+        np.testing.assert_array_equal(u, ou)
+        np.testing.assert_array_equal(c, oc)
+    dc.close()
+    ds.close()
+
+
 def test_visualize_kmers_c1(run_dir, golden):
     """visualize_kmers on the C1 result directory: low_dim_data.tsv equals the golden trace's best snapshot
     printed with the reference's %3.3f format (the file contract is 1e-3 granular)."""
