@@ -125,6 +125,23 @@ int kmap_counts_total(kmap_counts *c, int64_t *total);          /* sum of counts
 int kmap_counts_hamball_mass(kmap_counts *c, const uint64_t *cands, int n_cand, int radius, int revcom,
                              double *mass_out);
 
+/* ---- 2-bit-packed reads (device resident): the uint8 array contract (kmer_count.py:244-347) packed 16 positions per
+ * group: codes uint32[groups] (first base most significant) + invalid bitmask uint16[groups] (255 / past the end),
+ * groups = kmap_packed_groups(n) incl. two all-invalid halo groups.  Masking ORs bits into the invalid mask; the
+ * codes never change.  The packed entry points do what their uint8 counterparts above do, on the packed stream. */
+int64_t kmap_packed_groups(int64_t n);
+int kmap_pack_reads_dev(const uint8_t *seq_dev, int64_t n, uint32_t *codes_dev, uint16_t *inval_dev, void *stream);
+int kmap_unpack_reads_dev(const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n, uint8_t *seq_out_dev,
+                          void *stream);
+/* out_dev: uint32[n] (k < 16) or uint64[n] */
+int kmap_hash_kmers_packed_dev(const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n, int k, void *out_dev,
+                               void *stream);
+int kmap_counts_run_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n,
+                               const int64_t *borders_dev, int64_t n_seq, int k, int dedupe_per_read, int merge_revcom,
+                               int64_t *n_uniq, void *stream);
+int kmap_mask_hamball_packed_dev(const uint32_t *codes_dev, uint16_t *inval_dev, int64_t n, int k, const uint64_t *cons,
+                                 const int32_t *radius, int n_cons, void *stream);        /* cons/radius: host */
+
 /* ---- motif occurrence scan: get_motif_occurence motif_discovery.py:1422-1477.
  * For every read and one consensus: positions p in the reference's slice [0 : len-k+1] whose
  * min(fwd, revcom) distance is <= radius AND equals the read's minimum.  Two-call: run returns the
@@ -135,6 +152,9 @@ int kmap_scan_create(kmap_scan **s);
 int kmap_scan_destroy(kmap_scan *s);
 int kmap_scan_run_dev(kmap_scan *s, const uint8_t *seq_dev, int64_t n, const int64_t *borders_dev, int64_t n_seq,
                       int k, uint64_t cons, int radius, int revcom, int64_t *total_hits, void *stream);
+int kmap_scan_run_packed_dev(kmap_scan *s, const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n,
+                             const int64_t *borders_dev, int64_t n_seq, int k, uint64_t cons, int radius, int revcom,
+                             int64_t *total_hits, void *stream);
 int kmap_scan_fetch(kmap_scan *s, int32_t *hits_per_read, int8_t *min_dist, int32_t *positions);
 
 /* host-side writer of the occurrence table (gen_motif_occurence_file motif_discovery.py:1396-1419):

@@ -64,6 +64,13 @@ _SIGS = {
     "kmap_counts_fetch": (i32, [vp, vp, vp]),
     "kmap_counts_total": (i32, [vp, P(i64)]),
     "kmap_counts_hamball_mass": (i32, [vp, vp, i32, i32, i32, vp]),
+    "kmap_packed_groups": (i64, [i64]),
+    "kmap_pack_reads_dev": (i32, [vp, i64, vp, vp, vp]),
+    "kmap_unpack_reads_dev": (i32, [vp, vp, i64, vp, vp]),
+    "kmap_hash_kmers_packed_dev": (i32, [vp, vp, i64, i32, vp, vp]),
+    "kmap_counts_run_packed_dev": (i32, [vp, vp, vp, i64, vp, i64, i32, i32, i32, P(i64), vp]),
+    "kmap_mask_hamball_packed_dev": (i32, [vp, vp, i64, i32, vp, vp, i32, vp]),
+    "kmap_scan_run_packed_dev": (i32, [vp, vp, vp, i64, vp, i64, i32, u64, i32, i32, P(i64), vp]),
     "kmap_scan_create": (i32, [P(vp)]),
     "kmap_scan_destroy": (i32, [vp]),
     "kmap_scan_run_dev": (i32, [vp, vp, i64, vp, i64, i32, u64, i32, i32, P(i64), vp]),

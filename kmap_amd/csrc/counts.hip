@@ -233,33 +233,19 @@ int ensure_bins(kmap_counts *c, size_t n_bins) {
     return KMAP_OK;
 }
 
-template <typename H>
-int run_hashes(kmap_counts *c, const H *hash_dev, int64_t n, int k, int merge, int64_t *n_uniq, hipStream_t st) {
-    if (k > 16) {
-        if constexpr (sizeof(H) == 8) return kmap_counts_sort_path(c, (const uint64_t *)hash_dev, n, k, merge, n_uniq, st);
-        KMAP_REQUIRE(false, "counts: k=%d needs uint64 hashes", k);
-    }
+}  // namespace
+
+int kmap_counts_prepare_bins(kmap_counts *c, int k, hipStream_t st) {
+    KMAP_REQUIRE(k > 0 && k <= 16, "counts: direct histogram needs k <= 16 (k=%d)", k);
     const size_t n_bins = (size_t)1 << (2 * k);
     KMAP_TRY(ensure_bins(c, n_bins));
     KMAP_CHECK_HIP(hipMemsetAsync(c->bins, 0, n_bins * 4, st));
-    if (n > 0) {
-        const size_t passes = (n_bins + HL_BINS - 1) / HL_BINS;
-        if (sizeof(H) == 4 && passes <= 8 && n >= (1 << 20) && ((uintptr_t)hash_dev % 16) == 0) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)hist_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   HL_BINS * 4));
-                attr_set = true;
-            }
-            for (size_t p = 0; p < passes; ++p)
-                hist_lds_kernel<<<256, HL_TPB, HL_BINS * 4, st>>>((const uint32_t *)hash_dev, n, (uint32_t)(p * HL_BINS),
-                                                                 c->bins);
-        } else {
-            int64_t g = (n + BLK - 1) / BLK;
-            if (g > 256 * 32) g = 256 * 32;
-            hist_kernel<H><<<(unsigned)g, BLK, 0, st>>>(hash_dev, n, c->bins);
-        }
-    }
+    return KMAP_OK;
+}
+
+// order-preserving compaction of the filled histogram (+ revcom merge) into the handle's uniq/cnt arrays
+int kmap_counts_finish_hist(kmap_counts *c, int k, int merge, int64_t *n_uniq, hipStream_t st) {
+    const size_t n_bins = (size_t)1 << (2 * k);
     const unsigned nb = grid_for((int64_t)n_bins, CT_TILE);
     uint32_t *bc = nullptr;
     uint64_t *boff = nullptr;
@@ -281,13 +267,47 @@ int run_hashes(kmap_counts *c, const H *hash_dev, int64_t n, int k, int merge, i
         KMAP_CHECK_HIP(hipMalloc((void **)&c->cnt, cap * 4));
         c->cap = cap;
     }
-    if (total) compact_write_kernel<H><<<nb, BLK, 0, st>>>(c->bins, n_bins, k, merge, boff, (H *)c->uniq, c->cnt);
+    if (total) {
+        if (k < 16) compact_write_kernel<uint32_t><<<nb, BLK, 0, st>>>(c->bins, n_bins, k, merge, boff, (uint32_t *)c->uniq, c->cnt);
+        else compact_write_kernel<uint64_t><<<nb, BLK, 0, st>>>(c->bins, n_bins, k, merge, boff, (uint64_t *)c->uniq, c->cnt);
+    }
     KMAP_CHECK_HIP(hipGetLastError());
     c->k = k;
     c->narrow = (k < 16);
     c->n_uniq = (int64_t)total;
     if (n_uniq) *n_uniq = (int64_t)total;
     return KMAP_OK;
+}
+
+namespace {
+
+template <typename H>
+int run_hashes(kmap_counts *c, const H *hash_dev, int64_t n, int k, int merge, int64_t *n_uniq, hipStream_t st) {
+    if (k > 16) {
+        if constexpr (sizeof(H) == 8) return kmap_counts_sort_path(c, (const uint64_t *)hash_dev, n, k, merge, n_uniq, st);
+        KMAP_REQUIRE(false, "counts: k=%d needs uint64 hashes", k);
+    }
+    const size_t n_bins = (size_t)1 << (2 * k);
+    KMAP_TRY(kmap_counts_prepare_bins(c, k, st));
+    if (n > 0) {
+        const size_t passes = (n_bins + HL_BINS - 1) / HL_BINS;
+        if (sizeof(H) == 4 && passes <= 8 && n >= (1 << 20) && ((uintptr_t)hash_dev % 16) == 0) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)hist_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   HL_BINS * 4));
+                attr_set = true;
+            }
+            for (size_t p = 0; p < passes; ++p)
+                hist_lds_kernel<<<256, HL_TPB, HL_BINS * 4, st>>>((const uint32_t *)hash_dev, n, (uint32_t)(p * HL_BINS),
+                                                                 c->bins);
+        } else {
+            int64_t g = (n + BLK - 1) / BLK;
+            if (g > 256 * 32) g = 256 * 32;
+            hist_kernel<H><<<(unsigned)g, BLK, 0, st>>>(hash_dev, n, c->bins);
+        }
+    }
+    return kmap_counts_finish_hist(c, k, merge, n_uniq, st);
 }
 
 }  // namespace

@@ -17,3 +17,5 @@ struct kmap_counts {
 // k >= 17: sort + run-length encode + revcom merge (counts_sort.hip)
 int kmap_counts_sort_path(kmap_counts *c, const uint64_t *hash_dev, int64_t n, int k, int merge, int64_t *n_uniq,
                           hipStream_t st);
+int kmap_counts_prepare_bins(kmap_counts *c, int k, hipStream_t st);
+int kmap_counts_finish_hist(kmap_counts *c, int k, int merge, int64_t *n_uniq, hipStream_t st);

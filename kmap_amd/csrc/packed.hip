@@ -1,0 +1,462 @@
+// packed.hip -- 2-bit-packed reads resident in HBM and the kernels that work on them.
+//
+// Packed layout (one "group" = 16 consecutive positions of the reference's uint8 array, kmer_count.py:244-347):
+//   codes[g] : uint32, base i of the group in bits [31-2i, 30-2i]   (first base most significant, like the hash)
+//   inval[g] : uint16, bit (15-i) set when byte i is not A/C/G/T (255: N or read separator) or lies past the end
+// plus two all-invalid halo groups, so every kernel may read groups g, g+1, g+2 unguarded.  0.375 B per position
+// instead of 1 B, and a k-mer window is a funnel shift instead of a k-step byte loop.  Masking (mask_input,
+// kmer_count.py:580-610) only ever turns positions into 255, i.e. it ORs bits into `inval`: the codes are immutable
+// and "restore the unmasked array" (motif_discovery.py:263) is a copy of n/8 bytes.
+//
+// Kernels: pack / unpack, hash materialisation, histogram (LDS-privatised passes or global atomics) straight from the
+// packed stream, Hamming-ball mask (flag + coverage), and the per-read occurrence scan.
+#include "common.h"
+#include "counts_internal.h"
+#include "scan_internal.h"
+#include "scan_util.h"
+
+namespace {
+
+constexpr int BLK = 256;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- window extraction -------------------------------------------------------------------------------------
+struct Win {
+    uint64_t t0;    // bases 0..31 of the 48-base stream (group g and g+1), base 0 in bits 63:62
+    uint32_t c2;    // bases 32..47 (group g+2)
+    uint64_t m;     // 48 invalid flags, position 0 in bit 47
+};
+__device__ __forceinline__ Win load_win(const uint32_t *__restrict__ codes, const uint16_t *__restrict__ inval, int64_t g) {
+    Win w;
+    const uint32_t c0 = codes[g], c1 = codes[g + 1];
+    w.t0 = ((uint64_t)c0 << 32) | c1;
+    w.c2 = codes[g + 2];
+    w.m = ((uint64_t)inval[g] << 32) | ((uint64_t)inval[g + 1] << 16) | inval[g + 2];
+    return w;
+}
+// hash of the k bases starting at offset i (0..15) of the stream; invalid windows return all ones in the low 2k bits
+// (the value the reference's invalid hash has under its "compare like any value" rule); `bad` reports invalidity.
+template <bool WIDE>   // WIDE: k may exceed 16 (needs the third group)
+__device__ __forceinline__ uint64_t win_hash(const Win &w, int i, int k, uint64_t kmask, bool &bad) {
+    uint64_t v = w.t0 << (2 * i);
+    if (WIDE && i > 0) v |= (uint64_t)w.c2 >> (32 - 2 * i);
+    const uint64_t h = v >> (64 - 2 * k);
+    bad = ((w.m >> (48 - i - k)) & ((1ull << k) - 1ull)) != 0;
+    return bad ? kmask : h;
+}
+
+// ---- pack / unpack -------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pack4(uint32_t wd, uint32_t &code, uint32_t &flags) {
+    const uint32_t t = wd & 0x03030303u;
+    code = ((t << 6) | (t >> 4) | (t >> 14) | (t >> 24)) & 0xFFu;
+    uint32_t f = wd & 0xFCFCFCFCu;                 // any of bits 7:2 set -> not a base
+    f |= f >> 1; f |= f >> 2; f |= f >> 4;         // smear into bit 0 of every byte (cross-byte smear only goes downward
+    f &= 0x01010101u;                              //  from a byte that is itself non-zero, so bit 0 of byte j stays exact)
+    flags = ((f << 3) | (f >> 6) | (f >> 15) | (f >> 24)) & 0xFu;
+}
+__global__ __launch_bounds__(BLK) void pack_kernel(const uint8_t *__restrict__ seq, int64_t n, uint32_t *__restrict__ codes,
+                                                   uint16_t *__restrict__ inval, int64_t n_groups, int aligned) {
+    const int64_t g = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    if (g >= n_groups) return;
+    const int64_t p0 = g * 16;
+    uint32_t wd[4];
+    if (p0 + 16 <= n && aligned) {
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(seq + p0);
+        wd[0] = v.x; wd[1] = v.y; wd[2] = v.z; wd[3] = v.w;
+    } else {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int64_t p = p0 + 4 * d + b;
+                x |= (uint32_t)((p < n) ? seq[p] : 255u) << (8 * b);
+            }
+            wd[d] = x;
+        }
+    }
+    uint32_t c = 0, m = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        uint32_t cd, fd;
+        pack4(wd[d], cd, fd);
+        c |= cd << (24 - 8 * d);
+        m |= fd << (12 - 4 * d);
+    }
+    codes[g] = c;
+    inval[g] = (uint16_t)m;
+}
+__global__ __launch_bounds__(BLK) void unpack_kernel(const uint32_t *__restrict__ codes, const uint16_t *__restrict__ inval,
+                                                     int64_t n, uint8_t *__restrict__ seq) {
+    const int64_t p = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    if (p >= n) return;
+    const int64_t g = p >> 4;
+    const int i = (int)(p & 15);
+    const bool bad = (inval[g] >> (15 - i)) & 1;
+    seq[p] = bad ? 255 : (uint8_t)((codes[g] >> (30 - 2 * i)) & 3u);
+}
+
+// ---- hash materialisation (one thread per group, 16 hashes, 64/128 contiguous bytes out) -------------------------
+template <typename H, bool WIDE>
+__global__ __launch_bounds__(BLK) void hash_packed_kernel(const uint32_t *__restrict__ codes, const uint16_t *__restrict__ inval,
+                                                          int64_t n, int k, H *__restrict__ out) {
+    const int64_t g = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    const int64_t p0 = g * 16;
+    if (p0 >= n) return;
+    const Win w = load_win(codes, inval, g);
+    const uint64_t kmask = low_mask<uint64_t>(k);
+    H hs[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        bool bad;
+        const uint64_t h = win_hash<WIDE>(w, i, k, kmask, bad);
+        hs[i] = bad ? (H)~(H)0 : (H)h;
+    }
+    if (p0 + 16 <= n && ((uintptr_t)out % 16) == 0) {
+        u32x4 *o = reinterpret_cast<u32x4 *>(out + p0);
+        if constexpr (sizeof(H) == 4) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) o[v] = u32x4{(uint32_t)hs[4 * v], (uint32_t)hs[4 * v + 1], (uint32_t)hs[4 * v + 2], (uint32_t)hs[4 * v + 3]};
+        } else {
+#pragma unroll
+            for (int v = 0; v < 8; ++v)
+                o[v] = u32x4{(uint32_t)hs[2 * v], (uint32_t)((uint64_t)hs[2 * v] >> 32), (uint32_t)hs[2 * v + 1],
+                             (uint32_t)((uint64_t)hs[2 * v + 1] >> 32)};
+        }
+    } else {
+        for (int i = 0; i < 16 && p0 + i < n; ++i) out[p0 + i] = hs[i];
+    }
+}
+
+// ---- histogram straight from the packed stream (no per-read dedupe) ---------------------------------------------
+constexpr int HP_BINS = 32768;   // uint32 LDS bins per block (128 KiB)
+constexpr int HP_TPB = 1024;
+template <bool WIDE, bool LDSMODE>
+__global__ __launch_bounds__(LDSMODE ? HP_TPB : BLK) void hist_packed_kernel(const uint32_t *__restrict__ codes,
+                                                                             const uint16_t *__restrict__ inval, int64_t n,
+                                                                             int k, uint64_t bin0, uint32_t *__restrict__ bins) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lb[];
+    if (LDSMODE) {
+        for (int b = threadIdx.x; b < HP_BINS; b += blockDim.x) lb[b] = 0;
+        __syncthreads();
+    }
+    const uint64_t kmask = low_mask<uint64_t>(k);
+    const int64_t n_groups = (n + 15) >> 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += stride) {
+        const Win w = load_win(codes, inval, g);
+        if ((w.m >> 32) == 0xFFFFull) continue;   // group entirely invalid (cheap skip of masked regions)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            bool bad;
+            const uint64_t h = win_hash<WIDE>(w, i, k, kmask, bad);
+            if (bad) continue;
+            if (LDSMODE) {
+                const uint64_t a = h - bin0;
+                if (a < (uint64_t)HP_BINS) atomicAdd(&lb[a], 1u);
+            } else {
+                atomicAdd(&bins[h], 1u);
+            }
+        }
+    }
+    if (LDSMODE) {
+        __syncthreads();
+        for (int b = threadIdx.x; b < HP_BINS; b += blockDim.x) {
+            const uint32_t c = lb[b];
+            if (c) atomicAdd(&bins[bin0 + b], c);
+        }
+    }
+}
+
+// ---- Hamming-ball mask on the packed stream (mask_input, kmer_count.py:580-610) ---------------------------------------
+struct ConsTabP {
+    uint64_t cons[32];
+    int32_t radius[32];
+    int n;
+};
+// hit16[g]: bit (15-i) set when the window at position 16g+i (invalid = all ones, compared as is) is within radius of
+// any consensus.  Reads the CURRENT invalid mask; the coverage pass below writes it.
+template <bool WIDE>
+__global__ __launch_bounds__(BLK) void mask_flag_packed_kernel(const uint32_t *__restrict__ codes,
+                                                               const uint16_t *__restrict__ inval, int64_t n, int k,
+                                                               ConsTabP t, uint16_t *__restrict__ hit16) {
+    const int64_t g = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    const int64_t n_groups = (n + 15) >> 4;
+    if (g >= n_groups) return;
+    const Win w = load_win(codes, inval, g);
+    const uint64_t kmask = low_mask<uint64_t>(k);
+    uint32_t hits = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        bool bad;
+        const uint64_t h = win_hash<WIDE>(w, i, k, kmask, bad);
+        bool f = false;
+        for (int c = 0; c < t.n; ++c) f |= (popc2((h ^ t.cons[c]) & kmask) <= t.radius[c]);
+        if (16 * g + i >= n) f = false;           // positions past the end do not exist
+        hits |= (uint32_t)f << (15 - i);
+    }
+    hit16[g] = (uint16_t)hits;
+}
+// position q becomes invalid when a hit starts in [q-k+1, q]; k <= 31 reaches at most two groups back
+__global__ __launch_bounds__(BLK) void mask_cover_packed_kernel(const uint16_t *__restrict__ hit16, int64_t n, int k,
+                                                                uint16_t *__restrict__ inval) {
+    const int64_t g = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    const int64_t n_groups = (n + 15) >> 4;
+    if (g >= n_groups) return;
+    // 48-bit stream of hits: groups g-2, g-1, g (position 0 of g-2 in bit 47)
+    const uint64_t h2 = (g >= 2) ? hit16[g - 2] : 0, h1 = (g >= 1) ? hit16[g - 1] : 0, h0 = hit16[g];
+    uint64_t s = (h2 << 32) | (h1 << 16) | h0;
+    // cover = OR_{j=0}^{k-1} (s >> j): doubling
+    uint64_t cover = s;
+    int have = 1;
+    while (have < k) {
+        const int step = (have <= k - have) ? have : k - have;
+        cover |= cover >> step;
+        have += step;
+    }
+    const uint16_t add = (uint16_t)(cover & 0xFFFFull);
+    if (add) inval[g] = (uint16_t)(inval[g] | add);
+}
+
+// ---- occurrence scan on the packed stream (get_motif_occurence, motif_discovery.py:1422-1477) ------------------------
+constexpr int SC_WAVES = 4;
+__device__ __forceinline__ int64_t slice_stop(int64_t L, int k) {
+    int64_t stop = L - k + 1;
+    if (stop < 0) {
+        stop += L;
+        if (stop < 0) stop = 0;
+    }
+    return stop > L ? L : stop;
+}
+__device__ __forceinline__ int pos_dist(const uint32_t *__restrict__ codes, const uint16_t *__restrict__ inval, int64_t p,
+                                        int k, uint64_t kmask, uint64_t cons, uint64_t rcc, int revcom) {
+    const Win w = load_win(codes, inval, p >> 4);
+    bool bad;
+    const uint64_t h = win_hash<true>(w, (int)(p & 15), k, kmask, bad);
+    int d = popc2((h ^ cons) & kmask);
+    if (revcom) {
+        const int d2 = popc2((h ^ rcc) & kmask);
+        d = d2 < d ? d2 : d;
+    }
+    return d;
+}
+template <bool WRITE>
+__global__ __launch_bounds__(KMAP_WAVE *SC_WAVES) void scan_packed_kernel(const uint32_t *__restrict__ codes,
+                                                                           const uint16_t *__restrict__ inval, int64_t n,
+                                                                           const int64_t *__restrict__ borders, int64_t n_seq,
+                                                                           int k, uint64_t cons, uint64_t rcc, int radius,
+                                                                           int revcom, int32_t *__restrict__ hits,
+                                                                           int8_t *__restrict__ min_dist,
+                                                                           const uint64_t *__restrict__ offs,
+                                                                           int32_t *__restrict__ pos_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * SC_WAVES + (threadIdx.x >> 6);
+    if (s >= n_seq) return;
+    int64_t st = borders[2 * s], en = borders[2 * s + 1];
+    if (st < 0) st = 0;
+    if (en > n) en = n;
+    const int64_t L = en > st ? en - st : 0;
+    const int64_t stop = slice_stop(L, k);
+    const uint64_t kmask = low_mask<uint64_t>(k);
+    // the read's own end acts like a separator even if the caller's border does not sit on one
+    constexpr int REG = 4;                       // distances kept in registers for reads up to 256 positions
+    int dreg[REG];
+    int best = 1 << 30;
+#pragma unroll
+    for (int r = 0; r < REG; ++r) {
+        const int64_t p = (int64_t)r * 64 + lane;
+        int d = 1 << 29;
+        if (p < stop) {
+            d = (p + k > L) ? popc2((kmask ^ cons) & kmask) : pos_dist(codes, inval, st + p, k, kmask, cons, rcc, revcom);
+            if (p + k > L && revcom) { const int d2 = popc2((kmask ^ rcc) & kmask); d = d2 < d ? d2 : d; }
+        }
+        dreg[r] = d;
+        if (d <= radius && d < best) best = d;
+    }
+    for (int64_t p = (int64_t)REG * 64 + lane; p < stop; p += 64) {
+        int d = (p + k > L) ? popc2((kmask ^ cons) & kmask) : pos_dist(codes, inval, st + p, k, kmask, cons, rcc, revcom);
+        if (p + k > L && revcom) { const int d2 = popc2((kmask ^ rcc) & kmask); d = d2 < d ? d2 : d; }
+        if (d <= radius && d < best) best = d;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const int v = __shfl_xor(best, o);
+        best = v < best ? v : best;
+    }
+    int count = 0;
+    uint64_t base = WRITE ? offs[s] : 0;
+    if (best <= radius) {
+        for (int64_t p0 = 0; p0 < stop; p0 += 64) {
+            const int64_t p = p0 + lane;
+            int d;
+            if (p0 < (int64_t)REG * 64) d = dreg[p0 >> 6];
+            else {
+                d = 1 << 29;
+                if (p < stop) {
+                    d = (p + k > L) ? popc2((kmask ^ cons) & kmask) : pos_dist(codes, inval, st + p, k, kmask, cons, rcc, revcom);
+                    if (p + k > L && revcom) { const int d2 = popc2((kmask ^ rcc) & kmask); d = d2 < d ? d2 : d; }
+                }
+            }
+            const bool hit = (p < stop) && (d == best);
+            const unsigned long long mask = __ballot(hit);
+            if (WRITE && hit) pos_out[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)p;
+            const int c = __popcll(mask);
+            count += c;
+            base += c;
+        }
+    }
+    if (!WRITE && lane == 0) {
+        hits[s] = count;
+        min_dist[s] = (int8_t)((best <= radius) ? best : -1);
+    }
+}
+
+static inline unsigned grid_for(int64_t n, int64_t per) {
+    int64_t g = (n + per - 1) / per;
+    return (unsigned)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+
+extern "C" {
+
+int64_t kmap_packed_groups(int64_t n) { return ((n + 15) >> 4) + 2; }
+
+int kmap_pack_reads_dev(const uint8_t *seq_dev, int64_t n, uint32_t *codes_dev, uint16_t *inval_dev, void *stream) {
+    KMAP_REQUIRE(n >= 0 && (n == 0 || seq_dev) && codes_dev && inval_dev, "pack_reads: bad arguments");
+    const int64_t ng = kmap_packed_groups(n);
+    pack_kernel<<<grid_for(ng, BLK), BLK, 0, as_stream(stream)>>>(seq_dev, n, codes_dev, inval_dev, ng,
+                                                                   ((uintptr_t)seq_dev % 16) == 0);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+
+int kmap_unpack_reads_dev(const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n, uint8_t *seq_out_dev, void *stream) {
+    KMAP_REQUIRE(n >= 0 && codes_dev && inval_dev && (n == 0 || seq_out_dev), "unpack_reads: bad arguments");
+    if (n == 0) return KMAP_OK;
+    unpack_kernel<<<grid_for(n, BLK), BLK, 0, as_stream(stream)>>>(codes_dev, inval_dev, n, seq_out_dev);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+
+int kmap_hash_kmers_packed_dev(const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n, int k, void *out_dev,
+                               void *stream) {
+    KMAP_REQUIRE(k > 0 && k < 32, "hash_kmers_packed: k=%d out of range", k);
+    KMAP_REQUIRE(n >= 0 && codes_dev && inval_dev && (n == 0 || out_dev), "hash_kmers_packed: bad arguments");
+    if (n == 0) return KMAP_OK;
+    const unsigned g = grid_for((n + 15) >> 4, BLK);
+    hipStream_t st = as_stream(stream);
+    if (k < 16) hash_packed_kernel<uint32_t, false><<<g, BLK, 0, st>>>(codes_dev, inval_dev, n, k, (uint32_t *)out_dev);
+    else if (k == 16) hash_packed_kernel<uint64_t, false><<<g, BLK, 0, st>>>(codes_dev, inval_dev, n, k, (uint64_t *)out_dev);
+    else hash_packed_kernel<uint64_t, true><<<g, BLK, 0, st>>>(codes_dev, inval_dev, n, k, (uint64_t *)out_dev);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+
+int kmap_counts_run_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n,
+                               const int64_t *borders_dev, int64_t n_seq, int k, int dedupe_per_read, int merge_revcom,
+                               int64_t *n_uniq, void *stream) {
+    KMAP_REQUIRE(c, "counts_run_packed: null handle");
+    KMAP_REQUIRE(k > 0 && k < 32, "counts_run_packed: k=%d out of range", k);
+    KMAP_REQUIRE(n >= 0 && codes_dev && inval_dev, "counts_run_packed: bad input");
+    hipStream_t st = as_stream(stream);
+    if (dedupe_per_read || k > 16) {
+        // per-read dedupe (first round only) and the sort path work on a materialised hash array
+        void *hash = nullptr;
+        KMAP_TRY(kmap_scratch(&hash, (size_t)(n ? n : 1) * (k < 16 ? 4 : 8), st, KMAP_SLOT_HASH));
+        KMAP_TRY(kmap_hash_kmers_packed_dev(codes_dev, inval_dev, n, k, hash, stream));
+        if (dedupe_per_read) {
+            KMAP_REQUIRE(n_seq == 0 || borders_dev, "counts_run_packed: dedupe needs borders");
+            if (k < 16) KMAP_TRY(kmap_dedupe_per_read_u32_dev((uint32_t *)hash, n, borders_dev, n_seq, stream));
+            else KMAP_TRY(kmap_dedupe_per_read_u64_dev((uint64_t *)hash, n, borders_dev, n_seq, stream));
+        }
+        return kmap_counts_run_hashes_dev(c, hash, n, k, merge_revcom, n_uniq, stream);
+    }
+    KMAP_TRY(kmap_counts_prepare_bins(c, k, st));
+    if (n > 0) {
+        const size_t n_bins = (size_t)1 << (2 * k);
+        const size_t passes = (n_bins + HP_BINS - 1) / HP_BINS;
+        if (passes <= 8 && n >= (1 << 16)) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)hist_packed_kernel<false, true>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, HP_BINS * 4));
+                attr_set = true;
+            }
+            for (size_t p = 0; p < passes; ++p)
+                hist_packed_kernel<false, true><<<256, HP_TPB, HP_BINS * 4, st>>>(codes_dev, inval_dev, n, k,
+                                                                                  (uint64_t)p * HP_BINS, c->bins);
+        } else {
+            int64_t g = ((n + 15) / 16 + BLK - 1) / BLK;
+            if (g > 256 * 16) g = 256 * 16;
+            hist_packed_kernel<false, false><<<(unsigned)g, BLK, 16, st>>>(codes_dev, inval_dev, n, k, 0, c->bins);
+        }
+        KMAP_CHECK_HIP(hipGetLastError());
+    }
+    return kmap_counts_finish_hist(c, k, merge_revcom, n_uniq, st);
+}
+
+int kmap_mask_hamball_packed_dev(const uint32_t *codes_dev, uint16_t *inval_dev, int64_t n, int k, const uint64_t *cons,
+                                 const int32_t *radius, int n_cons, void *stream) {
+    KMAP_REQUIRE(k > 0 && k < 32, "mask_hamball_packed: k=%d out of range", k);
+    KMAP_REQUIRE(n_cons >= 0 && (n_cons == 0 || (cons && radius)), "mask_hamball_packed: null consensus list");
+    if (n <= 0 || n_cons == 0) return KMAP_OK;
+    KMAP_REQUIRE(codes_dev && inval_dev, "mask_hamball_packed: null pointer");
+    hipStream_t st = as_stream(stream);
+    const int64_t ng = (n + 15) >> 4;
+    const int batches = (n_cons + 31) / 32;
+    uint16_t *hit = nullptr;
+    KMAP_TRY(kmap_scratch((void **)&hit, (size_t)ng * 2 * batches, st, KMAP_SLOT_A));
+    // all flag passes read the mask as it is on entry (the reference hashes once, kmer_count.py:605-607) ...
+    for (int b = 0; b < batches; ++b) {
+        ConsTabP t;
+        t.n = (n_cons - 32 * b < 32) ? n_cons - 32 * b : 32;
+        for (int c = 0; c < t.n; ++c) {
+            t.cons[c] = cons[32 * b + c] & low_mask<uint64_t>(k);
+            t.radius[c] = radius[32 * b + c];
+        }
+        if (k <= 16) mask_flag_packed_kernel<false><<<grid_for(ng, BLK), BLK, 0, st>>>(codes_dev, inval_dev, n, k, t, hit + (size_t)b * ng);
+        else mask_flag_packed_kernel<true><<<grid_for(ng, BLK), BLK, 0, st>>>(codes_dev, inval_dev, n, k, t, hit + (size_t)b * ng);
+    }
+    // ... then the coverage passes OR into it
+    for (int b = 0; b < batches; ++b)
+        mask_cover_packed_kernel<<<grid_for(ng, BLK), BLK, 0, st>>>(hit + (size_t)b * ng, n, k, inval_dev);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+
+int kmap_scan_run_packed_dev(kmap_scan *s, const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n,
+                             const int64_t *borders_dev, int64_t n_seq, int k, uint64_t cons, int radius, int revcom,
+                             int64_t *total_hits, void *stream) {
+    KMAP_REQUIRE(s, "scan_run_packed: null handle");
+    KMAP_REQUIRE(k > 0 && k < 32, "scan_run_packed: k=%d out of range", k);
+    KMAP_REQUIRE(n >= 0 && n_seq >= 0 && radius >= 0, "scan_run_packed: negative size");
+    s->n_seq = n_seq;
+    s->total = 0;
+    if (total_hits) *total_hits = 0;
+    if (n_seq == 0) return KMAP_OK;
+    KMAP_REQUIRE(codes_dev && inval_dev && borders_dev, "scan_run_packed: null pointer");
+    hipStream_t st = as_stream(stream);
+    KMAP_TRY(kmap_scan_reserve(s, n_seq));
+    const uint64_t m = low_mask<uint64_t>(k);
+    const uint64_t c = cons & m;
+    uint64_t com = m - c, rcc = com & 3u;
+    for (int i = 0; i < k - 1; ++i) { rcc <<= 2; com >>= 2; rcc += com & 3u; }
+    const unsigned grid = (unsigned)((n_seq + SC_WAVES - 1) / SC_WAVES);
+    scan_packed_kernel<false><<<grid, KMAP_WAVE * SC_WAVES, 0, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, c, rcc,
+                                                                     radius, revcom, s->hits, s->mind, nullptr, nullptr);
+    KMAP_TRY(exclusive_scan_u32(reinterpret_cast<const uint32_t *>(s->hits), n_seq, s->offs, st));
+    uint64_t total = 0;
+    KMAP_CHECK_HIP(hipMemcpyAsync(&total, s->offs + n_seq, 8, hipMemcpyDeviceToHost, st));
+    KMAP_CHECK_HIP(hipStreamSynchronize(st));
+    KMAP_TRY(kmap_scan_reserve_pos(s, total));
+    if (total)
+        scan_packed_kernel<true><<<grid, KMAP_WAVE * SC_WAVES, 0, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, c, rcc,
+                                                                        radius, revcom, s->hits, s->mind, s->offs, s->pos);
+    KMAP_CHECK_HIP(hipGetLastError());
+    s->total = (int64_t)total;
+    if (total_hits) *total_hits = (int64_t)total;
+    return KMAP_OK;
+}
+
+}  // extern "C"

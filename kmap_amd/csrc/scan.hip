@@ -95,13 +95,32 @@ __global__ __launch_bounds__(KMAP_WAVE *SC_WAVES) void scan_kernel(const uint8_t
 
 }  // namespace
 
-struct kmap_scan {
-    int64_t n_seq = 0, total = 0, cap_seq = 0, cap_pos = 0;
-    int32_t *hits = nullptr;
-    int8_t *mind = nullptr;
-    uint64_t *offs = nullptr;
-    int32_t *pos = nullptr;
-};
+#include "scan_internal.h"
+
+int kmap_scan_reserve(kmap_scan *s, int64_t n_seq) {
+    if (s->cap_seq < n_seq) {
+        void *ptrs[] = {s->hits, s->mind, s->offs};
+        for (void *p : ptrs)
+            if (p) KMAP_CHECK_HIP(hipFree(p));
+        s->hits = nullptr; s->mind = nullptr; s->offs = nullptr; s->cap_seq = 0;
+        KMAP_CHECK_HIP(hipMalloc((void **)&s->hits, (size_t)n_seq * 4));
+        KMAP_CHECK_HIP(hipMalloc((void **)&s->mind, (size_t)n_seq));
+        KMAP_CHECK_HIP(hipMalloc((void **)&s->offs, ((size_t)n_seq + 1) * 8));
+        s->cap_seq = n_seq;
+    }
+    return KMAP_OK;
+}
+int kmap_scan_reserve_pos(kmap_scan *s, uint64_t total) {
+    if (s->cap_pos < (int64_t)total || !s->pos) {
+        if (s->pos) KMAP_CHECK_HIP(hipFree(s->pos));
+        s->pos = nullptr;
+        s->cap_pos = 0;
+        const size_t cap = total ? (size_t)total + (size_t)total / 8 : 1;
+        KMAP_CHECK_HIP(hipMalloc((void **)&s->pos, cap * 4));
+        s->cap_pos = (int64_t)cap;
+    }
+    return KMAP_OK;
+}
 
 extern "C" {
 
@@ -130,16 +149,7 @@ int kmap_scan_run_dev(kmap_scan *s, const uint8_t *seq_dev, int64_t n, const int
     if (n_seq == 0) return KMAP_OK;
     KMAP_REQUIRE(seq_dev && borders_dev, "scan_run: null pointer");
     hipStream_t st = as_stream(stream);
-    if (s->cap_seq < n_seq) {
-        void *ptrs[] = {s->hits, s->mind, s->offs};
-        for (void *p : ptrs)
-            if (p) KMAP_CHECK_HIP(hipFree(p));
-        s->hits = nullptr; s->mind = nullptr; s->offs = nullptr; s->cap_seq = 0;
-        KMAP_CHECK_HIP(hipMalloc((void **)&s->hits, (size_t)n_seq * 4));
-        KMAP_CHECK_HIP(hipMalloc((void **)&s->mind, (size_t)n_seq));
-        KMAP_CHECK_HIP(hipMalloc((void **)&s->offs, ((size_t)n_seq + 1) * 8));
-        s->cap_seq = n_seq;
-    }
+    KMAP_TRY(kmap_scan_reserve(s, n_seq));
     const uint64_t m = low_mask<uint64_t>(k);
     const uint64_t c = cons & m;
     // reverse complement on the host (same arithmetic as revcom_hash; u32 wrap for k < 16 is moot: c < 4^k)
@@ -152,14 +162,7 @@ int kmap_scan_run_dev(kmap_scan *s, const uint8_t *seq_dev, int64_t n, const int
     uint64_t total = 0;
     KMAP_CHECK_HIP(hipMemcpyAsync(&total, s->offs + n_seq, 8, hipMemcpyDeviceToHost, st));
     KMAP_CHECK_HIP(hipStreamSynchronize(st));
-    if (s->cap_pos < (int64_t)total || !s->pos) {
-        if (s->pos) KMAP_CHECK_HIP(hipFree(s->pos));
-        s->pos = nullptr;
-        s->cap_pos = 0;
-        const size_t cap = total ? (size_t)total : 1;
-        KMAP_CHECK_HIP(hipMalloc((void **)&s->pos, cap * 4));
-        s->cap_pos = (int64_t)cap;
-    }
+    KMAP_TRY(kmap_scan_reserve_pos(s, total));
     if (total)
         scan_kernel<true><<<grid, KMAP_WAVE * SC_WAVES, 0, st>>>(seq_dev, n, borders_dev, n_seq, k, c, rcc, radius, revcom,
                                                                  s->hits, s->mind, s->offs, s->pos);

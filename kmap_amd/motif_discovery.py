@@ -53,34 +53,52 @@ def write_lines(str_list: List, outfile):
 
 # ---- device-resident sequence array ----------------------------------------------------------------
 class DeviceSeq:
-    """uint8 sequence array (+ pristine copy) and (n_seq, 2) borders in HBM."""
+    """The encoded reads resident in HBM as 2-bit codes + invalid bitmask (packed.hip), plus the (n_seq, 2) borders.
+    `inval_orig` is the pristine mask, `inval_work` the one find_motif masks; the codes are shared."""
 
     def __init__(self, seq_np_arr, boarder_mat):
         seq = np.ascontiguousarray(seq_np_arr, dtype=np.uint8)
         self.n = len(seq)
         self.borders_host = np.ascontiguousarray(boarder_mat, dtype=np.int64).reshape(-1, 2)
         self.n_seq = len(self.borders_host)
-        self.orig = _ffi.DeviceBuffer.from_numpy(seq)
-        self.work = _ffi.DeviceBuffer(max(self.n, 1))
         self.borders = _ffi.DeviceBuffer.from_numpy(self.borders_host)
         self.read_len = (self.borders_host[:, 1] - self.borders_host[:, 0]).astype(np.int64)
+        self.groups = int(_ffi.lib().kmap_packed_groups(self.n))
+        self.codes = _ffi.DeviceBuffer(self.groups * 4)
+        self.inval_orig = _ffi.DeviceBuffer(self.groups * 2)
+        self.inval_work = _ffi.DeviceBuffer(self.groups * 2)
+        raw = _ffi.DeviceBuffer.from_numpy(seq) if self.n else _ffi.DeviceBuffer(16)
+        check(_ffi.lib().kmap_pack_reads_dev(raw.ptr, self.n, self.codes.ptr, self.inval_orig.ptr, None))
+        _ffi.sync()
+        raw.free()                      # the uint8 array does not stay on the device
         self.reset()
         self._scan = None
 
     def reset(self):
-        check(_ffi.lib().kmap_memcpy_d2d(self.work.ptr, self.orig.ptr, self.n, None))
+        """restore the unmasked reads (reference motif_discovery.py:263): n/8 bytes"""
+        check(_ffi.lib().kmap_memcpy_d2d(self.inval_work.ptr, self.inval_orig.ptr, self.groups * 2, None))
 
     def count(self, dc: DeviceCounts, k, dedupe, merge_revcom, use_work=True):
-        src = self.work if use_work else self.orig
-        return dc.run_seq(src.ptr, self.n, self.borders.ptr, self.n_seq, k, dedupe, merge_revcom)
+        inval = self.inval_work if use_work else self.inval_orig
+        nu = _ffi.i64(0)
+        check(_ffi.lib().kmap_counts_run_packed_dev(dc._h, self.codes.ptr, inval.ptr, self.n, self.borders.ptr, self.n_seq, k,
+                                                    int(dedupe), int(merge_revcom), C.byref(nu), None))
+        dc.k, dc.n_uniq = k, nu.value
+        return dc.n_uniq
 
     def mask(self, k, consensus_kh_arr, max_ham_dist_arr):
         cons = np.ascontiguousarray(consensus_kh_arr, dtype=np.uint64)
         rad = np.ascontiguousarray(max_ham_dist_arr, dtype=np.int32)
-        check(_ffi.lib().kmap_mask_hamball_dev(self.work.ptr, self.n, k, ptr(cons), ptr(rad), len(cons), None))
+        check(_ffi.lib().kmap_mask_hamball_packed_dev(self.codes.ptr, self.inval_work.ptr, self.n, k, ptr(cons), ptr(rad),
+                                                      len(cons), None))
 
     def download(self):
-        return self.work.to_numpy(np.uint8, (self.n,))
+        """the working reads as the reference's uint8 array (masked positions = 255)"""
+        out_d = _ffi.DeviceBuffer(max(self.n, 1))
+        check(_ffi.lib().kmap_unpack_reads_dev(self.codes.ptr, self.inval_work.ptr, self.n, out_d.ptr, None))
+        out = out_d.to_numpy(np.uint8, (self.n,))
+        out_d.free()
+        return out
 
     def scan(self, k, consensus_kh, radius, revcom):
         """positions at each read's minimum hit distance (original, unmasked reads):
@@ -90,8 +108,8 @@ class DeviceSeq:
             check(_ffi.lib().kmap_scan_create(C.byref(h)))
             self._scan = h.value
         tot = _ffi.i64(0)
-        check(_ffi.lib().kmap_scan_run_dev(self._scan, self.orig.ptr, self.n, self.borders.ptr, self.n_seq, k,
-                                           int(consensus_kh), int(radius), int(revcom), C.byref(tot), None))
+        check(_ffi.lib().kmap_scan_run_packed_dev(self._scan, self.codes.ptr, self.inval_orig.ptr, self.n, self.borders.ptr,
+                                                  self.n_seq, k, int(consensus_kh), int(radius), int(revcom), C.byref(tot), None))
         hits = np.empty(self.n_seq, np.int32)
         mind = np.empty(self.n_seq, np.int8)
         pos = np.empty(tot.value, np.int32)
@@ -102,7 +120,7 @@ class DeviceSeq:
         if self._scan:
             _ffi.lib().kmap_scan_destroy(self._scan)
             self._scan = None
-        for b in (self.orig, self.work, self.borders):
+        for b in (self.codes, self.inval_orig, self.inval_work, self.borders):
             b.free()
 
 

@@ -1,0 +1,137 @@
+"""GPU parity of the 2-bit-packed read path (packed.hip) against the CPU oracle: pack/unpack round trip, window
+hashes for every k, histogram counting, Hamming-ball masking (incl. the reference's invalid-hash quirk) and the
+occurrence scan.  Bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def synth(rng, n_reads, lo, hi, p_n=0.02):
+    lens = rng.integers(lo, hi + 1, size=n_reads)
+    parts, st, borders = [], 0, []
+    for L in lens:
+        r = rng.integers(0, 4, size=L).astype(np.uint8)
+        r[rng.random(L) < p_n] = 255
+        parts += [r, np.array([255], np.uint8)]
+        borders.append((st, st + L))
+        st += L + 1
+    return np.concatenate(parts), np.array(borders, dtype=np.int64)
+
+
+@pytest.fixture(scope="module")
+def env():
+    from kmap_amd import _ffi
+    from kmap_amd.kmer_count import DeviceCounts
+    from kmap_amd.motif_discovery import DeviceSeq
+    from oracle import oracle as O
+    return _ffi, DeviceCounts, DeviceSeq, O
+
+
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 1000, 4099])
+def test_pack_unpack_roundtrip(env, n):
+    _ffi, _, DeviceSeq, _ = env
+    rng = np.random.default_rng(n)
+    seq = rng.integers(0, 4, size=n).astype(np.uint8)
+    seq[rng.random(n) < 0.1] = 255
+    ds = DeviceSeq(seq, np.zeros((0, 2), np.int64))
+    np.testing.assert_array_equal(ds.download(), seq)
+    ds.close()
+
+
+@pytest.mark.parametrize("k", [1, 2, 7, 8, 15, 16, 17, 24, 31])
+def test_packed_hash_every_position(env, k):
+    _ffi, _, DeviceSeq, O = env
+    rng = np.random.default_rng(100 + k)
+    seq, borders = synth(rng, 200, 1, 120)
+    ds = DeviceSeq(seq, borders)
+    dt = np.uint32 if k < 16 else np.uint64
+    out_d = _ffi.DeviceBuffer(len(seq) * np.dtype(dt).itemsize)
+    _ffi.check(_ffi.lib().kmap_hash_kmers_packed_dev(ds.codes.ptr, ds.inval_orig.ptr, len(seq), k, out_d.ptr, None))
+    np.testing.assert_array_equal(out_d.to_numpy(dt, (len(seq),)), O.comp_kmer_hash(seq, k))
+    ds.close()
+
+
+def test_packed_counts_all_paths(env):
+    _ffi, DeviceCounts, DeviceSeq, O = env
+    rng = np.random.default_rng(7)
+    seq, borders = synth(rng, 12000, 20, 160)          # ~1.1 M positions: LDS-pass histogram (k <= 9) and atomics (k >= 10)
+    ds, dc = DeviceSeq(seq, borders), DeviceCounts()
+    for k in (4, 8, 9, 10, 13, 16, 19):
+        for dedupe in (False, True):
+            ds.count(dc, k, dedupe=dedupe, merge_revcom=True)
+            u, c = dc.fetch()
+            ou, oc = O.count_kmers(seq, borders, k, rep_mode=not dedupe, revcom_mode=True)
+            np.testing.assert_array_equal(u, ou)
+            np.testing.assert_array_equal(c, oc)
+    dc.close()
+    ds.close()
+
+
+def test_packed_mask_vs_oracle_incl_quirks(env):
+    _ffi, _, DeviceSeq, O = env
+    rng = np.random.default_rng(11)
+    seq, borders = synth(rng, 1500, 25, 150)
+    for k, r in ((4, 0), (6, 1), (8, 2), (16, 6), (17, 7), (31, 12)):
+        cons = rng.integers(0, 4 ** k, size=3, dtype=np.uint64)
+        cons[0] = int(O.kmer2hash("T" * k))            # poly-T matches invalid (all-ones) hashes: masks across separators
+        rad = np.array([r, r, 0])
+        ds = DeviceSeq(seq, borders)
+        ds.mask(k, cons, rad)
+        want = O.mask_input(seq.copy(), k, cons, rad)
+        np.testing.assert_array_equal(ds.download(), want)
+        # a second round masks the already masked array (hashes of the current state), like successive find_motif trials
+        cons2 = rng.integers(0, 4 ** k, size=2, dtype=np.uint64)
+        ds.mask(k, cons2, np.array([r, r]))
+        np.testing.assert_array_equal(ds.download(), O.mask_input(want.copy(), k, cons2, np.array([r, r])))
+        ds.reset()
+        np.testing.assert_array_equal(ds.download(), seq)
+        ds.close()
+    # golden quirk case
+    a = np.concatenate([O.dna2arr("ACGTACGTAC"), O.dna2arr("GGGGGGGGGG")])
+    ds = DeviceSeq(a, np.array([[0, 10], [11, 21]]))
+    ds.mask(4, np.array([O.kmer2hash("TTTT")]), np.array([0]))
+    assert O.arr2dna(ds.download()) == "ACGTACGNNNNNNNGGGGNNNN"
+    ds.close()
+
+
+def test_packed_mask_many_consensuses(env):
+    _ffi, _, DeviceSeq, O = env
+    rng = np.random.default_rng(13)
+    seq, borders = synth(rng, 300, 30, 100)
+    cons = rng.integers(0, 4 ** 7, size=70, dtype=np.uint64)      # > 32: batched flag passes on the entry state
+    rad = rng.integers(0, 2, size=70)
+    ds = DeviceSeq(seq, borders)
+    ds.mask(7, cons, rad)
+    np.testing.assert_array_equal(ds.download(), O.mask_input(seq.copy(), 7, cons, rad))
+    ds.close()
+
+
+@pytest.mark.parametrize("k,r", [(6, 1), (8, 2), (14, 5), (20, 8), (31, 10)])
+def test_packed_scan_vs_oracle(env, k, r):
+    _ffi, _, DeviceSeq, O = env
+    rng = np.random.default_rng(k)
+    lens = [0, 1, k - 1, k, k + 1, 63, 64, 65, 256, 257, 300, 700] + list(rng.integers(5, 200, size=300))
+    parts, borders, st = [], [], 0
+    for L in lens:
+        rd = rng.integers(0, 4 if L % 3 else 1, size=L).astype(np.uint8)   # some poly-A reads: many ties at the minimum
+        if L > 20 and L % 5 == 0:
+            rd[L // 2] = 255
+        parts += [rd, np.array([255], np.uint8)]
+        borders.append((st, st + L))
+        st += L + 1
+    seq, borders = np.concatenate(parts), np.array(borders, np.int64)
+    ds = DeviceSeq(seq, borders)
+    for cons in (0, int(O.kmer2hash("T" * k)), int(rng.integers(0, 4 ** k, dtype=np.uint64))):
+        for revcom in (True, False):
+            hits, pos = ds.scan(k, cons, r, revcom)
+            buf, md, off = np.empty(1024, np.int32), C.c_int(0), 0
+            for i, (a, b) in enumerate(borders):
+                m = O.lib().ko_scan_read(np.ascontiguousarray(seq[a:b]), b - a, k, cons, r, int(revcom), buf, C.byref(md))
+                assert hits[i] == m, (i, b - a, hits[i], m)
+                np.testing.assert_array_equal(pos[off:off + m], buf[:m])
+                off += m
+            assert off == len(pos)
+    ds.close()
