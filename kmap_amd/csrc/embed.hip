@@ -347,12 +347,69 @@ __global__ __launch_bounds__(KMAP_WAVE *F_WAVES) void forces_fast_kernel(ProbSrc
 }
 
 // =================================================================================================
-// SEQ forces: one lane per row, j ascending -- the reference's summation order
-// (taichi_core.py:305-326: ret_val += diff[i,j] * (y[k,i] - y[k,j]), j != i).  IEEE f32, no FMA.
-// The 8 terms of a column group are evaluated independently (ILP), then added in order.
+// SEQ forces: the reference's summation order (taichi_core.py:305-326: ret_val += diff[i,j] * (y[k,i] - y[k,j]),
+// j ascending, j != i), IEEE f32, no FMA.  A row is owned by the 4 lanes of a quad: for a group of 4 columns
+// each sub-lane evaluates one term (q, t, t*dx, t*dy -- independent work), then ALL lanes of the row add the
+// 4 terms in column order (DPP quad broadcasts), so they carry identical accumulators and the sum order is exactly
+// j = 0, 1, 2, ...  The loss needs no order (f64 accumulation of f32 terms), each sub-lane keeps its own.
 // =================================================================================================
+constexpr int SQ_SUB = 4;                       // sub-lanes per row = one DPP quad
+constexpr int SQ_ROWS = KMAP_WAVE / SQ_SUB;     // rows per wave
+// acc + (value of `v` in lane S of the caller's quad) as ONE v_add_f32 with a DPP quad_perm source.
+// hipcc does not fold __builtin_amdgcn_update_dpp into the add, so the instruction is written out; the DPP operand
+// `v` is always produced more than 2 VALU instructions earlier (the DPP read-after-VALU-write hazard, cdna_hip 5.7).
+template <int S>
+__device__ __forceinline__ float add_quad_bcast(float acc, float v) {
+    float r;
+    if constexpr (S == 0) asm("v_add_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "v"(acc));
+    if constexpr (S == 1) asm("v_add_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "v"(acc));
+    if constexpr (S == 2) asm("v_add_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "v"(acc));
+    if constexpr (S == 3) asm("v_add_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "v"(acc));
+    return r;
+}
+constexpr int SQ_CPL = 8;                       // consecutive columns per lane per batch (one 16-byte load of u16 sums)
+constexpr int SQ_BATCH = SQ_SUB * SQ_CPL;       // 32 columns per quad per batch
+
+struct SeqBatch {                                // raw operands of one batch of one lane
+    uint32_t w[4];                               // 8 u16 sums (LUT source) ...
+    float pf[SQ_CPL];                            // ... or 8 f32 probabilities
+    float x[SQ_CPL], y[SQ_CPL];
+};
 template <bool LUTSRC>
-__global__ __launch_bounds__(KMAP_WAVE) void forces_seq_kernel(ProbSrc src, const float *__restrict__ Y, int64_t n,
+__device__ __forceinline__ void seq_load(SeqBatch &b, const ProbSrc &src, const float *__restrict__ X,
+                                         const float *__restrict__ Yy, int64_t lrc, int64_t jl, int64_t n, bool vec) {
+    if (vec && jl + SQ_CPL <= n) {
+        if (LUTSRC) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(src.ps + lrc * src.ld + jl);
+            b.w[0] = v.x; b.w[1] = v.y; b.w[2] = v.z; b.w[3] = v.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < SQ_CPL; ++c) b.pf[c] = src.pf[lrc * src.ld + jl + c];
+        }
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(X + jl), a1 = *reinterpret_cast<const f32x4 *>(X + jl + 4);
+        const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Yy + jl), c1 = *reinterpret_cast<const f32x4 *>(Yy + jl + 4);
+        b.x[0] = a0.x; b.x[1] = a0.y; b.x[2] = a0.z; b.x[3] = a0.w; b.x[4] = a1.x; b.x[5] = a1.y; b.x[6] = a1.z; b.x[7] = a1.w;
+        b.y[0] = c0.x; b.y[1] = c0.y; b.y[2] = c0.z; b.y[3] = c0.w; b.y[4] = c1.x; b.y[5] = c1.y; b.y[6] = c1.z; b.y[7] = c1.w;
+    } else {
+#pragma unroll
+        for (int c = 0; c < SQ_CPL; ++c) {
+            const int64_t j = (jl + c < n) ? jl + c : n - 1;
+            if (LUTSRC) {
+                const uint32_t v = src.ps[lrc * src.ld + j];
+                if (c & 1) b.w[c >> 1] |= v << 16;
+                else b.w[c >> 1] = v;
+            } else {
+                b.pf[c] = src.pf[lrc * src.ld + j];
+            }
+            b.x[c] = X[j];
+            b.y[c] = Yy[j];
+        }
+    }
+}
+
+constexpr int SQ_WAVES = 4;                     // waves per block (the LUT is staged once per block)
+template <bool LUTSRC>
+__global__ __launch_bounds__(KMAP_WAVE *SQ_WAVES) void forces_seq_kernel(ProbSrc src, const float *__restrict__ Y, int64_t n,
                                                                int64_t row0, int64_t nrows, float *__restrict__ G,
                                                                double *__restrict__ loss_part) {
     extern __shared__ __attribute__((aligned(16))) float lut_s[];
@@ -360,94 +417,74 @@ __global__ __launch_bounds__(KMAP_WAVE) void forces_seq_kernel(ProbSrc src, cons
         for (int t = threadIdx.x; t < src.lut_len && t < F_LUT_LDS; t += blockDim.x) lut_s[t] = src.lut[t];
         __syncthreads();
     }
-    const int64_t lr = (int64_t)blockIdx.x * KMAP_WAVE + threadIdx.x;
+    __shared__ double wl[SQ_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & (SQ_SUB - 1);
+    const int64_t lr = ((int64_t)blockIdx.x * SQ_WAVES + wave) * SQ_ROWS + (lane / SQ_SUB);
     const bool valid = lr < nrows;
     const int64_t lrc = valid ? lr : nrows - 1;
     const int64_t i = row0 + lrc;
     const float *X = Y, *Yy = Y + n;
     const float xi = X[i], yi = Yy[i];
+    const bool vec = ((n & 3) == 0) && (!LUTSRC || (src.ld % 8 == 0));
+    const int n32 = (int)n, i32 = (int)i;        // n < 2^31 (checked by the host)
     float gx = 0.0f, gy = 0.0f, ce_acc = 0.0f;
     double loss = 0.0;
-    constexpr int U = 8;
-    const bool vec_ok = LUTSRC && (src.ld % 8 == 0);
-    int64_t j0 = 0;
-    for (; j0 + U <= n; j0 += U) {
-        float p[U], tx[U], ty[U], ce[U];
-        if (LUTSRC) {
-            const uint16_t *row = src.ps + lrc * src.ld + j0;
-            if (vec_ok) {
-                const u32x4 w = *reinterpret_cast<const u32x4 *>(row);
-                const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+    SeqBatch cur, nxt;
+    seq_load<LUTSRC>(cur, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n, vec);
+    for (int64_t j0 = 0; j0 < n; j0 += SQ_BATCH) {
+        const int64_t jl = j0 + (int64_t)sub * SQ_CPL;                       // this lane's first column of the batch
+        if (j0 + SQ_BATCH < n) seq_load<LUTSRC>(nxt, src, X, Yy, lrc, jl + SQ_BATCH, n, vec);   // prefetch
+        float tx[SQ_CPL], ty[SQ_CPL];
+        float ce2 = 0.0f;                                                    // loss terms in log2 units (order-free)
+        const int jl32 = (int)jl;
 #pragma unroll
-                for (int c = 0; c < U; ++c) p[c] = lut_s[(ws[c >> 1] >> (16 * (c & 1))) & 0xFFFFu];
-            } else {
-#pragma unroll
-                for (int c = 0; c < U; ++c) p[c] = lut_s[row[c]];
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < U; ++c) p[c] = src.pf[lrc * src.ld + j0 + c];
-        }
-        float xs[U], ys[U];
-        if ((n & 3) == 0) {   // 16-byte aligned rows: wave-uniform vector loads -> s_load_dwordx4
-            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(X + j0), a1 = *reinterpret_cast<const f32x4 *>(X + j0 + 4);
-            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(Yy + j0), b1 = *reinterpret_cast<const f32x4 *>(Yy + j0 + 4);
-            xs[0] = a0.x; xs[1] = a0.y; xs[2] = a0.z; xs[3] = a0.w; xs[4] = a1.x; xs[5] = a1.y; xs[6] = a1.z; xs[7] = a1.w;
-            ys[0] = b0.x; ys[1] = b0.y; ys[2] = b0.z; ys[3] = b0.w; ys[4] = b1.x; ys[5] = b1.y; ys[6] = b1.z; ys[7] = b1.w;
-        } else {
-#pragma unroll
-            for (int c = 0; c < U; ++c) {
-                xs[c] = X[j0 + c];
-                ys[c] = Yy[j0 + c];
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < U; ++c) {
-            const float xj = xs[c], yj = ys[c];
-            const float dx = xi - xj, dy = yi - yj;
+        for (int c = 0; c < SQ_CPL; ++c) {                                   // 8 independent terms
+            const int j = jl32 + c;
+            const float p = LUTSRC ? lut_s[(cur.w[c >> 1] >> (16 * (c & 1))) & 0xFFFFu] : cur.pf[c];
+            const float dx = xi - cur.x[c], dy = yi - cur.y[c];
             const float q = q_of(dx, dy);
-            const float t = t_of(p[c], q);
-            tx[c] = t * dx;                                  // products rounded on their own (-ffp-contract=off)
-            ty[c] = t * dy;
-            ce[c] = ce_of<false>(p[c], q);
+            const float t = t_of(p, q);
+            const bool use = (j < n32) && (j != i32);
+            tx[c] = use ? t * dx : 0.0f;                                     // products rounded on their own (-ffp-contract=off)
+            ty[c] = use ? t * dy : 0.0f;
+            // -(p ln q + (1-p) ln(1-q)) = -ln2 (l1 + p (lq - l1)); the reference's eps branches change a term by
+            // < 1e-9 relative (p < 1e-10) or not at all (p = 1), and the loss is not part of the bit-pinned path
+            const float lq = __builtin_amdgcn_logf(q), l1 = __builtin_amdgcn_logf(1.0f - q);
+            const float e = l1 + p * (lq - l1);
+            ce2 += (j < n32 && j > i32) ? e : 0.0f;
         }
-#pragma unroll
-        for (int c = 0; c < U; ++c) {                        // ordered accumulation: j ascending
-            const int64_t j = j0 + c;
-            if (j != i) {
-                gx = gx + tx[c];
-                gy = gy + ty[c];
-                if (j > i) ce_acc += ce[c];
-            }
+        ce_acc += ce2;
+        // ordered accumulation over the batch's 32 columns: column j0 + 8*s2 + c lives in sub-lane s2, slot c
+        asm volatile("s_nop 1");
+#define SEQ_ADD(S2)                                                                                   \
+        _Pragma("unroll") for (int c = 0; c < SQ_CPL; ++c) {                                          \
+            gx = add_quad_bcast<S2>(gx, tx[c]);                                                       \
+            gy = add_quad_bcast<S2>(gy, ty[c]);                                                       \
         }
-        if ((j0 & 127) == 120) {
+        SEQ_ADD(0) SEQ_ADD(1) SEQ_ADD(2) SEQ_ADD(3)
+#undef SEQ_ADD
+        if (((j0 / SQ_BATCH) & 7) == 7) {
             loss += (double)ce_acc;
             ce_acc = 0.0f;
         }
-    }
-    for (int64_t j = j0; j < n; ++j) {
-        const float xj = X[j], yj = Yy[j];
-        float p;
-        if (LUTSRC) p = lut_s[src.ps[lrc * src.ld + j]];
-        else p = src.pf[lrc * src.ld + j];
-        const float dx = xi - xj, dy = yi - yj;
-        const float q = q_of(dx, dy);
-        const float t = t_of(p, q);
-        if (j != i) {
-            gx = gx + t * dx;
-            gy = gy + t * dy;
-            if (j > i) ce_acc += ce_of<false>(p, q);
-        }
+        cur = nxt;
     }
     loss += (double)ce_acc;
-    if (valid) {
+    loss *= -0.6931471805599453;   // log2 units -> -ln
+    if (valid && sub == 0) {
         G[i] = gx;
         G[n + i] = gy;
-    } else {
-        loss = 0.0;
     }
+    if (!valid) loss = 0.0;
     for (int o = 32; o > 0; o >>= 1) loss += __shfl_down(loss, o);
-    if (threadIdx.x == 0) loss_part[blockIdx.x] = loss;
+    if (lane == 0) wl[wave] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < SQ_WAVES; ++w) t += wl[w];
+        loss_part[blockIdx.x] = t;
+    }
 }
 
 // deterministic reduction of the per-block loss partials into loss_out[0]
@@ -572,7 +609,7 @@ struct kmap_embed {
 
 namespace {
 int n_force_blocks(const kmap_embed *e) {
-    if (e->mode == KMAP_EMBED_SEQ) return (int)((e->nrows + KMAP_WAVE - 1) / KMAP_WAVE);
+    if (e->mode == KMAP_EMBED_SEQ) return (int)((e->nrows + SQ_ROWS * SQ_WAVES - 1) / (SQ_ROWS * SQ_WAVES));
     return (int)((e->nrows + F_RPW * F_WAVES - 1) / (F_RPW * F_WAVES));
 }
 }  // namespace
@@ -641,6 +678,7 @@ int kmap_embed_create(kmap_embed **out, int64_t n, int64_t row0, int64_t nrows, 
                       int mode) {
     KMAP_REQUIRE(out, "embed_create: null");
     KMAP_REQUIRE(n > 0 && row0 >= 0 && nrows >= 0 && row0 + nrows <= n, "embed_create: bad row range");
+    KMAP_REQUIRE(n < ((int64_t)1 << 31) - 64, "embed_create: n too large");
     KMAP_REQUIRE(n_best > 0 && n_best <= MAX_BEST, "embed_create: n_best must be in [1,%d]", MAX_BEST);
     KMAP_REQUIRE(mode == KMAP_EMBED_FAST || mode == KMAP_EMBED_SEQ, "embed_create: unknown mode %d", mode);
     kmap_embed *e = new kmap_embed();
@@ -740,8 +778,8 @@ int kmap_embed_forces(kmap_embed *e, float *grad_dev_2xn, double *loss_dev, void
     const bool lut = e->src.ps != nullptr;
     const size_t lds = lut ? (((size_t)e->src.lut_len * 4 + 15) & ~(size_t)15) : 16;
     if (e->mode == KMAP_EMBED_SEQ) {
-        if (lut) forces_seq_kernel<true><<<nblk, KMAP_WAVE, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
-        else forces_seq_kernel<false><<<nblk, KMAP_WAVE, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
+        if (lut) forces_seq_kernel<true><<<nblk, KMAP_WAVE * SQ_WAVES, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
+        else forces_seq_kernel<false><<<nblk, KMAP_WAVE * SQ_WAVES, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
     } else {
         if (lut) forces_fast_kernel<true><<<nblk, KMAP_WAVE * F_WAVES, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
         else forces_fast_kernel<false><<<nblk, KMAP_WAVE * F_WAVES, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
