@@ -165,6 +165,17 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "hamdist_matrix_kernel<u32>",
                          "kernel_ms": kern_ms, "algorithmic_bytes": algo_bytes},
         }
+        # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate
+        # runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); collected offline, stored under profiles/
+        pmc = sorted((ROOT / "profiles").glob("r*_bench_pmc.json"))
+        if pmc and world == 1:
+            try:
+                kern = json.loads(pmc[-1].read_text())["kernels"]
+                hk = [v for k_, v in kern.items() if "hamdist_matrix_kernel" in k_][0]
+                line["roofline"]["traffic"] = hk["hbm_bytes_per_launch"]
+                line["roofline"]["traffic_source"] = f"profiles/{pmc[-1].name}"
+            except Exception:
+                pass
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(kh, lab)
         if world == 1 and args.e2e != "none":

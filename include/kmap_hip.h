@@ -139,6 +139,13 @@ int kmap_hash_kmers_packed_dev(const uint32_t *codes_dev, const uint16_t *inval_
 int kmap_counts_run_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n,
                                const int64_t *borders_dev, int64_t n_seq, int k, int dedupe_per_read, int merge_revcom,
                                int64_t *n_uniq, void *stream);
+/* multi-GPU counting: every rank histograms ITS reads (`kmap_counts_hist_packed_dev`, k <= 16, bins zeroed
+ * first; the per-read dedupe is local to a read), the caller all-reduces the 4^k uint32 bins in place
+ * (`kmap_counts_bins` returns the device pointer), then every rank compacts identically (`kmap_counts_finish`). */
+int kmap_counts_hist_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n,
+                                const int64_t *borders_dev, int64_t n_seq, int k, int dedupe_per_read, void *stream);
+int kmap_counts_bins(kmap_counts *c, void **bins_dev, int64_t *n_bins);
+int kmap_counts_finish(kmap_counts *c, int k, int merge_revcom, int64_t *n_uniq, void *stream);
 int kmap_mask_hamball_packed_dev(const uint32_t *codes_dev, uint16_t *inval_dev, int64_t n, int k, const uint64_t *cons,
                                  const int32_t *radius, int n_cons, void *stream);        /* cons/radius: host */
 

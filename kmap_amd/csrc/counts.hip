@@ -282,11 +282,7 @@ int kmap_counts_finish_hist(kmap_counts *c, int k, int merge, int64_t *n_uniq, h
 namespace {
 
 template <typename H>
-int run_hashes(kmap_counts *c, const H *hash_dev, int64_t n, int k, int merge, int64_t *n_uniq, hipStream_t st) {
-    if (k > 16) {
-        if constexpr (sizeof(H) == 8) return kmap_counts_sort_path(c, (const uint64_t *)hash_dev, n, k, merge, n_uniq, st);
-        KMAP_REQUIRE(false, "counts: k=%d needs uint64 hashes", k);
-    }
+int hist_hashes(kmap_counts *c, const H *hash_dev, int64_t n, int k, hipStream_t st) {
     const size_t n_bins = (size_t)1 << (2 * k);
     KMAP_TRY(kmap_counts_prepare_bins(c, k, st));
     if (n > 0) {
@@ -306,11 +302,28 @@ int run_hashes(kmap_counts *c, const H *hash_dev, int64_t n, int k, int merge, i
             if (g > 256 * 32) g = 256 * 32;
             hist_kernel<H><<<(unsigned)g, BLK, 0, st>>>(hash_dev, n, c->bins);
         }
+        KMAP_CHECK_HIP(hipGetLastError());
     }
+    return KMAP_OK;
+}
+
+template <typename H>
+int run_hashes(kmap_counts *c, const H *hash_dev, int64_t n, int k, int merge, int64_t *n_uniq, hipStream_t st) {
+    if (k > 16) {
+        if constexpr (sizeof(H) == 8) return kmap_counts_sort_path(c, (const uint64_t *)hash_dev, n, k, merge, n_uniq, st);
+        KMAP_REQUIRE(false, "counts: k=%d needs uint64 hashes", k);
+    }
+    KMAP_TRY(hist_hashes<H>(c, hash_dev, n, k, st));
     return kmap_counts_finish_hist(c, k, merge, n_uniq, st);
 }
 
 }  // namespace
+
+int kmap_counts_hist_hashes(kmap_counts *c, const void *hash_dev, int64_t n, int k, hipStream_t st) {
+    KMAP_REQUIRE(k > 0 && k <= 16, "counts_hist_hashes: k=%d", k);
+    if (k < 16) return hist_hashes<uint32_t>(c, (const uint32_t *)hash_dev, n, k, st);
+    return hist_hashes<uint64_t>(c, (const uint64_t *)hash_dev, n, k, st);
+}
 
 extern "C" {
 

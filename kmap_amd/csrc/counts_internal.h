@@ -19,3 +19,4 @@ int kmap_counts_sort_path(kmap_counts *c, const uint64_t *hash_dev, int64_t n, i
                           hipStream_t st);
 int kmap_counts_prepare_bins(kmap_counts *c, int k, hipStream_t st);
 int kmap_counts_finish_hist(kmap_counts *c, int k, int merge, int64_t *n_uniq, hipStream_t st);
+int kmap_counts_hist_hashes(kmap_counts *c, const void *hash_dev, int64_t n, int k, hipStream_t st);

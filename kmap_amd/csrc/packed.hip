@@ -353,24 +353,22 @@ int kmap_hash_kmers_packed_dev(const uint32_t *codes_dev, const uint16_t *inval_
     return KMAP_OK;
 }
 
-int kmap_counts_run_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n,
-                               const int64_t *borders_dev, int64_t n_seq, int k, int dedupe_per_read, int merge_revcom,
-                               int64_t *n_uniq, void *stream) {
-    KMAP_REQUIRE(c, "counts_run_packed: null handle");
-    KMAP_REQUIRE(k > 0 && k < 32, "counts_run_packed: k=%d out of range", k);
-    KMAP_REQUIRE(n >= 0 && codes_dev && inval_dev, "counts_run_packed: bad input");
+// fills c->bins (zeroed first) with the k-mer histogram of the packed reads; k <= 16
+int kmap_counts_hist_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n,
+                                const int64_t *borders_dev, int64_t n_seq, int k, int dedupe_per_read, void *stream) {
+    KMAP_REQUIRE(c, "counts_hist_packed: null handle");
+    KMAP_REQUIRE(k > 0 && k <= 16, "counts_hist_packed: k=%d needs the sort path (no histogram)", k);
+    KMAP_REQUIRE(n >= 0 && codes_dev && inval_dev, "counts_hist_packed: bad input");
     hipStream_t st = as_stream(stream);
-    if (dedupe_per_read || k > 16) {
-        // per-read dedupe (first round only) and the sort path work on a materialised hash array
+    if (dedupe_per_read) {
+        // per-read dedupe (first round only) works on a materialised hash array
+        KMAP_REQUIRE(n_seq == 0 || borders_dev, "counts_hist_packed: dedupe needs borders");
         void *hash = nullptr;
         KMAP_TRY(kmap_scratch(&hash, (size_t)(n ? n : 1) * (k < 16 ? 4 : 8), st, KMAP_SLOT_HASH));
         KMAP_TRY(kmap_hash_kmers_packed_dev(codes_dev, inval_dev, n, k, hash, stream));
-        if (dedupe_per_read) {
-            KMAP_REQUIRE(n_seq == 0 || borders_dev, "counts_run_packed: dedupe needs borders");
-            if (k < 16) KMAP_TRY(kmap_dedupe_per_read_u32_dev((uint32_t *)hash, n, borders_dev, n_seq, stream));
-            else KMAP_TRY(kmap_dedupe_per_read_u64_dev((uint64_t *)hash, n, borders_dev, n_seq, stream));
-        }
-        return kmap_counts_run_hashes_dev(c, hash, n, k, merge_revcom, n_uniq, stream);
+        if (k < 16) KMAP_TRY(kmap_dedupe_per_read_u32_dev((uint32_t *)hash, n, borders_dev, n_seq, stream));
+        else KMAP_TRY(kmap_dedupe_per_read_u64_dev((uint64_t *)hash, n, borders_dev, n_seq, stream));
+        return kmap_counts_hist_hashes(c, hash, n, k, st);
     }
     KMAP_TRY(kmap_counts_prepare_bins(c, k, st));
     if (n > 0) {
@@ -393,6 +391,39 @@ int kmap_counts_run_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const 
         }
         KMAP_CHECK_HIP(hipGetLastError());
     }
+    return KMAP_OK;
+}
+
+int kmap_counts_bins(kmap_counts *c, void **bins_dev, int64_t *n_bins) {
+    KMAP_REQUIRE(c && bins_dev && n_bins, "counts_bins: null");
+    *bins_dev = c->bins;
+    *n_bins = (int64_t)c->bins_cap;
+    return KMAP_OK;
+}
+
+int kmap_counts_finish(kmap_counts *c, int k, int merge_revcom, int64_t *n_uniq, void *stream) {
+    KMAP_REQUIRE(c && c->bins && k > 0 && k <= 16 && c->bins_cap >= ((size_t)1 << (2 * k)), "counts_finish: no histogram for k=%d", k);
+    return kmap_counts_finish_hist(c, k, merge_revcom, n_uniq, as_stream(stream));
+}
+
+int kmap_counts_run_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n,
+                               const int64_t *borders_dev, int64_t n_seq, int k, int dedupe_per_read, int merge_revcom,
+                               int64_t *n_uniq, void *stream) {
+    KMAP_REQUIRE(c, "counts_run_packed: null handle");
+    KMAP_REQUIRE(k > 0 && k < 32, "counts_run_packed: k=%d out of range", k);
+    KMAP_REQUIRE(n >= 0 && codes_dev && inval_dev, "counts_run_packed: bad input");
+    hipStream_t st = as_stream(stream);
+    if (k > 16) {   // sort path on a materialised hash array
+        void *hash = nullptr;
+        KMAP_TRY(kmap_scratch(&hash, (size_t)(n ? n : 1) * 8, st, KMAP_SLOT_HASH));
+        KMAP_TRY(kmap_hash_kmers_packed_dev(codes_dev, inval_dev, n, k, hash, stream));
+        if (dedupe_per_read) {
+            KMAP_REQUIRE(n_seq == 0 || borders_dev, "counts_run_packed: dedupe needs borders");
+            KMAP_TRY(kmap_dedupe_per_read_u64_dev((uint64_t *)hash, n, borders_dev, n_seq, stream));
+        }
+        return kmap_counts_run_hashes_dev(c, hash, n, k, merge_revcom, n_uniq, stream);
+    }
+    KMAP_TRY(kmap_counts_hist_packed_dev(c, codes_dev, inval_dev, n, borders_dev, n_seq, k, dedupe_per_read, stream));
     return kmap_counts_finish_hist(c, k, merge_revcom, n_uniq, st);
 }
 

@@ -99,3 +99,70 @@ def kmap_from_kmers_distributed(samp_kh, samp_cnts, samp_label, conseq_list, kme
         return sess.best(), lab
     finally:
         sess.close()
+
+
+# ---- read-sharded k-mer counting / masking / scanning -----------------------------------------------------------
+class _DevArray:
+    """Zero-copy view of library-owned device memory for torch (via __cuda_array_interface__)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def read_partition(borders, world, rank):
+    """Contiguous read ranges cut at read borders, balanced by read count: returns (first_read, n_reads)."""
+    return row_partition(len(borders), world, rank)
+
+
+def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None):
+    """A DeviceSeq holding only this rank's reads whose count()/scan() results are global:
+    count = local histogram -> all-reduce(SUM) of the 4^k uint32 bins -> identical compaction on every rank
+    (k <= 16; per-read dedupe, masking and scanning are local to a read, hence to a rank).  Because every rank then
+    sees the same counts, find_motif(dev_seq=...) makes the same decisions everywhere without further exchange."""
+    import ctypes as C
+    import torch
+    from . import _ffi
+    from ._ffi import check
+    from .motif_discovery import DeviceSeq
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    borders = np.ascontiguousarray(boarder_mat, dtype=np.int64).reshape(-1, 2)
+    r0, nr = read_partition(borders, world, rank)
+    if nr:
+        lo, hi = int(borders[r0, 0]), int(borders[r0 + nr - 1, 1]) + 1          # include the last read's separator
+        hi = min(hi, len(seq_np_arr))
+    else:
+        lo = hi = 0
+    local_seq = np.ascontiguousarray(seq_np_arr[lo:hi])
+    local_borders = borders[r0:r0 + nr] - lo
+
+    class DistDeviceSeq(DeviceSeq):
+        first_read, n_local_reads, n_all_reads = r0, nr, len(borders)
+
+        def count(self, dc, k, dedupe, merge_revcom, use_work=True):
+            if k > 16:
+                raise ValueError("sharded counting all-reduces the 4^k histogram and needs k <= 16")
+            inval = self.inval_work if use_work else self.inval_orig
+            check(_ffi.lib().kmap_counts_hist_packed_dev(dc._h, self.codes.ptr, inval.ptr, self.n, self.borders.ptr,
+                                                         self.n_seq, k, int(dedupe), None))
+            p, nb = _ffi.vp(), _ffi.i64(0)
+            check(_ffi.lib().kmap_counts_bins(dc._h, C.byref(p), C.byref(nb)))
+            bins = torch.as_tensor(_DevArray(p.value, 4 ** k, "<i4"), device="cuda")   # int32 sum wraps like uint32
+            torch.cuda.synchronize()
+            dist.all_reduce(bins, op=dist.ReduceOp.SUM, group=group)
+            torch.cuda.synchronize()
+            nu = _ffi.i64(0)
+            check(_ffi.lib().kmap_counts_finish(dc._h, k, int(merge_revcom), C.byref(nu), None))
+            dc.k, dc.n_uniq = k, nu.value
+            return dc.n_uniq
+
+        def scan(self, k, consensus_kh, radius, revcom):
+            hits, pos = DeviceSeq.scan(self, k, consensus_kh, radius, revcom)
+            parts = [None] * world
+            dist.all_gather_object(parts, (hits, pos), group=group)                    # read order = rank order
+            return np.concatenate([h for h, _ in parts]), np.concatenate([q for _, q in parts])
+
+    ds = DistDeviceSeq(local_seq, local_borders)
+    all_len = (borders[:, 1] - borders[:, 0]).astype(np.int64)
+    ds.read_len_global = all_len
+    return ds

@@ -58,3 +58,71 @@ def test_two_ranks_one_gpu_equals_single(tmp_path, mode):
     # per-row sums do not depend on the sharding (a row is always summed by one lane / one wave)
     np.testing.assert_array_equal(r0["last"], tr["last_coords"])
     np.testing.assert_array_equal(r0["best"], best)
+
+
+def _count_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import pickle
+    import torch
+    import torch.distributed as dist
+    from kmap_amd import synth
+    from kmap_amd.distributed import make_dist_device_seq
+    from kmap_amd.kmer_count import DeviceCounts, kmer2hash
+    from kmap_amd.motif_discovery import find_motif
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seq, borders = synth.synth_reads(30011, 75, 4)          # odd read count: uneven shards
+        ds = make_dist_device_seq(seq, borders, dist)
+        dc = DeviceCounts()
+        out = {"shard": (ds.first_read, ds.n_local_reads)}
+        for k in (6, 9, 11):
+            for dedupe in (True, False):
+                ds.count(dc, k, dedupe=dedupe, merge_revcom=True)
+                out[(k, dedupe)] = dc.fetch()
+        out["scan"] = ds.scan(8, kmer2hash("ATCGATAG"), 2, True)
+        mdef = type("M", (), dict(max_ham_dist=2, p_uniform=0.004241943, ratio_mu=1.0, ratio_std=0.04864974, ratio_cutoff=1.3094))()
+        ds.reset()
+        r = find_motif(None, 8, mdef.max_ham_dist, mdef.p_uniform, mdef.ratio_mu, mdef.ratio_std, mdef.ratio_cutoff,
+                       save_kmer_cnt_flag=False, dev_seq=ds)
+        out["motifs"] = {int(h): v for h, v in r.items()}
+        with open(Path(out_dir) / f"cnt_rank{rank}.pkl", "wb") as fh:
+            pickle.dump(out, fh)
+        dc.close()
+        ds.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_read_sharded_counting_scan_and_find_motif(tmp_path):
+    """Reads sharded over two ranks (histogram all-reduce): counts, scan hits and find_motif decisions equal the
+    single-GPU run and the CPU oracle."""
+    import pickle
+    import torch.multiprocessing as mp
+    from kmap_amd import synth
+    from kmap_amd.kmer_count import DeviceCounts, kmer2hash
+    from kmap_amd.motif_discovery import DeviceSeq, find_motif
+    from oracle import oracle as O
+    mp.spawn(_count_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    res = [pickle.load(open(tmp_path / f"cnt_rank{r}.pkl", "rb")) for r in range(2)]
+    assert res[0]["shard"] == (0, 15006) and res[1]["shard"] == (15006, 15005)
+    seq, borders = synth.synth_reads(30011, 75, 4)
+    ds, dc = DeviceSeq(seq, borders), DeviceCounts()
+    for k in (6, 9, 11):
+        for dedupe in (True, False):
+            ou, oc = O.count_kmers(seq, borders, k, rep_mode=not dedupe, revcom_mode=True)
+            for r in res:
+                np.testing.assert_array_equal(r[(k, dedupe)][0], ou)
+                np.testing.assert_array_equal(r[(k, dedupe)][1], oc)
+    hits, pos = ds.scan(8, kmer2hash("ATCGATAG"), 2, True)
+    for r in res:
+        np.testing.assert_array_equal(r["scan"][0], hits)
+        np.testing.assert_array_equal(r["scan"][1], pos)
+    mdef = dict(max_ham_dist=2, p_uniform=0.004241943, ratio_mu=1.0, ratio_std=0.04864974, ratio_cutoff=1.3094)
+    single = find_motif(None, 8, mdef["max_ham_dist"], mdef["p_uniform"], mdef["ratio_mu"], mdef["ratio_std"], mdef["ratio_cutoff"],
+                        save_kmer_cnt_flag=False, dev_seq=ds)
+    assert len(single) >= 2
+    for r in res:
+        assert r["motifs"] == {int(h): v for h, v in single.items()}
+    dc.close()
+    ds.close()
