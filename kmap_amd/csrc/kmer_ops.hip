@@ -2,6 +2,8 @@
 // reverse complement, Hamming 1-vs-N (full / head / tail) and Hamming-ball masking.
 // Each replaces one numpy-in/numpy-out operator of the reference (cited at the entry points).
 // All of these are HBM-streaming integer kernels: 1 B (sequence) or 4/8 B (hash) per element.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -68,15 +70,24 @@ __global__ __launch_bounds__(BLK) void ham1vN_kernel(const H *__restrict__ h, in
 }
 
 // ---- per-read de-duplication (kmer_count.py:743-760) ---------------------------------------------
-// Short reads: one wave per read, the read's hashes staged in LDS, position i is a duplicate iff an
-// equal hash sits at an earlier position (LDS broadcast reads, O(L^2/64) per lane).
-constexpr int DD_CAP = 1024;            // hashes per wave staged in LDS
+// Short reads: one wave per read with a private open-addressing hash set in LDS (key -> smallest position).
+// Positions are inserted 64 at a time in read order (atomicCAS on the key, atomicMin on the position), and after each
+// chunk a position survives only if it is the stored minimum: the first occurrence wins, O(L) LDS operations.
+constexpr int DD_CAP = 512;             // longest read handled here; table = next_pow2(2L) <= 1024 slots per wave
+constexpr int DD_SLOTS = 2 * DD_CAP;
 constexpr int DD_WAVES = 4;
+template <typename H>
+__device__ __forceinline__ uint64_t mix(H v) {
+    uint64_t x = (uint64_t)v * 0x9E3779B97F4A7C15ull;
+    return x ^ (x >> 29);
+}
 template <typename H>
 __global__ __launch_bounds__(KMAP_WAVE *DD_WAVES) void dedupe_short_kernel(H *__restrict__ hash,
                                                                             const int64_t *__restrict__ borders,
                                                                             int64_t n_seq, int64_t n) {
-    __shared__ H buf[DD_WAVES][DD_CAP];
+    typedef typename std::conditional<sizeof(H) == 4, unsigned int, unsigned long long>::type K;
+    __shared__ K keys[DD_WAVES][DD_SLOTS];
+    __shared__ unsigned int minpos[DD_WAVES][DD_SLOTS];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t s = (int64_t)blockIdx.x * DD_WAVES + wave;
@@ -84,30 +95,41 @@ __global__ __launch_bounds__(KMAP_WAVE *DD_WAVES) void dedupe_short_kernel(H *__
     int64_t st = borders[2 * s], en = borders[2 * s + 1];
     if (st < 0) st = 0;
     if (en > n) en = n;
-    const int64_t L = en - st;
-    if (L <= 1 || L > DD_CAP) return;   // long reads: dedupe_long_kernel
-    H *b = buf[wave];
-    for (int i = lane; i < L; i += 64) b[i] = hash[st + i];
+    const int L = (int)((en - st > DD_CAP) ? 0 : (en - st));   // long reads: dedupe_long_kernel
+    if (L <= 1) return;
+    int T = 64;
+    while (T < 2 * L) T <<= 1;
+    K *kt = keys[wave];
+    unsigned int *pt = minpos[wave];
+    const K EMPTY = (K)~(K)0;                                    // the invalid hash is never inserted
+    for (int t = lane; t < T; t += 64) {
+        kt[t] = EMPTY;
+        pt[t] = 0xFFFFFFFFu;
+    }
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): LDS writes of this wave are visible to it
-    const H inval = (H)~(H)0;
-    for (int i = lane; i < L; i += 64) {
-        const H v = b[i];
-        if (v == inval) continue;
-        bool dup = false;
-        for (int j = 0; j < i; ++j) dup |= (b[j] == v);
-        if (dup) hash[st + i] = inval;
+    for (int p0 = 0; p0 < L; p0 += 64) {
+        const int p = p0 + lane;
+        const bool act = p < L;
+        const K v = act ? (K)hash[st + p] : EMPTY;
+        int slot = -1;
+        if (v != EMPTY) {
+            slot = (int)(mix((H)v) & (uint64_t)(T - 1));
+            for (;;) {
+                const K prev = atomicCAS(&kt[slot], EMPTY, v);
+                if (prev == EMPTY || prev == v) break;
+                slot = (slot + 1) & (T - 1);
+            }
+            atomicMin(&pt[slot], (unsigned int)p);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0): this wave's LDS atomics have landed
+        if (slot >= 0 && pt[slot] != (unsigned int)p) hash[st + p] = (H)~(H)0;
     }
 }
 
 // Long reads: one block per read, open-addressing table (key -> smallest position) in global
 // scratch sized >= 2*L; phase A inserts with atomicMin on the position, phase B keeps a
 // position only if it is the stored minimum.
-template <typename H>
-__device__ __forceinline__ uint64_t mix(H v) {
-    uint64_t x = (uint64_t)v * 0x9E3779B97F4A7C15ull;
-    return x ^ (x >> 29);
-}
 template <typename H>
 __global__ __launch_bounds__(BLK) void dedupe_long_kernel(H *__restrict__ hash, const int64_t *__restrict__ borders,
                                                           const int64_t *__restrict__ long_ids,

@@ -137,8 +137,8 @@ def test_dedupe_golden(K, golden, k):
 
 def test_dedupe_ragged_and_long_reads(K, O):
     rng = np.random.default_rng(5)
-    # low-complexity reads (many duplicates), ragged lengths incl. empty and > LDS capacity (1024)
-    lens = [0, 1, 2, 63, 64, 65, 500, 1024, 1025, 5000, 20000, 3, 0, 777]
+    # low-complexity reads (many duplicates), ragged lengths incl. empty and > LDS capacity (512)
+    lens = [0, 1, 2, 63, 64, 65, 500, 511, 512, 513, 1024, 1025, 5000, 20000, 3, 0, 777]
     parts, borders, st = [], [], 0
     for L in lens:
         parts += [rng.integers(0, 2, size=L).astype(np.uint8), np.array([255], np.uint8)]
