@@ -347,6 +347,158 @@ __global__ __launch_bounds__(KMAP_WAVE *F_WAVES) void forces_fast_kernel(ProbSrc
 }
 
 // =================================================================================================
+// FAST forces, symmetric form (single-GPU, all rows local): every unordered pair {i<j} is evaluated once.
+// A wave owns a tile of SY_R rows x 512 columns (lane = 8 consecutive columns); t*(y_i-y_j) goes to the row's sum
+// (wave reduction per row) and, negated, to the lane's column accumulators (registers, over the tile's rows).
+// Tiles write disjoint slices of two partial buffers -- rowpart[J][2][N] and colpart[I][2][N] -- and a second kernel
+// adds the partials in a fixed order: deterministic, no atomics.  Tiles entirely below the diagonal are skipped.
+// =================================================================================================
+constexpr int SY_RB = 64;                // rows per row block (one lane of the wave holds one row's coordinates)
+constexpr int SY_NRB = 4;                // row blocks a wave walks through with its column accumulators live
+constexpr int SY_R = SY_RB * SY_NRB;     // rows per tile
+constexpr int SY_C = KMAP_WAVE * F_CPL;  // 512 columns per tile
+constexpr int SY_WAVES = 4;              // tiles (consecutive column chunks) per block
+
+__device__ __forceinline__ bool sy_tile_live(int64_t I, int64_t J) {   // some pair of the tile has j > i
+    return (J + 1) * SY_C - 1 > I * SY_R;
+}
+// wave-wide sum by DPP (no LDS): inclusive row scan (row_shr 1,2,4,8), then row_bcast15 / row_bcast31; lane 63 = total
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = dpp_add<0x111, 0xF>(v);   // row_shr:1
+    v = dpp_add<0x112, 0xF>(v);   // row_shr:2
+    v = dpp_add<0x114, 0xF>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xF>(v);   // row_shr:8   -> lane 15 of every row holds the row's sum
+    v = dpp_add<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's sum
+    return v;
+}
+
+template <bool LUTSRC>
+__global__ __launch_bounds__(KMAP_WAVE *SY_WAVES) void forces_sym_kernel(ProbSrc src, const float *__restrict__ Y, int64_t n,
+                                                                         float *__restrict__ rowpart,
+                                                                         float *__restrict__ colpart,
+                                                                         double *__restrict__ loss_part, int64_t nJ) {
+    extern __shared__ __attribute__((aligned(16))) float lut_s[];
+    if (LUTSRC) {
+        for (int t = threadIdx.x; t < src.lut_len && t < F_LUT_LDS; t += blockDim.x) lut_s[t] = src.lut[t];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t I = blockIdx.y, J = (int64_t)blockIdx.x * SY_WAVES + wave;
+    const int64_t part_idx = I * (gridDim.x * SY_WAVES) + J;
+    double wave_loss = 0.0;
+    if (J < nJ && sy_tile_live(I, J)) {
+        const float *X = Y, *Yy = Y + n;
+        const int64_t j0 = J * SY_C + (int64_t)lane * F_CPL;
+        float xj[F_CPL], yj[F_CPL], cgx[F_CPL], cgy[F_CPL];
+        const bool full = (j0 + F_CPL <= n);
+#pragma unroll
+        for (int c = 0; c < F_CPL; ++c) {
+            const int64_t j = (j0 + c < n) ? j0 + c : n - 1;
+            xj[c] = X[j];
+            yj[c] = Yy[j];
+            cgx[c] = cgy[c] = 0.0f;
+        }
+        const bool vec_ok = LUTSRC && (src.ld % 8 == 0) && full;
+        float ce2 = 0.0f;
+        for (int rb = 0; rb < SY_NRB; ++rb) {
+            const int64_t r0 = I * SY_R + (int64_t)rb * SY_RB;
+            if (r0 >= n || !((J + 1) * SY_C - 1 > r0)) break;   // row blocks further down lie entirely below the diagonal
+            const int nr = (int)((n - r0 < SY_RB) ? n - r0 : SY_RB);
+            const int64_t myrow = (r0 + lane < n) ? r0 + lane : n - 1;
+            const float xr = X[myrow], yr = Yy[myrow];
+            for (int r = 0; r < nr; ++r) {
+                const int64_t gi = r0 + r;
+                const float xi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xr), r));
+                const float yi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yr), r));
+                float gx = 0.0f, gy = 0.0f;
+                if (j0 + F_CPL - 1 > gi && j0 < n) {   // this lane has at least one column right of the diagonal
+                    float p[F_CPL];
+                    if (LUTSRC) {
+                        const uint16_t *row = src.ps + gi * src.ld + j0;
+                        if (vec_ok) {
+                            const u32x4 w = *reinterpret_cast<const u32x4 *>(row);
+                            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                            for (int c = 0; c < F_CPL; ++c) p[c] = lut_s[(ws[c >> 1] >> (16 * (c & 1))) & 0xFFFFu];
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < F_CPL; ++c) p[c] = (j0 + c < n) ? lut_s[row[c]] : 0.0f;
+                        }
+                    } else {
+                        const float *row = src.pf + gi * src.ld + j0;
+#pragma unroll
+                        for (int c = 0; c < F_CPL; ++c) p[c] = (j0 + c < n) ? row[c] : 0.0f;
+                    }
+#pragma unroll
+                    for (int c = 0; c < F_CPL; ++c) {
+                        const int64_t j = j0 + c;
+                        const float dx = xi - xj[c], dy = yi - yj[c];
+                        const float sden = 1.0f + __builtin_fmaf(dx, dx, dy * dy);
+                        float q = __builtin_amdgcn_rcpf(sden);
+                        q = __builtin_fminf(__builtin_fmaxf(q, 0.001f), 0.999f);
+                        const float omq = 1.0f - q;
+                        float t = (q * __builtin_amdgcn_rcpf(omq)) * (p[c] - q);
+                        const float lq = __builtin_amdgcn_logf(q), l1 = __builtin_amdgcn_logf(omq);
+                        float e = __builtin_fmaf(p[c], lq - l1, l1);
+                        const bool live = (j > gi) && (j < n);
+                        t = live ? t : 0.0f;
+                        e = live ? e : 0.0f;
+                        const float fx = t * dx, fy = t * dy;
+                        gx += fx;
+                        gy += fy;
+                        cgx[c] -= fx;
+                        cgy[c] -= fy;
+                        ce2 += e;
+                    }
+                }
+                gx = wave_sum_to_lane63(gx);
+                gy = wave_sum_to_lane63(gy);
+                if (lane == 63) {
+                    rowpart[(J * 2 + 0) * n + gi] = gx;
+                    rowpart[(J * 2 + 1) * n + gi] = gy;
+                }
+                if ((r & 15) == 15) {
+                    wave_loss += (double)ce2;
+                    ce2 = 0.0f;
+                }
+            }
+        }
+        wave_loss += (double)ce2;
+        wave_loss *= -0.6931471805599453;
+#pragma unroll
+        for (int c = 0; c < F_CPL; ++c) {
+            if (j0 + c < n) {
+                colpart[(I * 2 + 0) * n + j0 + c] = cgx[c];
+                colpart[(I * 2 + 1) * n + j0 + c] = cgy[c];
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) wave_loss += __shfl_down(wave_loss, o);
+    }
+    if (lane == 0) loss_part[part_idx] = wave_loss;
+}
+
+// G[c][i] = sum_J rowpart[J][c][i] (tiles right of i's row block) + sum_I colpart[I][c][i] (row blocks above / at i)
+__global__ __launch_bounds__(BLK) void sym_reduce_kernel(const float *__restrict__ rowpart, const float *__restrict__ colpart,
+                                                         int64_t n, int64_t nI, int64_t nJ, float *__restrict__ G) {
+    const int64_t t = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    if (t >= 2 * n) return;
+    const int c = (int)(t / n);
+    const int64_t i = t % n;
+    const int64_t Ii = i / SY_R, Ji = i / SY_C;
+    float g = 0.0f;
+    for (int64_t J = 0; J < nJ; ++J)
+        if (sy_tile_live(Ii, J)) g += rowpart[(J * 2 + c) * n + i];
+    for (int64_t I = 0; I < nI; ++I)
+        if (sy_tile_live(I, Ji)) g += colpart[(I * 2 + c) * n + i];
+    G[t] = g;
+}
+
+// =================================================================================================
 // SEQ forces: the reference's summation order (taichi_core.py:305-326: ret_val += diff[i,j] * (y[k,i] - y[k,j]),
 // j ascending, j != i), IEEE f32, no FMA.  A row is owned by the 4 lanes of a quad: for a group of 4 columns
 // each sub-lane evaluates one term (q, t, t*dx, t*dy -- independent work), then ALL lanes of the row add the
@@ -605,10 +757,15 @@ struct kmap_embed {
     LoopState *states = nullptr;
     int cur = 0;
     bool have_prob = false, have_coords = false;
+    // symmetric FAST path (all rows local): partial buffers
+    float *rowpart = nullptr, *colpart = nullptr;
+    int64_t symI = 0, symJ = 0;
+    bool sym = false;
 };
 
 namespace {
 int n_force_blocks(const kmap_embed *e) {
+    if (e->sym) return (int)(e->symI * (((e->symJ + SY_WAVES - 1) / SY_WAVES) * SY_WAVES));
     if (e->mode == KMAP_EMBED_SEQ) return (int)((e->nrows + SQ_ROWS * SQ_WAVES - 1) / (SQ_ROWS * SQ_WAVES));
     return (int)((e->nrows + F_RPW * F_WAVES - 1) / (F_RPW * F_WAVES));
 }
@@ -683,6 +840,12 @@ int kmap_embed_create(kmap_embed **out, int64_t n, int64_t row0, int64_t nrows, 
     KMAP_REQUIRE(mode == KMAP_EMBED_FAST || mode == KMAP_EMBED_SEQ, "embed_create: unknown mode %d", mode);
     kmap_embed *e = new kmap_embed();
     e->n = n; e->row0 = row0; e->nrows = nrows; e->n_best = n_best; e->lr = learning_rate; e->mode = mode;
+    {   // symmetric FAST kernel: single-GPU all-rows sessions (KMAP_EMBED_SYM=0 switches it off for A/B runs)
+        const char *env = getenv("KMAP_EMBED_SYM");
+        e->sym = (mode == KMAP_EMBED_FAST) && row0 == 0 && nrows == n && n >= 16384 && !(env && env[0] == '0');   // below ~16k the tall tiles leave CUs idle
+        e->symI = (n + SY_R - 1) / SY_R;
+        e->symJ = (n + SY_C - 1) / SY_C;
+    }
     e->n_part = n_force_blocks(e) > 0 ? n_force_blocks(e) : 1;
     hipError_t err = hipSuccess;
     auto A = [&](void **p, size_t b) { if (err == hipSuccess) err = hipMalloc(p, b ? b : 16); };
@@ -694,6 +857,10 @@ int kmap_embed_create(kmap_embed **out, int64_t n, int64_t row0, int64_t nrows, 
     A((void **)&e->loss_sum, 8);
     A((void **)&e->states, 2 * sizeof(LoopState));
     A((void **)&e->lut_dev, F_LUT_LDS * 4);
+    if (e->sym) {
+        A((void **)&e->rowpart, (size_t)e->symJ * 2 * n * 4);
+        A((void **)&e->colpart, (size_t)e->symI * 2 * n * 4);
+    }
     if (err != hipSuccess) {
         kmap_set_error("embed_create: %s", hipGetErrorString(err));
         kmap_embed_destroy(e);
@@ -717,7 +884,8 @@ int kmap_embed_create(kmap_embed **out, int64_t n, int64_t row0, int64_t nrows, 
 
 int kmap_embed_destroy(kmap_embed *e) {
     if (!e) return KMAP_OK;
-    void *ptrs[] = {e->Y, e->G, e->snaps, e->loss_log, e->loss_part, e->loss_sum, e->states, e->lut_dev, e->normals};
+    void *ptrs[] = {e->Y, e->G, e->snaps, e->loss_log, e->loss_part, e->loss_sum, e->states, e->lut_dev, e->normals,
+                    e->rowpart, e->colpart};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete e;
@@ -777,7 +945,12 @@ int kmap_embed_forces(kmap_embed *e, float *grad_dev_2xn, double *loss_dev, void
     }
     const bool lut = e->src.ps != nullptr;
     const size_t lds = lut ? (((size_t)e->src.lut_len * 4 + 15) & ~(size_t)15) : 16;
-    if (e->mode == KMAP_EMBED_SEQ) {
+    if (e->sym) {
+        dim3 grid((unsigned)((e->symJ + SY_WAVES - 1) / SY_WAVES), (unsigned)e->symI);
+        if (lut) forces_sym_kernel<true><<<grid, KMAP_WAVE * SY_WAVES, lds, st>>>(e->src, e->Y, e->n, e->rowpart, e->colpart, e->loss_part, e->symJ);
+        else forces_sym_kernel<false><<<grid, KMAP_WAVE * SY_WAVES, lds, st>>>(e->src, e->Y, e->n, e->rowpart, e->colpart, e->loss_part, e->symJ);
+        sym_reduce_kernel<<<(unsigned)((2 * e->n + BLK - 1) / BLK), BLK, 0, st>>>(e->rowpart, e->colpart, e->n, e->symI, e->symJ, G);
+    } else if (e->mode == KMAP_EMBED_SEQ) {
         if (lut) forces_seq_kernel<true><<<nblk, KMAP_WAVE * SQ_WAVES, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
         else forces_seq_kernel<false><<<nblk, KMAP_WAVE * SQ_WAVES, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
     } else {

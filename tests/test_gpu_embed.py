@@ -219,3 +219,41 @@ def test_fast_vs_seq_at_default_size(V):
     np.testing.assert_allclose(tb["losses"], ta["losses"], rtol=5e-2)
     assert ta["losses"][-1] < ta["losses"][0] and tb["losses"][-1] < tb["losses"][0]
     assert ta["state"]["best_loss"] == ta["losses"].min()
+
+
+def test_symmetric_fast_kernel_matches_seq_per_step(V):
+    """N = 20 000 (>= the symmetric FAST kernel's threshold): one force evaluation from the same coordinates agrees with
+    SEQ to summation round-off, with and without the symmetric formulation."""
+    import os
+    from kmap_amd import _ffi
+    from kmap_amd.hamdist import hamdist_matrix_dev, pitch_for
+    rng = np.random.default_rng(3)
+    n, k = 20000, 8
+    kh = rng.integers(0, 4 ** k, size=n, dtype=np.uint64).astype(np.uint32)
+    lab = np.zeros(n, np.int32)
+    ldd = pitch_for(n)
+    kh_d, lab_d = _ffi.DeviceBuffer.from_numpy(kh), _ffi.DeviceBuffer.from_numpy(lab)
+    D_d = _ffi.DeviceBuffer(n * ldd)
+    hamdist_matrix_dev(kh_d.ptr, lab_d.ptr, n, k, [k], D_d.ptr, ldd)
+    nb_d = V.knn_select_dev(D_d.ptr, ldd, n, 20)
+    lut = V.hd_prob_lut(k, 20, 400 * k)
+    coords = rng.standard_normal((2, n)).astype(np.float32)
+    outs = {}
+    for tag, mode, sym in (("seq", V.EMBED_SEQ, "1"), ("sym", V.EMBED_FAST, "1"), ("fast", V.EMBED_FAST, "0")):
+        os.environ["KMAP_EMBED_SYM"] = sym
+        sums_d, lds = V.knn_sums_dev(D_d.ptr, ldd, nb_d, n, 20)
+        sess = V.EmbedSession(n, 10, 0.01, mode)
+        sess.set_prob_lut(sums_d, lds, lut)
+        sess.set_coords(coords)
+        g_d, l_d = _ffi.DeviceBuffer(2 * n * 4), _ffi.DeviceBuffer(8)
+        g_d.zero()
+        sess.forces(g_d.ptr, l_d.ptr)
+        _ffi.sync()
+        outs[tag] = (g_d.to_numpy(np.float32, (2, n)), l_d.to_numpy(np.float64, (1,))[0])
+        sess.close()
+    os.environ.pop("KMAP_EMBED_SYM", None)
+    gs, ls = outs["seq"]
+    for tag in ("sym", "fast"):
+        g, l = outs[tag]
+        assert abs(l - ls) <= 2e-6 * abs(ls), (tag, l, ls)
+        np.testing.assert_allclose(g, gs, rtol=0, atol=2e-5 * np.abs(gs).max())
