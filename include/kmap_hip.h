@@ -173,6 +173,15 @@ int kmap_write_occurrence_csv(const char *path, const char *header, int64_t n_se
                               const int32_t *const *hits, const int32_t *const *pos, const int64_t *read_len,
                               int64_t *rows_written);
 
+/* ---- FASTA -> uint8 array contract (host side; proc_input / dna2arr / convert_fasta_to_binary, kmer_count.py:182-347).
+ * Streaming parser (plain or .gz): header lines start with '>', sequence lines are concatenated with white space
+ * removed, A/C/G/T (either case) -> 0..3, anything else -> 255, one 255 separator after every record; borders
+ * [start, end) with end = index of the separator.  Two-call pattern: open parses and reports the sizes, read copies out. */
+typedef struct kmap_fasta kmap_fasta;
+int kmap_fasta_open(const char *path, kmap_fasta **f, int64_t *n_bytes, int64_t *n_seq);
+int kmap_fasta_read(kmap_fasta *f, uint8_t *seq_out, int64_t *borders_out);
+int kmap_fasta_close(kmap_fasta *f);
+
 /* ---- all-pairs Hamming matrix: cal_samp_kmer_hamdist_mat motif_discovery.py:759-808
  * (one launch instead of n_uniq launches + Python block expansion).  kh: N hashes (already
  * expanded by counts), label: N int32; pairs sharing label l with clen[l] < k are compared on the

@@ -1,5 +1,6 @@
 // host_io.hip -- native host-side writers for the file contracts on the hot path (no device code).
 #include <errno.h>
+#include <zlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -111,5 +112,88 @@ extern "C" int kmap_write_occurrence_csv(const char *path, const char *header, i
         kmap_set_error("write_occurrence_csv: write to %s failed", path);
         return KMAP_E_INVAL;
     }
+    return KMAP_OK;
+}
+
+// ---- FASTA encoder --------------------------------------------------------------------------------------------
+struct kmap_fasta {
+    std::vector<uint8_t> seq;
+    std::vector<int64_t> borders;   // start, end pairs
+};
+
+extern "C" int kmap_fasta_open(const char *path, kmap_fasta **out, int64_t *n_bytes, int64_t *n_seq) {
+    KMAP_REQUIRE(path && out && n_bytes && n_seq, "fasta_open: null argument");
+    gzFile gz = gzopen(path, "rb");   // transparently reads plain files too
+    if (!gz) {
+        kmap_set_error("fasta_open: cannot open %s: %s", path, strerror(errno));
+        return KMAP_E_INVAL;
+    }
+    gzbuffer(gz, 1 << 20);
+    uint8_t lut[256];
+    memset(lut, 255, sizeof lut);
+    lut[(int)'A'] = lut[(int)'a'] = 0;
+    lut[(int)'C'] = lut[(int)'c'] = 1;
+    lut[(int)'G'] = lut[(int)'g'] = 2;
+    lut[(int)'T'] = lut[(int)'t'] = 3;
+    kmap_fasta *f = new kmap_fasta();
+    std::vector<uint8_t> buf(1 << 22);
+    bool in_header = false, in_record = false, at_line_start = true;
+    int64_t start = 0;
+    for (;;) {
+        const int got = gzread(gz, buf.data(), (unsigned)buf.size());
+        if (got < 0) {
+            int errnum = 0;
+            kmap_set_error("fasta_open: read error in %s: %s", path, gzerror(gz, &errnum));
+            gzclose(gz);
+            delete f;
+            return KMAP_E_INVAL;
+        }
+        if (got == 0) break;
+        for (int i = 0; i < got; ++i) {
+            const uint8_t ch = buf[(size_t)i];
+            if (in_header) {
+                if (ch == '\n') { in_header = false; at_line_start = true; }
+                continue;
+            }
+            if (ch == '\n') { at_line_start = true; continue; }
+            if (at_line_start && ch == '>') {
+                if (in_record) {   // close the previous record
+                    f->borders.push_back(start);
+                    f->borders.push_back((int64_t)f->seq.size());
+                    f->seq.push_back(255);
+                }
+                in_record = true;
+                in_header = true;
+                start = (int64_t)f->seq.size();
+                continue;
+            }
+            at_line_start = false;
+            if (!in_record) continue;                                   // text before the first header
+            if (ch == ' ' || ch == '\t' || ch == '\r' || ch == '\v' || ch == '\f') continue;
+            f->seq.push_back(lut[ch]);
+        }
+    }
+    gzclose(gz);
+    if (in_record) {
+        f->borders.push_back(start);
+        f->borders.push_back((int64_t)f->seq.size());
+        f->seq.push_back(255);
+    }
+    *out = f;
+    *n_bytes = (int64_t)f->seq.size();
+    *n_seq = (int64_t)(f->borders.size() / 2);
+    return KMAP_OK;
+}
+
+extern "C" int kmap_fasta_read(kmap_fasta *f, uint8_t *seq_out, int64_t *borders_out) {
+    KMAP_REQUIRE(f, "fasta_read: null handle");
+    KMAP_REQUIRE((f->seq.empty() || seq_out) && (f->borders.empty() || borders_out), "fasta_read: null output");
+    if (!f->seq.empty()) memcpy(seq_out, f->seq.data(), f->seq.size());
+    if (!f->borders.empty()) memcpy(borders_out, f->borders.data(), f->borders.size() * sizeof(int64_t));
+    return KMAP_OK;
+}
+
+extern "C" int kmap_fasta_close(kmap_fasta *f) {
+    delete f;
     return KMAP_OK;
 }

@@ -370,7 +370,21 @@ def read_dnaseq_file(file_name, file_type="fasta"):
 
 
 def encode_fasta(fasta_file):
-    """Whole file -> (uint8 array with 255 separators, (n_seq,2) int64 [start, end-of-read))."""
+    """Whole file (plain or .gz) -> (uint8 array with 255 separators, (n_seq,2) int [start, end-of-read)) by the native
+    streaming parser of libkmap_hip (kmap_fasta_*); same output as concatenating read_dnaseq_file()."""
+    h, nb, ns = _ffi.vp(), _ffi.i64(0), _ffi.i64(0)
+    check(_ffi.lib().kmap_fasta_open(str(fasta_file).encode(), C.byref(h), C.byref(nb), C.byref(ns)))
+    try:
+        arr = np.empty(nb.value, dtype=np.uint8)
+        borders = np.empty((ns.value, 2), dtype=np.int64)
+        check(_ffi.lib().kmap_fasta_read(h.value, ptr(arr), ptr(borders)))
+    finally:
+        _ffi.lib().kmap_fasta_close(h.value)
+    return arr, borders.astype(int)
+
+
+def encode_fasta_py(fasta_file):
+    """Pure-Python equivalent of encode_fasta (record by record, like the reference); used to cross-check the parser."""
     parts = list(read_dnaseq_file(fasta_file))
     lens = np.array([len(p) for p in parts], dtype=np.int64)
     starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64) if len(parts) else np.zeros(0, np.int64)

@@ -85,6 +85,17 @@ def test_fasta_encoding_matches_reference_arrays(golden, tmp_path):
         fh.write(fa.read_text())
     a3, b3 = K.encode_fasta(str(tmp_path / "m.fa.gz"))
     np.testing.assert_array_equal(a2, a3)
+    np.testing.assert_array_equal(b2, b3)
+    # native parser == record-by-record Python encoder, incl. CRLF, text before the first header, no trailing newline
+    fb = tmp_path / "w.fa"
+    fb.write_bytes(b"junk before\r\n>a\r\nACGT\r\nnnAC\r\n>b x y\r\n\r\n>c\r\nTTGA")
+    for f in (GOLD / "test.fa", fa, fb):
+        an, bn = K.encode_fasta(str(f))
+        ap, bp = K.encode_fasta_py(str(f))
+        np.testing.assert_array_equal(an, ap)
+        np.testing.assert_array_equal(bn, bp)
+    with pytest.raises(ValueError):
+        K.encode_fasta(str(tmp_path / "missing.fa"))
 
 
 def test_merge_consensus_seqs_golden(golden):
