@@ -287,7 +287,7 @@ int hist_hashes(kmap_counts *c, const H *hash_dev, int64_t n, int k, hipStream_t
     KMAP_TRY(kmap_counts_prepare_bins(c, k, st));
     if (n > 0) {
         const size_t passes = (n_bins + HL_BINS - 1) / HL_BINS;
-        if (sizeof(H) == 4 && passes <= 8 && n >= (1 << 20) && ((uintptr_t)hash_dev % 16) == 0) {
+        if (sizeof(H) == 4 && passes <= 32 && n >= (1 << 20) && ((uintptr_t)hash_dev % 16) == 0) {
             static bool attr_set = false;
             if (!attr_set) {
                 KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)hist_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -429,18 +429,3 @@ def _visualize_kmers(res_dir: str, debug=False, mode=None):
     if vz.get("gen_fig_flag"):
         print("gen_fig_flag: plotting is outside the GPU hot path of kmap_amd; low_dim_data.tsv holds the embedding.")
     return ld_data
-
-
-def smoke_embed():
-    """Tiny end-to-end embedding on cuda:0 checked against the CPU oracle (used by __graft_entry__.smoke)."""
-    from oracle import oracle as O
-    rng = np.random.default_rng(1)
-    n, k = 96, 8
-    kh = rng.integers(0, 4 ** k, size=n, dtype=np.uint64)
-    D = O.hamdist_matrix_u8(kh, np.zeros(n, np.int32), k, [k]).astype(np.int64)
-    nb = np.argpartition(D, 20, axis=1)[:, :20]
-    tr_o, tr_g = {}, {}
-    want = O.kmap(D, k, n_max_iter=15, random_seed=3, nb=nb, trace=tr_o)
-    got = kmap(D, k, n_max_iter=15, random_seed=3, debug=False, mode=EMBED_SEQ, neighbor_inds_mat=nb, trace=tr_g)
-    assert np.allclose(tr_g["losses"], np.array(tr_o["losses"], np.float32), rtol=2e-6), "embedding loss mismatch"
-    assert np.allclose(got, want, atol=1e-5), "embedding coordinates mismatch"

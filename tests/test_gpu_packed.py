@@ -135,3 +135,42 @@ def test_packed_scan_vs_oracle(env, k, r):
                 off += m
             assert off == len(pos)
     ds.close()
+
+
+def test_counting_full_size_properties(env):
+    """3 M x 150 bp reads (4.5e8 positions; the C3 shape at 30 %): size-independent properties instead of a CPU recount:
+    sum of counts == number of valid windows, the revcom merge conserves the total up to palindrome doubling, per-read
+    dedupe never increases a count, and masking with radius 0 removes exactly the k-mers it targets."""
+    _ffi, DeviceCounts, DeviceSeq, O = env
+    from kmap_amd import synth
+    seq, borders = synth.synth_reads(3_000_000, 150, 5)
+    seq[::1009] = 255
+    ds, dc = DeviceSeq(seq, borders), DeviceCounts()
+    inv = (seq == 255).astype(np.int64)
+    csum = np.concatenate([[0], np.cumsum(inv)])
+    for k in (8, 10, 12):
+        n_valid = int(np.count_nonzero(csum[k:] - csum[:-k] == 0))                   # windows without a 255
+        ds.count(dc, k, dedupe=False, merge_revcom=False)
+        u, c = dc.fetch()
+        assert int(c.sum()) == n_valid == dc.total()
+        assert np.all(np.diff(u.astype(np.int64)) > 0) and u.max() < 4 ** k          # ascending unique keys
+        ds.count(dc, k, dedupe=False, merge_revcom=True)
+        mu, mc = dc.fetch()
+        rc = O.get_revcom_hash_arr(u, k)
+        pal = int(c[rc == u].sum())                                                  # palindromes are doubled by the reference
+        assert int(mc.sum()) == n_valid + pal
+        assert len(mu) == len(np.unique(np.minimum(u, rc.astype(u.dtype))))
+        ds.count(dc, k, dedupe=True, merge_revcom=False)
+        du, dcnt = dc.fetch()
+        np.testing.assert_array_equal(du, u)                                         # dedupe removes occurrences, not k-mers
+        assert np.all(dcnt <= c) and np.all(dcnt >= 1)
+        # mask the most frequent k-mer with radius 0: its count drops to 0, nothing new appears
+        top = u[np.argmax(c)]
+        ds.mask(k, np.array([top]), np.array([0]))
+        ds.count(dc, k, dedupe=False, merge_revcom=False)
+        u2, c2 = dc.fetch()
+        assert top not in set(u2[:0]) and not np.any(u2 == top)
+        assert np.all(np.isin(u2, u))
+        ds.reset()
+    dc.close()
+    ds.close()

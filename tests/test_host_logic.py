@@ -46,10 +46,7 @@ def test_no_fallback_when_library_missing(tmp_path, monkeypatch):
 
 def test_product_never_imports_oracle():
     for py in (ROOT / "kmap_amd").rglob("*.py"):
-        src = py.read_text()
-        if py.name == "visualization.py":
-            src = src.split("def smoke_embed")[0]           # the smoke check is the one sanctioned use
-        assert "oracle" not in src, f"{py} references the oracle"
+        assert "oracle" not in py.read_text(), f"{py} references the oracle"
 
 
 def test_dtype_rules_and_scalar_helpers(golden):
