@@ -58,10 +58,10 @@ def kmap_from_kmers_distributed(samp_kh, samp_cnts, samp_label, conseq_list, kme
     from . import visualization as vz
 
     rank, world = dist.get_rank(), dist.get_world_size()
-    mode = vz.default_mode() if mode is None else mode
     kh = np.repeat(np.asarray(samp_kh), samp_cnts).astype(get_hash_dtype(kmer_len))
     lab = np.repeat(np.asarray(samp_label), samp_cnts).astype(np.int32)
     n = len(kh)
+    mode = vz.default_mode(n) if mode is None else mode
     row0, nrows = row_partition(n, world, rank)
     lens = [len(c) for c in conseq_list]
     ldd = pitch_for(n)

@@ -17,13 +17,16 @@ CONFIGS = {
 }
 
 
-def run_e2e(config="C2", mode="seq", min_k=6, max_k=9, iters=None, keep=False, quiet=True):
+def run_e2e(config="C2", mode="default", min_k=6, max_k=9, iters=None, keep=False, quiet=True):
     import contextlib
     import io
     from . import motif_discovery as md, synth, visualization as vz
     c = CONFIGS[config]
     prev_mode = os.environ.get("KMAP_EMBED_MODE")
-    os.environ["KMAP_EMBED_MODE"] = mode
+    if mode in ("seq", "fast"):
+        os.environ["KMAP_EMBED_MODE"] = mode
+    else:
+        os.environ.pop("KMAP_EMBED_MODE", None)   # package default: SEQ up to N = 16384, FAST above
     md.STAGE_TIMES.clear()
     vz.STAGE_TIMES.clear()
     t = {}

@@ -19,13 +19,22 @@ from .kmer_count import FileNameDict, get_hash_dtype
 EMBED_FAST, EMBED_SEQ = 0, 1
 
 
-def default_mode():
-    """SEQ (the reference's f32 summation order; reproduces its trajectories) unless KMAP_EMBED_MODE=fast.
-    FAST sums each row wavefront-parallel: same per-pair values, different rounding of the row sums, and the
-    gradient-descent dynamics amplify that difference over hundreds of iterations (measured: 1e-3 relative
-    on the loss after 200 iterations at N=96) -- statistically equivalent embeddings, not the same digits."""
+def default_mode(n=None):
+    """Embedding arithmetic when the caller does not choose: KMAP_EMBED_MODE=seq|fast wins; otherwise
+    SEQ (the reference's f32 summation order; reproduces its trajectories digit for digit) up to the size at which
+    scan_motif still writes the int64 matrix (N <= 16384, the regime where the reference itself can run), and FAST above
+    it, where no digit-level reference exists anyway (neighbour ties are resolved by the device rule there, see knn_mode).
+    FAST sums each row wavefront-parallel: same per-pair values, different rounding of the row sums; gradient descent
+    amplifies that (measured: 1e-3 relative on the loss after 200 iterations at N=96) -- statistically equivalent
+    embeddings, not the same digits."""
     import os
-    return EMBED_FAST if os.environ.get("KMAP_EMBED_MODE", "seq").lower() == "fast" else EMBED_SEQ
+    forced = os.environ.get("KMAP_EMBED_MODE", "").lower()
+    if forced in ("seq", "fast"):
+        return EMBED_FAST if forced == "fast" else EMBED_SEQ
+    if n is None:
+        return EMBED_SEQ
+    from .motif_discovery import DENSE_PKL_MAX_N
+    return EMBED_SEQ if n <= DENSE_PKL_MAX_N else EMBED_FAST
 
 
 STAGE_TIMES = {}          # cumulative wall-clock per stage (tools/e2e.py, bench.py report it)
@@ -286,7 +295,7 @@ def umap(hd_dist_mat: np.ndarray, n_max_iter=2500, learning_rate=0.01, n_best_re
     """Drop-in for the reference's umap (visualization.py:270-326): transformed distance matrix in,
     lowest-loss 2 x N embedding out.  mode=EMBED_SEQ reproduces the reference's f32 summation order."""
     n = len(hd_dist_mat)
-    mode = default_mode() if mode is None else mode
+    mode = default_mode(n) if mode is None else mode
     ld_data, placeholders = _init_draws(n, n_best_result, random_seed)
     hd_prob_mat = np.exp(-hd_dist_mat / 0.5).astype("float32")          # sigma0 = 0.5 (:284,289)
     if n_max_iter <= 0 or n == 0:
@@ -309,7 +318,7 @@ def kmap(hamdist_mat: np.ndarray, kmer_len: int, n_neighbour=20, n_max_iter=2500
     Hamming matrices scan_motif writes) stay on the device end to end: uint8 D -> uint16 neighbour sums
     -> LUT probabilities -> embedding loop; other matrices go through the float operators."""
     n = len(hamdist_mat)
-    mode = default_mode() if mode is None else mode
+    mode = default_mode(n) if mode is None else mode
     if _is_small_int_matrix(hamdist_mat) and n_neighbour * n_neighbour * int(hamdist_mat.max()) + 1 <= _LUT_CAP \
             and n_max_iter > 0:
         if neighbor_inds_mat is None:
@@ -350,8 +359,8 @@ def kmap_from_kmers(samp_kh, samp_cnts, samp_label, conseq_list, kmer_len, n_nei
                     neighbor_inds_mat=None, trace=None):
     """Hot path used by visualize_kmers when sample_kmers.pkl is available: the Hamming matrix is computed
     on the device from the sampled hashes (never materialised as int64 on the host)."""
-    mode = default_mode() if mode is None else mode
     kh = np.repeat(np.asarray(samp_kh), samp_cnts).astype(get_hash_dtype(kmer_len))
+    mode = default_mode(len(kh)) if mode is None else mode
     lab = np.repeat(np.asarray(samp_label), samp_cnts).astype(np.int32)
     n = len(kh)
     lens = [len(c) for c in conseq_list]
