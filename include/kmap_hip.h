@@ -121,6 +121,10 @@ int kmap_counts_load(kmap_counts *c, const void *uniq, const void *cnt, int64_t 
 /* uniq_out: uint32[n_uniq] (k<16) or uint64[n_uniq]; cnt_out: int32 (k<16) or int64 */
 int kmap_counts_fetch(kmap_counts *c, void *uniq_out, void *cnt_out);
 int kmap_counts_total(kmap_counts *c, int64_t *total);          /* sum of counts */
+/* the top_k (<= 16) most frequent k-mers: largest count first, ties by lowest index (np.argpartition's tie order,
+ * motif_discovery.py:661, is numpy-specific; this rule is used when the arrays are too large to fetch per trial).
+ * idx_out int64[top_k], kh_out uint64[top_k], cnt_out int64[top_k]; returns the number found in *n_found. */
+int kmap_counts_topk(kmap_counts *c, int top_k, int64_t *idx_out, uint64_t *kh_out, int64_t *cnt_out, int *n_found);
 /* Hamming-ball mass of candidates over the counted k-mers: find_motif motif_discovery.py:666-673 */
 int kmap_counts_hamball_mass(kmap_counts *c, const uint64_t *cands, int n_cand, int radius, int revcom,
                              double *mass_out);

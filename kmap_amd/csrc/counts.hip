@@ -7,6 +7,9 @@
 // 288 GB: even the 16 GiB table of k = 16 is resident), followed by an order-preserving
 // compaction that applies the reverse-complement merge on the fly.  A uint32 bin wraps exactly
 // like the reference's int64 -> int32 cast of np.unique counts.
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
 #include "scan_util.h"
 
@@ -157,6 +160,51 @@ __global__ __launch_bounds__(BLK) void sum_counts_kernel(const uint32_t *__restr
         s += as_signed ? (long long)(int32_t)cnt[i] : (long long)cnt[i];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
     if ((threadIdx.x & 63) == 0) atomicAdd(total, (unsigned long long)s);
+}
+
+// ---- top-k by count ---------------------------------------------------------------------------
+// key = (count << 32) | ~index : the maximum key is the largest count, lowest index.  Every thread keeps its own top
+// TK of a grid-strided slice, the block merges them by TK rounds of a block-wide max, the host merges the blocks.
+constexpr int TK = 16;
+__global__ __launch_bounds__(BLK) void topk_kernel(const uint32_t *__restrict__ cnt, int64_t n, int as_signed, int top_k,
+                                                   unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long red[BLK];
+    unsigned long long best[TK];
+#pragma unroll
+    for (int t = 0; t < TK; ++t) best[t] = 0;
+    const int64_t stride = (int64_t)gridDim.x * BLK;
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
+        const long long cv = as_signed ? (long long)(int32_t)cnt[i] : (long long)cnt[i];
+        if (cv <= 0) continue;
+        unsigned long long key = ((unsigned long long)cv << 32) | (0xFFFFFFFFull - (unsigned long long)i);
+        if (key > best[top_k - 1]) {   // insertion into the descending list
+#pragma unroll
+            for (int t = 0; t < TK; ++t) {
+                if (t < top_k && key > best[t]) {
+                    const unsigned long long tmp = best[t];
+                    best[t] = key;
+                    key = tmp;
+                }
+            }
+        }
+    }
+    int head = 0;
+    for (int round = 0; round < top_k; ++round) {
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int t = 0; t < TK; ++t)
+            if (t == head) mine = best[t];
+        red[threadIdx.x] = (head < top_k) ? mine : 0;
+        __syncthreads();
+        for (int o = BLK / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o && red[threadIdx.x + o] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + o];
+            __syncthreads();
+        }
+        const unsigned long long win = red[0];
+        __syncthreads();
+        if (threadIdx.x == 0) out[(size_t)blockIdx.x * top_k + round] = win;
+        if (win != 0 && mine == win) ++head;   // keys are unique (they embed the index)
+    }
 }
 
 // ---- Hamming-ball mass -----------------------------------------------------------------------
@@ -436,6 +484,38 @@ int kmap_counts_total(kmap_counts *c, int64_t *total) {
     if (g > 4096) g = 4096;
     sum_counts_kernel<<<(unsigned)g, BLK>>>(c->cnt, c->n_uniq, c->narrow, t.as<unsigned long long>());
     KMAP_CHECK_HIP(hipMemcpy(total, t.p, 8, hipMemcpyDeviceToHost));
+    return KMAP_OK;
+}
+
+int kmap_counts_topk(kmap_counts *c, int top_k, int64_t *idx_out, uint64_t *kh_out, int64_t *cnt_out, int *n_found) {
+    KMAP_REQUIRE(c && c->k > 0, "counts_topk: nothing counted yet");
+    KMAP_REQUIRE(top_k > 0 && top_k <= TK && idx_out && kh_out && cnt_out && n_found, "counts_topk: bad arguments (top_k <= %d)", TK);
+    KMAP_REQUIRE(c->n_uniq < ((int64_t)1 << 32), "counts_topk: more than 2^32 unique k-mers");
+    *n_found = 0;
+    if (c->n_uniq == 0) return KMAP_OK;
+    int64_t g = (c->n_uniq + BLK - 1) / BLK;
+    if (g > 1024) g = 1024;
+    DevBuf out;
+    KMAP_TRY(out.alloc((size_t)g * top_k * 8));
+    topk_kernel<<<(unsigned)g, BLK>>>(c->cnt, c->n_uniq, c->narrow, top_k, out.as<unsigned long long>());
+    KMAP_CHECK_HIP(hipGetLastError());
+    std::vector<unsigned long long> keys((size_t)g * top_k);
+    KMAP_CHECK_HIP(hipMemcpy(keys.data(), out.p, keys.size() * 8, hipMemcpyDeviceToHost));
+    std::sort(keys.begin(), keys.end(), [](unsigned long long a, unsigned long long b) { return a > b; });
+    int m = 0;
+    for (; m < top_k && m < (int)keys.size() && keys[(size_t)m] != 0; ++m) {
+        const int64_t idx = (int64_t)(0xFFFFFFFFull - (keys[(size_t)m] & 0xFFFFFFFFull));
+        idx_out[m] = idx;
+        cnt_out[m] = (int64_t)(keys[(size_t)m] >> 32);
+        if (c->narrow) {
+            uint32_t h = 0;
+            KMAP_CHECK_HIP(hipMemcpy(&h, (const uint32_t *)c->uniq + idx, 4, hipMemcpyDeviceToHost));
+            kh_out[m] = h;
+        } else {
+            KMAP_CHECK_HIP(hipMemcpy(&kh_out[m], (const uint64_t *)c->uniq + idx, 8, hipMemcpyDeviceToHost));
+        }
+    }
+    *n_found = m;
     return KMAP_OK;
 }
 

@@ -183,6 +183,13 @@ class DeviceCounts:
         check(_ffi.lib().kmap_counts_total(self._h, C.byref(t)))
         return t.value
 
+    def topk(self, top_k):
+        """device top-k by count (largest first, ties by lowest index): (indices, hashes, counts)"""
+        idx, kh, cnt = np.empty(top_k, np.int64), np.empty(top_k, np.uint64), np.empty(top_k, np.int64)
+        m = _ffi.i32(0)
+        check(_ffi.lib().kmap_counts_topk(self._h, top_k, ptr(idx), ptr(kh), ptr(cnt), C.byref(m)))
+        return idx[:m.value], kh[:m.value].astype(get_hash_dtype(self.k)), cnt[:m.value]
+
     def hamball_mass(self, cands, radius, revcom=True):
         cands = np.ascontiguousarray(cands, dtype=np.uint64)
         out = np.zeros(len(cands), np.float64)

@@ -27,6 +27,9 @@ from .kmer_count import (DeviceCounts, FileNameDict, cal_hamming_dist_head, cal_
 # int64 N x N pickle is kept up to this many sampled k-mers (2 GiB); above it scan_motif writes the compact
 # hand-off [kmer_len, None, label_arr] and visualize_kmers recomputes the matrix on the device
 DENSE_PKL_MAX_N = 16384
+# above this many unique k-mers find_motif stops fetching the count arrays every trial: the top_k candidates come from
+# the device (largest count, then lowest index) instead of np.argpartition (whose tie order is numpy-specific anyway)
+TOPK_DEVICE_MIN = 4_000_000
 
 STAGE_TIMES = {}   # cumulative wall-clock per stage of the last runs (tools/e2e.py, bench.py report it)
 
@@ -183,26 +186,48 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
             dc.k, dc.n_uniq = kmer_len, len(u)
         else:
             dev_seq.count(dc, kmer_len, dedupe=not rep_mode, merge_revcom=merge_revcom_mode)   # first round
-            uniq_kh_arr, uniq_kh_cnt_arr = dc.fetch()
+            uniq_kh_arr, uniq_kh_cnt_arr = None, None
+        big = dc.n_uniq > TOPK_DEVICE_MIN
+        writer = None
         if save_kmer_cnt_flag and kmer_cnt_pkl_file and not Path(kmer_cnt_pkl_file).exists():
-            with open(kmer_cnt_pkl_file, "wb") as fh:
-                pickle.dump([kmer_len, uniq_kh_arr, uniq_kh_cnt_arr], fh)
+            if uniq_kh_arr is None:
+                uniq_kh_arr, uniq_kh_cnt_arr = dc.fetch()
+            payload = [kmer_len, uniq_kh_arr, uniq_kh_cnt_arr]
+
+            def _dump(path=kmer_cnt_pkl_file, obj=payload):
+                with open(path, "wb") as fh:
+                    pickle.dump(obj, fh, protocol=4)
+            if big:   # multi-GB pickle: write it while the trials run on the GPU
+                import threading
+                writer = threading.Thread(target=_dump)
+                writer.start()
+            else:
+                _dump()
+        elif uniq_kh_arr is None and not big:
+            uniq_kh_arr, uniq_kh_cnt_arr = dc.fetch()
         n_total_kmer = _wrap_total(dc.total(), kmer_len)   # first round only (:648)
 
         res = {}
         for i_trial in range(n_trial):
-            if top_k > len(uniq_kh_cnt_arr):
+            if top_k > dc.n_uniq:
                 if debug:
-                    print(f"There are only {len(uniq_kh_cnt_arr)} kmers, while top_k={top_k}.")
+                    print(f"There are only {dc.n_uniq} kmers, while top_k={top_k}.")
                 break
-            top_k_inds = np.array(np.argpartition(uniq_kh_cnt_arr, -top_k)[-top_k:])   # same numpy call -> same ties
-            if len(top_k_inds) == 0:
+            if big:
+                _, cand_kh, _ = dc.topk(top_k)
+                cand_kh = cand_kh[::-1]                      # ascending counts, like argpartition's tail
+            else:
+                if uniq_kh_arr is None:
+                    uniq_kh_arr, uniq_kh_cnt_arr = dc.fetch()
+                top_k_inds = np.array(np.argpartition(uniq_kh_cnt_arr, -top_k)[-top_k:])   # same numpy call -> same ties
+                cand_kh = uniq_kh_arr[top_k_inds]
+            if len(cand_kh) == 0:
                 break
-            hamball_cnt_arr = dc.hamball_mass(uniq_kh_arr[top_k_inds], max_ham_dist, merge_revcom_mode)
+            hamball_cnt_arr = dc.hamball_mass(cand_kh, max_ham_dist, merge_revcom_mode)
             if debug:
                 print(f"{i_trial= }")
             best = int(np.argmax(hamball_cnt_arr))
-            consensus_kh = uniq_kh_arr[top_k_inds[best]]
+            consensus_kh = cand_kh[best]
             hamball_proportion = (hamball_cnt_arr[best] + 0.0) / n_total_kmer
             hamball_ratio = hamball_proportion / p_unif
             if not hamball_ratio > ratio_cutoff:
@@ -212,7 +237,10 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
             cons = [consensus_kh, revcom_hash(consensus_kh, kmer_len)] if merge_revcom_mode else [consensus_kh]
             dev_seq.mask(kmer_len, np.array(cons), np.array([max_ham_dist] * len(cons)))
             dev_seq.count(dc, kmer_len, dedupe=False, merge_revcom=merge_revcom_mode)   # later rounds: no dedupe (:695)
-            uniq_kh_arr, uniq_kh_cnt_arr = dc.fetch()
+            big = dc.n_uniq > TOPK_DEVICE_MIN
+            uniq_kh_arr, uniq_kh_cnt_arr = None, None
+        if writer is not None:
+            writer.join()
         if own:
             seq_np_arr[:] = dev_seq.download()   # the reference mutates its argument
         return res
@@ -291,13 +319,17 @@ def sample_disp_kmer(conseq_list: List[str], kmer_len: int, motif_def_dict: dict
     uniq_kh_arr, uniq_kh_cnt_arr = res_list[1], res_list[2]
 
     sampling_flag = True
-    if n_total_sample > sum(uniq_kh_cnt_arr):
+    # the reference's builtin sum() over numpy scalars == a sum wrapped to the count dtype; np.sum is O(n) in C
+    n_seq_total = _wrap_total(int(uniq_kh_cnt_arr.sum(dtype=np.int64)), kmer_len)
+    if n_total_sample > n_seq_total:
         warnings.warn(f"The number of samples n_sample={n_total_sample} is larger than the original "
-                      f"data n_seq={sum(uniq_kh_cnt_arr)}, process and return original data.")
+                      f"data n_seq={n_seq_total}, process and return original data.")
         sampling_flag = False
 
     n_conseq, n_uniq = len(conseq_list), len(uniq_kh_arr)
-    ham_dist_mat = np.zeros((n_conseq, n_uniq), dtype=int)
+    big = n_uniq > TOPK_DEVICE_MIN
+    # distances are <= kmer_len < 32: a narrow matrix gives the same min/argmin and fits 1e9 unique k-mers in memory
+    ham_dist_mat = np.zeros((n_conseq, n_uniq), dtype=np.uint8 if big else int)
     rc_flag_mat = np.zeros((n_conseq, n_uniq), dtype=bool)
     for i, conseq in enumerate(conseq_list):
         conseq_kh = kmer2hash(conseq)
@@ -335,7 +367,17 @@ def sample_disp_kmer(conseq_list: List[str], kmer_len: int, motif_def_dict: dict
     for c in range(n_conseq + 1):
         c_inds = np.where(label_arr == c)[0]
         ws = uniq_kh_cnt_arr[c_inds]
-        ws = ws / sum(ws)
+        ws_total = _wrap_total(int(ws.sum(dtype=np.int64)), kmer_len)
+        if len(c_inds) > TOPK_DEVICE_MIN:
+            # np.random.multinomial walks every category with one binomial draw each (minutes for 1e9 categories):
+            # draw the same multinomial distribution by inverse CDF instead (global legacy RNG, different draws)
+            cdf = np.cumsum(ws, dtype=np.float64)
+            hits = np.searchsorted(cdf, np.random.random_sample(int(sample_cnt_arr[c])) * cdf[-1], side="right")
+            sel, tmp = np.unique(np.minimum(hits, len(ws) - 1), return_counts=True)
+            samp_inds.append(c_inds[sel])
+            samp_cnts.append(tmp)
+            continue
+        ws = ws / ws_total
         tmpcnts = np.random.multinomial(sample_cnt_arr[c], ws, size=1).squeeze()   # global legacy RNG, as the reference
         samp_inds.append(c_inds[tmpcnts > 0])
         samp_cnts.append(tmpcnts[tmpcnts > 0])

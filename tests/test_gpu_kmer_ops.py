@@ -213,4 +213,13 @@ def test_counts_random_vs_oracle(K, O):
             ou, oc = O.count_kmers(seq, borders, k, rep_mode=not dedupe, revcom_mode=True)
             np.testing.assert_array_equal(u, ou)
             np.testing.assert_array_equal(c, oc)
+            # device top-k: largest count first, ties by lowest index
+            for top_k in (1, 5, 16):
+                want = np.lexsort((np.arange(len(oc)), -oc.astype(np.int64)))[:top_k]
+                idx, kh, cn = dc.topk(top_k)
+                np.testing.assert_array_equal(idx, want)
+                np.testing.assert_array_equal(kh, ou[want])
+                np.testing.assert_array_equal(cn, oc[want])
+    with pytest.raises(ValueError):
+        dc.topk(17)
     dc.close()

@@ -105,6 +105,23 @@ def test_find_motif_dropin_signature(run_dir, golden, motif_defs):
             assert not np.array_equal(seq, s["seq"])                # masked in place
 
 
+def test_find_motif_device_topk_path(run_dir, golden, motif_defs, monkeypatch):
+    """Above TOPK_DEVICE_MIN unique k-mers the candidates come from the device top-k; on tests/test.fa (distinct top
+    counts) it must find the same motifs as the fetch + np.argpartition path."""
+    from kmap_amd import motif_discovery as MD
+    s = golden("scan_testfa.npz")
+    bpk = run_dir / "input.seqboarder.bin.pkl"
+    outs = []
+    for thr in (MD.TOPK_DEVICE_MIN, 0):
+        monkeypatch.setattr(MD, "TOPK_DEVICE_MIN", thr)
+        d = motif_defs[11]
+        outs.append(MD.find_motif(s["seq"].copy(), 11, d.max_ham_dist, d.p_uniform, d.ratio_mu, d.ratio_std, d.ratio_cutoff,
+                                  save_kmer_cnt_flag=False, boarder_pkl_file=bpk))
+    assert list(outs[0].keys()) == list(outs[1].keys()) and len(outs[0]) >= 1
+    for kh in outs[0]:
+        assert outs[0][kh] == outs[1][kh]
+
+
 def test_occurrence_scan_vs_oracle_with_subsample(motif_defs):
     """Low-complexity reads with > 20 hits at the minimum distance exercise the reference's random subsample
     (np.random.choice order) -- compared with the oracle's restatement under the same seed."""
