@@ -177,6 +177,20 @@ int kmap_write_occurrence_csv(const char *path, const char *header, int64_t n_se
                               const int32_t *const *hits, const int32_t *const *pos, const int64_t *read_len,
                               int64_t *rows_written);
 
+/* ---- consumers of the counts / the hit list -------------------------------------------
+ * Hamming ball of a consensus over counted k-mers (ex_hamball_kh_arr motif_discovery.py:924-975) fused with the
+ * position count matrix (cal_cnt_mat :978-986).  uniq/cnt are HOST arrays as stored in k{k}.pkl (u32+i32 for k<16,
+ * u64+i64 otherwise); members whose reverse complement is strictly closer are re-oriented (:968-973); output order =
+ * input order.  out_kh/out_cnt: caller-allocated, capacity n; *n_out = members; cnt_mat (optional) int64[4][k]. */
+int kmap_hamball_extract(const void *uniq_host, const void *cnt_host, int64_t n, int k, uint64_t conseq_kh, int max_ham_dist,
+                         int revcom_mode, void *out_kh, void *out_cnt, int64_t *n_out, int64_t *cnt_mat);
+/* motif position density (get_motif_pos_density motif_discovery.py:1255-1327): for every read with m > 0 hits,
+ * density[x] += (sum_i normpdf(x; loc_i / (seq_len - kmer_len + 1), x_step)) / m, f64.  HOST arrays: hits int32[n_seq],
+ * offs int64[n_seq+1] (exclusive prefix sums of hits), pos int32[offs[n_seq]], seq_len int64[n_seq]; density f64[nx].
+ * Per-term arithmetic follows scipy's norm.pdf operation order; reads are summed in chunks of 256 in read order. */
+int kmap_pos_density(const int32_t *hits, const int64_t *offs, const int32_t *pos, const int64_t *seq_len, int64_t n_seq,
+                     int kmer_len, const double *x_arr, int nx, double x_step, double *density);
+
 /* ---- FASTA -> uint8 array contract (host side; proc_input / dna2arr / convert_fasta_to_binary, kmer_count.py:182-347).
  * Streaming parser (plain or .gz): header lines start with '>', sequence lines are concatenated with white space
  * removed, A/C/G/T (either case) -> 0..3, anything else -> 255, one 255 separator after every record; borders

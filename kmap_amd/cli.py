@@ -1,7 +1,8 @@
 """`kmap` command line: the three verbs of the reference's CLI that sit on the GPU hot path
 (reference cli.py:9-36, kmer_count.py:70-101, motif_discovery.py:29-53, visualization.py:18-33),
-with the same option names.  The reference's reporting verbs (ex_hamball, draw_logo, align_conseq,
-extract_motif_locations, check_motif_co_occurence, plot_network) are out of scope here."""
+with the same option names, plus `ex_hamball` (motif_discovery.py:74-108; Hamming-ball extraction on the GPU).  The
+reference's plotting / alignment verbs (draw_logo, align_conseq, extract_motif_locations, check_motif_co_occurence,
+plot_network) are out of scope here."""
 import click
 
 from . import __version__
@@ -44,3 +45,15 @@ def scan_motif(res_dir, gpu_mode=True, debug=False):
 def visualize_kmers(res_dir, debug=False):
     from .visualization import _visualize_kmers
     _visualize_kmers(res_dir, debug)
+
+
+@cli.command(name="ex_hamball")
+@click.option("--res_dir", type=str, required=True, help="Result directory for storing all outputs")
+@click.option("--conseq", type=str, required=True, help="the consensus sequence")
+@click.option("--return_type", type=str, required=True, help='output file form, can be ["hash" | "kmer" | "matrix"]')
+@click.option("--output_file", type=str, required=True, help="output file name, including the suffix")
+@click.option("--max_ham_dist", type=int, default=-1, required=False,
+              help="The radius of the Hamming ball. -1 means taking the radius from motif_def_table.csv")
+def ex_hamball(res_dir, conseq, return_type, output_file, max_ham_dist=-1):
+    from .reports import _ex_hamball
+    _ex_hamball(res_dir, conseq, return_type, output_file, max_ham_dist)

@@ -1,0 +1,228 @@
+// reports.hip -- consumers of the counted k-mers / the occurrence hit list:
+//   * Hamming-ball extraction + position count matrix (reference motif_discovery.py:924-986: ex_hamball_kh_arr, cal_cnt_mat)
+//   * motif position density (reference motif_discovery.py:1255-1327: get_motif_pos_density)
+// Integer results are exact; the density is f64 with the reference's operation order per term (no FMA: the library is
+// built with -ffp-contract=off) and a fixed, chunked summation order over reads.
+#include "common.h"
+#include "scan_util.h"
+
+namespace {
+constexpr int HB_TPB = 256;
+constexpr int HB_ITEMS = 4;
+
+// bit0: inside the ball, bit1: the reverse complement is strictly closer (the member is re-oriented)
+template <typename H>
+__device__ __forceinline__ uint32_t ball_flags(H h, H c, H rc, H mask, int radius, int revcom) {
+    int d = popc2((H)((h ^ c) & mask));
+    uint32_t f = 0;
+    if (revcom) {
+        const int drc = popc2((H)((h ^ rc) & mask));
+        if (drc < d) {
+            f = 2;
+            d = drc;
+        }
+    }
+    return (d <= radius) ? (f | 1u) : 0u;
+}
+
+template <typename H>
+__global__ __launch_bounds__(HB_TPB) void hamball_count_kernel(const H *__restrict__ uniq, int64_t n, H c, H rc, int k,
+                                                               int radius, int revcom, uint32_t *__restrict__ block_counts) {
+    __shared__ uint32_t wsum[HB_TPB / 64];
+    const H mask = low_mask<H>(k);
+    const int64_t x0 = ((int64_t)blockIdx.x * HB_TPB + threadIdx.x) * HB_ITEMS;
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < HB_ITEMS; ++j)
+        if (x0 + j < n) m += ball_flags<H>(uniq[x0 + j], c, rc, mask, radius, revcom) & 1u;
+    for (int o = 32; o > 0; o >>= 1) m += __shfl_down(m, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// ordered write of the ball members (re-oriented where flagged) + per-position base counts weighted by the k-mer counts
+template <typename H, typename CT>
+__global__ __launch_bounds__(HB_TPB) void hamball_write_kernel(const H *__restrict__ uniq, const CT *__restrict__ cnt, int64_t n,
+                                                               H c, H rc, int k, int radius, int revcom,
+                                                               const uint64_t *__restrict__ block_off, H *__restrict__ out_kh,
+                                                               CT *__restrict__ out_cnt, unsigned long long *__restrict__ cnt_mat) {
+    __shared__ uint32_t wsum[HB_TPB / 64];
+    __shared__ unsigned long long mat[4 * 32];
+    if (threadIdx.x < 128) mat[threadIdx.x] = 0;
+    const H mask = low_mask<H>(k);
+    const int64_t x0 = ((int64_t)blockIdx.x * HB_TPB + threadIdx.x) * HB_ITEMS;
+    H keys[HB_ITEMS];
+    CT cnts[HB_ITEMS];
+    uint32_t flags = 0, m = 0;
+#pragma unroll
+    for (int j = 0; j < HB_ITEMS; ++j) {
+        keys[j] = 0;
+        cnts[j] = 0;
+        if (x0 + j < n) {
+            const H h = uniq[x0 + j];
+            const uint32_t f = ball_flags<H>(h, c, rc, mask, radius, revcom);
+            if (f & 1u) {
+                keys[j] = (f & 2u) ? revcom_hash(h, k) : h;
+                cnts[j] = cnt[x0 + j];
+                flags |= 1u << j;
+                ++m;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = m;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    uint64_t pos = block_off[blockIdx.x] + woff + (inc - m);
+#pragma unroll
+    for (int j = 0; j < HB_ITEMS; ++j) {
+        if (flags & (1u << j)) {
+            out_kh[pos] = keys[j];
+            out_cnt[pos] = cnts[j];
+            ++pos;
+            for (int p = 0; p < k; ++p) {   // base at position p (first base most significant)
+                const int b = (int)((keys[j] >> (2 * (k - 1 - p))) & 3);
+                atomicAdd(&mat[b * 32 + p], (unsigned long long)(long long)cnts[j]);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 128 && (threadIdx.x & 31) < k && mat[threadIdx.x])
+        atomicAdd(&cnt_mat[(threadIdx.x >> 5) * k + (threadIdx.x & 31)], mat[threadIdx.x]);
+}
+
+template <typename H, typename CT>
+int hamball_extract(const void *uniq_host, const void *cnt_host, int64_t n, int k, uint64_t conseq_kh, int radius, int revcom,
+                    void *out_kh, void *out_cnt, int64_t *n_out, int64_t *cnt_mat) {
+    hipStream_t st = nullptr;
+    DevBuf u, c, ou, oc, mat;
+    KMAP_TRY(u.alloc((size_t)n * sizeof(H)));
+    KMAP_TRY(c.alloc((size_t)n * sizeof(CT)));
+    KMAP_TRY(mat.alloc(4 * 32 * 8));
+    KMAP_CHECK_HIP(hipMemcpy(u.p, uniq_host, (size_t)n * sizeof(H), hipMemcpyHostToDevice));
+    KMAP_CHECK_HIP(hipMemcpy(c.p, cnt_host, (size_t)n * sizeof(CT), hipMemcpyHostToDevice));
+    KMAP_CHECK_HIP(hipMemset(mat.p, 0, 4 * 32 * 8));
+    const unsigned nb = (unsigned)((n + HB_TPB * HB_ITEMS - 1) / (HB_TPB * HB_ITEMS));
+    uint32_t *bc = nullptr;
+    uint64_t *boff = nullptr;
+    KMAP_TRY(kmap_scratch((void **)&bc, (size_t)nb * 4, st, KMAP_SLOT_A));
+    KMAP_TRY(kmap_scratch((void **)&boff, ((size_t)nb + 1) * 8, st, KMAP_SLOT_B));
+    const H ch = (H)conseq_kh;
+    // host-side reverse complement of the consensus (same arithmetic as the device helper)
+    H rc = 0;
+    {
+        const H com = (H)(low_mask<H>(k) - ch);
+        for (int p = 0; p < k; ++p) rc = (H)((rc << 2) | ((com >> (2 * p)) & 3));
+    }
+    hamball_count_kernel<H><<<nb, HB_TPB, 0, st>>>(u.as<H>(), n, ch, rc, k, radius, revcom, bc);
+    KMAP_TRY(exclusive_scan_u32(bc, nb, boff, st));
+    uint64_t total = 0;
+    KMAP_CHECK_HIP(hipMemcpyAsync(&total, boff + nb, 8, hipMemcpyDeviceToHost, st));
+    KMAP_CHECK_HIP(hipStreamSynchronize(st));
+    KMAP_TRY(ou.alloc((size_t)total * sizeof(H)));
+    KMAP_TRY(oc.alloc((size_t)total * sizeof(CT)));
+    hamball_write_kernel<H, CT><<<nb, HB_TPB, 0, st>>>(u.as<H>(), c.as<CT>(), n, ch, rc, k, radius, revcom, boff, ou.as<H>(),
+                                                       oc.as<CT>(), mat.as<unsigned long long>());
+    KMAP_CHECK_HIP(hipGetLastError());
+    KMAP_CHECK_HIP(hipMemcpy(out_kh, ou.p, (size_t)total * sizeof(H), hipMemcpyDeviceToHost));
+    KMAP_CHECK_HIP(hipMemcpy(out_cnt, oc.p, (size_t)total * sizeof(CT), hipMemcpyDeviceToHost));
+    if (cnt_mat) KMAP_CHECK_HIP(hipMemcpy(cnt_mat, mat.p, (size_t)4 * k * 8, hipMemcpyDeviceToHost));
+    *n_out = (int64_t)total;
+    return KMAP_OK;
+}
+
+// ---- position density ------------------------------------------------------------------------------------------
+constexpr int PD_TPB = 128;
+constexpr int PD_READS = 256;   // reads per block: one partial density row per block, summed in block order afterwards
+
+__global__ __launch_bounds__(PD_TPB) void pos_density_kernel(const int32_t *__restrict__ hits, const int64_t *__restrict__ offs,
+                                                             const int32_t *__restrict__ pos, const int64_t *__restrict__ seq_len,
+                                                             int64_t n_seq, int kmer_len, const double *__restrict__ x_arr, int nx,
+                                                             double scale, double *__restrict__ partial) {
+    const int64_t r0 = (int64_t)blockIdx.x * PD_READS;
+    const int64_t r1 = (r0 + PD_READS < n_seq) ? r0 + PD_READS : n_seq;
+    for (int xi = threadIdx.x; xi < nx; xi += PD_TPB) {
+        const double x = x_arr[xi];
+        double acc = 0.0;
+        for (int64_t r = r0; r < r1; ++r) {
+            const int m = hits[r];
+            if (m <= 0) continue;
+            const double denom = (double)seq_len[r] - (double)kmer_len + 1.0;   // float(seq_len) - kmer_len + 1
+            const int64_t o = offs[r];
+            double s = 0.0;
+            for (int i = 0; i < m; ++i) {
+                const double rel = ((double)pos[o + i] + 0.0) / denom;
+                const double z = (x - rel) / scale;
+                s += exp(-(z * z) / 2.0) / 2.5066282746310002 / scale;     // scipy norm.pdf: exp(-z**2/2)/sqrt(2*pi), /scale
+            }
+            acc += s / (double)m;
+        }
+        partial[(size_t)blockIdx.x * nx + xi] = acc;
+    }
+}
+
+__global__ void pos_density_reduce_kernel(const double *__restrict__ partial, int64_t n_blocks, int nx, double *__restrict__ out) {
+    const int xi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (xi >= nx) return;
+    double acc = 0.0;
+    for (int64_t b = 0; b < n_blocks; ++b) acc += partial[(size_t)b * nx + xi];
+    out[xi] = acc;
+}
+}  // namespace
+
+extern "C" {
+
+int kmap_hamball_extract(const void *uniq_host, const void *cnt_host, int64_t n, int k, uint64_t conseq_kh, int max_ham_dist,
+                         int revcom_mode, void *out_kh, void *out_cnt, int64_t *n_out, int64_t *cnt_mat) {
+    KMAP_REQUIRE(k > 0 && k < 32, "hamball_extract: kmer_len %d outside 1..31", k);
+    KMAP_REQUIRE(n >= 0 && n_out && (n == 0 || (uniq_host && cnt_host && out_kh && out_cnt)), "hamball_extract: null argument");
+    *n_out = 0;
+    if (cnt_mat) memset(cnt_mat, 0, (size_t)4 * k * 8);
+    if (n == 0) return KMAP_OK;
+    if (k < 16)
+        return hamball_extract<uint32_t, int32_t>(uniq_host, cnt_host, n, k, conseq_kh, max_ham_dist, revcom_mode, out_kh, out_cnt,
+                                                  n_out, cnt_mat);
+    return hamball_extract<uint64_t, int64_t>(uniq_host, cnt_host, n, k, conseq_kh, max_ham_dist, revcom_mode, out_kh, out_cnt,
+                                              n_out, cnt_mat);
+}
+
+int kmap_pos_density(const int32_t *hits, const int64_t *offs, const int32_t *pos, const int64_t *seq_len, int64_t n_seq,
+                     int kmer_len, const double *x_arr, int nx, double x_step, double *density) {
+    KMAP_REQUIRE(n_seq >= 0 && nx > 0 && x_arr && density && x_step > 0.0, "pos_density: bad arguments");
+    KMAP_REQUIRE(n_seq == 0 || (hits && offs && seq_len), "pos_density: null argument");
+    for (int i = 0; i < nx; ++i) density[i] = 0.0;
+    if (n_seq == 0) return KMAP_OK;
+    const int64_t total = offs[n_seq];
+    KMAP_REQUIRE(total == 0 || pos, "pos_density: null positions");
+    for (int64_t r = 0; r < n_seq; ++r)   // shapes are checked on the host before any launch
+        KMAP_REQUIRE(hits[r] >= 0 && offs[r + 1] - offs[r] == hits[r], "pos_density: offs[%lld] does not match hits", (long long)r);
+    DevBuf dh, doff, dpos, dlen, dx, dpart, dout;
+    const int64_t nb = (n_seq + PD_READS - 1) / PD_READS;
+    KMAP_TRY(dh.alloc((size_t)n_seq * 4));
+    KMAP_TRY(doff.alloc((size_t)(n_seq + 1) * 8));
+    KMAP_TRY(dpos.alloc((size_t)total * 4));
+    KMAP_TRY(dlen.alloc((size_t)n_seq * 8));
+    KMAP_TRY(dx.alloc((size_t)nx * 8));
+    KMAP_TRY(dpart.alloc((size_t)nb * nx * 8));
+    KMAP_TRY(dout.alloc((size_t)nx * 8));
+    KMAP_CHECK_HIP(hipMemcpy(dh.p, hits, (size_t)n_seq * 4, hipMemcpyHostToDevice));
+    KMAP_CHECK_HIP(hipMemcpy(doff.p, offs, (size_t)(n_seq + 1) * 8, hipMemcpyHostToDevice));
+    if (total) KMAP_CHECK_HIP(hipMemcpy(dpos.p, pos, (size_t)total * 4, hipMemcpyHostToDevice));
+    KMAP_CHECK_HIP(hipMemcpy(dlen.p, seq_len, (size_t)n_seq * 8, hipMemcpyHostToDevice));
+    KMAP_CHECK_HIP(hipMemcpy(dx.p, x_arr, (size_t)nx * 8, hipMemcpyHostToDevice));
+    pos_density_kernel<<<(unsigned)nb, PD_TPB>>>(dh.as<int32_t>(), doff.as<int64_t>(), dpos.as<int32_t>(), dlen.as<int64_t>(), n_seq,
+                                                 kmer_len, dx.as<double>(), nx, x_step, dpart.as<double>());
+    pos_density_reduce_kernel<<<(nx + 127) / 128, 128>>>(dpart.as<double>(), nb, nx, dout.as<double>());
+    KMAP_CHECK_HIP(hipGetLastError());
+    KMAP_CHECK_HIP(hipMemcpy(density, dout.p, (size_t)nx * 8, hipMemcpyDeviceToHost));
+    return KMAP_OK;
+}
+
+}  // extern "C"

@@ -17,7 +17,7 @@ CONFIGS = {
 }
 
 
-def run_e2e(config="C2", mode="default", min_k=6, max_k=9, iters=None, keep=False, quiet=True):
+def run_e2e(config="C2", mode="default", min_k=6, max_k=9, iters=None, keep=False, quiet=True, reports=False):
     import contextlib
     import io
     from . import motif_discovery as md, synth, visualization as vz
@@ -35,7 +35,7 @@ def run_e2e(config="C2", mode="default", min_k=6, max_k=9, iters=None, keep=Fals
     t["synth_s"] = time.perf_counter() - t0
     res = Path(tempfile.mkdtemp(prefix=f"kmap_{config}_"))
     over = {"kmer_count": {"min_k": min_k, "max_k": max_k},
-            "motif_discovery": {"motif_pos_density_flag": False, "motif_co_occurence_flag": False, "gen_hamball_flag": False,
+            "motif_discovery": {"motif_pos_density_flag": reports, "motif_co_occurence_flag": reports, "gen_hamball_flag": reports,
                                 "n_total_sample": c["n_total"], "n_motif_sample": c["n_motif"]},
             "visualization": {"gen_fig_flag": False, "random_seed": 7, "n_max_iter": iters or c["iters"]}}
     t0 = time.perf_counter()

@@ -301,10 +301,8 @@ def gen_motif_occurence_file(conseq_list: List[str], motif_def_dict: dict, input
             dev_seq.close()
 
 
-def get_motif_seq_num(per, motif_index):
-    """(reads with the motif, total occurrences) -- what the reference parses back out of the CSV (:1345-1393)."""
-    hits = per[motif_index][0]
-    return int(np.count_nonzero(hits)), int(hits.sum())
+from .reports import (Occurrence, get_motif_seq_num, get_motif_pos_density, get_motif_co_occurence_mat,   # noqa: E402,F401
+                      write_co_occurence_mat, write_co_occurence_dist_arr, ex_hamball_kh_arr, cal_cnt_mat, _ex_hamball)
 
 
 # ---- sampling (reference motif_discovery.py:812-921) -------------------------------------------------------
@@ -502,12 +500,38 @@ def _scan_motif(res_dir: str, debug=False):
 
     occurence_file = res / FileNameDict["motif_occurence_file"]
     with _stage("occurrence_final"):
-        gen_motif_occurence_file(final_conseq_list, motif_def_dict, input_fasta_file, occurence_file, revcom_mode,
-                                 dev_seq=scan_seq)
+        per_final = gen_motif_occurence_file(final_conseq_list, motif_def_dict, input_fasta_file, occurence_file, revcom_mode,
+                                             dev_seq=scan_seq)
+    occ = Occurrence.from_per(per_final, scan_seq.read_len)   # the consumers below use the hit list, not the CSV
 
-    for flag in ("motif_pos_density_flag", "motif_co_occurence_flag", "gen_hamball_flag"):
-        if md.get(flag):
-            print(f"{flag}: plot/report branch is outside kmap_amd's GPU hot path, skipped.")
+    # the reference also draws pdf figures in these branches (motif_discovery.py:364-425); only the data files are produced
+    if md["motif_pos_density_flag"]:
+        with _stage("pos_density"):
+            x_step = 0.01
+            x_arr = np.arange(0, 1.0 + x_step, x_step)
+            rows = [get_motif_pos_density(occ, i, len(conseq), x_step=x_step, x_arr=x_arr)[2]
+                    for i, conseq in enumerate(final_conseq_list)]
+            with open(res / FileNameDict["motif_pos_density_file"], "wb") as fh:
+                pickle.dump([x_arr, np.vstack(rows)], fh)
+        print("motif position distribution generated.")
+
+    if md["motif_co_occurence_flag"]:
+        co_occur_dir = res / FileNameDict["co_occur_dir"]
+        co_occur_dir.mkdir(exist_ok=True)
+        co_occur_mat_file = co_occur_dir / FileNameDict["co_occur_mat_file"]
+        if co_occur_mat_file.exists():
+            print(f"{co_occur_mat_file}, re-use it!")
+        else:
+            with _stage("co_occurrence"):
+                co_occur_mat, loc_dist_mat, loc_dist_dict = get_motif_co_occurence_mat(occ, len(final_conseq_list))
+                co_sum_mat = np.diag(co_occur_mat) + np.diag(co_occur_mat).reshape((-1, 1))
+                co_occur_norm_mat = 2 * co_occur_mat / co_sum_mat
+                write_co_occurence_mat(co_occur_mat_file, co_occur_mat + 0.0, final_conseq_list)
+                write_co_occurence_mat(co_occur_dir / FileNameDict["co_occur_mat_norm_file"], co_occur_norm_mat, final_conseq_list)
+                write_co_occurence_mat(co_occur_dir / FileNameDict["co_occur_dist_mat_file"], loc_dist_mat, final_conseq_list)
+                write_co_occurence_dist_arr(co_occur_dir / FileNameDict["co_occur_dist_data_file"], loc_dist_dict,
+                                            final_conseq_list)
+        print("motif co-occurence matrix generated.")
 
     sample_kmer_pkl_file = res / FileNameDict["sample_kmer_pkl_file"]
     if md["sample_kmer_flag"] and not save_kmer_cnt_flag:
@@ -541,6 +565,19 @@ def _scan_motif(res_dir: str, debug=False):
             with open(res / FileNameDict["sample_kmer_hamdist_mat_file"], "wb") as fh:
                 pickle.dump([kmer_len, hamdist_mat, label_arr], fh)
         print("Hamming distance matrix of sampled kmers are generated.")
+
+    if md["gen_hamball_flag"]:
+        out_dir_path = res / FileNameDict["hamball_dir"]
+        out_dir_path.mkdir(exist_ok=True)
+        with _stage("hamming_balls"):
+            for i, conseq in enumerate(final_conseq_list):
+                output_cntmat_file = out_dir_path / f"cntmat_motif{i}_{conseq}.csv"
+                if output_cntmat_file.exists():
+                    print(f"motif matrix file {output_cntmat_file} exist, skip generating.")
+                    continue
+                _ex_hamball(str(res), conseq, "matrix", str(output_cntmat_file),
+                            max_ham_dist=motif_def_dict[len(conseq)].max_ham_dist)
+        print("Motif count matrix extracted.")
 
     if count_seq is not scan_seq:
         count_seq.close()

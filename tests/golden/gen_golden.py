@@ -13,7 +13,8 @@ are stored (as .npz / text data files).
     python tests/golden/gen_golden.py ops scan   # selected groups
 
 Groups: ops (G2-G5 operator vectors), scan (G1,G6-G8 pipeline on tests/test.fa),
-embed (G9,G10 smoothing + umap traces).
+embed (G9,G10 smoothing + umap traces), report (occurrence-file consumers and Hamming-ball
+extraction: position density, co-occurrence matrices, count matrices).
 """
 import os
 import pickle
@@ -373,8 +374,116 @@ def gen_embed():
              coords=np.array(snaps, dtype=np.float32), jitter_hits=np.array(jit), final=final)
 
 
+def _synthetic_occurrence_file(path, rng, n_reads=400, n_motif=4):
+    """An occurrence CSV in the reference's format with 4 motifs, multi-hit cells (up to 20 sorted locations), empty
+    cells and varying read lengths -- input data for the consumers, written by this script (not by the reference)."""
+    names = ["AATCGATAGC", "ACCTACGTA", "GGATCCAAT", "CCGTTAAC"][:n_motif]
+    lines = ["seq_ind;" + ";".join(f"motif_{i}_{c}" for i, c in enumerate(names)) + ";seq_len"]
+    for r in range(n_reads):
+        seq_len = int(rng.integers(60, 400))
+        cells, any_hit = [], False
+        for m in range(n_motif):
+            if rng.random() < (0.55, 0.4, 0.25, 0.05)[m]:
+                n_hit = int(rng.choice([1, 1, 1, 2, 3, 4, 7, 20]))
+                locs = np.sort(rng.choice(seq_len - len(names[m]) + 1, size=min(n_hit, seq_len - 20), replace=False))
+                cells.append(",".join(str(int(v)) for v in locs))
+                any_hit = True
+            else:
+                cells.append("")
+        if any_hit:
+            lines.append(f"{r};" + ";".join(cells) + f";{seq_len}")
+    Path(path).write_text("\n".join(lines) + "\n")
+    return names
+
+
+def gen_report():
+    """get_motif_pos_density, get_motif_co_occurence_mat (+ their writers), ex_hamball_kh_arr,
+    cal_cnt_mat, _ex_hamball -- outputs of the reference on tests/test.fa (flags on) and on a synthetic occurrence file."""
+    for name in ("_draw_motif_pos_density", "_draw_motif_pos_density_all", "draw_motif_distance_distribution", "_draw_logo"):
+        setattr(md, name, lambda *a, **k: None)   # plotting only
+    fa_src = REF / "tests" / "test.fa"
+    tmp = Path(tempfile.mkdtemp(prefix="kmap_golden_"))
+    res = tmp / "res"
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    shutil.copyfile(fa_src, tmp / "test.fa")
+    dst = HERE / "report_testfa"
+    dst.mkdir(exist_ok=True)
+    try:
+        cfg = kc.read_default_config_file()
+        cfg["general"]["input_fasta_file"] = "test.fa"
+        cfg["general"]["res_dir"] = "res"
+        cfg["kmer_count"]["min_k"] = 6
+        cfg["kmer_count"]["max_k"] = 12
+        for f in ("motif_pos_density_flag", "motif_co_occurence_flag", "gen_hamball_flag"):
+            cfg["motif_discovery"][f] = True
+        cfg["motif_discovery"]["n_total_sample"] = 300
+        cfg["motif_discovery"]["n_motif_sample"] = 150
+        cfg["visualization"]["gen_fig_flag"] = False
+        res.mkdir()
+        import tomli_w
+        with open(res / "config.toml", "wb") as fh:
+            tomli_w.dump(cfg, fh)
+        kc._preproc("test.fa", "res")
+        np.random.seed(123)
+        md._scan_motif("res")
+        shutil.copyfile(res / "config.toml", dst / "config.toml")
+        with open(res / "motif_pos_density.np.pkl", "rb") as fh:
+            x_arr, dens = pickle.load(fh)
+        out = {"x_arr": x_arr, "density": dens}
+        finals = (res / "final_conseq.txt").read_text().split()
+        out["final_conseq"] = np.array(finals)
+        for i, c in enumerate(finals):
+            n_seq, n_occ, d = md.get_motif_pos_density(res / "final.motif_occurence.csv", i, len(c))   # default grid
+            out[f"dens_default_{i}"], out[f"dens_default_{i}_n"] = d, np.array([n_seq, n_occ])
+        for f in ("co_occurence_mat.tsv", "co_occurence_mat.norm.tsv", "co_occurence_motif_dist_mat.tsv",
+                  "co_occurence_motif_dist_data.txt"):
+            shutil.copyfile(res / "co_occurence" / f, dst / f)
+        for f in sorted((res / "hamming_balls").glob("cntmat_*.csv")):
+            shutil.copyfile(f, dst / f.name)
+        # ex_hamball return types + arrays, default radius (-1) and an explicit one, revcom on/off
+        c0 = finals[0]
+        for rt in ("hash", "kmer", "matrix"):
+            md._ex_hamball("res", c0, rt, str(dst / f"exhamball_{rt}.txt"), max_ham_dist=1)
+        for tag, (cs, r, rc) in {"a": (finals[0], -1, True), "b": (finals[1], 3, True), "c": (finals[1], 2, False),
+                                 "d": ("ACGTAC", 1, True)}.items():
+            u, c = md.ex_hamball_kh_arr("res", cs, r, str(res / "motif_def_table.csv"), rc)
+            out[f"ball_{tag}_kh"], out[f"ball_{tag}_cnt"] = u, c
+            out[f"ball_{tag}_mat"] = md.cal_cnt_mat(u, c, len(cs))
+            out[f"ball_{tag}_def"] = np.array([cs, str(r), str(int(rc))])
+        for k in {len(finals[0]), len(finals[1]), 6}:
+            with open(res / "kmer_count" / f"k{k}.pkl", "rb") as fh:
+                kk, u, c = pickle.load(fh)
+            out[f"k{k}_uniq"], out[f"k{k}_cnt"] = u, c
+        shutil.copyfile(res / "final.motif_occurence.csv", dst / "final.motif_occurence.csv")
+        shutil.copyfile(res / "motif_def_table.csv", dst / "motif_def_table.csv")
+
+        # synthetic 4-motif occurrence file through the reference's consumers
+        names = _synthetic_occurrence_file(dst / "synth4.motif_occurence.csv", np.random.default_rng(5))
+        occ = dst / "synth4.motif_occurence.csv"
+        co, dist, dd = md.get_motif_co_occurence_mat(occ, len(names))
+        out["s4_names"], out["s4_co"], out["s4_dist"] = np.array(names), co, dist
+        for (i, j), v in dd.items():
+            out[f"s4_dd_{i}_{j}"] = np.array(v, dtype=np.float64)
+        co_sum = np.diag(co) + np.diag(co).reshape((-1, 1))
+        md.write_co_occurence_mat(dst / "s4_co_occurence_mat.tsv", co + 0.0, names)
+        md.write_co_occurence_mat(dst / "s4_co_occurence_mat.norm.tsv", 2 * co / co_sum, names)
+        md.write_co_occurence_mat(dst / "s4_co_occurence_motif_dist_mat.tsv", dist, names)
+        md.write_co_occurence_dist_arr(dst / "s4_co_occurence_motif_dist_data.txt", dd, names)
+        x_step = 0.01
+        xa = np.arange(0, 1.0 + x_step, x_step)
+        for i, c in enumerate(names):
+            n_seq, n_occ, d = md.get_motif_pos_density(occ, i, len(c), x_step=x_step, x_arr=xa)
+            out[f"s4_dens_{i}"], out[f"s4_dens_{i}_n"] = d, np.array([n_seq, n_occ])
+            out[f"s4_seqnum_{i}"] = np.array(md.get_motif_seq_num(occ, i))
+        save("report.npz", **out)
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 if __name__ == "__main__":
-    groups = sys.argv[1:] or ["ops", "scan", "embed"]
+    groups = sys.argv[1:] or ["ops", "scan", "embed", "report"]
     for g in groups:
         print(f"[{g}]")
-        {"ops": gen_ops, "scan": gen_scan, "embed": gen_embed}[g]()
+        {"ops": gen_ops, "scan": gen_scan, "embed": gen_embed, "report": gen_report}[g]()

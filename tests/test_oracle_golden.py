@@ -229,3 +229,76 @@ def test_umap_trace(golden, tag):
     # coordinates depend only on IEEE f32 ops + numpy's exp for p (<= ~1 ulp across ISAs): 1e-5 abs
     np.testing.assert_allclose(coords, u["coords"], rtol=0, atol=1e-5)
     np.testing.assert_allclose(final, u["final"], rtol=0, atol=1e-5)
+
+
+# ---- report consumers: oracle and host logic vs the reference's outputs -----------------------
+from pathlib import Path  # noqa: E402
+
+RGOLD = Path(GOLD) / "report_testfa"
+
+def _parse_occ(path):
+    import csv
+    rows = []
+    with open(path, newline="") as fh:
+        rd = csv.reader(fh, delimiter=";")
+        next(rd)
+        for row in rd:
+            rows.append(([[int(v) for v in c.split(",")] if c.strip() else [] for c in row[1:-1]], float(row[-1])))
+    return rows
+
+
+def test_report_hamball_and_cnt_mat(golden):
+    g = golden("report.npz")
+    for tag in "abcd":
+        conseq, r, rc = g[f"ball_{tag}_def"]
+        k, r = len(conseq), int(r)
+        if r == -1:
+            from kmap_amd.kmer_count import init_motif_def_dict
+            r = init_motif_def_dict(RGOLD / "motif_def_table.csv")[k].max_ham_dist
+        u, c = O.ex_hamball(g[f"k{k}_uniq"], g[f"k{k}_cnt"], k, O.kmer2hash(conseq), r, bool(int(rc)))
+        np.testing.assert_array_equal(u, g[f"ball_{tag}_kh"])
+        np.testing.assert_array_equal(c, g[f"ball_{tag}_cnt"])
+        np.testing.assert_array_equal(O.cal_cnt_mat(u, c, k), g[f"ball_{tag}_mat"])
+
+
+def test_report_pos_density_oracle(golden):
+    g = golden("report.npz")
+    rows = _parse_occ(RGOLD / "synth4.motif_occurence.csv")
+    for i, name in enumerate(g["s4_names"]):
+        sel = [(cells[i], sl) for cells, sl in rows if cells[i]]
+        d = O.motif_pos_density(sel, len(name), np.arange(0, 1.01, 0.01), 0.01)
+        np.testing.assert_allclose(d, g[f"s4_dens_{i}"], rtol=1e-13, atol=1e-300)
+        assert [len(sel), sum(len(c) for c, _ in sel)] == list(g[f"s4_dens_{i}_n"])
+
+
+def test_report_co_occurrence_oracle_and_host(golden, tmp_path):
+    """the oracle's per-row restatement and the product's vectorised host code both reproduce the reference's matrices,
+    distance lists and the four text files (synthetic 4-motif file and tests/test.fa)"""
+    from kmap_amd import reports as R
+    g = golden("report.npz")
+    src = RGOLD
+    rows = _parse_occ(src / "synth4.motif_occurence.csv")
+    names = [str(s) for s in g["s4_names"]]
+    for res, dist, dd in (O.co_occurrence([c for c, _ in rows], 4), R.get_motif_co_occurence_mat(src / "synth4.motif_occurence.csv", 4)):
+        np.testing.assert_array_equal(res, g["s4_co"])
+        np.testing.assert_array_equal(dist, g["s4_dist"])
+        for (i, j), v in dd.items():
+            np.testing.assert_array_equal(np.array(v, np.float64), g[f"s4_dd_{i}_{j}"])
+    co, dist, dd = R.get_motif_co_occurence_mat(src / "synth4.motif_occurence.csv", 4)
+    co_sum = np.diag(co) + np.diag(co).reshape((-1, 1))
+    R.write_co_occurence_mat(tmp_path / "a.tsv", co + 0.0, names)
+    R.write_co_occurence_mat(tmp_path / "b.tsv", 2 * co / co_sum, names)
+    R.write_co_occurence_mat(tmp_path / "c.tsv", dist, names)
+    R.write_co_occurence_dist_arr(tmp_path / "d.txt", dd, names)
+    for mine, ref in (("a.tsv", "s4_co_occurence_mat.tsv"), ("b.tsv", "s4_co_occurence_mat.norm.tsv"),
+                      ("c.tsv", "s4_co_occurence_motif_dist_mat.tsv"), ("d.txt", "s4_co_occurence_motif_dist_data.txt")):
+        assert (tmp_path / mine).read_text() == (src / ref).read_text(), ref
+    for i in range(4):
+        assert list(R.get_motif_seq_num(src / "synth4.motif_occurence.csv", i)) == list(g[f"s4_seqnum_{i}"])
+    # tests/test.fa finals
+    finals = [str(s) for s in g["final_conseq"]]
+    co, dist, dd = R.get_motif_co_occurence_mat(src / "final.motif_occurence.csv", len(finals))
+    R.write_co_occurence_mat(tmp_path / "e.tsv", co + 0.0, finals)
+    R.write_co_occurence_dist_arr(tmp_path / "f.txt", dd, finals)
+    assert (tmp_path / "e.tsv").read_text() == (src / "co_occurence_mat.tsv").read_text()
+    assert (tmp_path / "f.txt").read_text() == (src / "co_occurence_motif_dist_data.txt").read_text()

@@ -21,8 +21,9 @@ def main():
     ap.add_argument("--max_k", type=int, default=9)
     ap.add_argument("--iters", type=int, default=None)
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--reports", action="store_true", help="also produce the position-density / co-occurrence / Hamming-ball data files")
     args = ap.parse_args()
-    print(json.dumps(run_e2e(args.config, args.mode, args.min_k, args.max_k, args.iters, args.keep)))
+    print(json.dumps(run_e2e(args.config, args.mode, args.min_k, args.max_k, args.iters, args.keep, reports=args.reports)))
 
 
 if __name__ == "__main__":
