@@ -10,6 +10,8 @@
 //
 // Kernels: pack / unpack, hash materialisation, histogram (LDS-privatised passes or global atomics) straight from the
 // packed stream, Hamming-ball mask (flag + coverage), and the per-read occurrence scan.
+#include <cstdlib>
+
 #include "common.h"
 #include "counts_internal.h"
 #include "scan_internal.h"
@@ -310,6 +312,227 @@ __global__ __launch_bounds__(KMAP_WAVE *SC_WAVES) void scan_packed_kernel(const 
     }
 }
 
+
+// ---- occurrence scan, flat formulation ---------------------------------------------------------------------------
+// The wave-per-read kernel above spends its time on per-read latency chains (borders -> codes -> reduce -> ballot): 10^7
+// waves of ~3 positions per lane.  Split instead into
+//   (1) a flat pass, thread per 16-position group, that stores the capped distance of EVERY window as a nibble
+//       (d <= radius ? d : 15; 8 B per group = 0.5 B per position) -- independent of read borders because a window that
+//       the scan may use (p < L-k+1) lies entirely inside its read;
+//   (2) a thread-per-read pass over that read's nibbles: minimum, number of positions at the minimum;
+//   (3) after the scan of the counts, a thread-per-read pass that writes those positions in ascending order.
+// Reads longer than FL_LONG positions are handled by their whole wave (64 words per step) inside (2) and (3).
+// Needs radius <= 14; larger radii take the wave-per-read kernel.
+constexpr int FL_TPB = 256;
+constexpr int FL_LONG = 1024;
+constexpr int FL_STAGE = 8192;   // nibble words staged per block (64 KiB of LDS)
+constexpr uint64_t NIB_ONES = 0x1111111111111111ull;
+
+template <bool WIDE>
+__global__ __launch_bounds__(BLK) void scan_nibble_kernel(const uint32_t *__restrict__ codes, const uint16_t *__restrict__ inval,
+                                                          int64_t n, int k, uint64_t cons, uint64_t rcc, int radius, int revcom,
+                                                          uint64_t *__restrict__ nib) {
+    const int64_t g = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    if (g >= ((n + 15) >> 4)) return;
+    const Win w = load_win(codes, inval, g);
+    const uint64_t kmask = low_mask<uint64_t>(k);
+    uint64_t out = 0;
+    if (!WIDE) {   // k <= 16: the hash fits 32 bits
+        const uint32_t km = (uint32_t)kmask, c32 = (uint32_t)cons, r32 = (uint32_t)rcc;
+        const uint64_t vm = (1ull << k) - 1ull;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            uint32_t h = (uint32_t)((w.t0 << (2 * i)) >> 32) >> (32 - 2 * k);
+            if ((w.m >> (48 - i - k)) & vm) h = km;
+            int d = popc2((h ^ c32) & km);
+            if (revcom) {
+                const int d2 = popc2((h ^ r32) & km);
+                d = d2 < d ? d2 : d;
+            }
+            out |= (uint64_t)(d <= radius ? d : 15) << (4 * i);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            bool bad;
+            const uint64_t h = win_hash<true>(w, i, k, kmask, bad);
+            int d = popc2((h ^ cons) & kmask);
+            if (revcom) {
+                const int d2 = popc2((h ^ rcc) & kmask);
+                d = d2 < d ? d2 : d;
+            }
+            out |= (uint64_t)(d <= radius ? d : 15) << (4 * i);
+        }
+    }
+    nib[g] = out;
+}
+
+// nibbles of word wi restricted to absolute positions [a, b): everything else reads as 15.  `src` is the nibble array
+// shifted so that src[wi - wsh] is word wi (global array: wsh = 0; block-staged LDS copy: wsh = first staged word).
+__device__ __forceinline__ uint64_t nib_load(const uint64_t *src, int64_t wsh, int64_t wi, int64_t a, int64_t b) {
+    uint64_t x = src[wi - wsh];
+    const int64_t w0 = wi << 4;
+    if (a > w0) x |= (1ull << (4 * (int)(a - w0))) - 1ull;
+    if (b < w0 + 16) x |= ~0ull << (4 * (int)(b - w0));
+    return x;
+}
+__device__ __forceinline__ int nib_min(uint64_t x) {
+    // pairwise minimum of the 16 nibbles (SWAR: compare 8 nibble pairs held in separate bytes, then fold)
+    int m = 15;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int v = (int)((x >> (4 * i)) & 15);
+        m = v < m ? v : m;
+    }
+    return m;
+}
+// 16-bit mask (bit i = position i of the word) of the nibbles equal to v
+__device__ __forceinline__ uint32_t nib_eq_mask(uint64_t x, int v) {
+    uint64_t y = x ^ (NIB_ONES * (uint64_t)v);         // zero nibble <=> equal
+    y |= y >> 1;
+    y |= y >> 2;
+    y = ~y & NIB_ONES;                                 // bit 4i set <=> nibble i equal
+    y = (y | (y >> 3)) & 0x0303030303030303ull;        // gather: 2 bits per byte
+    y = (y | (y >> 6)) & 0x000F000F000F000Full;        // 4 bits per 16
+    y = (y | (y >> 12)) & 0x000000FF000000FFull;       // 8 bits per 32
+    return (uint32_t)((y | (y >> 24)) & 0xFFFFull);
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(FL_TPB) void scan_reads_kernel(const uint64_t *__restrict__ nib, int64_t n,
+                                                            const int64_t *__restrict__ borders, int64_t n_seq, int k, int d_inv,
+                                                            int radius, int32_t *__restrict__ hits, int8_t *__restrict__ min_dist,
+                                                            const uint64_t *__restrict__ offs, int32_t *__restrict__ pos_out,
+                                                            int stage_words) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t st = 0, stop = 0;
+    bool quirk = false;
+    if (s < n_seq) {
+        st = borders[2 * s];
+        int64_t en = borders[2 * s + 1];
+        if (st < 0) st = 0;
+        if (en > n) en = n;
+        const int64_t L = en > st ? en - st : 0;
+        quirk = (L - k + 1 < 0);                 // negative slice stop (motif_discovery.py:1443): every window runs off the read
+        stop = slice_stop(L, k);
+    }
+    int best = 15, count = 0;
+    uint64_t base = 0;
+    if (WRITE && s < n_seq) {
+        count = hits[s];
+        best = min_dist[s];
+        base = offs[s];
+        if (count == 0) stop = 0;                // nothing to write for this read
+    }
+    if (quirk) {
+        if (!WRITE) {
+            best = d_inv <= radius ? d_inv : 15;
+            count = d_inv <= radius ? (int)stop : 0;
+        } else {
+            for (int64_t p = 0; p < stop; ++p) pos_out[base + p] = (int32_t)p;
+        }
+        stop = 0;
+    }
+    const bool is_long = stop > FL_LONG;
+    // Stage the block's span of nibble words in LDS with coalesced loads: a thread-per-read walk straight over global
+    // memory touches a different 128-B line per lane and per step (16x the bytes through L2).  Blocks whose reads are not
+    // (nearly) contiguous in the array exceed FL_STAGE words and read global memory directly.
+    extern __shared__ __attribute__((aligned(16))) uint64_t stage[];
+    __shared__ long long span_lo, span_hi;
+    if (threadIdx.x == 0) {
+        span_lo = INT64_MAX;
+        span_hi = -1;
+    }
+    __syncthreads();
+    if (stop > 0 && !is_long) {
+        atomicMin(&span_lo, (long long)(st >> 4));
+        atomicMax(&span_hi, (long long)((st + stop - 1) >> 4));
+    }
+    __syncthreads();
+    const int64_t wlo = span_lo, whi = span_hi;
+    const uint64_t *src = nib;
+    int64_t wsh = 0;
+    if (whi >= wlo && whi - wlo < stage_words) {
+        for (int64_t i = threadIdx.x; i <= whi - wlo; i += blockDim.x) stage[i] = nib[wlo + i];
+        src = stage;
+        wsh = wlo;
+    }
+    __syncthreads();
+    if (stop > 0 && !is_long) {
+        const int64_t a = st, b = st + stop;
+        const int64_t w0 = a >> 4, w1 = (b - 1) >> 4;
+        if (!WRITE) {
+            for (int64_t wi = w0; wi <= w1; ++wi) {
+                const int m = nib_min(nib_load(src, wsh, wi, a, b));
+                best = m < best ? m : best;
+            }
+            if (best < 15)
+                for (int64_t wi = w0; wi <= w1; ++wi) count += __builtin_popcount(nib_eq_mask(nib_load(src, wsh, wi, a, b), best));
+        } else {
+            for (int64_t wi = w0; wi <= w1; ++wi) {
+                uint32_t m = nib_eq_mask(nib_load(src, wsh, wi, a, b), best);
+                while (m) {
+                    const int i = __builtin_ctz(m);
+                    m &= m - 1;
+                    pos_out[base++] = (int32_t)((wi << 4) + i - st);
+                }
+            }
+        }
+    }
+    // long reads: the whole wave works on one read at a time, 64 words per step
+    unsigned long long todo = __ballot(is_long);
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int64_t a = __shfl(st, src), b = a + __shfl(stop, src);
+        const int64_t w0 = a >> 4, w1 = (b - 1) >> 4;
+        if (!WRITE) {
+            int m = 15;
+            for (int64_t wi = w0 + lane; wi <= w1; wi += 64) {
+                const int v = nib_min(nib_load(nib, 0, wi, a, b));
+                m = v < m ? v : m;
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const int v = __shfl_xor(m, o);
+                m = v < m ? v : m;
+            }
+            int c = 0;
+            if (m < 15)
+                for (int64_t wi = w0 + lane; wi <= w1; wi += 64) c += __builtin_popcount(nib_eq_mask(nib_load(nib, 0, wi, a, b), m));
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+            if (lane == src) {
+                best = m;
+                count = c;
+            }
+        } else {
+            const int bst = __shfl(best, src);
+            uint64_t wbase = __shfl(base, src);
+            for (int64_t c0 = w0; c0 <= w1; c0 += 64) {
+                const int64_t wi = c0 + lane;
+                uint32_t m = (wi <= w1) ? nib_eq_mask(nib_load(nib, 0, wi, a, b), bst) : 0u;
+                const int c = __builtin_popcount(m);
+                int inc = c;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(inc, o);
+                    if (lane >= o) inc += v;
+                }
+                uint64_t at = wbase + (uint64_t)(inc - c);
+                while (m) {
+                    const int i = __builtin_ctz(m);
+                    m &= m - 1;
+                    pos_out[at++] = (int32_t)((wi << 4) + i - a);
+                }
+                wbase += (uint64_t)__shfl(inc, 63);
+            }
+        }
+    }
+    if (!WRITE && s < n_seq) {
+        hits[s] = count;
+        min_dist[s] = (int8_t)(best < 15 ? best : -1);
+    }
+}
+
 static inline unsigned grid_for(int64_t n, int64_t per) {
     int64_t g = (n + per - 1) / per;
     return (unsigned)(g < 1 ? 1 : g);
@@ -473,17 +696,63 @@ int kmap_scan_run_packed_dev(kmap_scan *s, const uint32_t *codes_dev, const uint
     const uint64_t c = cons & m;
     uint64_t com = m - c, rcc = com & 3u;
     for (int i = 0; i < k - 1; ++i) { rcc <<= 2; com >>= 2; rcc += com & 3u; }
+    static const bool flat_ok = !(getenv("KMAP_SCAN_FLAT") && getenv("KMAP_SCAN_FLAT")[0] == '0');
+    const bool flat = flat_ok && radius <= 14;
     const unsigned grid = (unsigned)((n_seq + SC_WAVES - 1) / SC_WAVES);
-    scan_packed_kernel<false><<<grid, KMAP_WAVE * SC_WAVES, 0, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, c, rcc,
-                                                                     radius, revcom, s->hits, s->mind, nullptr, nullptr);
+    // reads per block and staged words: about 1.25x the block's expected span, at most 24 KiB of LDS where the average
+    // read length allows it (several blocks per CU hide the staging latency), never more than FL_STAGE words
+    int ftpb = FL_TPB, stage_words = FL_STAGE;
+    {
+        const double wpr = (double)(n + n_seq) / (double)n_seq / 16.0 + 1.0;   // nibble words per read, separators included
+        for (ftpb = FL_TPB; ftpb > 64 && wpr * ftpb * 1.25 * 8.0 > 24.0 * 1024; ftpb >>= 1) {}
+        double want = wpr * ftpb * 1.25 + 64.0;
+        if (want > FL_STAGE) want = FL_STAGE;
+        stage_words = ((int)want + 127) & ~127;
+    }
+    const unsigned fgrid = (unsigned)((n_seq + ftpb - 1) / ftpb);
+    uint64_t *nib = nullptr;
+    int d_inv = 0;
+    if (flat) {
+        const int64_t ng = (n + 15) >> 4;
+        KMAP_TRY(kmap_scratch((void **)&nib, (size_t)(ng ? ng : 1) * 8, st, KMAP_SLOT_HASH));
+        if (ng) {
+            if (k <= 16) scan_nibble_kernel<false><<<grid_for(ng, BLK), BLK, 0, st>>>(codes_dev, inval_dev, n, k, c, rcc, radius, revcom, nib);
+            else scan_nibble_kernel<true><<<grid_for(ng, BLK), BLK, 0, st>>>(codes_dev, inval_dev, n, k, c, rcc, radius, revcom, nib);
+        }
+        // distance of an invalid window (all ones, compared like any value)
+        auto pc2 = [](uint64_t x) { return __builtin_popcountll((x | (x >> 1)) & 0x5555555555555555ull); };
+        d_inv = pc2((m ^ c) & m);
+        if (revcom) {
+            const int d2 = pc2((m ^ rcc) & m);
+            d_inv = d2 < d_inv ? d2 : d_inv;
+        }
+        static bool attr_set = false;
+        if (!attr_set) {
+            KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)scan_reads_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               FL_STAGE * 8));
+            KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)scan_reads_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               FL_STAGE * 8));
+            attr_set = true;
+        }
+        scan_reads_kernel<false><<<fgrid, ftpb, (size_t)stage_words * 8, st>>>(nib, n, borders_dev, n_seq, k, d_inv, radius, s->hits, s->mind, nullptr,
+                                                                               nullptr, stage_words);
+    } else {
+        scan_packed_kernel<false><<<grid, KMAP_WAVE * SC_WAVES, 0, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, c, rcc,
+                                                                         radius, revcom, s->hits, s->mind, nullptr, nullptr);
+    }
     KMAP_TRY(exclusive_scan_u32(reinterpret_cast<const uint32_t *>(s->hits), n_seq, s->offs, st));
     uint64_t total = 0;
     KMAP_CHECK_HIP(hipMemcpyAsync(&total, s->offs + n_seq, 8, hipMemcpyDeviceToHost, st));
     KMAP_CHECK_HIP(hipStreamSynchronize(st));
     KMAP_TRY(kmap_scan_reserve_pos(s, total));
-    if (total)
-        scan_packed_kernel<true><<<grid, KMAP_WAVE * SC_WAVES, 0, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, c, rcc,
-                                                                        radius, revcom, s->hits, s->mind, s->offs, s->pos);
+    if (total) {
+        if (flat)
+            scan_reads_kernel<true><<<fgrid, ftpb, (size_t)stage_words * 8, st>>>(nib, n, borders_dev, n_seq, k, d_inv, radius, s->hits, s->mind, s->offs,
+                                                                                  s->pos, stage_words);
+        else
+            scan_packed_kernel<true><<<grid, KMAP_WAVE * SC_WAVES, 0, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, c, rcc,
+                                                                            radius, revcom, s->hits, s->mind, s->offs, s->pos);
+    }
     KMAP_CHECK_HIP(hipGetLastError());
     s->total = (int64_t)total;
     if (total_hits) *total_hits = (int64_t)total;

@@ -109,11 +109,14 @@ def test_packed_mask_many_consensuses(env):
     ds.close()
 
 
-@pytest.mark.parametrize("k,r", [(6, 1), (8, 2), (14, 5), (20, 8), (31, 10)])
+@pytest.mark.parametrize("k,r", [(6, 1), (8, 2), (14, 5), (16, 14), (17, 3), (20, 8), (31, 10), (31, 15)])
 def test_packed_scan_vs_oracle(env, k, r):
+    """flat nibble path (radius <= 14; reads above 1024 positions are scanned by a whole wave) and the wave-per-read
+    kernel (radius 15), incl. the negative-slice quirk for reads shorter than k-1 and borders off the separators"""
     _ffi, _, DeviceSeq, O = env
     rng = np.random.default_rng(k)
-    lens = [0, 1, k - 1, k, k + 1, 63, 64, 65, 256, 257, 300, 700] + list(rng.integers(5, 200, size=300))
+    lens = [0, 1, k - 2, k - 1, k, k + 1, 63, 64, 65, 256, 257, 300, 700, 1023 + k, 1024 + k, 1025 + k, 3000, 5003] \
+        + list(rng.integers(5, 200, size=300))
     parts, borders, st = [], [], 0
     for L in lens:
         rd = rng.integers(0, 4 if L % 3 else 1, size=L).astype(np.uint8)   # some poly-A reads: many ties at the minimum
@@ -123,11 +126,16 @@ def test_packed_scan_vs_oracle(env, k, r):
         borders.append((st, st + L))
         st += L + 1
     seq, borders = np.concatenate(parts), np.array(borders, np.int64)
+    sub = borders.copy()                                      # a second set of "reads": windows strictly inside the first
+    wide = (borders[:, 1] - borders[:, 0]) > 12
+    sub[wide, 0] += 3
+    sub[wide, 1] -= 2
+    borders = np.concatenate([borders, sub[wide]])
     ds = DeviceSeq(seq, borders)
     for cons in (0, int(O.kmer2hash("T" * k)), int(rng.integers(0, 4 ** k, dtype=np.uint64))):
         for revcom in (True, False):
             hits, pos = ds.scan(k, cons, r, revcom)
-            buf, md, off = np.empty(1024, np.int32), C.c_int(0), 0
+            buf, md, off = np.empty(8192, np.int32), C.c_int(0), 0
             for i, (a, b) in enumerate(borders):
                 m = O.lib().ko_scan_read(np.ascontiguousarray(seq[a:b]), b - a, k, cons, r, int(revcom), buf, C.byref(md))
                 assert hits[i] == m, (i, b - a, hits[i], m)

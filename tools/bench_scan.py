@@ -39,6 +39,15 @@ def main():
     dt = (time.perf_counter() - t0) / args.reps
     out["scan"] = {"s_per_pass_incl_fetch": dt, "positions_per_s": n / dt, "GBps_algorithmic": n / dt / 1e9,
                    "reads_with_hit": int(np.count_nonzero(hits)), "total_hits": int(hits.sum())}
+    import ctypes as C
+    tot = _ffi.i64(0)
+    t0 = time.perf_counter()
+    for _ in range(args.reps):   # device part only: nibble pass + per-read passes + scan of the counts (results stay in HBM)
+        _ffi.check(_ffi.lib().kmap_scan_run_packed_dev(ds._scan, ds.codes.ptr, ds.inval_orig.ptr, ds.n, ds.borders.ptr, ds.n_seq,
+                                                       args.k, int(kmer2hash(motif)), args.radius, 1, C.byref(tot), None))
+    _ffi.sync()
+    dt = (time.perf_counter() - t0) / args.reps
+    out["scan"].update({"s_per_pass_device": dt, "positions_per_s_device": n / dt})
     dc = DeviceCounts()
     for dedupe in (True, False):
         ds.count(dc, args.k, dedupe=dedupe, merge_revcom=True)
