@@ -69,12 +69,48 @@ def cpu_baseline(kh, lab, target_s=12.0):
             "sample": f"{rows2} of {n} rows x {n} cols (oracle ko_hamdist_rows, OpenMP, {dt:.1f} s)"}
 
 
+def embed_dist_leg(dist, torch, kh, lab, n, out_d, iters=(20, 120)):
+    """Row-sharded embedding of the same N sampled k-mers on all ranks (kmap_amd.distributed): per-iteration time from
+    the difference of two runs (setup = D, neighbour selection, sums cancels).  Errors are reported, not raised: a rank
+    that failed sets a flag that every rank sees before anyone enters the next collective-bearing phase."""
+    from kmap_amd.distributed import kmap_from_kmers_distributed
+    out_d.free()
+    res, err = {}, ""
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    times = []
+    for it in iters:
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            break
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        try:
+            kmap_from_kmers_distributed(kh, np.ones(n, np.int64), lab, ["A" * K, "C" * K], K, n_max_iter=it, random_seed=7)
+        except Exception as e:   # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"[:300]
+            flag.fill_(1)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()) or len(times) < 2:
+        return {"error": err or "another rank failed"}
+    t = torch.tensor(times, dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = t.tolist()
+    res = {"n_kmers": n, "mode": "default (FAST above N = 16384)", "iterations": list(iters), "wall_s": t,
+           "ms_per_iteration": (t[1] - t[0]) / (iters[1] - iters[0]) * 1e3, "setup_s": t[0] - iters[0] * (t[1] - t[0]) / (iters[1] - iters[0]),
+           "collectives_per_iteration": 2}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-embed-dist", action="store_true", help="skip the multi-GPU embedding leg (world > 1)")
     ap.add_argument("--e2e", default="C3", choices=["none", "C2", "C3"],
                     help="also time scan_motif + visualize_kmers end to end on this synthetic config (rank 0, N=1 only)")
     args = ap.parse_args()
@@ -150,6 +186,11 @@ def main():
                                 len(CONSEQ_LENS), row0, chk_rows, want)
         assert np.array_equal(got, want), "timed kernel output differs from the oracle"
 
+    # ---- multi-GPU embedding leg (world > 1): the row-sharded iteration with its two all-reduces over RCCL ----
+    embed_dist = None
+    if dist is not None and not args.no_embed_dist:
+        embed_dist = embed_dist_leg(dist, torch, kh, lab, n, out_d)
+
     if rank == 0:
         pairs_total = float(n) * float(n)
         algo_bytes = nrows * n + 5 * n          # u8 out + u32 hashes + u8 group ids, per launch on this rank
@@ -176,6 +217,8 @@ def main():
                 line["roofline"]["traffic_source"] = f"profiles/{pmc[-1].name}"
             except Exception:
                 pass
+        if embed_dist is not None:
+            line["embed_dist"] = embed_dist
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(kh, lab)
         if world == 1 and args.e2e != "none":
