@@ -21,7 +21,8 @@ from . import _ffi
 from ._ffi import check, ptr
 from .hamdist import _convert_to_block_arr, cal_samp_kmer_hamdist_mat  # noqa: F401  (re-exported, reference names)
 from .kmer_count import (DeviceCounts, FileNameDict, cal_hamming_dist_head, cal_hamming_dist_tail, encode_fasta,
-                         gen_motif_def_dict, get_cnt_dtype, get_hash_dtype, get_revcom_hash_arr, hash2kmer, kmer2hash,
+                         gen_motif_def_dict, get_cnt_dtype, get_hash_dtype, get_revcom_hash_arr, hash2kmer, init_motif_def_dict,
+                         kmer2hash,
                          mask_ham_ball, revcom_hash, reverse_complement)
 
 # int64 N x N pickle is kept up to this many sampled k-mers (2 GiB); above it scan_motif writes the compact
@@ -299,6 +300,37 @@ def gen_motif_occurence_file(conseq_list: List[str], motif_def_dict: dict, input
     finally:
         if own:
             dev_seq.close()
+
+
+def get_user_motif_occurence_file(input_fasta_file, conseq_list: List[str], max_hamdist_list: List[int], output_file,
+                                  revcom_mode=True):
+    """Occurrence file for user-given consensuses and radii (reference motif_discovery.py:1480-1507): the default motif
+    table with `max_ham_dist` overridden per consensus LENGTH, in list order (a later consensus of the same length wins,
+    as in the reference).  Returns the hit list."""
+    from .kmer_count import _pkg_file
+    assert Path(input_fasta_file).exists()
+    motif_def_dict = init_motif_def_dict(_pkg_file(FileNameDict["default_motif_def_file"]))
+    for conseq, max_ham_dist in zip(conseq_list, max_hamdist_list):
+        motif_def_dict[len(conseq)].max_ham_dist = max_ham_dist
+    return gen_motif_occurence_file(conseq_list, motif_def_dict, input_fasta_file, output_file, revcom_mode)
+
+
+def check_motif_co_occurence(input_fasta_file: str, motif1: str, motif2: str, max_ham_dist1: int, max_ham_dist2: int,
+                             output_dir: str, revcom_mode: bool):
+    """`kmap check_motif_co_occurence` without its figures (reference motif_discovery.py:155-178): writes
+    user_motif_occurence.csv and returns (co-occurrence matrix, median-distance matrix, distance lists, info string)."""
+    assert Path(input_fasta_file).exists()
+    out = Path(output_dir)
+    out.mkdir(parents=True, exist_ok=True)
+    occurence_file = out / "user_motif_occurence.csv"
+    get_user_motif_occurence_file(Path(input_fasta_file), [motif1, motif2], [max_ham_dist1, max_ham_dist2], occurence_file,
+                                  revcom_mode)
+    co_occur_mat, loc_dist_mat, loc_dist_dict = get_motif_co_occurence_mat(occurence_file, 2)
+    info_str = ""
+    if np.any(co_occur_mat):
+        co_occur_freq = co_occur_mat[0][1] * 2 / (co_occur_mat[0][0] + co_occur_mat[1][1])
+        info_str = f"co_occur_freq={co_occur_freq * 100:.2f}%"
+    return co_occur_mat, loc_dist_mat, loc_dist_dict, info_str
 
 
 from .reports import (Occurrence, get_motif_seq_num, get_motif_pos_density, get_motif_co_occurence_mat,   # noqa: E402,F401

@@ -476,6 +476,10 @@ def gen_report():
             n_seq, n_occ, d = md.get_motif_pos_density(occ, i, len(c), x_step=x_step, x_arr=xa)
             out[f"s4_dens_{i}"], out[f"s4_dens_{i}_n"] = d, np.array([n_seq, n_occ])
             out[f"s4_seqnum_{i}"] = np.array(md.get_motif_seq_num(occ, i))
+        # user-given motifs / radii on tests/test.fa (get_user_motif_occurence_file; same-length radius override quirk)
+        np.random.seed(321)
+        md.get_user_motif_occurence_file(Path("test.fa"), ["AATCGATAGC", "CCTACGTA", "GGGGGGGG"], [3, 1, 2],
+                                         dst / "user_motif_occurence.csv", True)
         save("report.npz", **out)
     finally:
         os.chdir(cwd)
