@@ -402,8 +402,44 @@ def kmap_from_kmers(samp_kh, samp_cnts, samp_label, conseq_list, kmer_len, n_nei
 
 
 # ---- `kmap visualize_kmers` --------------------------------------------------------------------------
+def _dist_context():
+    """Multi-GPU launch (`python -m torch.distributed.run --nproc-per-node G -m kmap_amd visualize_kmers ...`): returns
+    (dist, rank, owns_group) with the process group initialised on this rank's GPU, or (None, 0, False) single-process.
+    KMAP_DIST_BACKEND / KMAP_DIST_SAME_GPU exist for rehearsals on a one-GPU box (gloo, every rank on GPU 0)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None, 0, False
+    import torch
+    import torch.distributed as dist
+    dev = 0 if os.environ.get("KMAP_DIST_SAME_GPU") else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(dev)
+    check(_ffi.lib().kmap_set_device(dev))
+    owns = not dist.is_initialized()
+    if owns:
+        backend = os.environ.get("KMAP_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
+    return dist, dist.get_rank(), owns
+
+
 def _visualize_kmers(res_dir: str, debug=False, mode=None):
-    """reference visualization.py:36-87: config.toml + sample_kmer_hamdist_mat.pkl -> low_dim_data.tsv"""
+    """reference visualization.py:36-87: config.toml + sample_kmer_hamdist_mat.pkl -> low_dim_data.tsv.
+    Under a torch.distributed launch the compact hand-off is embedded row-sharded over all ranks (rank 0 writes the file);
+    a dense int64 matrix (N <= 16384) is embedded by rank 0 alone."""
+    dist, rank, owns_group = _dist_context()
+    try:
+        return _visualize_kmers_impl(res_dir, debug, mode, dist, rank)
+    finally:
+        if dist is not None:
+            dist.barrier()
+            if owns_group:
+                dist.destroy_process_group()
+
+
+def _visualize_kmers_impl(res_dir, debug, mode, dist, rank):
     from ._toml import load_toml
     cfg_path = Path(res_dir) / FileNameDict["config_file"]
     assert cfg_path.exists()
@@ -422,13 +458,24 @@ def _visualize_kmers(res_dir: str, debug=False, mode=None):
         # compact hand-off written by scan_motif above the int64-matrix size threshold
         with open(Path(res_dir) / FileNameDict["sample_kmer_pkl_file"], "rb") as fh:
             samp_kh, samp_cnts, samp_label, conseq_list = pickle.load(fh)
-        ld_data, _ = kmap_from_kmers(samp_kh, samp_cnts, samp_label, conseq_list, kmer_len, n_neighbour=vz["n_neighbour"],
-                                     n_max_iter=vz["n_max_iter"], learning_rate=vz["learning_rate"],
-                                     n_best_result=vz["n_best_result"], random_seed=random_seed, debug=debug, mode=mode)
+        if dist is not None:
+            from .distributed import kmap_from_kmers_distributed
+            ld_data, _ = kmap_from_kmers_distributed(samp_kh, samp_cnts, samp_label, conseq_list, kmer_len,
+                                                     n_neighbour=vz["n_neighbour"], n_max_iter=vz["n_max_iter"],
+                                                     learning_rate=vz["learning_rate"], n_best_result=vz["n_best_result"],
+                                                     random_seed=random_seed, mode=mode)
+        else:
+            ld_data, _ = kmap_from_kmers(samp_kh, samp_cnts, samp_label, conseq_list, kmer_len, n_neighbour=vz["n_neighbour"],
+                                         n_max_iter=vz["n_max_iter"], learning_rate=vz["learning_rate"],
+                                         n_best_result=vz["n_best_result"], random_seed=random_seed, debug=debug, mode=mode)
+    elif rank != 0:
+        return None      # dense hand-off: rank 0 embeds alone
     else:
         ld_data = kmap(hamdist_mat, kmer_len, n_neighbour=vz["n_neighbour"], n_max_iter=vz["n_max_iter"],
                        learning_rate=vz["learning_rate"], n_best_result=vz["n_best_result"], random_seed=random_seed,
                        debug=debug, mode=mode)
+    if rank != 0:
+        return ld_data
     lines = ["x\ty\tlabel"]
     for x, y, label in zip(ld_data[0], ld_data[1], label_arr):
         lines.append(f"{x:3.3f}\t{y:3.3f}\t{int(label)}")

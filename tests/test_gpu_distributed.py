@@ -126,3 +126,39 @@ def test_read_sharded_counting_scan_and_find_motif(tmp_path):
         assert r["motifs"] == {int(h): v for h, v in single.items()}
     dc.close()
     ds.close()
+
+
+def test_visualize_kmers_cli_under_torchrun(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m kmap_amd visualize_kmers` (compact hand-off, rows sharded over
+    two ranks that share the test box's GPU, gloo) writes the same low_dim_data.tsv as the single-process verb."""
+    import pickle
+    import shutil
+    import subprocess
+    from kmap_amd._toml import dump_toml
+    from kmap_amd.kmer_count import read_default_config_file
+    kh, cnts, lab, conseqs = _inputs()
+    kh = np.unique(kh).astype(np.uint32)
+    lab, cnts = lab[:len(kh)], np.ones(len(kh), np.int64)
+    cnts[::7] = 3                                               # expanded N > number of unique k-mers
+    outs = []
+    for tag in ("single", "dist"):
+        res = tmp_path / tag
+        res.mkdir()
+        cfg = read_default_config_file()
+        cfg["visualization"].update(n_max_iter=15, random_seed=11, gen_fig_flag=False)
+        dump_toml(cfg, res / "config.toml")
+        with open(res / "sample_kmers.pkl", "wb") as fh:
+            pickle.dump([kh, cnts, lab, conseqs], fh)
+        with open(res / "sample_kmer_hamdist_mat.pkl", "wb") as fh:
+            pickle.dump([K, None, np.repeat(lab, cnts)], fh)
+        env = dict(os.environ, PYTHONPATH=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if tag == "single":
+            cmd = [sys.executable, "-m", "kmap_amd", "visualize_kmers", "--res_dir", str(res)]
+        else:
+            env.update(KMAP_DIST_BACKEND="gloo", KMAP_DIST_SAME_GPU="1")
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                   "--master-port", str(_free_port()), "-m", "kmap_amd", "visualize_kmers", "--res_dir", str(res)]
+        r = subprocess.run(cmd, env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append((res / "low_dim_data.tsv").read_text())
+    assert outs[0] == outs[1] and outs[0].count("\n") == int(cnts.sum()) + 1
