@@ -5,8 +5,11 @@
 // expansion (:705-730) become ONE launch that writes the expanded N x N uint8 matrix.
 //
 // Roofline: HBM-write bound.  Algorithmic bytes per launch = nrows*N (u8 out) + N*sizeof(hash)
-// (+N gid bytes).  Per output byte the VALU does xor / lshr / or3 / bcnt / lshl_or.
+// (+N gid bytes).
 //
+// Two kernels: hamdist_tile_kernel (k <= 16, 4-KiB pitch with an odd chunk count per row, N >= 4096: XCD-affine 4-KiB
+// chunk tiles + one-hot codes, see its header below) and hamdist_matrix_kernel, the general path described here: per
+// output byte the VALU does xor / lshr / or3 / bcnt / lshl_or.
 // Mapping (wave64): a lane owns 16 consecutive columns -> one 16-byte store per row; a wave owns
 // 1024 consecutive columns x 8 rows (short-lived waves keep the chip's stores close to memory order:
 // 8 rows/wave 5.83 TB/s, 16: 5.45, 64: 4.95 at N = 50k); the row's hash is wave-uniform (v_readlane from a
@@ -161,6 +164,152 @@ __global__ __launch_bounds__(KMAP_WAVE *WAVES_PER_BLOCK) void hamdist_matrix_ker
     }
 }
 
+
+// ---- tiled one-hot path (k <= 16) -----------------------------------------------------------------------------------
+// Two measured facts about MI355X stores (tools/probes/write_bw4..8.hip) shape this kernel:
+//  * the chip sustains 6.5-6.9 TB/s of stores only when (a) every 4-KiB-aligned chunk is written by one short-lived
+//    workgroup, (b) each XCD keeps writing the same residue class of (chunk index mod 8) -- workgroups are dispatched
+//    round-robin over the 8 XCDs, so block b serves residue b % 8 -- and (c) few chunks are in flight (~2048: R rows per
+//    block x 2-4 resident blocks per CU, enforced with a dynamic-LDS reservation).  Row-strided tiles without these rules
+//    stay at 5.3-5.8 TB/s, persistent blocks at 5.5.
+//  * at 5.25 VALU ops per output byte the 2-bit formulation is itself within 10 % of the VALU ceiling (0.334 ms at
+//    N = 50 k).  With one-hot codes (4 bits per base, built once per launch) a distance is popcount(a & ~b): and + bcnt +
+//    pack = 2.75 ops per byte for k <= 8, 4.75 for k <= 16.
+// Tile = one 4-KiB column block x R rows spaced 8 apart (all its chunks share one residue); requires ld % 4096 == 0 and
+// ld / 4096 odd (kmap_amd.hamdist.pitch_for provides it).
+constexpr int T_TPB = 256;
+
+template <typename H>
+__global__ void build_codes_kernel(const H *__restrict__ kh, int64_t n, int k, H mask, uint32_t *__restrict__ c0,
+                                   uint32_t *__restrict__ c1) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t h = (uint64_t)(kh[i] & mask);
+    uint64_t code = 0;
+    for (int b = 0; b < k; ++b) code |= 1ull << (4 * b + (int)((h >> (2 * (k - 1 - b))) & 3));   // base b -> nibble b
+    c0[i] = (uint32_t)code;
+    if (c1) c1[i] = (uint32_t)(code >> 32);
+}
+
+__device__ __forceinline__ uint32_t bcnt(uint32_t x, uint32_t acc) { return (uint32_t)__builtin_popcount(x) + acc; }
+
+template <int CW, int R, bool NT>
+__global__ __launch_bounds__(T_TPB) void hamdist_tile_kernel(const uint32_t *__restrict__ c0, const uint32_t *__restrict__ c1,
+                                                             const uint8_t *__restrict__ gid, ByteTab gshift, int k, int64_t n,
+                                                             int64_t row0, int64_t nrows, uint8_t *__restrict__ out, int64_t ld,
+                                                             int cb, int inv, int shift) {
+    const int64_t b = blockIdx.x;
+    const int x = (int)(b & 7);
+    const int64_t q = b >> 3;
+    const int c = (int)(q % cb);
+    const int64_t g = q / cb;
+    const int rho = ((((x - c - shift) % 8 + 8) % 8) * inv) & 7;      // (ld/4096 * row + c + shift) % 8 == x
+    const int64_t col0 = (int64_t)c * 4096 + (int64_t)threadIdx.x * COLS_PER_LANE;
+    if (col0 >= n) return;
+    const bool full = col0 + COLS_PER_LANE <= n;
+
+    uint32_t nb0[COLS_PER_LANE], nb1[CW == 2 ? COLS_PER_LANE : 1], gcol[COLS_PER_LANE / 4];
+    if (full) {
+#pragma unroll
+        for (int v = 0; v < COLS_PER_LANE / 4; ++v) {
+            const u32x4 t = *reinterpret_cast<const u32x4 *>(c0 + col0 + 4 * v);
+            nb0[4 * v] = ~t.x; nb0[4 * v + 1] = ~t.y; nb0[4 * v + 2] = ~t.z; nb0[4 * v + 3] = ~t.w;
+            if constexpr (CW == 2) {
+                const u32x4 u = *reinterpret_cast<const u32x4 *>(c1 + col0 + 4 * v);
+                nb1[4 * v] = ~u.x; nb1[4 * v + 1] = ~u.y; nb1[4 * v + 2] = ~u.z; nb1[4 * v + 3] = ~u.w;
+            }
+        }
+        const u32x4 gg = *reinterpret_cast<const u32x4 *>(gid + col0);
+        gcol[0] = gg.x; gcol[1] = gg.y; gcol[2] = gg.z; gcol[3] = gg.w;
+    } else {
+#pragma unroll
+        for (int cc = 0; cc < COLS_PER_LANE; ++cc) {
+            nb0[cc] = (col0 + cc < n) ? ~c0[col0 + cc] : 0u;
+            if constexpr (CW == 2) nb1[cc] = (col0 + cc < n) ? ~c1[col0 + cc] : 0u;
+        }
+#pragma unroll
+        for (int v = 0; v < COLS_PER_LANE / 4; ++v) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+                if (col0 + 4 * v + cc < n) w |= (uint32_t)gid[col0 + 4 * v + cc] << (8 * cc);
+            gcol[v] = w;
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int64_t rl = g * (8 * R) + rho + 8 * j;          // row inside this call's output (wave-uniform)
+        if (rl >= nrows) break;
+        const int64_t gr = row0 + rl;
+        const uint32_t a0 = c0[gr];
+        const uint32_t a1 = (CW == 2) ? c1[gr] : 0u;
+        const uint32_t rg = gid[gr];
+        uint32_t w[COLS_PER_LANE / 4];
+        if (rg == 0) {
+#pragma unroll
+            for (int v = 0; v < COLS_PER_LANE / 4; ++v) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int cc = 3; cc >= 0; --cc) {
+                    uint32_t d = bcnt(a0 & nb0[4 * v + cc], 0u);
+                    if constexpr (CW == 2) d = bcnt(a1 & nb1[4 * v + cc], d);
+                    acc = (acc << 8) | d;
+                }
+                w[v] = acc;
+            }
+        } else {   // row of a short consensus: same-group pairs are compared on the first clen bases (= low 4*clen code bits)
+            const int clen = k - (int)(gshift.v[rg] >> 1);
+            const uint64_t pm = (clen >= 16) ? ~0ull : ((1ull << (4 * clen)) - 1ull);
+            const uint32_t p0 = a0 & (uint32_t)pm, p1 = a1 & (uint32_t)(pm >> 32);
+#pragma unroll
+            for (int v = 0; v < COLS_PER_LANE / 4; ++v) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int cc = 3; cc >= 0; --cc) {
+                    const bool same = ((gcol[v] >> (8 * cc)) & 0xFFu) == rg;
+                    uint32_t d = bcnt((same ? p0 : a0) & nb0[4 * v + cc], 0u);
+                    if constexpr (CW == 2) d = bcnt((same ? p1 : a1) & nb1[4 * v + cc], d);
+                    acc = (acc << 8) | d;
+                }
+                w[v] = acc;
+            }
+        }
+        uint8_t *orow = out + rl * ld + col0;
+        if (full) {
+            u32x4 o = {w[0], w[1], w[2], w[3]};
+            if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(orow));
+            else *reinterpret_cast<u32x4 *>(orow) = o;
+        } else {
+#pragma unroll
+            for (int cc = 0; cc < COLS_PER_LANE; ++cc)
+                if (col0 + cc < n) orow[cc] = (uint8_t)(w[cc >> 2] >> (8 * (cc & 3)));
+        }
+    }
+}
+
+template <int CW, int R>
+int launch_tile(const uint32_t *c0, const uint32_t *c1, const uint8_t *gid, const ByteTab &gshift, int k, int64_t n, int64_t row0,
+                int64_t nrows, uint8_t *out, int64_t ld, bool nt, int lds_bytes, hipStream_t st) {
+    const int cb = (int)((n + 4095) / 4096);
+    const int cpr = (int)(ld >> 12);
+    int inv = 1;
+    for (int t = 1; t < 8; t += 2)
+        if (((cpr * t) & 7) == 1) inv = t;
+    const int shift = (int)(((uintptr_t)out >> 12) & 7);
+    const int64_t groups = (nrows + 8 * R - 1) / (8 * R);
+    const int64_t blocks = groups * cb * 8;
+    KMAP_REQUIRE(blocks < ((int64_t)1 << 31), "hamdist_matrix: nrows too large for one launch (%lld)", (long long)nrows);
+    const void *fn = nt ? (const void *)hamdist_tile_kernel<CW, R, true> : (const void *)hamdist_tile_kernel<CW, R, false>;
+    KMAP_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (nt)
+        hamdist_tile_kernel<CW, R, true><<<(unsigned)blocks, T_TPB, lds_bytes, st>>>(c0, c1, gid, gshift, k, n, row0, nrows, out, ld, cb, inv, shift);
+    else
+        hamdist_tile_kernel<CW, R, false><<<(unsigned)blocks, T_TPB, lds_bytes, st>>>(c0, c1, gid, gshift, k, n, row0, nrows, out, ld, cb, inv, shift);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+
 template <typename H>
 int launch_matrix(const H *kh_dev, const int32_t *label_dev, int64_t n, int k, const int32_t *clen, int n_lab,
                   int64_t row0, int64_t nrows, uint8_t *out_dev, int64_t ld, void *stream) {
@@ -191,6 +340,23 @@ int launch_matrix(const H *kh_dev, const int32_t *label_dev, int64_t n, int k, c
     KMAP_TRY(kmap_scratch((void **)&gid, ((size_t)n + 15) & ~(size_t)15, st, KMAP_SLOT_A));
     build_gid_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(label_dev, n, lab2gid, n_lab, gid);
 
+    static const bool nt = !(getenv("KMAP_HAMDIST_NT") && getenv("KMAP_HAMDIST_NT")[0] == '0');
+    // tiled one-hot path: k <= 16, 4-KiB row pitch with an odd number of chunks per row, at least one full column block
+    static const int tile_on = [] { const char *e = getenv("KMAP_HAMDIST_TILE"); return e ? atoi(e) : 1; }();
+    static const int tile_r = [] { const char *e = getenv("KMAP_HAMDIST_TILE_R"); int v = e ? atoi(e) : 8; return (v == 2 || v == 4 || v == 8 || v == 16) ? v : 8; }();
+    static const int tile_lds = [] { const char *e = getenv("KMAP_HAMDIST_TILE_LDS_KB"); int v = e ? atoi(e) : 40; return (v >= 0 && v <= 160) ? v : 40; }();
+    if (tile_on && k <= 16 && (ld % 4096) == 0 && ((ld >> 12) & 1) && n >= 4096 && ((uintptr_t)out_dev % 4096) == 0) {
+        uint32_t *codes = nullptr;
+        const size_t npad = ((size_t)n + 63) & ~(size_t)63;
+        KMAP_TRY(kmap_scratch((void **)&codes, npad * 8, st, KMAP_SLOT_B));
+        uint32_t *c0 = codes, *c1 = (k > 8) ? codes + npad : nullptr;
+        build_codes_kernel<H><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(kh_dev, n, k, low_mask<H>(k), c0, c1);
+        const int lds = tile_lds * 1024;
+#define KMAP_TILE(CW, R) launch_tile<CW, R>(c0, c1, gid, gshift, k, n, row0, nrows, out_dev, ld, nt, lds, st)
+        if (k <= 8) return tile_r == 2 ? KMAP_TILE(1, 2) : tile_r == 8 ? KMAP_TILE(1, 8) : tile_r == 16 ? KMAP_TILE(1, 16) : KMAP_TILE(1, 4);
+        return tile_r == 2 ? KMAP_TILE(2, 2) : tile_r == 8 ? KMAP_TILE(2, 8) : tile_r == 16 ? KMAP_TILE(2, 16) : KMAP_TILE(2, 4);
+#undef KMAP_TILE
+    }
     const int vec_ok = ((uintptr_t)kh_dev % 16 == 0) && ((uintptr_t)out_dev % 16 == 0) && (ld % 16 == 0);
     static const int rpw = [] { const char *e = getenv("KMAP_HAMDIST_RPW"); int v = e ? atoi(e) : ROWS_PER_WAVE; return (v >= 1 && v <= 64) ? v : ROWS_PER_WAVE; }();
     static const int row_major = [] { const char *e = getenv("KMAP_HAMDIST_ROWMAJOR"); return e ? atoi(e) : 0; }();
@@ -201,7 +367,6 @@ int launch_matrix(const H *kh_dev, const int32_t *label_dev, int64_t n, int k, c
     KMAP_REQUIRE(grid.y <= 65535u, "hamdist_matrix: nrows too large for one launch (%lld)", (long long)nrows);
     // non-temporal stores by default (write-once streaming output: 5.02 vs 4.77 TB/s measured at N=50k);
     // KMAP_HAMDIST_NT=0 switches back to default-policy stores for A/B runs
-    static const bool nt = !(getenv("KMAP_HAMDIST_NT") && getenv("KMAP_HAMDIST_NT")[0] == '0');
     if (nt)
         hamdist_matrix_kernel<H, true><<<grid, dim3(KMAP_WAVE * wpb), 0, st>>>(
             kh_dev, gid, gshift, n, low_mask<H>(k), row0, nrows, out_dev, ld, vec_ok, rpw, row_major, wpb);
@@ -231,7 +396,7 @@ int kmap_hamdist_matrix_u8(const uint64_t *kh, const int32_t *label, int64_t n, 
     KMAP_REQUIRE(n >= 0 && k > 0 && k < 32, "hamdist_matrix_u8: bad n/k");
     if (n == 0) return KMAP_OK;
     KMAP_REQUIRE(kh && label && out, "hamdist_matrix_u8: null pointer");
-    const int64_t ld = (n + 255) & ~(int64_t)255;
+    const int64_t ld = (n < 4096) ? ((n + 255) & ~(int64_t)255) : ((((n + 4095) >> 12) | 1) << 12);   // see pitch_for
     DevBuf dkh, dlab, dout;
     KMAP_TRY(dkh.alloc((size_t)n * 8));
     KMAP_TRY(dlab.alloc((size_t)n * 4));

@@ -8,9 +8,15 @@ from .kmer_count import get_hash_dtype
 
 
 def pitch_for(n):
-    """Row pitch (bytes) of the device-resident uint8 matrix.  256-byte aligned rows: every 1-KiB wave
-    store then covers whole 128-byte lines (measured on MI355X: 5.3 TB/s vs 3.3 TB/s with a 16-byte pitch)."""
-    return (int(n) + 255) & ~255
+    """Row pitch (bytes) of the device-resident uint8 matrix.  From one 4-KiB column block up: a multiple of 4 KiB with an
+    ODD number of 4-KiB chunks per row, which is what the tiled Hamming kernel needs to give every XCD its own residue
+    class of chunks (6.5+ TB/s of stores instead of 5.3-5.8; csrc/hamdist_matrix.hip).  Below that: 256-byte aligned rows
+    (every 1-KiB wave store covers whole 128-byte lines: 5.3 TB/s vs 3.3 TB/s with a 16-byte pitch)."""
+    n = int(n)
+    if n < 4096:
+        return (n + 255) & ~255
+    chunks = (n + 4095) >> 12
+    return (chunks | 1) << 12
 
 
 def hamdist_matrix_dev(kh_dev_ptr, label_dev_ptr, n, k, conseq_lens, out_dev_ptr, ld, row0=0, nrows=None, stream=None):

@@ -35,7 +35,7 @@ for t in ("write", "fetch"):
     for (k, c), v in agg.items():
         out["kernels"].setdefault(k, {})[c + "_KB_mean"] = sum(v) / len(v)
         out["kernels"][k][c + "_n"] = len(v)
-hk = [k for k in out["kernels"] if "hamdist_matrix_kernel" in k]
+hk = [k for k in out["kernels"] if "hamdist_tile_kernel" in k or "hamdist_matrix_kernel" in k]
 if hk:
     d = out["kernels"][hk[0]]
     d["hbm_bytes_per_launch"] = (2 * d.get("FETCH_SIZE_KB_mean", 0) + d.get("WRITE_SIZE_KB_mean", 0)) * 1024
