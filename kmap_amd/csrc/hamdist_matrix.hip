@@ -180,11 +180,15 @@ __global__ __launch_bounds__(KMAP_WAVE *WAVES_PER_BLOCK) void hamdist_matrix_ker
 constexpr int T_TPB = 256;
 
 template <typename H>
-__global__ void build_codes_kernel(const H *__restrict__ kh, int64_t n, int k, H mask, uint32_t *__restrict__ c0,
+__global__ void build_codes_kernel(const H *__restrict__ kh, int64_t n, int k, H mask, int onehot, uint32_t *__restrict__ c0,
                                    uint32_t *__restrict__ c1) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t h = (uint64_t)(kh[i] & mask);
+    if (onehot == 0) {          // 9 <= k <= 15: the tile kernel compares the 2-bit hashes themselves
+        c0[i] = (uint32_t)h;
+        return;
+    }
     uint64_t code = 0;
     for (int b = 0; b < k; ++b) code |= 1ull << (4 * b + (int)((h >> (2 * (k - 1 - b))) & 3));   // base b -> nibble b
     c0[i] = (uint32_t)code;
@@ -213,7 +217,10 @@ __global__ __launch_bounds__(T_TPB) void hamdist_tile_kernel(const uint32_t *__r
 #pragma unroll
         for (int v = 0; v < COLS_PER_LANE / 4; ++v) {
             const u32x4 t = *reinterpret_cast<const u32x4 *>(c0 + col0 + 4 * v);
-            nb0[4 * v] = ~t.x; nb0[4 * v + 1] = ~t.y; nb0[4 * v + 2] = ~t.z; nb0[4 * v + 3] = ~t.w;
+            nb0[4 * v] = t.x; nb0[4 * v + 1] = t.y; nb0[4 * v + 2] = t.z; nb0[4 * v + 3] = t.w;
+            if constexpr (CW != 0) {   // one-hot: keep the complement
+                nb0[4 * v] = ~t.x; nb0[4 * v + 1] = ~t.y; nb0[4 * v + 2] = ~t.z; nb0[4 * v + 3] = ~t.w;
+            }
             if constexpr (CW == 2) {
                 const u32x4 u = *reinterpret_cast<const u32x4 *>(c1 + col0 + 4 * v);
                 nb1[4 * v] = ~u.x; nb1[4 * v + 1] = ~u.y; nb1[4 * v + 2] = ~u.z; nb1[4 * v + 3] = ~u.w;
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(T_TPB) void hamdist_tile_kernel(const uint32_t *__r
     } else {
 #pragma unroll
         for (int cc = 0; cc < COLS_PER_LANE; ++cc) {
-            nb0[cc] = (col0 + cc < n) ? ~c0[col0 + cc] : 0u;
+            nb0[cc] = (col0 + cc < n) ? (CW != 0 ? ~c0[col0 + cc] : c0[col0 + cc]) : 0u;
             if constexpr (CW == 2) nb1[cc] = (col0 + cc < n) ? ~c1[col0 + cc] : 0u;
         }
 #pragma unroll
@@ -246,7 +253,31 @@ __global__ __launch_bounds__(T_TPB) void hamdist_tile_kernel(const uint32_t *__r
         const uint32_t a1 = (CW == 2) ? c1[gr] : 0u;
         const uint32_t rg = gid[gr];
         uint32_t w[COLS_PER_LANE / 4];
-        if (rg == 0) {
+        if constexpr (CW == 0) {   // 2-bit hashes: xor / lshr / or3 / bcnt / pack, as in hamdist_matrix_kernel
+            if (rg == 0) {
+#pragma unroll
+                for (int v = 0; v < COLS_PER_LANE / 4; ++v) {
+                    uint32_t acc = p2(a0 ^ nb0[4 * v]) + pack_bias<uint32_t>();
+                    acc += p2(a0 ^ nb0[4 * v + 1]) << 8;
+                    acc += p2(a0 ^ nb0[4 * v + 2]) << 16;
+                    acc += p2(a0 ^ nb0[4 * v + 3]) << 24;
+                    w[v] = acc;
+                }
+            } else {
+                const uint32_t sh = (uint32_t)gshift.v[rg];
+#pragma unroll
+                for (int v = 0; v < COLS_PER_LANE / 4; ++v) {
+                    uint32_t acc = pack_bias<uint32_t>();
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        uint32_t xx = a0 ^ nb0[4 * v + cc];
+                        if (((gcol[v] >> (8 * cc)) & 0xFFu) == rg) xx >>= sh;
+                        acc += p2(xx) << (8 * cc);
+                    }
+                    w[v] = acc;
+                }
+            }
+        } else if (rg == 0) {
 #pragma unroll
             for (int v = 0; v < COLS_PER_LANE / 4; ++v) {
                 uint32_t acc = 0;
@@ -349,11 +380,13 @@ int launch_matrix(const H *kh_dev, const int32_t *label_dev, int64_t n, int k, c
         uint32_t *codes = nullptr;
         const size_t npad = ((size_t)n + 63) & ~(size_t)63;
         KMAP_TRY(kmap_scratch((void **)&codes, npad * 8, st, KMAP_SLOT_B));
-        uint32_t *c0 = codes, *c1 = (k > 8) ? codes + npad : nullptr;
-        build_codes_kernel<H><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(kh_dev, n, k, low_mask<H>(k), c0, c1);
+        const int onehot = (k <= 8) ? 1 : (k == 16) ? 2 : 0;      // 9..15: 2-bit compare (one register per column)
+        uint32_t *c0 = codes, *c1 = (onehot == 2) ? codes + npad : nullptr;
+        build_codes_kernel<H><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(kh_dev, n, k, low_mask<H>(k), onehot, c0, c1);
         const int lds = tile_lds * 1024;
 #define KMAP_TILE(CW, R) launch_tile<CW, R>(c0, c1, gid, gshift, k, n, row0, nrows, out_dev, ld, nt, lds, st)
-        if (k <= 8) return tile_r == 2 ? KMAP_TILE(1, 2) : tile_r == 8 ? KMAP_TILE(1, 8) : tile_r == 16 ? KMAP_TILE(1, 16) : KMAP_TILE(1, 4);
+        if (onehot == 1) return tile_r == 2 ? KMAP_TILE(1, 2) : tile_r == 8 ? KMAP_TILE(1, 8) : tile_r == 16 ? KMAP_TILE(1, 16) : KMAP_TILE(1, 4);
+        if (onehot == 0) return tile_r == 2 ? KMAP_TILE(0, 2) : tile_r == 8 ? KMAP_TILE(0, 8) : tile_r == 16 ? KMAP_TILE(0, 16) : KMAP_TILE(0, 4);
         return tile_r == 2 ? KMAP_TILE(2, 2) : tile_r == 8 ? KMAP_TILE(2, 8) : tile_r == 16 ? KMAP_TILE(2, 16) : KMAP_TILE(2, 4);
 #undef KMAP_TILE
     }
