@@ -169,8 +169,8 @@ __global__ __launch_bounds__(KMAP_WAVE *WAVES_PER_BLOCK) void hamdist_matrix_ker
 // Two measured facts about MI355X stores (tools/probes/write_bw4..8.hip) shape this kernel:
 //  * the chip sustains 6.5-6.9 TB/s of stores only when (a) every 4-KiB-aligned chunk is written by one short-lived
 //    workgroup, (b) each XCD keeps writing the same residue class of (chunk index mod 8) -- workgroups are dispatched
-//    round-robin over the 8 XCDs, so block b serves residue b % 8 -- and (c) few chunks are in flight (~2048: R rows per
-//    block x 2-4 resident blocks per CU, enforced with a dynamic-LDS reservation).  Row-strided tiles without these rules
+//    round-robin over the 8 XCDs, so block b serves residue b % 8 -- and (c) few chunks are in flight (R = 4 rows per
+//    block x 4 resident blocks per CU, enforced with a 40-KiB dynamic-LDS reservation; sweep in DESIGN.md).  Row-strided tiles without these rules
 //    stay at 5.3-5.8 TB/s, persistent blocks at 5.5.
 //  * at 5.25 VALU ops per output byte the 2-bit formulation is itself within 10 % of the VALU ceiling (0.334 ms at
 //    N = 50 k).  With one-hot codes (4 bits per base, built once per launch) a distance is popcount(a & ~b): and + bcnt +
@@ -181,9 +181,12 @@ constexpr int T_TPB = 256;
 
 template <typename H>
 __global__ void build_codes_kernel(const H *__restrict__ kh, int64_t n, int k, H mask, int onehot, uint32_t *__restrict__ c0,
-                                   uint32_t *__restrict__ c1) {
+                                   uint32_t *__restrict__ c1, const int32_t *__restrict__ label, ByteTab lab2gid, int n_lab,
+                                   uint8_t *__restrict__ gid) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const int32_t l = label[i];                       // group ids in the same pass (build_gid_kernel's job on the general path)
+    gid[i] = (l >= 0 && l < n_lab) ? lab2gid.v[l] : 0;
     const uint64_t h = (uint64_t)(kh[i] & mask);
     if (onehot == 0) {          // 9 <= k <= 15: the tile kernel compares the 2-bit hashes themselves
         c0[i] = (uint32_t)h;
@@ -202,14 +205,25 @@ __global__ __launch_bounds__(T_TPB) void hamdist_tile_kernel(const uint32_t *__r
                                                              const uint8_t *__restrict__ gid, ByteTab gshift, int k, int64_t n,
                                                              int64_t row0, int64_t nrows, uint8_t *__restrict__ out, int64_t ld,
                                                              int cb, int inv, int shift) {
-    const int64_t b = blockIdx.x;
-    const int x = (int)(b & 7);
-    const int64_t q = b >> 3;
-    const int c = (int)(q % cb);
-    const int64_t g = q / cb;
+    // grid = (8 * cb, groups): the linear workgroup id is y * 8cb + x, so (blockIdx.x & 7) is the XCD the block lands on
+    const int x = (int)(blockIdx.x & 7);
+    const int c = (int)(blockIdx.x >> 3);
+    const int64_t g = blockIdx.y;
     const int rho = ((((x - c - shift) % 8 + 8) % 8) * inv) & 7;      // (ld/4096 * row + c + shift) % 8 == x
+    // the tile's R row codes / group ids: one vector load per wave up front (lane j holds row j), v_readlane per row.
+    // Nothing is loaded inside the row loop, so no s_waitcnt vmcnt ever waits on the stores already issued.  Loaded BEFORE
+    // lanes past the last column leave: v_readlane must find lanes 0..R-1 written even in a wave that keeps only lane 0.
+    const int lane = threadIdx.x & (KMAP_WAVE - 1);
+    const int64_t my_rl = g * (8 * R) + rho + 8 * (lane < R ? lane : 0);
+    const bool rv = lane < R && my_rl < nrows;
+    const uint32_t ra0 = rv ? c0[row0 + my_rl] : 0u;
+    const uint32_t ra1 = (CW == 2 && rv) ? c1[row0 + my_rl] : 0u;
+    const uint32_t rgid = rv ? (uint32_t)gid[row0 + my_rl] : 0u;
+
     const int64_t col0 = (int64_t)c * 4096 + (int64_t)threadIdx.x * COLS_PER_LANE;
-    if (col0 >= n) return;
+    // only whole waves leave (wave-uniform); lanes past the last column stay and are predicated off, so that every lane the
+    // v_readlane's below read from is live
+    if ((int64_t)c * 4096 + (int64_t)(threadIdx.x & ~(KMAP_WAVE - 1)) * COLS_PER_LANE >= n) return;
     const bool full = col0 + COLS_PER_LANE <= n;
 
     uint32_t nb0[COLS_PER_LANE], nb1[CW == 2 ? COLS_PER_LANE : 1], gcol[COLS_PER_LANE / 4];
@@ -246,12 +260,11 @@ __global__ __launch_bounds__(T_TPB) void hamdist_tile_kernel(const uint32_t *__r
 
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const int64_t rl = g * (8 * R) + rho + 8 * j;          // row inside this call's output (wave-uniform)
-        if (rl >= nrows) break;
-        const int64_t gr = row0 + rl;
-        const uint32_t a0 = c0[gr];
-        const uint32_t a1 = (CW == 2) ? c1[gr] : 0u;
-        const uint32_t rg = gid[gr];
+        const int64_t rloc = g * (8 * R) + rho + 8 * j;          // row inside this call's output (wave-uniform)
+        if (rloc >= nrows) break;
+        const uint32_t a0 = rl(ra0, j);
+        const uint32_t a1 = (CW == 2) ? rl(ra1, j) : 0u;
+        const uint32_t rg = rl(rgid, j);
         uint32_t w[COLS_PER_LANE / 4];
         if constexpr (CW == 0) {   // 2-bit hashes: xor / lshr / or3 / bcnt / pack, as in hamdist_matrix_kernel
             if (rg == 0) {
@@ -306,7 +319,7 @@ __global__ __launch_bounds__(T_TPB) void hamdist_tile_kernel(const uint32_t *__r
                 w[v] = acc;
             }
         }
-        uint8_t *orow = out + rl * ld + col0;
+        uint8_t *orow = out + rloc * ld + col0;
         if (full) {
             u32x4 o = {w[0], w[1], w[2], w[3]};
             if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(orow));
@@ -329,14 +342,14 @@ int launch_tile(const uint32_t *c0, const uint32_t *c1, const uint8_t *gid, cons
         if (((cpr * t) & 7) == 1) inv = t;
     const int shift = (int)(((uintptr_t)out >> 12) & 7);
     const int64_t groups = (nrows + 8 * R - 1) / (8 * R);
-    const int64_t blocks = groups * cb * 8;
-    KMAP_REQUIRE(blocks < ((int64_t)1 << 31), "hamdist_matrix: nrows too large for one launch (%lld)", (long long)nrows);
+    KMAP_REQUIRE(groups <= 65535, "hamdist_matrix: nrows too large for one launch (%lld)", (long long)nrows);
+    const dim3 blocks((unsigned)(8 * cb), (unsigned)groups);
     const void *fn = nt ? (const void *)hamdist_tile_kernel<CW, R, true> : (const void *)hamdist_tile_kernel<CW, R, false>;
     KMAP_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (nt)
-        hamdist_tile_kernel<CW, R, true><<<(unsigned)blocks, T_TPB, lds_bytes, st>>>(c0, c1, gid, gshift, k, n, row0, nrows, out, ld, cb, inv, shift);
+        hamdist_tile_kernel<CW, R, true><<<blocks, T_TPB, lds_bytes, st>>>(c0, c1, gid, gshift, k, n, row0, nrows, out, ld, cb, inv, shift);
     else
-        hamdist_tile_kernel<CW, R, false><<<(unsigned)blocks, T_TPB, lds_bytes, st>>>(c0, c1, gid, gshift, k, n, row0, nrows, out, ld, cb, inv, shift);
+        hamdist_tile_kernel<CW, R, false><<<blocks, T_TPB, lds_bytes, st>>>(c0, c1, gid, gshift, k, n, row0, nrows, out, ld, cb, inv, shift);
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;
 }
@@ -369,12 +382,13 @@ int launch_matrix(const H *kh_dev, const int32_t *label_dev, int64_t n, int k, c
     // scratch: gid[n] (cached arena; the tables travel in the kernarg segment)
     uint8_t *gid = nullptr;
     KMAP_TRY(kmap_scratch((void **)&gid, ((size_t)n + 15) & ~(size_t)15, st, KMAP_SLOT_A));
-    build_gid_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(label_dev, n, lab2gid, n_lab, gid);
 
     static const bool nt = !(getenv("KMAP_HAMDIST_NT") && getenv("KMAP_HAMDIST_NT")[0] == '0');
     // tiled one-hot path: k <= 16, 4-KiB row pitch with an odd number of chunks per row, at least one full column block
     static const int tile_on = [] { const char *e = getenv("KMAP_HAMDIST_TILE"); return e ? atoi(e) : 1; }();
-    static const int tile_r = [] { const char *e = getenv("KMAP_HAMDIST_TILE_R"); int v = e ? atoi(e) : 8; return (v == 2 || v == 4 || v == 8 || v == 16) ? v : 8; }();
+    // rows per tile: 4 for the one-word one-hot compare (2.75 ops per byte), 8 for the heavier compares (k = 12: 0.428 vs 0.464 ms)
+    static const int tile_r_env = [] { const char *e = getenv("KMAP_HAMDIST_TILE_R"); int v = e ? atoi(e) : 0; return (v == 2 || v == 4 || v == 8 || v == 16) ? v : 0; }();
+    const int tile_r = tile_r_env ? tile_r_env : (k <= 8 ? 4 : 8);
     static const int tile_lds = [] { const char *e = getenv("KMAP_HAMDIST_TILE_LDS_KB"); int v = e ? atoi(e) : 40; return (v >= 0 && v <= 160) ? v : 40; }();
     if (tile_on && k <= 16 && (ld % 4096) == 0 && ((ld >> 12) & 1) && n >= 4096 && ((uintptr_t)out_dev % 4096) == 0) {
         uint32_t *codes = nullptr;
@@ -382,7 +396,8 @@ int launch_matrix(const H *kh_dev, const int32_t *label_dev, int64_t n, int k, c
         KMAP_TRY(kmap_scratch((void **)&codes, npad * 8, st, KMAP_SLOT_B));
         const int onehot = (k <= 8) ? 1 : (k == 16) ? 2 : 0;      // 9..15: 2-bit compare (one register per column)
         uint32_t *c0 = codes, *c1 = (onehot == 2) ? codes + npad : nullptr;
-        build_codes_kernel<H><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(kh_dev, n, k, low_mask<H>(k), onehot, c0, c1);
+        build_codes_kernel<H><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(kh_dev, n, k, low_mask<H>(k), onehot, c0, c1,
+                                                                                       label_dev, lab2gid, n_lab, gid);
         const int lds = tile_lds * 1024;
 #define KMAP_TILE(CW, R) launch_tile<CW, R>(c0, c1, gid, gshift, k, n, row0, nrows, out_dev, ld, nt, lds, st)
         if (onehot == 1) return tile_r == 2 ? KMAP_TILE(1, 2) : tile_r == 8 ? KMAP_TILE(1, 8) : tile_r == 16 ? KMAP_TILE(1, 16) : KMAP_TILE(1, 4);
@@ -390,6 +405,7 @@ int launch_matrix(const H *kh_dev, const int32_t *label_dev, int64_t n, int k, c
         return tile_r == 2 ? KMAP_TILE(2, 2) : tile_r == 8 ? KMAP_TILE(2, 8) : tile_r == 16 ? KMAP_TILE(2, 16) : KMAP_TILE(2, 4);
 #undef KMAP_TILE
     }
+    build_gid_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(label_dev, n, lab2gid, n_lab, gid);
     const int vec_ok = ((uintptr_t)kh_dev % 16 == 0) && ((uintptr_t)out_dev % 16 == 0) && (ld % 16 == 0);
     static const int rpw = [] { const char *e = getenv("KMAP_HAMDIST_RPW"); int v = e ? atoi(e) : ROWS_PER_WAVE; return (v >= 1 && v <= 64) ? v : ROWS_PER_WAVE; }();
     static const int row_major = [] { const char *e = getenv("KMAP_HAMDIST_ROWMAJOR"); return e ? atoi(e) : 0; }();

@@ -23,7 +23,7 @@ def test_matrix_golden(golden):
                                       (3000, 15, [15, 3]), (2049, 16, [16, 12]), (1500, 31, [31, 20, 4]), (0, 8, []),
                                       # n >= 4096, k <= 16: the tiled one-hot kernel (1 or 2 code words, ragged last lanes / rows)
                                       (4096, 8, [8, 5]), (5003, 8, [8, 6]), (4500, 5, [5, 2]), (4100, 12, [12, 7, 12]),
-                                      (6000, 16, [16, 3]), (8200, 9, [9]), (4200, 17, [17, 9])])
+                                      (6000, 16, [16, 3]), (8200, 9, [9]), (4200, 17, [17, 9]), (4097, 8, [8, 4]), (4111, 16, [16, 9])])
 def test_matrix_vs_oracle(n, k, lens):
     from kmap_amd.hamdist import hamdist_matrix_u8
     from oracle import oracle as O
