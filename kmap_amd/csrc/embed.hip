@@ -21,6 +21,8 @@
 
 #include <vector>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -222,30 +224,45 @@ constexpr int F_CPL = 8;          // columns per lane per step (16 B of u16 sums
 constexpr int F_LUT_LDS = 12416;  // floats of LUT cached in LDS (n_nb^2*k+1 <= 400*31+1 = 12401)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <bool GUARD>
+// FAST per-pair core.  q = clip(1/(1+d2), 1e-3, 1-1e-3) is obtained by clamping d2 to [1/999, 999] (the same interval),
+// which turns q, 1-q = d2/(1+d2) and q/(1-q) = 1/d2 into products of ONE reciprocal: r = 1/(d2 (1+d2)), q = r d2,
+// q/(1-q) = r (1+d2).  The cross-entropy term -(p ln q + (1-p) ln(1-q)) = -ln2 (log2(1-q) - p log2 d2) needs one log per
+// pair plus one log of the product of the (1-q) of a lane's 8 columns (each in [1e-3, 0.999]: the product stays normal in
+// f32, and for far pairs -- q = 1e-3, the bulk of the sum -- the product form has a smaller systematic error than 8 logs).
+constexpr float FAST_D2_MIN = 1.0f / 999.0f, FAST_D2_MAX = 999.0f;
+__device__ __forceinline__ void fast_core(float dx, float dy, float p, float &t, float &omq, float &d2c) {
+    d2c = __builtin_amdgcn_fmed3f(__builtin_fmaf(dx, dx, dy * dy), FAST_D2_MIN, FAST_D2_MAX);
+    const float s1 = 1.0f + d2c;
+    const float r = __builtin_amdgcn_rcpf(d2c * s1);
+    const float q = r * d2c;
+    omq = 1.0f - q;
+    t = (r * s1) * (p - q);
+}
+enum { PL_NONE = 0, PL_ALL = 1, PL_MASK = 2 };   // loss terms: none of the 8 pairs / all of them / only j > i (and j < n)
+template <int PL, bool GUARD>
 __device__ __forceinline__ void fast_pairs(const float (&p)[F_CPL], const float (&xj)[F_CPL], const float (&yj)[F_CPL],
                                            float xi, float yi, int64_t gi, int64_t j0, int64_t n, float &gx, float &gy,
                                            float &ce2) {
+    float esum = 0.0f, prod = 1.0f;
 #pragma unroll
     for (int c = 0; c < F_CPL; ++c) {
         const float dx = xi - xj[c], dy = yi - yj[c];
-        const float s = 1.0f + __builtin_fmaf(dx, dx, dy * dy);
-        float q = __builtin_amdgcn_rcpf(s);
-        q = __builtin_fminf(__builtin_fmaxf(q, 0.001f), 0.999f);
-        const float omq = 1.0f - q;
-        float t = (q * __builtin_amdgcn_rcpf(omq)) * (p[c] - q);
-        const float lq = __builtin_amdgcn_logf(q), l1 = __builtin_amdgcn_logf(omq);   // log2
-        float e = __builtin_fmaf(p[c], lq - l1, l1);
+        float t, omq, d2c;
+        fast_core(dx, dy, p[c], t, omq, d2c);
         const int64_t j = j0 + c;
-        if (GUARD) {
-            const bool in = j < n;
-            t = in ? t : 0.0f;
-            e = in ? e : 0.0f;
-        }
+        if (GUARD) t = (j < n) ? t : 0.0f;
         gx = __builtin_fmaf(t, dx, gx);
         gy = __builtin_fmaf(t, dy, gy);
-        ce2 += (j > gi) ? e : 0.0f;
+        if (PL == PL_ALL) {
+            esum = __builtin_fmaf(p[c], __builtin_amdgcn_logf(d2c), esum);
+            prod *= omq;
+        } else if (PL == PL_MASK) {
+            const bool live = (j > gi) && (j < n);
+            esum += live ? p[c] * __builtin_amdgcn_logf(d2c) : 0.0f;
+            prod *= live ? omq : 1.0f;
+        }
     }
+    if (PL != PL_NONE) ce2 += __builtin_amdgcn_logf(prod) - esum;
 }
 
 template <bool LUTSRC>
@@ -313,8 +330,13 @@ __global__ __launch_bounds__(KMAP_WAVE *F_WAVES) void forces_fast_kernel(ProbSrc
                     for (int c = 0; c < F_CPL; ++c) p[c] = (j0 + c < n) ? row[c] : 0.0f;
                 }
                 float e = 0.0f;
-                if (full) fast_pairs<false>(p, xj, yj, xi[r], yi[r], gi[r], j0, n, gx[r], gy[r], e);
-                else fast_pairs<true>(p, xj, yj, xi[r], yi[r], gi[r], j0, n, gx[r], gy[r], e);
+                // wave-uniform choice: the step's 512 columns lie right of the diagonal (all loss terms), left of it (none:
+                // each unordered pair is charged once, to its j > i side) or straddle it / the end of the row (masked)
+                const int64_t sj0 = (int64_t)step * (KMAP_WAVE * F_CPL);
+                const bool wfull = sj0 + KMAP_WAVE * F_CPL <= n;
+                if (wfull && sj0 > gi[r]) fast_pairs<PL_ALL, false>(p, xj, yj, xi[r], yi[r], gi[r], j0, n, gx[r], gy[r], e);
+                else if (wfull && sj0 + KMAP_WAVE * F_CPL - 1 <= gi[r]) fast_pairs<PL_NONE, false>(p, xj, yj, xi[r], yi[r], gi[r], j0, n, gx[r], gy[r], e);
+                else fast_pairs<PL_MASK, true>(p, xj, yj, xi[r], yi[r], gi[r], j0, n, gx[r], gy[r], e);
                 ce2 += (rbase + r < nrows) ? e : 0.0f;
             }
             if ((step & 15) == 15) {
@@ -404,6 +426,7 @@ __global__ __launch_bounds__(KMAP_WAVE *SY_WAVES) void forces_sym_kernel(ProbSrc
             cgx[c] = cgy[c] = 0.0f;
         }
         const bool vec_ok = LUTSRC && (src.ld % 8 == 0) && full;
+        const bool full_tile = (J + 1) * SY_C <= n;   // wave-uniform: every lane's 8 columns exist
         float ce2 = 0.0f;
         for (int rb = 0; rb < SY_NRB; ++rb) {
             const int64_t r0 = I * SY_R + (int64_t)rb * SY_RB;
@@ -411,62 +434,71 @@ __global__ __launch_bounds__(KMAP_WAVE *SY_WAVES) void forces_sym_kernel(ProbSrc
             const int nr = (int)((n - r0 < SY_RB) ? n - r0 : SY_RB);
             const int64_t myrow = (r0 + lane < n) ? r0 + lane : n - 1;
             const float xr = X[myrow], yr = Yy[myrow];
-            for (int r = 0; r < nr; ++r) {
-                const int64_t gi = r0 + r;
-                const float xi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xr), r));
-                const float yi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yr), r));
-                float gx = 0.0f, gy = 0.0f;
-                if (j0 + F_CPL - 1 > gi && j0 < n) {   // this lane has at least one column right of the diagonal
-                    float p[F_CPL];
-                    if (LUTSRC) {
-                        const uint16_t *row = src.ps + gi * src.ld + j0;
-                        if (vec_ok) {
-                            const u32x4 w = *reinterpret_cast<const u32x4 *>(row);
-                            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+            // row blocks whose rows all lie left of the tile's first column (and full-width tiles) need no j > i / j < n tests
+            const bool interior = full_tile && (J * SY_C > r0 + nr - 1);
+            auto run_rows = [&](auto check_tag) {
+                constexpr bool CHECK = decltype(check_tag)::value;
+                for (int r = 0; r < nr; ++r) {
+                    const int64_t gi = r0 + r;
+                    const float xi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xr), r));
+                    const float yi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yr), r));
+                    float gx = 0.0f, gy = 0.0f;
+                    if (!CHECK || (j0 + F_CPL - 1 > gi && j0 < n)) {   // this lane has at least one column right of the diagonal
+                        float p[F_CPL];
+                        if (LUTSRC) {
+                            const uint16_t *row = src.ps + gi * src.ld + j0;
+                            if (vec_ok) {
+                                const u32x4 w = *reinterpret_cast<const u32x4 *>(row);
+                                const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-                            for (int c = 0; c < F_CPL; ++c) p[c] = lut_s[(ws[c >> 1] >> (16 * (c & 1))) & 0xFFFFu];
+                                for (int c = 0; c < F_CPL; ++c) p[c] = lut_s[(ws[c >> 1] >> (16 * (c & 1))) & 0xFFFFu];
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < F_CPL; ++c) p[c] = (j0 + c < n) ? lut_s[row[c]] : 0.0f;
+                            }
                         } else {
+                            const float *row = src.pf + gi * src.ld + j0;
 #pragma unroll
-                            for (int c = 0; c < F_CPL; ++c) p[c] = (j0 + c < n) ? lut_s[row[c]] : 0.0f;
+                            for (int c = 0; c < F_CPL; ++c) p[c] = (j0 + c < n) ? row[c] : 0.0f;
                         }
-                    } else {
-                        const float *row = src.pf + gi * src.ld + j0;
+                        float esum = 0.0f, prod = 1.0f;
 #pragma unroll
-                        for (int c = 0; c < F_CPL; ++c) p[c] = (j0 + c < n) ? row[c] : 0.0f;
+                        for (int c = 0; c < F_CPL; ++c) {
+                            const int64_t j = j0 + c;
+                            const float dx = xi - xj[c], dy = yi - yj[c];
+                            float t, omq, d2c;
+                            fast_core(dx, dy, p[c], t, omq, d2c);
+                            const float lterm = p[c] * __builtin_amdgcn_logf(d2c);
+                            if (CHECK) {
+                                const bool live = (j > gi) && (j < n);
+                                t = live ? t : 0.0f;
+                                esum += live ? lterm : 0.0f;
+                                prod *= live ? omq : 1.0f;
+                            } else {
+                                esum += lterm;
+                                prod *= omq;
+                            }
+                            gx = __builtin_fmaf(t, dx, gx);            // row side: + t (y_i - y_j)
+                            gy = __builtin_fmaf(t, dy, gy);
+                            cgx[c] = __builtin_fmaf(-t, dx, cgx[c]);   // column side: - t (y_i - y_j)  (negation is an operand modifier)
+                            cgy[c] = __builtin_fmaf(-t, dy, cgy[c]);
+                        }
+                        ce2 += __builtin_amdgcn_logf(prod) - esum;
                     }
-#pragma unroll
-                    for (int c = 0; c < F_CPL; ++c) {
-                        const int64_t j = j0 + c;
-                        const float dx = xi - xj[c], dy = yi - yj[c];
-                        const float sden = 1.0f + __builtin_fmaf(dx, dx, dy * dy);
-                        float q = __builtin_amdgcn_rcpf(sden);
-                        q = __builtin_fminf(__builtin_fmaxf(q, 0.001f), 0.999f);
-                        const float omq = 1.0f - q;
-                        float t = (q * __builtin_amdgcn_rcpf(omq)) * (p[c] - q);
-                        const float lq = __builtin_amdgcn_logf(q), l1 = __builtin_amdgcn_logf(omq);
-                        float e = __builtin_fmaf(p[c], lq - l1, l1);
-                        const bool live = (j > gi) && (j < n);
-                        t = live ? t : 0.0f;
-                        e = live ? e : 0.0f;
-                        const float fx = t * dx, fy = t * dy;
-                        gx += fx;
-                        gy += fy;
-                        cgx[c] -= fx;
-                        cgy[c] -= fy;
-                        ce2 += e;
+                    gx = wave_sum_to_lane63(gx);
+                    gy = wave_sum_to_lane63(gy);
+                    if (lane == 63) {
+                        rowpart[(J * 2 + 0) * n + gi] = gx;
+                        rowpart[(J * 2 + 1) * n + gi] = gy;
+                    }
+                    if ((r & 15) == 15) {
+                        wave_loss += (double)ce2;
+                        ce2 = 0.0f;
                     }
                 }
-                gx = wave_sum_to_lane63(gx);
-                gy = wave_sum_to_lane63(gy);
-                if (lane == 63) {
-                    rowpart[(J * 2 + 0) * n + gi] = gx;
-                    rowpart[(J * 2 + 1) * n + gi] = gy;
-                }
-                if ((r & 15) == 15) {
-                    wave_loss += (double)ce2;
-                    ce2 = 0.0f;
-                }
-            }
+            };
+            if (interior) run_rows(std::false_type{});
+            else run_rows(std::true_type{});
         }
         wave_loss += (double)ce2;
         wave_loss *= -0.6931471805599453;
