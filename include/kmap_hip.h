@@ -203,8 +203,11 @@ int kmap_fasta_close(kmap_fasta *f);
 /* ---- all-pairs Hamming matrix: cal_samp_kmer_hamdist_mat motif_discovery.py:759-808
  * (one launch instead of n_uniq launches + Python block expansion).  kh: N hashes (already
  * expanded by counts), label: N int32; pairs sharing label l with clen[l] < k are compared on the
- * first clen[l] bases only.  Writes rows [row0, row0+nrows) as uint8 with leading dimension ld
- * (ld % 16 == 0 and a 16-byte aligned out_dev give the fast path). */
+ * first clen[l] bases only.  Writes rows [row0, row0+nrows) as uint8 with leading dimension ld.
+ * Fastest path (k <= 16, N >= 4096): ld = kmap_hamdist_pitch(n) -- a multiple of 4 KiB with an odd number of 4-KiB chunks
+ * per row -- and a 4-KiB aligned out_dev; any other ld >= n works through the general kernel (ld % 16 == 0 and a 16-byte
+ * aligned out_dev keep its vector stores). */
+int64_t kmap_hamdist_pitch(int64_t n);
 int kmap_hamdist_matrix_u32_dev(const uint32_t *kh_dev, const int32_t *label_dev, int64_t n, int k,
                                 const int32_t *clen, int n_lab, int64_t row0, int64_t nrows, uint8_t *out_dev,
                                 int64_t ld, void *stream);                 /* clen: host array */

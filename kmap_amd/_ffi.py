@@ -65,6 +65,7 @@ _SIGS = {
     "kmap_counts_total": (i32, [vp, P(i64)]),
     "kmap_hamball_extract": (i32, [vp, vp, i64, i32, u64, i32, i32, vp, vp, P(i64), vp]),
     "kmap_pos_density": (i32, [vp, vp, vp, vp, i64, i32, vp, i32, f64, vp]),
+    "kmap_hamdist_pitch": (i64, [i64]),
     "kmap_counts_topk": (i32, [vp, i32, vp, vp, vp, P(i32)]),
     "kmap_counts_hamball_mass": (i32, [vp, vp, i32, i32, i32, vp]),
     "kmap_packed_groups": (i64, [i64]),

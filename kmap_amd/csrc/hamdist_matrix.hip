@@ -430,6 +430,11 @@ int launch_matrix(const H *kh_dev, const int32_t *label_dev, int64_t n, int k, c
 
 extern "C" {
 
+int64_t kmap_hamdist_pitch(int64_t n) {
+    if (n < 4096) return (n + 255) & ~(int64_t)255;
+    return (((n + 4095) >> 12) | 1) << 12;
+}
+
 int kmap_hamdist_matrix_u32_dev(const uint32_t *kh_dev, const int32_t *label_dev, int64_t n, int k, const int32_t *clen,
                                 int n_lab, int64_t row0, int64_t nrows, uint8_t *out_dev, int64_t ld, void *stream) {
     KMAP_REQUIRE(k < 16, "hamdist_matrix_u32: k=%d needs the u64 entry point", k);
@@ -445,7 +450,7 @@ int kmap_hamdist_matrix_u8(const uint64_t *kh, const int32_t *label, int64_t n, 
     KMAP_REQUIRE(n >= 0 && k > 0 && k < 32, "hamdist_matrix_u8: bad n/k");
     if (n == 0) return KMAP_OK;
     KMAP_REQUIRE(kh && label && out, "hamdist_matrix_u8: null pointer");
-    const int64_t ld = (n < 4096) ? ((n + 255) & ~(int64_t)255) : ((((n + 4095) >> 12) | 1) << 12);   // see pitch_for
+    const int64_t ld = kmap_hamdist_pitch(n);
     DevBuf dkh, dlab, dout;
     KMAP_TRY(dkh.alloc((size_t)n * 8));
     KMAP_TRY(dlab.alloc((size_t)n * 4));

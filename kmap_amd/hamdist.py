@@ -12,11 +12,7 @@ def pitch_for(n):
     ODD number of 4-KiB chunks per row, which is what the tiled Hamming kernel needs to give every XCD its own residue
     class of chunks (6.5+ TB/s of stores instead of 5.3-5.8; csrc/hamdist_matrix.hip).  Below that: 256-byte aligned rows
     (every 1-KiB wave store covers whole 128-byte lines: 5.3 TB/s vs 3.3 TB/s with a 16-byte pitch)."""
-    n = int(n)
-    if n < 4096:
-        return (n + 255) & ~255
-    chunks = (n + 4095) >> 12
-    return (chunks | 1) << 12
+    return int(_ffi.lib().kmap_hamdist_pitch(int(n)))
 
 
 def hamdist_matrix_dev(kh_dev_ptr, label_dev_ptr, n, k, conseq_lens, out_dev_ptr, ld, row0=0, nrows=None, stream=None):
