@@ -148,6 +148,29 @@ __global__ __launch_bounds__(LDSMODE ? HP_TPB : BLK) void hist_packed_kernel(con
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += stride) {
         const Win w = load_win(codes, inval, g);
         if ((w.m >> 32) == 0xFFFFull) continue;   // group entirely invalid (cheap skip of masked regions)
+        if constexpr (LDSMODE && !WIDE) {
+            // 32-bit fast path (k <= 16): window i = bits [63-2i, 64-2i-2k) of t0 -> one v_alignbit + one shift; the 16
+            // "window touches an invalid position" flags come from one doubling pass over the 48-bit invalid stream
+            // (bit 47-p of `bad` = OR of m[p .. p+k-1]) instead of a 64-bit shift-and-mask per window
+            uint64_t bad = w.m;
+            for (int have = 1; have < k;) {
+                const int step = (have <= k - have) ? have : k - have;
+                bad |= bad << step;
+                have += step;
+            }
+            const uint32_t bad16 = (uint32_t)(bad >> 32);          // windows 0..15 in bits 15..0
+            const uint32_t hi = (uint32_t)(w.t0 >> 32), lo = (uint32_t)w.t0;
+            const uint32_t b0 = (uint32_t)bin0;
+            const int sh = 32 - 2 * k;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t top = (i == 0) ? hi : __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * i);
+                uint32_t a = (top >> sh) - b0;
+                a = ((bad16 >> (15 - i)) & 1u) ? 0xFFFFFFFFu : a;
+                if (a < (uint32_t)HP_BINS) atomicAdd(&lb[a], 1u);
+            }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             bool bad;
