@@ -191,6 +191,25 @@ int kmap_hamball_extract(const void *uniq_host, const void *cnt_host, int64_t n,
 int kmap_pos_density(const int32_t *hits, const int64_t *offs, const int32_t *pos, const int64_t *seq_len, int64_t n_seq,
                      int kmer_len, const double *x_arr, int nx, double x_step, double *density);
 
+/* labelled sampling of the counted k-mers on the device (sample_disp_kmer motif_discovery.py:812-921), for k-mer tables too
+ * large for the reference's n_conseq x n_uniq host matrices.  label: nearest consensus by head (forward) / tail (reverse
+ * complement) partial Hamming distance, distances above the consensus' own radius count as k, first minimum wins, noise
+ * label n_cons when the minimum exceeds radius_k; members whose reverse complement is closer are re-oriented IN uniq_dev. */
+int kmap_label_kmers_dev(void *uniq_dev, int64_t n, int k, int n_cons, const uint64_t *cons_kh, const int32_t *cons_len,
+                         const int32_t *cons_radius, int radius_k, int revcom_mode, uint8_t *label_dev, void *stream);
+/* per label l < n_labels (<= 64): sum of the counts (np.bincount weights) and number of members; cnt int32 or int64 */
+int kmap_label_sums_dev(const uint8_t *label_dev, const void *cnt_dev, int cnt64, int64_t n, int n_labels, int64_t *weight_sums,
+                        int64_t *member_counts);
+/* excl_dev[0..n] (uint64) = exclusive prefix sums of label c's weights (counts; 1 per member if cnt_dev is NULL), [n] = total */
+int kmap_label_prefix_dev(const uint8_t *label_dev, const void *cnt_dev, int cnt64, int64_t n, int c, uint32_t *scratch_dev,
+                          uint64_t *excl_dev, void *stream);
+/* idx_out[j] = first i whose inclusive prefix exceeds targets[j] (np.searchsorted(cdf, x, "right") on integer weights) */
+int kmap_prefix_search_dev(const uint64_t *excl_dev, int64_t n, const int64_t *targets, int64_t m, int64_t *idx_out);
+/* ascending indices of label c's members (excl_dev from kmap_label_prefix_dev with cnt_dev = NULL; m = excl[n]) */
+int kmap_label_members_dev(const uint8_t *label_dev, const uint64_t *excl_dev, int64_t n, int c, int64_t m, int64_t *idx_out);
+/* out[j] = src_dev[idx[j]], elements of 1, 4 or 8 bytes; idx / out on the host */
+int kmap_gather_dev(const void *src_dev, int elem_bytes, const int64_t *idx, int64_t m, void *out);
+
 /* ---- FASTA -> uint8 array contract (host side; proc_input / dna2arr / convert_fasta_to_binary, kmer_count.py:182-347).
  * Streaming parser (plain or .gz): header lines start with '>', sequence lines are concatenated with white space
  * removed, A/C/G/T (either case) -> 0..3, anything else -> 255, one 255 separator after every record; borders

@@ -66,6 +66,12 @@ _SIGS = {
     "kmap_hamball_extract": (i32, [vp, vp, i64, i32, u64, i32, i32, vp, vp, P(i64), vp]),
     "kmap_pos_density": (i32, [vp, vp, vp, vp, i64, i32, vp, i32, f64, vp]),
     "kmap_hamdist_pitch": (i64, [i64]),
+    "kmap_label_kmers_dev": (i32, [vp, i64, i32, i32, vp, vp, vp, i32, i32, vp, vp]),
+    "kmap_label_sums_dev": (i32, [vp, vp, i32, i64, i32, vp, vp]),
+    "kmap_label_prefix_dev": (i32, [vp, vp, i32, i64, i32, vp, vp, vp]),
+    "kmap_prefix_search_dev": (i32, [vp, i64, vp, i64, vp]),
+    "kmap_label_members_dev": (i32, [vp, vp, i64, i32, i64, vp]),
+    "kmap_gather_dev": (i32, [vp, i32, vp, i64, vp]),
     "kmap_counts_topk": (i32, [vp, i32, vp, vp, vp, P(i32)]),
     "kmap_counts_hamball_mass": (i32, [vp, vp, i32, i32, i32, vp]),
     "kmap_packed_groups": (i64, [i64]),

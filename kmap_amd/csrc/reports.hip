@@ -226,3 +226,218 @@ int kmap_pos_density(const int32_t *hits, const int64_t *offs, const int32_t *po
 }
 
 }  // extern "C"
+
+// ---- labelled sampling on the device (sample_disp_kmer, reference motif_discovery.py:812-921) --------------------------
+// For the k-mer counts of a long final k (10^8..10^9 unique k-mers) the reference's numpy formulation builds n_conseq x n_uniq
+// matrices on the host.  Here the unique k-mers stay on the device: one kernel labels them (and re-orients reverse-complement
+// members), per-label weight sums / prefix sums / searches run on the device, and only the sampled entries come back.
+namespace {
+struct LabTab {
+    uint64_t cons[32], rccons[32];
+    int32_t clen[32], radius[32];
+    int n;
+};
+
+template <typename H>
+__global__ __launch_bounds__(256) void label_kernel(H *__restrict__ uniq, int64_t n, int k, LabTab t, int radius_k, int revcom,
+                                                    uint8_t *__restrict__ label) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const H h = uniq[i];
+    int best = 1 << 20, lab = t.n;
+    bool best_rc = false;
+    for (int c = 0; c < t.n; ++c) {
+        const int cl = t.clen[c];
+        const H cm = low_mask<H>(cl);
+        int d = popc2((H)(((h >> (2 * (k - cl))) ^ (H)t.cons[c]) & cm));      // head: first cl bases vs the consensus
+        bool rc = false;
+        if (revcom) {
+            const int d2 = popc2((H)((h ^ (H)t.rccons[c]) & cm));             // tail: last cl bases vs its reverse complement
+            rc = d2 < d;
+            d = rc ? d2 : d;
+        }
+        if (d > t.radius[c]) d = k;                                           // outside this consensus' ball (:869-870)
+        if (d < best) {                                                       // np.argmin: first minimum
+            best = d;
+            lab = c;
+            best_rc = rc;
+        }
+    }
+    if (best > radius_k) lab = t.n;                                           // noise label (:873)
+    label[i] = (uint8_t)lab;
+    if (revcom && lab < t.n && best_rc) uniq[i] = revcom_hash(h, k);          // align members with their consensus (:876-883)
+}
+
+template <typename CT>
+__global__ __launch_bounds__(256) void label_sums_kernel(const uint8_t *__restrict__ label, const CT *__restrict__ cnt, int64_t n,
+                                                         int n_labels, unsigned long long *__restrict__ wsum,
+                                                         unsigned long long *__restrict__ members) {
+    __shared__ unsigned long long sw[64], sm[64];
+    if (threadIdx.x < 64) sw[threadIdx.x] = sm[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const int l = label[i];
+        if (l < n_labels) {
+            atomicAdd(&sw[l], (unsigned long long)(long long)cnt[i]);
+            atomicAdd(&sm[l], 1ull);
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < n_labels) {
+        if (sw[threadIdx.x]) atomicAdd(&wsum[threadIdx.x], sw[threadIdx.x]);
+        if (sm[threadIdx.x]) atomicAdd(&members[threadIdx.x], sm[threadIdx.x]);
+    }
+}
+
+// w[i] = weight of entry i if it carries label c (its count, or 1 when cnt == nullptr), else 0
+template <typename CT>
+__global__ __launch_bounds__(256) void label_weight_kernel(const uint8_t *__restrict__ label, const CT *__restrict__ cnt, int64_t n,
+                                                           int c, uint32_t *__restrict__ w) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    w[i] = (label[i] == c) ? (cnt ? (uint32_t)cnt[i] : 1u) : 0u;
+}
+
+// first index whose inclusive prefix sum exceeds the target: np.searchsorted(cdf, x, side="right") on integer weights
+__global__ __launch_bounds__(256) void prefix_search_kernel(const uint64_t *__restrict__ excl, int64_t n, const int64_t *__restrict__ target,
+                                                            int64_t m, int64_t *__restrict__ idx) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const uint64_t t = (uint64_t)target[j];
+    int64_t lo = 0, hi = n;                       // smallest i in [0, n) with excl[i + 1] > t; n if none
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (excl[mid + 1] > t) hi = mid;
+        else lo = mid + 1;
+    }
+    idx[j] = lo;
+}
+
+__global__ __launch_bounds__(256) void compact_label_kernel(const uint8_t *__restrict__ label, const uint64_t *__restrict__ excl,
+                                                            int64_t n, int c, int64_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && label[i] == c) out[excl[i]] = i;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_kernel(const T *__restrict__ src, const int64_t *__restrict__ idx, int64_t m,
+                                                     T *__restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < m) out[j] = src[idx[j]];
+}
+}  // namespace
+
+extern "C" {
+
+int kmap_label_kmers_dev(void *uniq_dev, int64_t n, int k, int n_cons, const uint64_t *cons_kh, const int32_t *cons_len,
+                         const int32_t *cons_radius, int radius_k, int revcom_mode, uint8_t *label_dev, void *stream) {
+    KMAP_REQUIRE(k > 0 && k < 32 && n >= 0, "label_kmers: bad k / n");
+    KMAP_REQUIRE(n_cons > 0 && n_cons <= 32 && cons_kh && cons_len && cons_radius, "label_kmers: 1..32 consensuses");
+    if (n == 0) return KMAP_OK;
+    KMAP_REQUIRE(uniq_dev && label_dev, "label_kmers: null pointer");
+    LabTab t;
+    t.n = n_cons;
+    for (int c = 0; c < n_cons; ++c) {
+        const int cl = cons_len[c];
+        KMAP_REQUIRE(cl > 0 && cl <= k, "label_kmers: consensus length %d not in (0, k]", cl);
+        const uint64_t m = low_mask<uint64_t>(cl), ch = cons_kh[c] & m;
+        uint64_t com = m - ch, rc = 0;
+        for (int p = 0; p < cl; ++p) rc = (rc << 2) | ((com >> (2 * p)) & 3);
+        t.cons[c] = ch;
+        t.rccons[c] = rc;
+        t.clen[c] = cl;
+        t.radius[c] = cons_radius[c];
+    }
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (k < 16) label_kernel<uint32_t><<<nb, 256, 0, as_stream(stream)>>>((uint32_t *)uniq_dev, n, k, t, radius_k, revcom_mode, label_dev);
+    else label_kernel<uint64_t><<<nb, 256, 0, as_stream(stream)>>>((uint64_t *)uniq_dev, n, k, t, radius_k, revcom_mode, label_dev);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+
+/* per label l < n_labels (<= 64): sum of the counts and number of members; cnt is int32 (cnt64 = 0) or int64 */
+int kmap_label_sums_dev(const uint8_t *label_dev, const void *cnt_dev, int cnt64, int64_t n, int n_labels, int64_t *weight_sums,
+                        int64_t *member_counts) {
+    KMAP_REQUIRE(n >= 0 && n_labels > 0 && n_labels <= 64 && weight_sums && member_counts, "label_sums: bad arguments");
+    for (int l = 0; l < n_labels; ++l) weight_sums[l] = member_counts[l] = 0;
+    if (n == 0) return KMAP_OK;
+    KMAP_REQUIRE(label_dev && cnt_dev, "label_sums: null pointer");
+    DevBuf acc;
+    KMAP_TRY(acc.alloc(128 * 8));
+    KMAP_CHECK_HIP(hipMemset(acc.p, 0, 128 * 8));
+    int64_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    unsigned long long *w = acc.as<unsigned long long>();
+    if (cnt64) label_sums_kernel<int64_t><<<(unsigned)g, 256>>>(label_dev, (const int64_t *)cnt_dev, n, n_labels, w, w + 64);
+    else label_sums_kernel<int32_t><<<(unsigned)g, 256>>>(label_dev, (const int32_t *)cnt_dev, n, n_labels, w, w + 64);
+    KMAP_CHECK_HIP(hipGetLastError());
+    unsigned long long host[128];
+    KMAP_CHECK_HIP(hipMemcpy(host, acc.p, sizeof host, hipMemcpyDeviceToHost));
+    for (int l = 0; l < n_labels; ++l) {
+        weight_sums[l] = (int64_t)host[l];
+        member_counts[l] = (int64_t)host[64 + l];
+    }
+    return KMAP_OK;
+}
+
+/* excl_dev[0..n] (uint64) = exclusive prefix sums of the label-c weights (counts, or 1 per member when cnt_dev is NULL);
+ * excl_dev[n] = total.  scratch_dev: n uint32. */
+int kmap_label_prefix_dev(const uint8_t *label_dev, const void *cnt_dev, int cnt64, int64_t n, int c, uint32_t *scratch_dev,
+                          uint64_t *excl_dev, void *stream) {
+    KMAP_REQUIRE(n > 0 && label_dev && scratch_dev && excl_dev, "label_prefix: bad arguments");
+    hipStream_t st = as_stream(stream);
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (cnt_dev && cnt64) label_weight_kernel<int64_t><<<nb, 256, 0, st>>>(label_dev, (const int64_t *)cnt_dev, n, c, scratch_dev);
+    else label_weight_kernel<int32_t><<<nb, 256, 0, st>>>(label_dev, (const int32_t *)cnt_dev, n, c, scratch_dev);
+    KMAP_TRY(exclusive_scan_u32(scratch_dev, n, excl_dev, st));
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+
+/* idx_out[j] = first i with (inclusive prefix)[i] > targets[j]  (n if none); targets / idx_out are host arrays */
+int kmap_prefix_search_dev(const uint64_t *excl_dev, int64_t n, const int64_t *targets, int64_t m, int64_t *idx_out) {
+    KMAP_REQUIRE(n > 0 && excl_dev && m >= 0 && (m == 0 || (targets && idx_out)), "prefix_search: bad arguments");
+    if (m == 0) return KMAP_OK;
+    DevBuf t, o;
+    KMAP_TRY(t.alloc((size_t)m * 8));
+    KMAP_TRY(o.alloc((size_t)m * 8));
+    KMAP_CHECK_HIP(hipMemcpy(t.p, targets, (size_t)m * 8, hipMemcpyHostToDevice));
+    prefix_search_kernel<<<(unsigned)((m + 255) / 256), 256>>>(excl_dev, n, t.as<int64_t>(), m, o.as<int64_t>());
+    KMAP_CHECK_HIP(hipGetLastError());
+    KMAP_CHECK_HIP(hipMemcpy(idx_out, o.p, (size_t)m * 8, hipMemcpyDeviceToHost));
+    return KMAP_OK;
+}
+
+/* indices (ascending) of the entries carrying label c, using the member-count prefix from kmap_label_prefix_dev(cnt = NULL);
+ * idx_out: host int64[excl[n]] */
+int kmap_label_members_dev(const uint8_t *label_dev, const uint64_t *excl_dev, int64_t n, int c, int64_t m, int64_t *idx_out) {
+    KMAP_REQUIRE(n > 0 && label_dev && excl_dev && m >= 0 && (m == 0 || idx_out), "label_members: bad arguments");
+    if (m == 0) return KMAP_OK;
+    DevBuf o;
+    KMAP_TRY(o.alloc((size_t)m * 8));
+    compact_label_kernel<<<(unsigned)((n + 255) / 256), 256>>>(label_dev, excl_dev, n, c, o.as<int64_t>());
+    KMAP_CHECK_HIP(hipGetLastError());
+    KMAP_CHECK_HIP(hipMemcpy(idx_out, o.p, (size_t)m * 8, hipMemcpyDeviceToHost));
+    return KMAP_OK;
+}
+
+/* out[j] = src_dev[idx[j]] for elem_bytes in {1, 4, 8}; idx / out are host arrays */
+int kmap_gather_dev(const void *src_dev, int elem_bytes, const int64_t *idx, int64_t m, void *out) {
+    KMAP_REQUIRE(elem_bytes == 1 || elem_bytes == 4 || elem_bytes == 8, "gather: element size %d", elem_bytes);
+    KMAP_REQUIRE(m >= 0 && (m == 0 || (src_dev && idx && out)), "gather: bad arguments");
+    if (m == 0) return KMAP_OK;
+    DevBuf di, dout;
+    KMAP_TRY(di.alloc((size_t)m * 8));
+    KMAP_TRY(dout.alloc((size_t)m * elem_bytes));
+    KMAP_CHECK_HIP(hipMemcpy(di.p, idx, (size_t)m * 8, hipMemcpyHostToDevice));
+    const unsigned nb = (unsigned)((m + 255) / 256);
+    if (elem_bytes == 1) gather_kernel<uint8_t><<<nb, 256>>>((const uint8_t *)src_dev, di.as<int64_t>(), m, dout.as<uint8_t>());
+    else if (elem_bytes == 4) gather_kernel<uint32_t><<<nb, 256>>>((const uint32_t *)src_dev, di.as<int64_t>(), m, dout.as<uint32_t>());
+    else gather_kernel<uint64_t><<<nb, 256>>>((const uint64_t *)src_dev, di.as<int64_t>(), m, dout.as<uint64_t>());
+    KMAP_CHECK_HIP(hipGetLastError());
+    KMAP_CHECK_HIP(hipMemcpy(out, dout.p, (size_t)m * elem_bytes, hipMemcpyDeviceToHost));
+    return KMAP_OK;
+}
+
+}  // extern "C"

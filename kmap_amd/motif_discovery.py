@@ -31,6 +31,7 @@ DENSE_PKL_MAX_N = 16384
 # above this many unique k-mers find_motif stops fetching the count arrays every trial: the top_k candidates come from
 # the device (largest count, then lowest index) instead of np.argpartition (whose tie order is numpy-specific anyway)
 TOPK_DEVICE_MIN = 4_000_000
+SAMPLE_ON_DEVICE = True      # sample_disp_kmer: keep tables above TOPK_DEVICE_MIN on the device (False: numpy formulation)
 
 STAGE_TIMES = {}   # cumulative wall-clock per stage of the last runs (tools/e2e.py, bench.py report it)
 
@@ -195,9 +196,11 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
                 uniq_kh_arr, uniq_kh_cnt_arr = dc.fetch()
             payload = [kmer_len, uniq_kh_arr, uniq_kh_cnt_arr]
 
-            def _dump(path=kmer_cnt_pkl_file, obj=payload):
+            def _dump(path=kmer_cnt_pkl_file, obj=payload, proto=5 if big else 4):
+                # protocol 5 streams the array buffers straight to the file (no intermediate bytes copy of a multi-GB table);
+                # any Python >= 3.8 pickle.load reads it
                 with open(path, "wb") as fh:
-                    pickle.dump(obj, fh, protocol=4)
+                    pickle.dump(obj, fh, protocol=proto)
             if big:   # multi-GB pickle: write it while the trials run on the GPU
                 import threading
                 writer = threading.Thread(target=_dump)
@@ -358,6 +361,9 @@ def sample_disp_kmer(conseq_list: List[str], kmer_len: int, motif_def_dict: dict
 
     n_conseq, n_uniq = len(conseq_list), len(uniq_kh_arr)
     big = n_uniq > TOPK_DEVICE_MIN
+    if big and sampling_flag and n_conseq <= 32 and SAMPLE_ON_DEVICE:
+        return _sample_disp_kmer_dev(uniq_kh_arr, uniq_kh_cnt_arr, conseq_list, kmer_len, motif_def_dict, n_total_sample,
+                                     n_motif_kmer, revcom_mode)
     # distances are <= kmer_len < 32: a narrow matrix gives the same min/argmin and fits 1e9 unique k-mers in memory
     ham_dist_mat = np.zeros((n_conseq, n_uniq), dtype=np.uint8 if big else int)
     rc_flag_mat = np.zeros((n_conseq, n_uniq), dtype=bool)
@@ -414,6 +420,72 @@ def sample_disp_kmer(conseq_list: List[str], kmer_len: int, motif_def_dict: dict
     samp_inds = np.concatenate(samp_inds)
     samp_cnts = np.concatenate(samp_cnts)
     return uniq_kh_arr[samp_inds], samp_cnts, label_arr[samp_inds], conseq_list
+
+
+def _sample_disp_kmer_dev(uniq_kh_arr, uniq_kh_cnt_arr, conseq_list, kmer_len, motif_def_dict, n_total_sample, n_motif_kmer,
+                          revcom_mode):
+    """sample_disp_kmer for k-mer tables above TOPK_DEVICE_MIN entries: the table stays on the device (labels, re-orientation,
+    per-label weight sums, prefix sums and searches are kernels), only the sampled entries come back.  Draws the same random
+    numbers in the same order as the host formulation above (np.random.multinomial for labels up to TOPK_DEVICE_MIN members,
+    inverse CDF beyond), so both give identical samples."""
+    lib = _ffi.lib()
+    n, n_conseq = len(uniq_kh_arr), len(conseq_list)
+    hd, cd = get_hash_dtype(kmer_len), get_cnt_dtype(kmer_len)
+    u_d = _ffi.DeviceBuffer.from_numpy(np.ascontiguousarray(uniq_kh_arr, hd))
+    c_d = _ffi.DeviceBuffer.from_numpy(np.ascontiguousarray(uniq_kh_cnt_arr, cd))
+    lab_d, scratch_d, excl_d = _ffi.DeviceBuffer(n), _ffi.DeviceBuffer(n * 4), _ffi.DeviceBuffer((n + 1) * 8)
+    cnt64 = int(cd == np.int64)
+    try:
+        cons = np.array([int(kmer2hash(s)) for s in conseq_list], np.uint64)
+        lens = np.array([len(s) for s in conseq_list], np.int32)
+        rads = np.array([motif_def_dict[len(s)].max_ham_dist for s in conseq_list], np.int32)
+        if revcom_mode:
+            for s in conseq_list:
+                assert kmer2hash(s) <= revcom_hash(kmer2hash(s), len(s))
+        check(lib.kmap_label_kmers_dev(u_d.ptr, n, kmer_len, n_conseq, ptr(cons), ptr(lens), ptr(rads),
+                                       int(motif_def_dict[kmer_len].max_ham_dist), int(bool(revcom_mode)), lab_d.ptr, None))
+        wsum, members = np.zeros(n_conseq + 1, np.int64), np.zeros(n_conseq + 1, np.int64)
+        check(lib.kmap_label_sums_dev(lab_d.ptr, c_d.ptr, cnt64, n, n_conseq + 1, ptr(wsum), ptr(members)))
+
+        sample_cnt_arr = wsum.astype(np.float64)                       # np.bincount(label_arr, weights=uniq_kh_cnt_arr)
+        motif_weights = sample_cnt_arr[:-1] / sum(sample_cnt_arr[:-1])
+        sample_cnt_arr[:-1] = np.around(n_motif_kmer * motif_weights)
+        sample_cnt_arr[-1] = n_total_sample - sum(sample_cnt_arr[0:-1])
+        sample_cnt_arr = sample_cnt_arr.astype(int)
+
+        samp_inds, samp_cnts = [], []
+        for c in range(n_conseq + 1):
+            m = int(members[c])
+            if m > TOPK_DEVICE_MIN:                                    # inverse CDF over the integer prefix sums
+                check(lib.kmap_label_prefix_dev(lab_d.ptr, c_d.ptr, cnt64, n, c, scratch_d.ptr, excl_d.ptr, None))
+                total = float(wsum[c])
+                x = np.random.random_sample(int(sample_cnt_arr[c])) * total
+                targets = np.minimum(np.floor(x).astype(np.int64), int(wsum[c]) - 1)
+                hits = np.empty(len(targets), np.int64)
+                check(lib.kmap_prefix_search_dev(excl_d.ptr, n, ptr(targets), len(targets), ptr(hits)))
+                sel, tmp = np.unique(hits, return_counts=True)
+                samp_inds.append(sel)
+                samp_cnts.append(tmp)
+                continue
+            c_inds = np.empty(m, np.int64)
+            if m:
+                check(lib.kmap_label_prefix_dev(lab_d.ptr, None, 0, n, c, scratch_d.ptr, excl_d.ptr, None))
+                check(lib.kmap_label_members_dev(lab_d.ptr, excl_d.ptr, n, c, m, ptr(c_inds)))
+            ws = np.empty(m, cd)
+            check(lib.kmap_gather_dev(c_d.ptr, np.dtype(cd).itemsize, ptr(c_inds), m, ptr(ws)))
+            ws = ws / _wrap_total(int(ws.sum(dtype=np.int64)), kmer_len)
+            tmpcnts = np.random.multinomial(sample_cnt_arr[c], ws, size=1).squeeze()
+            samp_inds.append(c_inds[tmpcnts > 0])
+            samp_cnts.append(tmpcnts[tmpcnts > 0])
+        samp_inds = np.concatenate(samp_inds)
+        samp_cnts = np.concatenate(samp_cnts)
+        out_kh, out_lab = np.empty(len(samp_inds), hd), np.empty(len(samp_inds), np.uint8)
+        check(lib.kmap_gather_dev(u_d.ptr, np.dtype(hd).itemsize, ptr(samp_inds), len(samp_inds), ptr(out_kh)))
+        check(lib.kmap_gather_dev(lab_d.ptr, 1, ptr(samp_inds), len(samp_inds), ptr(out_lab)))
+        return out_kh, samp_cnts, out_lab.astype(np.int64), conseq_list
+    finally:
+        for b in (u_d, c_d, lab_d, scratch_d, excl_d):
+            b.free()
 
 
 # ---- `kmap scan_motif` (reference motif_discovery.py:187-486) ------------------------------------------------
@@ -473,7 +545,7 @@ def _scan_motif(res_dir: str, debug=False):
             count_seq.reset()
             d = motif_def_dict[kmer_len]
             kmer_cnt_file = res / FileNameDict["kmer_count_dir"] / f"k{kmer_len}.pkl"
-            with _stage("find_motif"):
+            with _stage("find_motif"), _stage(f"find_motif_k{kmer_len}"):
                 consensus_kh_dict = find_motif(None, kmer_len, d.max_ham_dist, d.p_uniform, d.ratio_mu, d.ratio_std,
                                                d.ratio_cutoff, top_k, n_trial, revcom_mode, rep_mode,
                                                save_kmer_cnt_flag=save_kmer_cnt_flag, kmer_cnt_pkl_file=kmer_cnt_file,
