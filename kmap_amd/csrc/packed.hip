@@ -342,19 +342,31 @@ __global__ __launch_bounds__(KMAP_WAVE *SC_WAVES) void scan_packed_kernel(const 
 //   (1) a flat pass, thread per 16-position group, that stores the capped distance of EVERY window as a nibble
 //       (d <= radius ? d : 15; 8 B per group = 0.5 B per position) -- independent of read borders because a window that
 //       the scan may use (p < L-k+1) lies entirely inside its read;
-//   (2) a thread-per-read pass over that read's nibbles: minimum, number of positions at the minimum;
+//       plus the smallest nibble of every group as one byte;
+//   (2) a thread-per-read pass: minimum over the read = its two boundary words (masked) and the group minima of the words
+//       in between (consecutive threads read consecutive bytes); then the number of positions at that minimum, decoding
+//       only the words whose group minimum equals it;
 //   (3) after the scan of the counts, a thread-per-read pass that writes those positions in ascending order.
 // Reads longer than FL_LONG positions are handled by their whole wave (64 words per step) inside (2) and (3).
 // Needs radius <= 14; larger radii take the wave-per-read kernel.
 constexpr int FL_TPB = 256;
 constexpr int FL_LONG = 1024;
-constexpr int FL_STAGE = 8192;   // nibble words staged per block (64 KiB of LDS)
 constexpr uint64_t NIB_ONES = 0x1111111111111111ull;
 
+__device__ __forceinline__ int nib_min(uint64_t x) {
+    // pairwise minimum of the 16 nibbles (SWAR: compare 8 nibble pairs held in separate bytes, then fold)
+    int m = 15;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int v = (int)((x >> (4 * i)) & 15);
+        m = v < m ? v : m;
+    }
+    return m;
+}
 template <bool WIDE>
 __global__ __launch_bounds__(BLK) void scan_nibble_kernel(const uint32_t *__restrict__ codes, const uint16_t *__restrict__ inval,
                                                           int64_t n, int k, uint64_t cons, uint64_t rcc, int radius, int revcom,
-                                                          uint64_t *__restrict__ nib) {
+                                                          uint64_t *__restrict__ nib, uint8_t *__restrict__ wmin) {
     const int64_t g = (int64_t)blockIdx.x * BLK + threadIdx.x;
     if (g >= ((n + 15) >> 4)) return;
     const Win w = load_win(codes, inval, g);
@@ -388,6 +400,7 @@ __global__ __launch_bounds__(BLK) void scan_nibble_kernel(const uint32_t *__rest
         }
     }
     nib[g] = out;
+    wmin[g] = (uint8_t)nib_min(out);   // smallest nibble of the word: the per-read passes skip words that cannot matter
 }
 
 // nibbles of word wi restricted to absolute positions [a, b): everything else reads as 15.  `src` is the nibble array
@@ -398,16 +411,6 @@ __device__ __forceinline__ uint64_t nib_load(const uint64_t *src, int64_t wsh, i
     if (a > w0) x |= (1ull << (4 * (int)(a - w0))) - 1ull;
     if (b < w0 + 16) x |= ~0ull << (4 * (int)(b - w0));
     return x;
-}
-__device__ __forceinline__ int nib_min(uint64_t x) {
-    // pairwise minimum of the 16 nibbles (SWAR: compare 8 nibble pairs held in separate bytes, then fold)
-    int m = 15;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int v = (int)((x >> (4 * i)) & 15);
-        m = v < m ? v : m;
-    }
-    return m;
 }
 // 16-bit mask (bit i = position i of the word) of the nibbles equal to v
 __device__ __forceinline__ uint32_t nib_eq_mask(uint64_t x, int v) {
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(FL_TPB) void scan_reads_kernel(const uint64_t *__re
                                                             const int64_t *__restrict__ borders, int64_t n_seq, int k, int d_inv,
                                                             int radius, int32_t *__restrict__ hits, int8_t *__restrict__ min_dist,
                                                             const uint64_t *__restrict__ offs, int32_t *__restrict__ pos_out,
-                                                            int stage_words) {
+                                                            const uint8_t *__restrict__ wmin) {
     const int lane = threadIdx.x & 63;
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t st = 0, stop = 0;
@@ -458,49 +461,40 @@ __global__ __launch_bounds__(FL_TPB) void scan_reads_kernel(const uint64_t *__re
         stop = 0;
     }
     const bool is_long = stop > FL_LONG;
-    // Stage the block's span of nibble words in LDS with coalesced loads: a thread-per-read walk straight over global
-    // memory touches a different 128-B line per lane and per step (16x the bytes through L2).  Blocks whose reads are not
-    // (nearly) contiguous in the array exceed FL_STAGE words and read global memory directly.
-    extern __shared__ __attribute__((aligned(16))) uint64_t stage[];
-    __shared__ long long span_lo, span_hi;
-    if (threadIdx.x == 0) {
-        span_lo = INT64_MAX;
-        span_hi = -1;
-    }
-    __syncthreads();
-    if (stop > 0 && !is_long) {
-        atomicMin(&span_lo, (long long)(st >> 4));
-        atomicMax(&span_hi, (long long)((st + stop - 1) >> 4));
-    }
-    __syncthreads();
-    const int64_t wlo = span_lo, whi = span_hi;
-    const uint64_t *src = nib;
-    int64_t wsh = 0;
-    if (whi >= wlo && whi - wlo < stage_words) {
-        for (int64_t i = threadIdx.x; i <= whi - wlo; i += blockDim.x) stage[i] = nib[wlo + i];
-        src = stage;
-        wsh = wlo;
-    }
-    __syncthreads();
     if (stop > 0 && !is_long) {
         const int64_t a = st, b = st + stop;
         const int64_t w0 = a >> 4, w1 = (b - 1) >> 4;
+        auto edge = [&](int64_t wi) -> uint64_t {            // boundary word: nibbles outside [a, b) read as 15
+            uint64_t x = nib[wi];
+            const int64_t p0 = wi << 4;
+            if (a > p0) x |= (1ull << (4 * (int)(a - p0))) - 1ull;
+            if (b < p0 + 16) x |= ~0ull << (4 * (int)(b - p0));
+            return x;
+        };
+        // interior words are judged by their precomputed minimum (1 byte, consecutive threads read consecutive bytes);
+        // only the two boundary words and the words that hold the read's minimum are decoded
+        const uint64_t xa = edge(w0), xb = (w1 > w0) ? edge(w1) : ~0ull;
         if (!WRITE) {
-            for (int64_t wi = w0; wi <= w1; ++wi) {
-                const int m = nib_min(nib_load(src, wsh, wi, a, b));
-                best = m < best ? m : best;
+            best = min(nib_min(xa), nib_min(xb));
+            for (int64_t wi = w0 + 1; wi < w1; ++wi) best = min(best, (int)wmin[wi]);
+            if (best < 15) {
+                count = __builtin_popcount(nib_eq_mask(xa, best)) + __builtin_popcount(nib_eq_mask(xb, best));
+                for (int64_t wi = w0 + 1; wi < w1; ++wi)
+                    if (wmin[wi] == best) count += __builtin_popcount(nib_eq_mask(nib[wi], best));
             }
-            if (best < 15)
-                for (int64_t wi = w0; wi <= w1; ++wi) count += __builtin_popcount(nib_eq_mask(nib_load(src, wsh, wi, a, b), best));
         } else {
-            for (int64_t wi = w0; wi <= w1; ++wi) {
-                uint32_t m = nib_eq_mask(nib_load(src, wsh, wi, a, b), best);
+            auto emit = [&](uint64_t x, int64_t wi) {
+                uint32_t m = nib_eq_mask(x, best);
                 while (m) {
                     const int i = __builtin_ctz(m);
                     m &= m - 1;
                     pos_out[base++] = (int32_t)((wi << 4) + i - st);
                 }
-            }
+            };
+            emit(xa, w0);
+            for (int64_t wi = w0 + 1; wi < w1; ++wi)
+                if (wmin[wi] == best) emit(nib[wi], wi);
+            if (w1 > w0) emit(xb, w1);
         }
     }
     // long reads: the whole wave works on one read at a time, 64 words per step
@@ -722,25 +716,18 @@ int kmap_scan_run_packed_dev(kmap_scan *s, const uint32_t *codes_dev, const uint
     static const bool flat_ok = !(getenv("KMAP_SCAN_FLAT") && getenv("KMAP_SCAN_FLAT")[0] == '0');
     const bool flat = flat_ok && radius <= 14;
     const unsigned grid = (unsigned)((n_seq + SC_WAVES - 1) / SC_WAVES);
-    // reads per block and staged words: about 1.25x the block's expected span, at most 24 KiB of LDS where the average
-    // read length allows it (several blocks per CU hide the staging latency), never more than FL_STAGE words
-    int ftpb = FL_TPB, stage_words = FL_STAGE;
-    {
-        const double wpr = (double)(n + n_seq) / (double)n_seq / 16.0 + 1.0;   // nibble words per read, separators included
-        for (ftpb = FL_TPB; ftpb > 64 && wpr * ftpb * 1.25 * 8.0 > 24.0 * 1024; ftpb >>= 1) {}
-        double want = wpr * ftpb * 1.25 + 64.0;
-        if (want > FL_STAGE) want = FL_STAGE;
-        stage_words = ((int)want + 127) & ~127;
-    }
-    const unsigned fgrid = (unsigned)((n_seq + ftpb - 1) / ftpb);
+    const unsigned fgrid = (unsigned)((n_seq + FL_TPB - 1) / FL_TPB);
     uint64_t *nib = nullptr;
+    uint8_t *wmin = nullptr;
     int d_inv = 0;
     if (flat) {
         const int64_t ng = (n + 15) >> 4;
-        KMAP_TRY(kmap_scratch((void **)&nib, (size_t)(ng ? ng : 1) * 8, st, KMAP_SLOT_HASH));
+        const size_t ngp = ((size_t)(ng ? ng : 1) + 15) & ~(size_t)15;
+        KMAP_TRY(kmap_scratch((void **)&nib, ngp * 9, st, KMAP_SLOT_HASH));   // 8 B of nibbles + 1 B minimum per group
+        wmin = reinterpret_cast<uint8_t *>(nib + ngp);
         if (ng) {
-            if (k <= 16) scan_nibble_kernel<false><<<grid_for(ng, BLK), BLK, 0, st>>>(codes_dev, inval_dev, n, k, c, rcc, radius, revcom, nib);
-            else scan_nibble_kernel<true><<<grid_for(ng, BLK), BLK, 0, st>>>(codes_dev, inval_dev, n, k, c, rcc, radius, revcom, nib);
+            if (k <= 16) scan_nibble_kernel<false><<<grid_for(ng, BLK), BLK, 0, st>>>(codes_dev, inval_dev, n, k, c, rcc, radius, revcom, nib, wmin);
+            else scan_nibble_kernel<true><<<grid_for(ng, BLK), BLK, 0, st>>>(codes_dev, inval_dev, n, k, c, rcc, radius, revcom, nib, wmin);
         }
         // distance of an invalid window (all ones, compared like any value)
         auto pc2 = [](uint64_t x) { return __builtin_popcountll((x | (x >> 1)) & 0x5555555555555555ull); };
@@ -749,16 +736,7 @@ int kmap_scan_run_packed_dev(kmap_scan *s, const uint32_t *codes_dev, const uint
             const int d2 = pc2((m ^ rcc) & m);
             d_inv = d2 < d_inv ? d2 : d_inv;
         }
-        static bool attr_set = false;
-        if (!attr_set) {
-            KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)scan_reads_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               FL_STAGE * 8));
-            KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)scan_reads_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               FL_STAGE * 8));
-            attr_set = true;
-        }
-        scan_reads_kernel<false><<<fgrid, ftpb, (size_t)stage_words * 8, st>>>(nib, n, borders_dev, n_seq, k, d_inv, radius, s->hits, s->mind, nullptr,
-                                                                               nullptr, stage_words);
+        scan_reads_kernel<false><<<fgrid, FL_TPB, 0, st>>>(nib, n, borders_dev, n_seq, k, d_inv, radius, s->hits, s->mind, nullptr, nullptr, wmin);
     } else {
         scan_packed_kernel<false><<<grid, KMAP_WAVE * SC_WAVES, 0, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, c, rcc,
                                                                          radius, revcom, s->hits, s->mind, nullptr, nullptr);
@@ -770,8 +748,7 @@ int kmap_scan_run_packed_dev(kmap_scan *s, const uint32_t *codes_dev, const uint
     KMAP_TRY(kmap_scan_reserve_pos(s, total));
     if (total) {
         if (flat)
-            scan_reads_kernel<true><<<fgrid, ftpb, (size_t)stage_words * 8, st>>>(nib, n, borders_dev, n_seq, k, d_inv, radius, s->hits, s->mind, s->offs,
-                                                                                  s->pos, stage_words);
+            scan_reads_kernel<true><<<fgrid, FL_TPB, 0, st>>>(nib, n, borders_dev, n_seq, k, d_inv, radius, s->hits, s->mind, s->offs, s->pos, wmin);
         else
             scan_packed_kernel<true><<<grid, KMAP_WAVE * SC_WAVES, 0, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, c, rcc,
                                                                             radius, revcom, s->hits, s->mind, s->offs, s->pos);
