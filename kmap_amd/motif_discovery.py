@@ -116,9 +116,8 @@ class DeviceSeq:
         check(_ffi.lib().kmap_scan_run_packed_dev(self._scan, self.codes.ptr, self.inval_orig.ptr, self.n, self.borders.ptr,
                                                   self.n_seq, k, int(consensus_kh), int(radius), int(revcom), C.byref(tot), None))
         hits = np.empty(self.n_seq, np.int32)
-        mind = np.empty(self.n_seq, np.int8)
         pos = np.empty(tot.value, np.int32)
-        check(_ffi.lib().kmap_scan_fetch(self._scan, ptr(hits), ptr(mind), ptr(pos)))
+        check(_ffi.lib().kmap_scan_fetch(self._scan, ptr(hits), None, ptr(pos)))   # per-read minimum distances stay on the device
         return hits, pos
 
     def close(self):
