@@ -185,6 +185,20 @@ __device__ __forceinline__ float q_of(float dx, float dy) {
     q = fmaxf(q, 0.001f);                            // np.maximum(prob, 1e-3)       visualization.py:255
     return q;
 }
+// a / b exactly as hipcc's IEEE f32 division computes it (v_div_scale, v_rcp, 2 + 3 fma refinements, v_div_fmas, v_div_fixup)
+// for operands on which v_div_scale does not rescale and v_div_fixup passes the quotient through: finite, normal, quotient and
+// 1/b normal.  Both divisions of the SEQ path are of that kind (1/(1+d2) with d2 < 1e30; q/(1-q) with both in [1e-3, 0.999]),
+// which saves the three wrapper instructions per division.
+__device__ __forceinline__ float div_normal(float a, float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = a * r;
+    float m = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(m, r, q);
+    m = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(m, r, q);
+}
 __device__ __forceinline__ float t_of(float p, float q) {
     return (q / (1.0f - q)) * (p - q);               // visualization.py:132-134
 }
@@ -612,6 +626,7 @@ __global__ __launch_bounds__(KMAP_WAVE *SQ_WAVES) void forces_seq_kernel(ProbSrc
     const float xi = X[i], yi = Yy[i];
     const bool vec = ((n & 3) == 0) && (!LUTSRC || (src.ld % 8 == 0));
     const int n32 = (int)n, i32 = (int)i;        // n < 2^31 (checked by the host)
+    const int64_t wave_row_min = row0 + ((int64_t)blockIdx.x * SQ_WAVES + wave) * SQ_ROWS;   // smallest global row of the wave
     float gx = 0.0f, gy = 0.0f, ce_acc = 0.0f;
     double loss = 0.0;
     SeqBatch cur, nxt;
@@ -622,21 +637,51 @@ __global__ __launch_bounds__(KMAP_WAVE *SQ_WAVES) void forces_seq_kernel(ProbSrc
         float tx[SQ_CPL], ty[SQ_CPL];
         float ce2 = 0.0f;                                                    // loss terms in log2 units (order-free)
         const int jl32 = (int)jl;
+        // wave-uniform choices: (a) no column of the batch lies right of any of the wave's 16 rows -> no loss terms (each
+        // unordered pair is charged to its j > i side); (b) some squared distance is too large for div_normal -> generic division
+        const bool want_loss = (j0 + SQ_BATCH - 1) > wave_row_min;
+        float d2max = 0.0f;
 #pragma unroll
-        for (int c = 0; c < SQ_CPL; ++c) {                                   // 8 independent terms
-            const int j = jl32 + c;
-            const float p = LUTSRC ? lut_s[(cur.w[c >> 1] >> (16 * (c & 1))) & 0xFFFFu] : cur.pf[c];
+        for (int c = 0; c < SQ_CPL; ++c) {
             const float dx = xi - cur.x[c], dy = yi - cur.y[c];
-            const float q = q_of(dx, dy);
-            const float t = t_of(p, q);
-            const bool use = (j < n32) && (j != i32);
-            tx[c] = use ? t * dx : 0.0f;                                     // products rounded on their own (-ffp-contract=off)
-            ty[c] = use ? t * dy : 0.0f;
-            // -(p ln q + (1-p) ln(1-q)) = -ln2 (l1 + p (lq - l1)); the reference's eps branches change a term by
-            // < 1e-9 relative (p < 1e-10) or not at all (p = 1), and the loss is not part of the bit-pinned path
-            const float lq = __builtin_amdgcn_logf(q), l1 = __builtin_amdgcn_logf(1.0f - q);
-            const float e = l1 + p * (lq - l1);
-            ce2 += (j < n32 && j > i32) ? e : 0.0f;
+            d2max = fmaxf(d2max, dx * dx + dy * dy);
+        }
+        const bool slow = __any(!(d2max < 1e30f));
+        auto terms = [&](auto slow_tag, auto loss_tag) {
+            constexpr bool SLOW = decltype(slow_tag)::value, LOSS = decltype(loss_tag)::value;
+            float prod = 1.0f, esum = 0.0f;
+#pragma unroll
+            for (int c = 0; c < SQ_CPL; ++c) {                               // 8 independent terms
+                const int j = jl32 + c;
+                const float p = LUTSRC ? lut_s[(cur.w[c >> 1] >> (16 * (c & 1))) & 0xFFFFu] : cur.pf[c];
+                const float dx = xi - cur.x[c], dy = yi - cur.y[c];
+                const float d2 = dx * dx + dy * dy;                          // (dx*dx) + (dy*dy), no FMA (taichi_core.py:254)
+                float q = SLOW ? 1.0f / (1.0f + d2) : div_normal(1.0f, 1.0f + d2);          // :255
+                q = fminf(q, 0.999f);
+                q = fmaxf(q, 0.001f);
+                const float omq = 1.0f - q;
+                const float u = SLOW ? q / omq : div_normal(q, omq);         // visualization.py:132-134
+                const float t = u * (p - q);
+                const bool use = (j < n32) && (j != i32);
+                tx[c] = use ? t * dx : 0.0f;                                 // products rounded on their own (-ffp-contract=off)
+                ty[c] = use ? t * dy : 0.0f;
+                if (LOSS) {
+                    // -(p ln q + (1-p) ln(1-q)) = -ln2 (log2(1-q) + p log2(q/(1-q))): one log per pair + one log of the product
+                    // of the eight (1-q); the reference's eps branches change a term by < 1e-9 relative (p < 1e-10) or not at
+                    // all (p = 1), and the loss is not part of the bit-pinned path
+                    const bool live = (j < n32) && (j > i32);
+                    esum += live ? p * __builtin_amdgcn_logf(u) : 0.0f;
+                    prod *= live ? omq : 1.0f;
+                }
+            }
+            if (LOSS) ce2 = __builtin_amdgcn_logf(prod) + esum;
+        };
+        if (slow) {
+            if (want_loss) terms(std::true_type{}, std::true_type{});
+            else terms(std::true_type{}, std::false_type{});
+        } else {
+            if (want_loss) terms(std::false_type{}, std::true_type{});
+            else terms(std::false_type{}, std::false_type{});
         }
         ce_acc += ce2;
         // ordered accumulation over the batch's 32 columns: column j0 + 8*s2 + c lives in sub-lane s2, slot c

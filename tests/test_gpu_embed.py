@@ -257,3 +257,41 @@ def test_symmetric_fast_kernel_matches_seq_per_step(V):
         g, l = outs[tag]
         assert abs(l - ls) <= 2e-6 * abs(ls), (tag, l, ls)
         np.testing.assert_allclose(g, gs, rtol=0, atol=2e-5 * np.abs(gs).max())
+
+
+@pytest.mark.parametrize("scale", [1.0, 30.0, 1e3, 1e16])
+def test_seq_forces_bit_exact_vs_oracle(V, scale):
+    """SEQ forces == the oracle's restatement of the reference arithmetic (IEEE f32 division, j-ascending sums), bit for bit,
+    on random coordinates at several scales: coincident points, far points, and squared distances beyond 1e30 (the generic
+    division path; the wrapper-free division used elsewhere must not change a single bit)."""
+    from kmap_amd import _ffi
+    from oracle import oracle as O
+    rng = np.random.default_rng(int(scale) % 1000 + 3)
+    n = 701
+    P = rng.random((n, n), dtype=np.float32)
+    P = np.triu(P, 1)
+    P = (P + P.T).astype(np.float32)
+    P[rng.random((n, n)) < 0.05] = 1.0
+    P = np.maximum(P, P.T)
+    np.fill_diagonal(P, 0.0)
+    ld = (rng.standard_normal((2, n)) * scale).astype(np.float32)
+    ld[:, 5] = ld[:, 4]                                                # coincident points
+    ld[:, 17] = ld[:, 16] + np.float32(1e-4 * scale)
+    q = O.cal_ld_prob_mat(ld)
+    want = O.gradient_loss(P, q, ld) / np.float32(4.0)
+    p_d = _ffi.DeviceBuffer.from_numpy(P)
+    sess = V.EmbedSession(n, 10, 0.01, V.EMBED_SEQ)
+    try:
+        sess.set_prob_f32(p_d, n)
+        sess.set_coords(ld)
+        g_d, l_d = _ffi.DeviceBuffer(2 * n * 4), _ffi.DeviceBuffer(8)
+        g_d.zero()
+        sess.forces(g_d.ptr, l_d.ptr)
+        _ffi.sync()
+        got = g_d.to_numpy(np.float32, (2, n))
+        np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+        loss = l_d.to_numpy(np.float64, (1,))[0]
+        ref = float(O.cross_entropy(P, q))
+        assert abs(loss * 2 - ref) <= 3e-6 * abs(ref) or abs(loss - ref) <= 3e-6 * abs(ref)
+    finally:
+        sess.close()
