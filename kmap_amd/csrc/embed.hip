@@ -647,8 +647,10 @@ __global__ __launch_bounds__(KMAP_WAVE *SQ_WAVES) void forces_seq_kernel(ProbSrc
             d2max = fmaxf(d2max, dx * dx + dy * dy);
         }
         const bool slow = __any(!(d2max < 1e30f));
-        auto terms = [&](auto slow_tag, auto loss_tag) {
-            constexpr bool SLOW = decltype(slow_tag)::value, LOSS = decltype(loss_tag)::value;
+        // (c) the batch neither reaches past column n-1 nor contains the diagonal of any of the wave's rows -> no per-term masks
+        const bool plain = (j0 + SQ_BATCH <= n) && (j0 + SQ_BATCH - 1 < wave_row_min || j0 > wave_row_min + SQ_ROWS - 1);
+        auto terms = [&](auto slow_tag, auto loss_tag, auto mask_tag) {
+            constexpr bool SLOW = decltype(slow_tag)::value, LOSS = decltype(loss_tag)::value, MASK = decltype(mask_tag)::value;
             float prod = 1.0f, esum = 0.0f;
 #pragma unroll
             for (int c = 0; c < SQ_CPL; ++c) {                               // 8 independent terms
@@ -657,31 +659,31 @@ __global__ __launch_bounds__(KMAP_WAVE *SQ_WAVES) void forces_seq_kernel(ProbSrc
                 const float dx = xi - cur.x[c], dy = yi - cur.y[c];
                 const float d2 = dx * dx + dy * dy;                          // (dx*dx) + (dy*dy), no FMA (taichi_core.py:254)
                 float q = SLOW ? 1.0f / (1.0f + d2) : div_normal(1.0f, 1.0f + d2);          // :255
-                q = fminf(q, 0.999f);
-                q = fmaxf(q, 0.001f);
+                q = __builtin_amdgcn_fmed3f(q, 0.001f, 0.999f);              // np.minimum(.., 1 - 1e-3), np.maximum(.., 1e-3)
                 const float omq = 1.0f - q;
                 const float u = SLOW ? q / omq : div_normal(q, omq);         // visualization.py:132-134
                 const float t = u * (p - q);
-                const bool use = (j < n32) && (j != i32);
+                const bool use = !MASK || ((j < n32) && (j != i32));
                 tx[c] = use ? t * dx : 0.0f;                                 // products rounded on their own (-ffp-contract=off)
                 ty[c] = use ? t * dy : 0.0f;
                 if (LOSS) {
                     // -(p ln q + (1-p) ln(1-q)) = -ln2 (log2(1-q) + p log2(q/(1-q))): one log per pair + one log of the product
                     // of the eight (1-q); the reference's eps branches change a term by < 1e-9 relative (p < 1e-10) or not at
                     // all (p = 1), and the loss is not part of the bit-pinned path
-                    const bool live = (j < n32) && (j > i32);
+                    const bool live = !MASK || ((j < n32) && (j > i32));   // a plain batch with loss lies right of all 16 rows
                     esum += live ? p * __builtin_amdgcn_logf(u) : 0.0f;
                     prod *= live ? omq : 1.0f;
                 }
             }
             if (LOSS) ce2 = __builtin_amdgcn_logf(prod) + esum;
         };
-        if (slow) {
-            if (want_loss) terms(std::true_type{}, std::true_type{});
-            else terms(std::true_type{}, std::false_type{});
+        if (slow) {   // rare (coordinates beyond 1e15): one generic instantiation
+            terms(std::true_type{}, std::true_type{}, std::true_type{});
+        } else if (plain) {
+            if (want_loss) terms(std::false_type{}, std::true_type{}, std::false_type{});
+            else terms(std::false_type{}, std::false_type{}, std::false_type{});
         } else {
-            if (want_loss) terms(std::false_type{}, std::true_type{});
-            else terms(std::false_type{}, std::false_type{});
+            terms(std::false_type{}, std::true_type{}, std::true_type{});
         }
         ce_acc += ce2;
         // ordered accumulation over the batch's 32 columns: column j0 + 8*s2 + c lives in sub-lane s2, slot c
