@@ -154,3 +154,14 @@ def test_lut_expression_matches_matrix_expression(golden):
     p_mat = np.exp(-T / 0.5).astype("float32")
     sums = np.rint(S.astype(np.float64) * n_nb * n_nb).astype(np.int64)
     np.testing.assert_array_equal(hd_prob_lut(k, n_nb, n_nb * n_nb * k)[sums], p_mat)
+
+
+def test_hamdist_pitch_rule():
+    """kmap_hamdist_pitch (pure host code in the C-ABI library): 256-byte rows below one 4-KiB column block, then a multiple
+    of 4 KiB with an odd number of 4-KiB chunks per row (what the tiled Hamming kernel's XCD-affine chunk ownership needs)."""
+    from kmap_amd.hamdist import pitch_for
+    assert pitch_for(1) == 256 and pitch_for(300) == 512 and pitch_for(4095) == 4096
+    for n in (4096, 4097, 8192, 8193, 50_000, 65_536, 70_704, 100_000, 141_424, 200_000):
+        ld = pitch_for(n)
+        assert ld >= n and ld % 4096 == 0 and (ld // 4096) % 2 == 1 and ld - n < 2 * 4096
+    assert pitch_for(50_000) == 53_248
