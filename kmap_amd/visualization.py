@@ -349,11 +349,6 @@ def kmap(hamdist_mat: np.ndarray, kmer_len: int, n_neighbour=20, n_max_iter=2500
     return out
 
 
-def device_knn_indices_note():
-    return ("neighbour selection uses numpy.argpartition on the host for drop-in fidelity; its tie order is "
-            "numpy/ISA specific (SURVEY.md hard part 1)")
-
-
 def kmap_from_kmers(samp_kh, samp_cnts, samp_label, conseq_list, kmer_len, n_neighbour=20, n_max_iter=2500,
                     learning_rate=0.01, n_best_result=10, random_seed=None, debug=False, mode=None,
                     neighbor_inds_mat=None, trace=None):
