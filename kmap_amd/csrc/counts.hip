@@ -283,6 +283,11 @@ int ensure_bins(kmap_counts *c, size_t n_bins) {
 
 }  // namespace
 
+int kmap_counts_reserve_bins(kmap_counts *c, int k) {
+    KMAP_REQUIRE(k > 0 && k <= 16, "counts: direct histogram needs k <= 16 (k=%d)", k);
+    return ensure_bins(c, (size_t)1 << (2 * k));
+}
+
 int kmap_counts_prepare_bins(kmap_counts *c, int k, hipStream_t st) {
     KMAP_REQUIRE(k > 0 && k <= 16, "counts: direct histogram needs k <= 16 (k=%d)", k);
     const size_t n_bins = (size_t)1 << (2 * k);
@@ -332,6 +337,8 @@ namespace {
 template <typename H>
 int hist_hashes(kmap_counts *c, const H *hash_dev, int64_t n, int k, hipStream_t st) {
     const size_t n_bins = (size_t)1 << (2 * k);
+    if (sizeof(H) == 4 && kmap_counts_part_applies(k, n))
+        return kmap_counts_part_hist_u32(c, (const uint32_t *)hash_dev, n, k, st);
     KMAP_TRY(kmap_counts_prepare_bins(c, k, st));
     if (n > 0) {
         const size_t passes = (n_bins + HL_BINS - 1) / HL_BINS;

@@ -20,3 +20,7 @@ int kmap_counts_sort_path(kmap_counts *c, const uint64_t *hash_dev, int64_t n, i
 int kmap_counts_prepare_bins(kmap_counts *c, int k, hipStream_t st);
 int kmap_counts_finish_hist(kmap_counts *c, int k, int merge, int64_t *n_uniq, hipStream_t st);
 int kmap_counts_hist_hashes(kmap_counts *c, const void *hash_dev, int64_t n, int k, hipStream_t st);
+int kmap_counts_reserve_bins(kmap_counts *c, int k);   // allocation only (the partitioned histogram writes every bin)
+// 11 <= k <= 15, uint32 hashes: bucket-partitioned histogram without global atomics (counts_part.hip)
+bool kmap_counts_part_applies(int k, int64_t n);
+int kmap_counts_part_hist_u32(kmap_counts *c, const uint32_t *hash_dev, int64_t n, int k, hipStream_t st);

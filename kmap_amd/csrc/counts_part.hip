@@ -1,0 +1,186 @@
+// counts_part.hip -- partitioned histogram for 11 <= k <= 15 (uint32 hashes).
+//
+// A 4^k-bin table (16 MiB .. 4 GiB) does not fit LDS, and device-scope atomics into it run at ~20 G updates/s (74 ms for
+// 1.5e9 k-mers, random bins: every update is a read-modify-write of a DRAM sector).  Instead:
+//   (1) count the valid hashes per bucket (bucket = top 10 bits of the 2k-bit hash; 1024-bin LDS histogram per block);
+//   (2) exclusive scan -> bucket offsets; (3) counting-sort tiles of 32768 hashes into bucket order (LDS counts, one global
+//   fetch-add per non-empty bucket per tile, LDS cursors) -> a bucket-ordered key array (4 B per valid k-mer);
+//   (4) one block per (bucket, 32768-bin range): stream the bucket's keys, LDS histogram of the range, plain coalesced stores
+//   of the LDS bins into the table.  Every bin of the table is written exactly once (no memset, no global atomics).
+// The table then goes through the usual compaction / reverse-complement merge (counts.hip).
+#include <stdlib.h>
+
+#include "common.h"
+#include "counts_internal.h"
+#include "scan_util.h"
+
+namespace {
+constexpr int PB = 10, NBK = 1 << PB;
+constexpr int PT_TPB = 256, PT_PER = 128, PT_TILE = PT_TPB * PT_PER;   // 32768 hashes per tile
+constexpr int PH_TPB = 1024, PH_BINS = 32768;
+constexpr uint32_t INV32 = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(PT_TPB) void part_count_kernel(const uint32_t *__restrict__ h, int64_t n, int shift,
+                                                            uint32_t *__restrict__ gcount) {
+    __shared__ uint32_t cnt[NBK];
+    for (int b = threadIdx.x; b < NBK; b += PT_TPB) cnt[b] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * PT_TPB;
+    for (int64_t i = (int64_t)blockIdx.x * PT_TPB + threadIdx.x; i < n; i += stride) {
+        const uint32_t v = h[i];
+        if (v != INV32) atomicAdd(&cnt[v >> shift], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < NBK; b += PT_TPB)
+        if (cnt[b]) atomicAdd(&gcount[b], cnt[b]);
+}
+
+__global__ void part_init_cursor_kernel(const uint64_t *__restrict__ goff, unsigned long long *__restrict__ cursor) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < NBK) cursor[b] = goff[b];
+}
+
+// Counting sort of one 32768-hash tile per block iteration, staged in LDS so that every bucket's run leaves the CU as
+// consecutive addresses (scattering single dwords straight to the buckets left partially written lines to be evicted from
+// L2: 27 ms for 1.5e9 hashes against 6 GB of output).  LDS: sorted tile 128 KiB + offsets 4 KiB + global bases 8 KiB.
+constexpr int PS_TPB = 1024, PS_PER = PT_TILE / PS_TPB;   // 32 hashes per thread
+__global__ __launch_bounds__(PS_TPB) void part_scatter_kernel(const uint32_t *__restrict__ h, int64_t n, int shift,
+                                                              unsigned long long *__restrict__ cursor, uint32_t *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sorted[];      // PT_TILE entries
+    __shared__ uint32_t cnt[NBK];                                           // counts -> exclusive offsets -> running cursors
+    __shared__ uint32_t loff[NBK];                                          // exclusive offsets of the buckets inside the tile
+    __shared__ unsigned long long base[NBK];
+    __shared__ uint32_t wsum[PS_TPB / 64];
+    const int64_t n_tiles = (n + PT_TILE - 1) / PT_TILE;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t t0 = tile * PT_TILE;
+        cnt[threadIdx.x] = 0;                                               // NBK == PS_TPB
+        __syncthreads();
+        uint32_t v[PS_PER];
+#pragma unroll
+        for (int j = 0; j < PS_PER; ++j) {
+            const int64_t i = t0 + (int64_t)j * PS_TPB + threadIdx.x;
+            v[j] = (i < n) ? h[i] : INV32;
+            if (v[j] != INV32) atomicAdd(&cnt[v[j] >> shift], 1u);
+        }
+        __syncthreads();
+        // exclusive scan of the 1024 counts (one per thread): wave scan + wave sums
+        const uint32_t c = cnt[threadIdx.x];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        uint32_t inc = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const uint32_t excl = woff + inc - c;
+        __syncthreads();
+        loff[threadIdx.x] = excl;
+        cnt[threadIdx.x] = excl;                                            // running cursor of the bucket inside the tile
+        base[threadIdx.x] = c ? atomicAdd(&cursor[threadIdx.x], (unsigned long long)c) : 0ull;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PS_PER; ++j)
+            if (v[j] != INV32) sorted[atomicAdd(&cnt[v[j] >> shift], 1u)] = v[j];
+        __syncthreads();
+        const uint32_t n_valid = cnt[NBK - 1];                              // the last bucket's cursor ended at the tile's valid count
+        for (uint32_t p = threadIdx.x; p < n_valid; p += PS_TPB) {
+            const uint32_t key = sorted[p];
+            const uint32_t b = key >> shift;
+            out[base[b] + (p - loff[b])] = key;                             // consecutive p of a bucket -> consecutive addresses
+        }
+        __syncthreads();
+    }
+}
+
+// block = (bucket, bin range): LDS histogram of the bucket's keys restricted to the range, then plain stores into the table
+__global__ __launch_bounds__(PH_TPB) void part_hist_kernel(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ goff,
+                                                           uint32_t bins_per_bucket, int passes, uint32_t sub,
+                                                           uint32_t *__restrict__ table) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lb[];
+    const uint32_t bucket = blockIdx.x / passes, p = blockIdx.x % passes;
+    for (uint32_t j = threadIdx.x; j < sub; j += PH_TPB) lb[j] = 0;
+    __syncthreads();
+    const uint64_t lo = goff[bucket], hi = goff[bucket + 1];
+    const uint32_t low = bins_per_bucket - 1u, r0 = p * sub;
+    // 16-byte loads over the 4-key-aligned interior of [lo, hi), scalar head and tail
+    const uint64_t lo4 = (lo + 3) & ~(uint64_t)3, hi4 = hi & ~(uint64_t)3;
+    if (lo4 < hi4) {
+        for (uint64_t i = lo + threadIdx.x; i < lo4; i += PH_TPB) {
+            const uint32_t a = (keys[i] & low) - r0;
+            if (a < sub) atomicAdd(&lb[a], 1u);
+        }
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys);
+        for (uint64_t q = (lo4 >> 2) + threadIdx.x; q < (hi4 >> 2); q += PH_TPB) {
+            const u32x4 kv = k4[q];
+            const uint32_t a0 = (kv.x & low) - r0, a1 = (kv.y & low) - r0, a2 = (kv.z & low) - r0, a3 = (kv.w & low) - r0;
+            if (a0 < sub) atomicAdd(&lb[a0], 1u);
+            if (a1 < sub) atomicAdd(&lb[a1], 1u);
+            if (a2 < sub) atomicAdd(&lb[a2], 1u);
+            if (a3 < sub) atomicAdd(&lb[a3], 1u);
+        }
+        for (uint64_t i = hi4 + threadIdx.x; i < hi; i += PH_TPB) {
+            const uint32_t a = (keys[i] & low) - r0;
+            if (a < sub) atomicAdd(&lb[a], 1u);
+        }
+    } else {
+        for (uint64_t i = lo + threadIdx.x; i < hi; i += PH_TPB) {
+            const uint32_t a = (keys[i] & low) - r0;
+            if (a < sub) atomicAdd(&lb[a], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t *dst = table + (size_t)bucket * bins_per_bucket + r0;
+    for (uint32_t j = threadIdx.x; j < sub; j += PH_TPB) dst[j] = lb[j];
+}
+}  // namespace
+
+bool kmap_counts_part_applies(int k, int64_t n) {
+    static const int on = [] { const char *e = getenv("KMAP_COUNT_PART"); return e ? atoi(e) : 1; }();
+    return on && k >= 11 && k <= 15 && n >= ((int64_t)1 << 20);
+}
+
+// bins of c <- histogram of the valid (!= 0xFFFFFFFF) hashes; the whole table is written (no prior memset needed)
+int kmap_counts_part_hist_u32(kmap_counts *c, const uint32_t *hash_dev, int64_t n, int k, hipStream_t st) {
+    const size_t n_bins = (size_t)1 << (2 * k);
+    KMAP_TRY(kmap_counts_reserve_bins(c, k));
+    const int shift = 2 * k - PB;
+    uint32_t *gcount = nullptr, *keys = nullptr;
+    uint64_t *goff = nullptr;
+    unsigned long long *cursor = nullptr;
+    void *small = nullptr;
+    KMAP_TRY(kmap_scratch(&small, (size_t)NBK * 4 + ((size_t)NBK + 1) * 8 + (size_t)NBK * 8, st, KMAP_SLOT_A));
+    goff = reinterpret_cast<uint64_t *>(small);                       // 8-byte aligned parts first
+    cursor = reinterpret_cast<unsigned long long *>(goff + NBK + 1);
+    gcount = reinterpret_cast<uint32_t *>(cursor + NBK);
+    KMAP_TRY(kmap_scratch((void **)&keys, (size_t)n * 4, st, KMAP_SLOT_PART));
+    KMAP_CHECK_HIP(hipMemsetAsync(gcount, 0, (size_t)NBK * 4, st));
+    int64_t g = (n + PT_TPB - 1) / PT_TPB;
+    if (g > 2048) g = 2048;
+    part_count_kernel<<<(unsigned)g, PT_TPB, 0, st>>>(hash_dev, n, shift, gcount);
+    KMAP_TRY(exclusive_scan_u32(gcount, NBK, goff, st));              // goff[NBK] = number of valid hashes
+    part_init_cursor_kernel<<<NBK / 256, 256, 0, st>>>(goff, cursor);
+    int64_t tiles = (n + PT_TILE - 1) / PT_TILE;
+    if (tiles > 1024) tiles = 1024;
+    static bool sc_attr = false;
+    if (!sc_attr) {
+        KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)part_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PT_TILE * 4));
+        sc_attr = true;
+    }
+    part_scatter_kernel<<<(unsigned)tiles, PS_TPB, (size_t)PT_TILE * 4, st>>>(hash_dev, n, shift, cursor, keys);
+    const uint32_t bins_per_bucket = (uint32_t)(n_bins >> PB);
+    const uint32_t sub = bins_per_bucket < (uint32_t)PH_BINS ? bins_per_bucket : (uint32_t)PH_BINS;
+    const int passes = (int)(bins_per_bucket / sub);
+    static bool attr_set = false;
+    if (!attr_set) {
+        KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)part_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PH_BINS * 4));
+        attr_set = true;
+    }
+    part_hist_kernel<<<(unsigned)(NBK * passes), PH_TPB, (size_t)sub * 4, st>>>(keys, goff, bins_per_bucket, passes, sub, c->bins);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}

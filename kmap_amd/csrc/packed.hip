@@ -610,6 +610,13 @@ int kmap_counts_hist_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const
         else KMAP_TRY(kmap_dedupe_per_read_u64_dev((uint64_t *)hash, n, borders_dev, n_seq, stream));
         return kmap_counts_hist_hashes(c, hash, n, k, st);
     }
+    if (k < 16 && kmap_counts_part_applies(k, n)) {
+        // 11 <= k <= 15: materialise the hashes once (4 B/position) and take the bucket-partitioned histogram
+        void *hash = nullptr;
+        KMAP_TRY(kmap_scratch(&hash, (size_t)n * 4, st, KMAP_SLOT_HASH));
+        KMAP_TRY(kmap_hash_kmers_packed_dev(codes_dev, inval_dev, n, k, hash, stream));
+        return kmap_counts_part_hist_u32(c, (const uint32_t *)hash, n, k, st);
+    }
     KMAP_TRY(kmap_counts_prepare_bins(c, k, st));
     if (n > 0) {
         const size_t n_bins = (size_t)1 << (2 * k);
