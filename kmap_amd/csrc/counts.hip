@@ -85,6 +85,10 @@ __device__ __forceinline__ bool bin_entry(const uint32_t *__restrict__ bins, uin
     cnt = c;
     if (!merge) return true;
     const uint64_t r = rc_bits(x, k);
+    if (merge == 2) {   // table already merged in place by rc_merge_tiles_kernel: a surviving x > rc(x) had no partner
+        key = (x > r) ? r : x;
+        return true;
+    }
     if (r == x) {   // palindrome: its own partner, the reference adds the count to itself
         cnt = c + c;
         return true;
@@ -94,6 +98,67 @@ __device__ __forceinline__ bool bin_entry(const uint32_t *__restrict__ bins, uin
     key = (x > r) ? r : x;               // partner absent and x > rc(x): replaced in place, not re-sorted
     cnt = c + cr;
     return true;
+}
+
+// ---- reverse-complement merge of the whole table as a tiled transpose (k >= 11) ------------------------------------------
+// bin_entry's partner lookup is one random 4-byte read per non-empty bin (22 G/s: 6.7 + 7.8 ms per compaction at k = 14).
+// Split x into (a, m, b) with a / b the top / bottom three bases: rc(x) = (rc3(b), rc(m), rc3(a)), so the 64 x 64 entries
+// that share m pair up with the 64 x 64 entries that share rc(m), transposed.  One block loads both tiles (64 rows of 256
+// contiguous bytes each), merges them through LDS and writes both back in place: bins[x] becomes the merged count of a
+// kept entry, 0 for a deleted or empty one.  The compaction then runs without any gather (merge mode 2).
+__device__ __forceinline__ uint32_t rc3(uint32_t v) {   // reverse complement of a 3-base group (6 bits)
+    v = 63u - v;
+    return ((v & 3u) << 4) | (v & 12u) | (v >> 4);
+}
+__global__ __launch_bounds__(BLK) void rc_merge_tiles_kernel(uint32_t *__restrict__ bins, int k) {
+    __shared__ uint32_t A[64][65], B[64][65];
+    const int mg = k - 6;                                     // middle groups (k >= 7)
+    const uint64_t m = blockIdx.x;
+    const uint64_t m2 = revcom_hash(m, mg);
+    if (m > m2) return;                                      // the pair is handled by the block of the smaller middle
+    const bool self = (m == m2);
+    const uint64_t row_stride = (uint64_t)1 << (2 * (k - 3));
+    // 256 threads: 16 lanes x 16 B cover one 256-byte row; 16 rows per step
+    const int lr = threadIdx.x >> 4, lc = (threadIdx.x & 15) * 4;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int a = s * 16 + lr;
+        const u32x4 va = *reinterpret_cast<const u32x4 *>(bins + (uint64_t)a * row_stride + (m << 6) + lc);
+        A[a][lc] = va.x; A[a][lc + 1] = va.y; A[a][lc + 2] = va.z; A[a][lc + 3] = va.w;
+        if (!self) {
+            const u32x4 vb = *reinterpret_cast<const u32x4 *>(bins + (uint64_t)a * row_stride + (m2 << 6) + lc);
+            B[a][lc] = vb.x; B[a][lc + 1] = vb.y; B[a][lc + 2] = vb.z; B[a][lc + 3] = vb.w;
+        }
+    }
+    __syncthreads();
+    // entry (a, mm, b) against its partner (rc3(b), mo, rc3(a)): compare the tuples lexicographically
+    auto merged = [&](uint32_t (&own)[64][65], uint32_t (&oth)[64][65], uint64_t mm, uint64_t mo, int a, int b) -> uint32_t {
+        const uint32_t c = own[a][b];
+        if (c == 0) return 0u;
+        const uint32_t pa = rc3((uint32_t)b), pb = rc3((uint32_t)a);
+        const bool eq = ((uint32_t)a == pa) && (mm == mo) && ((uint32_t)b == pb);
+        if (eq) return c + c;                                // palindrome: its own partner
+        const bool greater = ((uint32_t)a != pa) ? ((uint32_t)a > pa) : (mm != mo) ? (mm > mo) : ((uint32_t)b > pb);
+        const uint32_t cr = oth[pa][pb];
+        return (cr > 0 && greater) ? 0u : c + cr;            // higher member of a present pair is deleted
+    };
+    uint32_t ra[4][4], rb[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int a = s * 16 + lr, b = lc + j;
+            ra[s][j] = self ? merged(A, A, m, m, a, b) : merged(A, B, m, m2, a, b);
+            rb[s][j] = self ? 0u : merged(B, A, m2, m, a, b);
+        }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int a = s * 16 + lr;
+        *reinterpret_cast<u32x4 *>(bins + (uint64_t)a * row_stride + (m << 6) + lc) = u32x4{ra[s][0], ra[s][1], ra[s][2], ra[s][3]};
+        if (!self)
+            *reinterpret_cast<u32x4 *>(bins + (uint64_t)a * row_stride + (m2 << 6) + lc) = u32x4{rb[s][0], rb[s][1], rb[s][2], rb[s][3]};
+    }
 }
 
 __global__ __launch_bounds__(BLK) void compact_count_kernel(const uint32_t *__restrict__ bins, uint64_t n_bins, int k,
@@ -304,6 +369,11 @@ int kmap_counts_finish_hist(kmap_counts *c, int k, int merge, int64_t *n_uniq, h
     uint64_t *boff = nullptr;
     KMAP_TRY(kmap_scratch((void **)&bc, (size_t)nb * 4, st, KMAP_SLOT_A));
     KMAP_TRY(kmap_scratch((void **)&boff, ((size_t)nb + 1) * 8, st, KMAP_SLOT_B));
+    static const int tiles_on = [] { const char *e = getenv("KMAP_COUNT_RCTILES"); return e ? atoi(e) : 1; }();
+    if (merge == 1 && k >= 11 && tiles_on) {   // merge the table in place first; the compaction then needs no partner gathers
+        rc_merge_tiles_kernel<<<(unsigned)((size_t)1 << (2 * (k - 6))), BLK, 0, st>>>(c->bins, k);
+        merge = 2;
+    }
     compact_count_kernel<<<nb, BLK, 0, st>>>(c->bins, n_bins, k, merge, bc);
     KMAP_TRY(exclusive_scan_u32(bc, nb, boff, st));
     uint64_t total = 0;
