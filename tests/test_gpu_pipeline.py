@@ -252,3 +252,49 @@ def test_sample_disp_kmer_device_path(run_dir, golden, motif_defs, monkeypatch):
             np.testing.assert_array_equal(a, b)
             assert a.dtype == b.dtype
         assert outs[0][2].max() == len(cons_list) and int(outs[0][1].sum()) == 4000
+
+
+def test_genome_like_input_vs_oracle(motif_defs):
+    """A few very long records (chromosome-like, with N runs and low-complexity stretches) among short reads: counting with
+    and without per-read dedupe (LDS tables for k <= 10, partitioned histogram + tiled merge for k = 11..15, device atomics
+    at k = 16, global hash set for the long reads' dedupe), masking, and the occurrence scan (whole-wave walk of long reads)
+    all agree with the oracle."""
+    from kmap_amd.kmer_count import DeviceCounts, kmer2hash
+    from kmap_amd.motif_discovery import DeviceSeq
+    from oracle import oracle as O
+    import ctypes as C
+    rng = np.random.default_rng(2024)
+    lens = [150_000, 60_000, 20_001, 7] + list(rng.integers(30, 400, size=4000))
+    parts, borders, st = [], [], 0
+    for L in lens:
+        rd = rng.integers(0, 4, size=L).astype(np.uint8)
+        if L > 10_000:
+            rd[L // 3:L // 3 + 5000] = 255                                 # an N run
+            rd[L // 2:L // 2 + 3000] = np.tile(np.array([0, 1, 0, 3], np.uint8), 750)   # tandem repeat: many duplicates
+            rd[100:2100] = 0                                               # poly-A
+        parts += [rd, np.array([255], np.uint8)]
+        borders.append((st, st + L))
+        st += L + 1
+    seq, borders = np.concatenate(parts), np.array(borders, np.int64)
+    ds = DeviceSeq(seq, borders)
+    dc = DeviceCounts()
+    for k in (8, 12, 14, 16):
+        for dedupe in (True, False):
+            ds.count(dc, k, dedupe=dedupe, merge_revcom=True)
+            u, c = dc.fetch()
+            ou, oc = O.count_kmers(seq, borders, k, rep_mode=not dedupe, revcom_mode=True)
+            np.testing.assert_array_equal(u, ou)
+            np.testing.assert_array_equal(c, oc)
+    cons = int(kmer2hash("ACATACATACAT"))
+    ds.mask(12, np.array([cons]), np.array([2]))
+    np.testing.assert_array_equal(ds.download(), O.mask_input(seq.copy(), 12, np.array([cons], np.uint64), np.array([2])))
+    hits, pos = ds.scan(12, cons, 2, True)                                 # scans the ORIGINAL (unmasked) reads
+    buf, md, off = np.empty(400_000, np.int32), C.c_int(0), 0
+    for i, (a, b) in enumerate(borders):
+        m = O.lib().ko_scan_read(np.ascontiguousarray(seq[a:b]), b - a, 12, cons, 2, 1, buf, C.byref(md))
+        assert hits[i] == m, (i, b - a, hits[i], m)
+        np.testing.assert_array_equal(pos[off:off + m], buf[:m])
+        off += m
+    assert off == len(pos) and hits[0] > 100
+    dc.close()
+    ds.close()
