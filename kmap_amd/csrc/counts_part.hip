@@ -44,6 +44,7 @@ __global__ void part_init_cursor_kernel(const uint64_t *__restrict__ goff, unsig
 // consecutive addresses (scattering single dwords straight to the buckets left partially written lines to be evicted from
 // L2: 27 ms for 1.5e9 hashes against 6 GB of output).  LDS: sorted tile 128 KiB + offsets 4 KiB + global bases 8 KiB.
 constexpr int PS_TPB = 1024, PS_PER = PT_TILE / PS_TPB;   // 32 hashes per thread
+static_assert(PS_TPB == NBK, "one thread per bucket in the scan / reservation steps");
 __global__ __launch_bounds__(PS_TPB) void part_scatter_kernel(const uint32_t *__restrict__ h, int64_t n, int shift,
                                                               unsigned long long *__restrict__ cursor, uint32_t *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sorted[];      // PT_TILE entries
