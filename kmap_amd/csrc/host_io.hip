@@ -3,9 +3,11 @@
 #include <zlib.h>
 #include <stdio.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -41,19 +43,40 @@ extern "C" int kmap_write_occurrence_csv(const char *path, const char *header, i
     const int64_t n_chunks = std::max<int64_t>(1, std::min<int64_t>((n_seq + 65535) / 65536, 4096));
     const int64_t per = (n_seq + n_chunks - 1) / n_chunks;
     std::vector<std::vector<int64_t>> start((size_t)n_chunks, std::vector<int64_t>((size_t)n_cons, 0));
-    {
+    {   // per-chunk hit sums in parallel, then a serial prefix over the (few thousand) chunks
+        std::atomic<int64_t> nx{0};
+        auto sum_worker = [&]() {
+            for (;;) {
+                const int64_t ch = nx.fetch_add(1);
+                if (ch >= n_chunks) return;
+                const int64_t lo = ch * per, hi = std::min(n_seq, lo + per);
+                for (int c = 0; c < n_cons; ++c) {
+                    int64_t s2 = 0;
+                    for (int64_t i = lo; i < hi; ++i) s2 += hits[c][i];
+                    start[(size_t)ch][(size_t)c] = s2;
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; ++t) pool.emplace_back(sum_worker);
+        for (auto &t : pool) t.join();
         std::vector<int64_t> cur((size_t)n_cons, 0);
-        for (int64_t ch = 0; ch < n_chunks; ++ch) {
-            start[(size_t)ch] = cur;
-            const int64_t lo = ch * per, hi = std::min(n_seq, lo + per);
+        for (int64_t ch = 0; ch < n_chunks; ++ch)
             for (int c = 0; c < n_cons; ++c) {
-                int64_t s2 = 0;
-                for (int64_t i = lo; i < hi; ++i) s2 += hits[c][i];
+                const int64_t s2 = start[(size_t)ch][(size_t)c];
+                start[(size_t)ch][(size_t)c] = cur[(size_t)c];
                 cur[(size_t)c] += s2;
             }
-        }
     }
-    std::vector<std::vector<char>> bufs((size_t)n_chunks);
+    // uninitialised buffers: a vector<char>::resize would zero-fill (and page-fault) every byte before it is formatted over
+    struct Chunk {
+        std::unique_ptr<char[]> mem;
+        size_t len = 0;
+        char *data() const { return mem.get(); }
+        size_t size() const { return len; }
+        bool empty() const { return len == 0; }
+    };
+    std::vector<Chunk> bufs((size_t)n_chunks);
     std::vector<int64_t> rows_of((size_t)n_chunks, 0);
     std::atomic<int64_t> next{0};
     auto worker = [&]() {
@@ -62,14 +85,14 @@ extern "C" int kmap_write_occurrence_csv(const char *path, const char *header, i
             if (ch >= n_chunks) return;
             const int64_t lo = ch * per, hi = std::min(n_seq, lo + per);
             std::vector<int64_t> cursor = start[(size_t)ch];
-            std::vector<char> &buf = bufs[(size_t)ch];
+            Chunk &buf = bufs[(size_t)ch];
             size_t need = 0;
             for (int64_t i = lo; i < hi; ++i) {
                 size_t r = 48;
                 for (int c = 0; c < n_cons; ++c) r += 12 * (size_t)hits[c][i] + 2;
                 need += r;
             }
-            buf.resize(need + 64);
+            buf.mem.reset(new char[need + 64]);
             char *p = buf.data();
             int64_t rows = 0;
             for (int64_t i = lo; i < hi; ++i) {
@@ -92,7 +115,7 @@ extern "C" int kmap_write_occurrence_csv(const char *path, const char *header, i
                 }
                 for (int c = 0; c < n_cons; ++c) cursor[(size_t)c] += hits[c][i];
             }
-            buf.resize((size_t)(p - buf.data()));
+            buf.len = (size_t)(p - buf.data());
             rows_of[(size_t)ch] = rows;
         }
     };
@@ -101,14 +124,46 @@ extern "C" int kmap_write_occurrence_csv(const char *path, const char *header, i
         for (int t = 0; t < n_threads; ++t) pool.emplace_back(worker);
         for (auto &t : pool) t.join();
     }
+    // the chunks go to their final offsets with parallel pwrite()s (one memcpy into the page cache per thread instead of
+    // one serial stream: 185 MB per file at C3)
     int64_t rows = 0;
+    fflush(fh);
+    const int fd = fileno(fh);
+    std::vector<int64_t> off((size_t)n_chunks + 1, 0);
+    off[0] = (int64_t)ftello(fh);
     for (int64_t ch = 0; ch < n_chunks; ++ch) {
-        if (!bufs[(size_t)ch].empty()) fwrite(bufs[(size_t)ch].data(), 1, bufs[(size_t)ch].size(), fh);
+        off[(size_t)ch + 1] = off[(size_t)ch] + (int64_t)bufs[(size_t)ch].size();
         rows += rows_of[(size_t)ch];
+    }
+    std::atomic<bool> write_ok{true};
+    {
+        std::atomic<int64_t> nx{0};
+        auto write_worker = [&]() {
+            for (;;) {
+                const int64_t ch = nx.fetch_add(1);
+                if (ch >= n_chunks) return;
+                const char *src = bufs[(size_t)ch].data();
+                size_t left = bufs[(size_t)ch].size();
+                int64_t at = off[(size_t)ch];
+                while (left) {
+                    const ssize_t w = pwrite(fd, src, left, (off_t)at);
+                    if (w <= 0) {
+                        write_ok = false;
+                        return;
+                    }
+                    src += w;
+                    at += w;
+                    left -= (size_t)w;
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 0; t < std::min(n_threads, 16); ++t) pool.emplace_back(write_worker);
+        for (auto &t : pool) t.join();
     }
     const int rc = fclose(fh);
     if (rows_written) *rows_written = rows;
-    if (rc != 0) {
+    if (rc != 0 || !write_ok) {
         kmap_set_error("write_occurrence_csv: write to %s failed", path);
         return KMAP_E_INVAL;
     }
