@@ -202,7 +202,14 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
                     pickle.dump(obj, fh, protocol=proto)
             if big:   # multi-GB pickle: write it while the trials run on the GPU
                 import threading
-                writer = threading.Thread(target=_dump)
+                writer_err = []
+
+                def _dump_bg():
+                    try:
+                        _dump()
+                    except BaseException as e:   # noqa: BLE001 -- re-raised on the caller's thread at join time
+                        writer_err.append(e)
+                writer = threading.Thread(target=_dump_bg)
                 writer.start()
             else:
                 _dump()
@@ -244,6 +251,8 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
             uniq_kh_arr, uniq_kh_cnt_arr = None, None
         if writer is not None:
             writer.join()
+            if writer_err:
+                raise writer_err[0]
         if own:
             seq_np_arr[:] = dev_seq.download()   # the reference mutates its argument
         return res
