@@ -120,6 +120,20 @@ def test_find_motif_device_topk_path(run_dir, golden, motif_defs, monkeypatch):
     assert list(outs[0].keys()) == list(outs[1].keys()) and len(outs[0]) >= 1
     for kh in outs[0]:
         assert outs[0][kh] == outs[1][kh]
+    # the large-table path writes k{k}.pkl from a background thread (protocol 5) while the trials run: same content
+    pkl = run_dir.parent / "bg_k11.pkl"
+    if pkl.exists():
+        pkl.unlink()
+    d = motif_defs[11]
+    r = MD.find_motif(s["seq"].copy(), 11, d.max_ham_dist, d.p_uniform, d.ratio_mu, d.ratio_std, d.ratio_cutoff,
+                      save_kmer_cnt_flag=True, kmer_cnt_pkl_file=pkl, boarder_pkl_file=bpk)
+    assert list(r.keys()) == list(outs[0].keys())
+    with open(pkl, "rb") as fh:
+        kk, u, c = pickle.load(fh)
+    assert kk == 11
+    np.testing.assert_array_equal(u, s["k11_uniq"])
+    np.testing.assert_array_equal(c, s["k11_cnt"])
+    assert u.dtype == s["k11_uniq"].dtype and c.dtype == s["k11_cnt"].dtype
 
 
 def test_occurrence_scan_vs_oracle_with_subsample(motif_defs):
