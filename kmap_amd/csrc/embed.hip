@@ -107,6 +107,130 @@ __global__ __launch_bounds__(KNN_TPB) void knn_sums_kernel(const uint8_t *__rest
     }
 }
 
+// R output rows per block: the transposed neighbour table (n x n_nb indices) is the dominant traffic of the one-row kernel
+// above -- it is re-read for every output row (N x 4 MB = 200 GB at N = 50 k) -- so R rows share one pass over it.  The R
+// neighbour-sum rows live in LDS as uint8 when n_nb * max(D) <= 255 (k <= 12 with 20 neighbours; 50 KB per row at N = 50 k),
+// else uint16, and the indices are uint16 when n <= 65536.
+template <typename IT>
+__global__ void transpose_nb_t_kernel(const int32_t *__restrict__ nb, int64_t n, int n_nb, IT *__restrict__ nbT) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * n_nb) return;
+    nbT[(t % n_nb) * n + t / n_nb] = (IT)nb[t];
+}
+__global__ __launch_bounds__(256) void max_u8_kernel(const uint8_t *__restrict__ D, int64_t ldd, int64_t n, uint32_t *__restrict__ out) {
+    uint32_t m = 0;
+    const int64_t total16 = n * (ldd / 16);
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total16; q += (int64_t)gridDim.x * 256) {
+        const int64_t r = q / (ldd / 16), c = (q % (ldd / 16)) * 16;
+        if (c >= n) continue;                                      // pitch padding is not part of the matrix
+        const u32x4 w = *reinterpret_cast<const u32x4 *>(D + r * ldd + c);
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+                if (c + 4 * d + f < n) m = max(m, (ws[d] >> (8 * f)) & 0xFFu);
+    }
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_down(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+template <int R, typename MT, typename IT>
+__global__ __launch_bounds__(KNN_TPB) void knn_sums_rows_kernel(const uint8_t *__restrict__ D, int64_t ldd,
+                                                                 const int32_t *__restrict__ nb, const IT *__restrict__ nbT,
+                                                                 int64_t n, int n_nb, int64_t row0, int64_t nrows,
+                                                                 uint16_t *__restrict__ T, int64_t ldt, int64_t mpitch) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t Mraw[];
+    MT *Ms = reinterpret_cast<MT *>(Mraw);
+    const int tid = threadIdx.x;
+    const int64_t n_groups = (nrows + R - 1) / R;
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        // ---- step 1: Ms[r][b] = sum_a D[nb[i_r][a], b] ----
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t lr = grp * R + r;
+            if (lr >= nrows) break;
+            const int64_t i = row0 + lr;
+            MT *Mr = Ms + (int64_t)r * mpitch;
+            for (int64_t b = (int64_t)tid * 16; b < n; b += (int64_t)KNN_TPB * 16) {
+                uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};   // 16-bit fields: bytes 0,2 / 1,3 of each dword
+                if (b + 16 <= n) {
+                    for (int a = 0; a < n_nb; ++a) {
+                        const int64_t rr = nb[i * n_nb + a];   // block-uniform -> scalar load
+                        const u32x4 w = *reinterpret_cast<const u32x4 *>(D + rr * ldd + b);
+                        lo[0] += w.x & 0x00FF00FFu; hi[0] += (w.x >> 8) & 0x00FF00FFu;
+                        lo[1] += w.y & 0x00FF00FFu; hi[1] += (w.y >> 8) & 0x00FF00FFu;
+                        lo[2] += w.z & 0x00FF00FFu; hi[2] += (w.z >> 8) & 0x00FF00FFu;
+                        lo[3] += w.w & 0x00FF00FFu; hi[3] += (w.w >> 8) & 0x00FF00FFu;
+                    }
+                } else {   // ragged right edge: byte loads
+                    for (int a = 0; a < n_nb; ++a) {
+                        const int64_t rr = nb[i * n_nb + a];
+                        for (int c = 0; c < 16 && b + c < n; ++c) {
+                            const uint32_t v = D[rr * ldd + b + c];
+                            const int d = c >> 2, f = c & 3;
+                            if (f & 1) hi[d] += v << (8 * (f & 2));
+                            else lo[d] += v << (8 * (f & 2));
+                        }
+                    }
+                }
+                if constexpr (sizeof(MT) == 1) {   // sums fit a byte: bytes 0,2 from lo, bytes 1,3 from hi
+                    u32x4 o;
+                    o.x = (lo[0] & 0x00FF00FFu) | ((hi[0] & 0x00FF00FFu) << 8);
+                    o.y = (lo[1] & 0x00FF00FFu) | ((hi[1] & 0x00FF00FFu) << 8);
+                    o.z = (lo[2] & 0x00FF00FFu) | ((hi[2] & 0x00FF00FFu) << 8);
+                    o.w = (lo[3] & 0x00FF00FFu) | ((hi[3] & 0x00FF00FFu) << 8);
+                    *reinterpret_cast<u32x4 *>(Mr + b) = o;
+                } else {
+                    uint32_t o[8];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        o[2 * d] = (lo[d] & 0xFFFFu) | (hi[d] << 16);
+                        o[2 * d + 1] = (lo[d] >> 16) | (hi[d] & 0xFFFF0000u);
+                    }
+                    u32x4 *dst = reinterpret_cast<u32x4 *>(Mr + b);
+                    dst[0] = u32x4{o[0], o[1], o[2], o[3]};
+                    dst[1] = u32x4{o[4], o[5], o[6], o[7]};
+                }
+            }
+        }
+        __syncthreads();
+        // ---- step 2: T[i_r, j] = sum_{b in nb[j]} Ms[r][b], one pass over the neighbour table for all R rows ----
+        for (int64_t j = tid; j < n; j += KNN_TPB) {
+            uint32_t sacc[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) sacc[r] = 0;
+            for (int a = 0; a < n_nb; ++a) {
+                const int64_t b = (int64_t)nbT[(int64_t)a * n + j];
+#pragma unroll
+                for (int r = 0; r < R; ++r) sacc[r] += Ms[(int64_t)r * mpitch + b];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t lr = grp * R + r;
+                if (lr < nrows) T[lr * ldt + j] = (j == row0 + lr) ? (uint16_t)0 : (uint16_t)sacc[r];   // diagonal forced to 0
+            }
+        }
+        __syncthreads();
+    }
+}
+template <int R, typename MT, typename IT>
+int launch_knn_rows(const uint8_t *D_dev, int64_t ldd, const int32_t *nb_dev, const IT *nbT, int64_t n, int n_nb, int64_t row0,
+                    int64_t nrows, uint16_t *sums_dev, int64_t lds, int64_t mpitch, hipStream_t st) {
+    const size_t bytes = (size_t)R * mpitch * sizeof(MT);
+    static bool attr_set = false;
+    if (!attr_set) {
+        KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)knn_sums_rows_kernel<R, MT, IT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           150 * 1024));
+        attr_set = true;
+    }
+    const int64_t groups = (nrows + R - 1) / R;
+    const int64_t grid = groups < 2048 ? groups : 2048;
+    knn_sums_rows_kernel<R, MT, IT><<<(unsigned)grid, KNN_TPB, bytes, st>>>(D_dev, ldd, nb_dev, nbT, n, n_nb, row0, nrows, sums_dev,
+                                                                          lds, mpitch);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+
 // k-NN selection on uint8 rows: wave per row.  Pass 1 histograms the row's values (LDS, 256 bins per wave);
 // the threshold value t is where the cumulative count reaches n_nb; pass 2 walks the row in index order and
 // takes every entry < t plus the first (n_nb - count_lt) entries == t (ballot-ordered compaction).
@@ -863,6 +987,32 @@ int kmap_knn_sums_u8_dev(const uint8_t *D_dev, int64_t ldd, const int32_t *nb_de
     hipStream_t st = as_stream(stream);
     int32_t *nbT = nullptr;
     KMAP_TRY(kmap_scratch((void **)&nbT, (size_t)n * n_nb * 4, st, KMAP_SLOT_D));
+    {   // several output rows per block when their neighbour-sum rows fit LDS together
+        static const int rows_on = [] { const char *e = getenv("KMAP_KNN_ROWS"); return e ? atoi(e) : 1; }();
+        uint32_t *dmax_dev = nullptr, dmax = 255;
+        KMAP_TRY(kmap_scratch((void **)&dmax_dev, 64, st, KMAP_SLOT_C));
+        KMAP_CHECK_HIP(hipMemsetAsync(dmax_dev, 0, 4, st));
+        max_u8_kernel<<<2048, 256, 0, st>>>(D_dev, ldd, n, dmax_dev);
+        KMAP_CHECK_HIP(hipMemcpyAsync(&dmax, dmax_dev, 4, hipMemcpyDeviceToHost, st));
+        KMAP_CHECK_HIP(hipStreamSynchronize(st));
+        const bool m8 = (uint64_t)dmax * (uint64_t)n_nb <= 255u;
+        const int64_t mpitch = (n + 15) & ~(int64_t)15;
+        const int64_t row_bytes = mpitch * (m8 ? 1 : 2);
+        int R = (int)((150 * 1024) / row_bytes);
+        if (R > 4) R = 4;
+        if (rows_on && R >= 2) {
+            const bool i16 = n <= 65536;
+            const unsigned tb = (unsigned)((n * n_nb + 255) / 256);
+            if (i16) transpose_nb_t_kernel<uint16_t><<<tb, 256, 0, st>>>(nb_dev, n, n_nb, (uint16_t *)nbT);
+            else transpose_nb_t_kernel<int32_t><<<tb, 256, 0, st>>>(nb_dev, n, n_nb, nbT);
+#define KMAP_KNN(RR, MT, IT) launch_knn_rows<RR, MT, IT>(D_dev, ldd, nb_dev, (const IT *)nbT, n, n_nb, row0, nrows, sums_dev, lds, mpitch, st)
+#define KMAP_KNN_R(MT, IT) (R == 2 ? KMAP_KNN(2, MT, IT) : R == 3 ? KMAP_KNN(3, MT, IT) : KMAP_KNN(4, MT, IT))
+            if (m8) return i16 ? KMAP_KNN_R(uint8_t, uint16_t) : KMAP_KNN_R(uint8_t, int32_t);
+            return i16 ? KMAP_KNN_R(uint16_t, uint16_t) : KMAP_KNN_R(uint16_t, int32_t);
+#undef KMAP_KNN_R
+#undef KMAP_KNN
+        }
+    }
     transpose_nb_kernel<<<(unsigned)((n * n_nb + 255) / 256), 256, 0, st>>>(nb_dev, n, n_nb, nbT);
     int64_t chunk = (n + 15) & ~(int64_t)15;
     if (chunk > KNN_CHUNK_MAX) chunk = KNN_CHUNK_MAX;
