@@ -243,6 +243,17 @@ int kmap_hamdist_matrix_u8(const uint64_t *kh, const int32_t *label, int64_t n, 
  * writes uint16 rows [row0,row0+nrows) with leading dimension lds. */
 int kmap_knn_sums_u8_dev(const uint8_t *D_dev, int64_t ldd, const int32_t *nb_dev, int64_t n, int n_nb,
                          int64_t row0, int64_t nrows, uint16_t *sums_dev, int64_t lds, void *stream);
+/* the same sums straight from the k-mers, without reading D: the double sum over neighbour pairs of mismatching bases is
+ * n_nb^2 k minus the dot product of two per-position base-count profiles (plus a tail correction per short consensus label,
+ * the matrix rule of cal_samp_kmer_hamdist_mat motif_discovery.py:789-800); identical to kmap_knn_sums_u8_dev on the matrix
+ * kmap_hamdist_matrix_* writes for (kh, label, clen).  k <= 16, at most 4 labels with clen < k, n_nb^2 k <= 65535; returns
+ * KMAP_E_UNSUP otherwise (use the matrix-based entry point). */
+int kmap_knn_sums_kmers_u32_dev(const uint32_t *kh_dev, const int32_t *label_dev, int64_t n, int k, const int32_t *clen, int n_lab,
+                                const int32_t *nb_dev, int n_nb, int64_t row0, int64_t nrows, uint16_t *sums_dev, int64_t lds,
+                                void *stream);
+int kmap_knn_sums_kmers_u64_dev(const uint64_t *kh_dev, const int32_t *label_dev, int64_t n, int k, const int32_t *clen, int n_lab,
+                                const int32_t *nb_dev, int n_nb, int64_t row0, int64_t nrows, uint16_t *sums_dev, int64_t lds,
+                                void *stream);
 /* deterministic device k-NN selection for rows [row0,row0+nrows): the n_nb smallest entries of each row of D,
  * ties broken by the lowest column index (self included, like the reference's argpartition over the full row).
  * The reference uses np.argpartition (visualization.py:100) whose choice among ties is numpy/ISA specific; this

@@ -66,6 +66,8 @@ _SIGS = {
     "kmap_hamball_extract": (i32, [vp, vp, i64, i32, u64, i32, i32, vp, vp, P(i64), vp]),
     "kmap_pos_density": (i32, [vp, vp, vp, vp, i64, i32, vp, i32, f64, vp]),
     "kmap_hamdist_pitch": (i64, [i64]),
+    "kmap_knn_sums_kmers_u32_dev": (i32, [vp, vp, i64, i32, vp, i32, vp, i32, i64, i64, vp, i64, vp]),
+    "kmap_knn_sums_kmers_u64_dev": (i32, [vp, vp, i64, i32, vp, i32, vp, i32, i64, i64, vp, i64, vp]),
     "kmap_label_kmers_dev": (i32, [vp, i64, i32, i32, vp, vp, vp, i32, i32, vp, vp]),
     "kmap_label_sums_dev": (i32, [vp, vp, i32, i64, i32, vp, vp]),
     "kmap_label_prefix_dev": (i32, [vp, vp, i32, i64, i32, vp, vp, vp]),

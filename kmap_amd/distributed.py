@@ -81,7 +81,8 @@ def kmap_from_kmers_distributed(samp_kh, samp_cnts, samp_label, conseq_list, kme
         parts = [None] * world
         dist.all_gather_object(parts, nb_local)
         nb = np.concatenate(parts)
-    sums_d, lds = vz.knn_sums_dev(D_d.ptr, ldd, nb, n, n_neighbour, row0=row0, nrows=nrows)
+    res = vz.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, kmer_len, lens, nb, n_neighbour, row0=row0, nrows=nrows)
+    sums_d, lds = res if res is not None else vz.knn_sums_dev(D_d.ptr, ldd, nb, n, n_neighbour, row0=row0, nrows=nrows)
     if isinstance(nb, _ffi.DeviceBuffer):
         nb.free()
     for b in (D_d, kh_d, lab_d):

@@ -106,6 +106,28 @@ def knn_sums_dev(D_dev_ptr, ldd, nb, n, n_nb, row0=0, nrows=None, stream=None):
     return sums_d, lds
 
 
+def knn_sums_kmers_dev(kh_dev_ptr, lab_dev_ptr, n, kmer_len, conseq_lens, nb, n_nb, row0=0, nrows=None, stream=None):
+    """Same sums as knn_sums_dev but from the k-mers themselves (base-count profiles, csrc/knn_profile.hip): no matrix is
+    read.  Returns None when the profile kernel does not cover the request (k > 16, more than 4 short consensuses)."""
+    nrows = n - row0 if nrows is None else nrows
+    lds = (n + 127) & ~127
+    clen = np.ascontiguousarray(conseq_lens, dtype=np.int32)
+    own = not isinstance(nb, _ffi.DeviceBuffer)
+    nb_d = _ffi.DeviceBuffer.from_numpy(np.ascontiguousarray(nb, np.int32)) if own else nb
+    sums_d = _ffi.DeviceBuffer(max(nrows, 1) * lds * 2)
+    fn = _ffi.lib().kmap_knn_sums_kmers_u32_dev if get_hash_dtype(kmer_len) == np.uint32 else _ffi.lib().kmap_knn_sums_kmers_u64_dev
+    rc = fn(kh_dev_ptr, lab_dev_ptr, n, kmer_len, ptr(clen) if len(clen) else None, len(clen), nb_d.ptr, n_nb, row0, nrows,
+            sums_d.ptr, lds, stream)
+    if own:
+        nb_d.free()
+    if rc == -4:                      # KMAP_E_UNSUP
+        sums_d.free()
+        return None
+    check(rc)
+    _ffi.sync(stream)
+    return sums_d, lds
+
+
 def knn_smooth(dist_mat: np.ndarray, n_neighbour: int, neighbor_inds_mat=None) -> np.ndarray:
     """Smoothed distance matrix, float32 (reference visualization.py:90-109).
     neighbor_inds_mat: optional (N, n_neighbour) indices to use instead of np.argpartition's choice
@@ -378,7 +400,8 @@ def kmap_from_kmers(samp_kh, samp_cnts, samp_label, conseq_list, kmer_len, n_nei
                 nbs.append(np.argpartition(rows.astype(np.int64), n_neighbour, axis=1)[:, :n_neighbour])
             neighbor_inds_mat = np.concatenate(nbs)
     with _stage("knn_sums"):
-        sums_d, lds = knn_sums_dev(D_d.ptr, ldd, neighbor_inds_mat, n, n_neighbour)
+        res = knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, kmer_len, lens, neighbor_inds_mat, n_neighbour)
+        sums_d, lds = res if res is not None else knn_sums_dev(D_d.ptr, ldd, neighbor_inds_mat, n, n_neighbour)
     if isinstance(neighbor_inds_mat, _ffi.DeviceBuffer):
         neighbor_inds_mat.free()
     for b in (D_d, kh_d, lab_d):

@@ -295,3 +295,32 @@ def test_seq_forces_bit_exact_vs_oracle(V, scale):
         assert abs(loss * 2 - ref) <= 3e-6 * abs(ref) or abs(loss - ref) <= 3e-6 * abs(ref)
     finally:
         sess.close()
+
+
+@pytest.mark.parametrize("n,k,lens", [(700, 8, [8, 8]), (1003, 8, [8, 6, 5]), (900, 12, [12, 7]), (1200, 16, [16, 9, 16, 4]),
+                                      (513, 5, [5, 3]), (600, 11, [11])])
+def test_knn_sums_from_kmers_equals_matrix_sums(V, n, k, lens):
+    """neighbour sums from base-count profiles (no matrix read) == the sums gathered from the Hamming matrix, incl. the
+    short-consensus prefix rule, uint32 / uint64 hashes, row blocks; unsupported requests fall back (None)."""
+    from kmap_amd import _ffi
+    from kmap_amd.hamdist import hamdist_matrix_dev, pitch_for
+    from kmap_amd.kmer_count import get_hash_dtype
+    rng = np.random.default_rng(n + k)
+    n_nb = 20
+    kh = rng.integers(0, 4 ** k, size=n, dtype=np.uint64).astype(get_hash_dtype(k))
+    kh[::9] = kh[0]                                                     # duplicates, as in expanded samples
+    lab = np.sort(rng.integers(0, len(lens) + 1, size=n)).astype(np.int32)
+    nb = np.stack([rng.choice(n, size=n_nb, replace=False) for _ in range(n)]).astype(np.int32)
+    nb[3] = 7                                                           # a row whose neighbours are all the same k-mer
+    kh_d, lab_d = _ffi.DeviceBuffer.from_numpy(kh), _ffi.DeviceBuffer.from_numpy(lab)
+    ldd = pitch_for(n)
+    D_d = _ffi.DeviceBuffer(n * ldd)
+    hamdist_matrix_dev(kh_d.ptr, lab_d.ptr, n, k, lens, D_d.ptr, ldd)
+    want_d, lds = V.knn_sums_dev(D_d.ptr, ldd, nb, n, n_nb)
+    want = want_d.to_numpy(np.uint16, (n, lds))[:, :n]
+    got_d, lds2 = V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, k, lens, nb, n_nb)
+    np.testing.assert_array_equal(got_d.to_numpy(np.uint16, (n, lds2))[:, :n], want)
+    r0, nr = n // 3, n // 2                                             # a row block, as the multi-GPU path asks for
+    blk_d, lds3 = V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, k, lens, nb, n_nb, row0=r0, nrows=nr)
+    np.testing.assert_array_equal(blk_d.to_numpy(np.uint16, (nr, lds3))[:, :n], want[r0:r0 + nr])
+    assert V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, k, [max(1, k - 1)] * 5, nb, n_nb) is None   # 5 short consensuses
