@@ -99,9 +99,9 @@ def _as_occurrence(occ, n_conseq=None) -> Occurrence:
 def get_motif_seq_num(occurence_file_path, motif_index: int):
     """(rows with the motif, total occurrences) -- reference motif_discovery.py:1345-1393"""
     if isinstance(occurence_file_path, list):          # bare hit list from scan_motif_occurence: no container needed
-        hits = occurence_file_path[motif_index][0]
-    else:
-        hits = _as_occurrence(occurence_file_path).hits[motif_index]
+        hits, pos = occurence_file_path[motif_index]
+        return int(np.count_nonzero(hits)), len(pos)    # the positions array holds exactly sum(hits) entries
+    hits = _as_occurrence(occurence_file_path).hits[motif_index]
     return int(np.count_nonzero(hits)), int(hits.sum(dtype=np.int64))
 
 
