@@ -211,6 +211,28 @@ __global__ __launch_bounds__(BLK) void mask_flag_packed_kernel(const uint32_t *_
     const Win w = load_win(codes, inval, g);
     const uint64_t kmask = low_mask<uint64_t>(k);
     uint32_t hits = 0;
+    if constexpr (!WIDE) {   // k <= 16: 32-bit windows (v_alignbit + shift), validity of the 16 windows from one doubling pass
+        uint64_t bad = w.m;
+        for (int have = 1; have < k;) {
+            const int step = (have <= k - have) ? have : k - have;
+            bad |= bad << step;
+            have += step;
+        }
+        const uint32_t bad16 = (uint32_t)(bad >> 32), km = (uint32_t)kmask;
+        const uint32_t hi = (uint32_t)(w.t0 >> 32), lo = (uint32_t)w.t0;
+        const int sh = 32 - 2 * k;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t top = (i == 0) ? hi : __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * i);
+            const uint32_t h = ((bad16 >> (15 - i)) & 1u) ? km : (top >> sh);   // invalid window: all ones, compared as is
+            bool f = false;
+            for (int c = 0; c < t.n; ++c) f |= (popc2((h ^ (uint32_t)t.cons[c]) & km) <= t.radius[c]);
+            if (16 * g + i >= n) f = false;       // positions past the end do not exist
+            hits |= (uint32_t)f << (15 - i);
+        }
+        hit16[g] = (uint16_t)hits;
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         bool bad;
