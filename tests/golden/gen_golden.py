@@ -14,7 +14,8 @@ are stored (as .npz / text data files).
 
 Groups: ops (G2-G5 operator vectors), scan (G1,G6-G8 pipeline on tests/test.fa),
 embed (G9,G10 smoothing + umap traces), report (occurrence-file consumers and Hamming-ball
-extraction: position density, co-occurrence matrices, count matrices).
+extraction: position density, co-occurrence matrices, count matrices), occ20 (occurrence rows with the
+> 20-hit random subsample).
 """
 import os
 import pickle
@@ -486,8 +487,42 @@ def gen_report():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def gen_occ20():
+    """Occurrence rows for reads with MORE THAN 20 hits at the minimum distance: the reference then keeps a random 20 of them
+    (np.random.choice, motif_discovery.py:1466-1470).  Input FASTA written by this script; output by the reference."""
+    rng = np.random.default_rng(20)
+    dst = HERE / "occ20"
+    dst.mkdir(exist_ok=True)
+    recs = []
+    for i in range(80):
+        L = int(rng.integers(60, 260))
+        seq = rng.choice(list("ACGT"), size=L)
+        kind = i % 4
+        if kind == 0:                                   # long poly-A run: dozens of exact AAAAAAAA hits
+            a = int(rng.integers(0, L - 50))
+            seq[a:a + int(rng.integers(35, 50))] = "A"
+        elif kind == 1:                                 # poly-T run: hits through the reverse complement
+            a = int(rng.integers(0, L - 50))
+            seq[a:a + int(rng.integers(30, 45))] = "T"
+        elif kind == 2:                                 # tandem ACGT repeats + an N
+            a = int(rng.integers(0, L - 60))
+            seq[a:a + 56] = list("ACGT" * 14)
+            seq[int(rng.integers(0, L))] = "N"
+        recs.append(f">r{i}\n" + "".join(seq) + "\n")
+    (dst / "occ20.fa").write_text("".join(recs))
+    cfg = kc.read_default_config_file()
+    mdd = kc.gen_motif_def_dict(cfg)
+    conseqs = ["AAAAAAAA", "ACGTACGT", "AACCGGTTAA"]
+    np.random.seed(77)
+    md.gen_motif_occurence_file(conseqs, mdd, dst / "occ20.fa", dst / "occ20.motif_occurence.csv", True)
+    n_big = sum(1 for ln in (dst / "occ20.motif_occurence.csv").read_text().splitlines()[1:]
+                for cell in ln.split(";")[1:-1] if cell.count(",") == 19)
+    print(f"  wrote occ20/: {n_big} cells with exactly 20 (subsampled) locations")
+    assert n_big >= 10
+
+
 if __name__ == "__main__":
-    groups = sys.argv[1:] or ["ops", "scan", "embed", "report"]
+    groups = sys.argv[1:] or ["ops", "scan", "embed", "report", "occ20"]
     for g in groups:
         print(f"[{g}]")
-        {"ops": gen_ops, "scan": gen_scan, "embed": gen_embed, "report": gen_report}[g]()
+        {"ops": gen_ops, "scan": gen_scan, "embed": gen_embed, "report": gen_report, "occ20": gen_occ20}[g]()

@@ -312,3 +312,13 @@ def test_genome_like_input_vs_oracle(motif_defs):
     assert off == len(pos) and hits[0] > 100
     dc.close()
     ds.close()
+
+
+def test_occurrence_file_with_subsample_golden(tmp_path):
+    """gen_motif_occurence_file on reads with > 20 hits: same file as the reference wrote with the same np.random seed"""
+    from kmap_amd.kmer_count import init_motif_def_dict, _pkg_file
+    from kmap_amd.motif_discovery import gen_motif_occurence_file
+    mdd = init_motif_def_dict(_pkg_file("default_motif_def_table.csv"))
+    np.random.seed(77)
+    gen_motif_occurence_file(["AAAAAAAA", "ACGTACGT", "AACCGGTTAA"], mdd, GOLD / "occ20" / "occ20.fa", tmp_path / "o.csv", True)
+    assert (tmp_path / "o.csv").read_text() == (GOLD / "occ20" / "occ20.motif_occurence.csv").read_text()

@@ -302,3 +302,17 @@ def test_report_co_occurrence_oracle_and_host(golden, tmp_path):
     R.write_co_occurence_dist_arr(tmp_path / "f.txt", dd, finals)
     assert (tmp_path / "e.tsv").read_text() == (src / "co_occurence_mat.tsv").read_text()
     assert (tmp_path / "f.txt").read_text() == (src / "co_occurence_motif_dist_data.txt").read_text()
+
+
+def test_occurrence_subsample_golden():
+    """reads with more than 20 hits at the minimum distance: the oracle's np.random.choice subsample reproduces the
+    reference's rows (tests/golden/occ20, seed 77) -- this pins the RNG protocol the GPU tests check the product against"""
+    from kmap_amd.kmer_count import encode_fasta_py, init_motif_def_dict, _pkg_file
+    seq, borders = encode_fasta_py(f"{GOLD}/occ20/occ20.fa")
+    mdd = init_motif_def_dict(_pkg_file("default_motif_def_table.csv"))
+    r_of = {k: d.max_ham_dist for k, d in mdd.items() if isinstance(k, int)}
+    rng = np.random.RandomState(77)
+    lines = O.motif_occurence_lines(seq, borders, ["AAAAAAAA", "ACGTACGT", "AACCGGTTAA"], r_of, True, rng)
+    want = open(f"{GOLD}/occ20/occ20.motif_occurence.csv").read().splitlines()
+    assert lines == want
+    assert sum(cell.count(",") == 19 for ln in want[1:] for cell in ln.split(";")[1:-1]) >= 10
