@@ -487,6 +487,78 @@ def gen_report():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def gen_scan2():
+    """A second end-to-end run of the reference: synthetic reads with two planted motifs, repetitive_mode = true (no per-read
+    dedupe), a noise k-mer file (masked before counting), k = 6..9.  FASTA / noise file written by this script."""
+    rng = np.random.default_rng(42)
+    dst = HERE / "scan2"
+    dst.mkdir(exist_ok=True)
+    motifs = ["AATCGATAGC", "CCTACGTA"]
+    recs = []
+    for i in range(700):
+        L = int(rng.integers(40, 90))
+        seq = rng.choice(list("ACGT"), size=L)
+        if i % 5 < 2:
+            m = list(motifs[i % 2])
+            if rng.random() < 0.3:
+                m[int(rng.integers(0, len(m)))] = rng.choice(list("ACGT"))
+            a = int(rng.integers(0, L - len(m)))
+            seq[a:a + len(m)] = m
+        if i % 11 == 0:
+            a = int(rng.integers(0, L - 16))
+            seq[a:a + 16] = list("ACACACACACACACAC")          # low-complexity noise, listed in the noise k-mer file
+        if i % 37 == 0:
+            seq[int(rng.integers(0, L))] = "N"
+        recs.append(f">s{i}\n" + "".join(seq) + "\n")
+    (dst / "scan2.fa").write_text("".join(recs))
+    (dst / "noise_kmers.txt").write_text("ACACACAC\nCACACACA\n")
+    tmp = Path(tempfile.mkdtemp(prefix="kmap_golden_"))
+    res = tmp / "res"
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    shutil.copyfile(dst / "scan2.fa", tmp / "scan2.fa")
+    shutil.copyfile(dst / "noise_kmers.txt", tmp / "noise_kmers.txt")
+    try:
+        cfg = kc.read_default_config_file()
+        cfg["general"]["input_fasta_file"] = "scan2.fa"
+        cfg["general"]["res_dir"] = "res"
+        cfg["general"]["repetitive_mode"] = True
+        cfg["kmer_count"]["min_k"] = 6
+        cfg["kmer_count"]["max_k"] = 9
+        cfg["motif_discovery"]["noise_kmer_file"] = "noise_kmers.txt"
+        for f in ("motif_pos_density_flag", "motif_co_occurence_flag", "gen_hamball_flag"):
+            cfg["motif_discovery"][f] = False
+        cfg["motif_discovery"]["n_total_sample"] = 200
+        cfg["motif_discovery"]["n_motif_sample"] = 100
+        cfg["visualization"]["gen_fig_flag"] = False
+        res.mkdir()
+        import tomli_w
+        with open(res / "config.toml", "wb") as fh:
+            tomli_w.dump(cfg, fh)
+        kc._preproc("scan2.fa", "res")
+        np.random.seed(9)
+        md._scan_motif("res")
+        out = {}
+        for k in range(6, 10):
+            with open(res / "kmer_count" / f"k{k}.pkl", "rb") as fh:
+                kk, u, c = pickle.load(fh)
+            out[f"k{k}_uniq"], out[f"k{k}_cnt"] = u, c
+        with open(res / "sample_kmers.pkl", "rb") as fh:
+            skh, scnt, slab, conseqs = pickle.load(fh)
+        out["samp_kh"], out["samp_cnts"], out["samp_label"], out["samp_conseqs"] = skh, scnt, slab, np.array(conseqs)
+        with open(res / "sample_kmer_hamdist_mat.pkl", "rb") as fh:
+            klen, mat, lab = pickle.load(fh)
+        out["hamdist_kmer_len"], out["hamdist_mat_u8"], out["hamdist_label"] = np.array(klen), mat.astype(np.uint8), lab
+        save("scan2.npz", **out)
+        for f in ("candidate_conseq.csv", "final_conseq.txt", "final_conseq.info.csv", "final.motif_occurence.csv",
+                  "sample_kmers.tsv", "config.toml", "motif_def_table.csv"):
+            shutil.copyfile(res / f, dst / f)
+        print("  finals:", (res / "final_conseq.txt").read_text().split())
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def gen_occ20():
     """Occurrence rows for reads with MORE THAN 20 hits at the minimum distance: the reference then keeps a random 20 of them
     (np.random.choice, motif_discovery.py:1466-1470).  Input FASTA written by this script; output by the reference."""
@@ -522,7 +594,7 @@ def gen_occ20():
 
 
 if __name__ == "__main__":
-    groups = sys.argv[1:] or ["ops", "scan", "embed", "report", "occ20"]
+    groups = sys.argv[1:] or ["ops", "scan", "embed", "report", "occ20", "scan2"]
     for g in groups:
         print(f"[{g}]")
-        {"ops": gen_ops, "scan": gen_scan, "embed": gen_embed, "report": gen_report, "occ20": gen_occ20}[g]()
+        {"ops": gen_ops, "scan": gen_scan, "embed": gen_embed, "report": gen_report, "occ20": gen_occ20, "scan2": gen_scan2}[g]()

@@ -322,3 +322,44 @@ def test_occurrence_file_with_subsample_golden(tmp_path):
     np.random.seed(77)
     gen_motif_occurence_file(["AAAAAAAA", "ACGTACGT", "AACCGGTTAA"], mdd, GOLD / "occ20" / "occ20.fa", tmp_path / "o.csv", True)
     assert (tmp_path / "o.csv").read_text() == (GOLD / "occ20" / "occ20.motif_occurence.csv").read_text()
+
+
+def test_second_dataset_repetitive_mode_and_noise_kmers(golden, tmp_path):
+    """preproc + scan_motif on a second dataset (tests/golden/scan2: planted motifs, repetitive_mode = true, a noise k-mer
+    file masked before counting, k = 6..9) == the files and arrays the reference produced with the same np.random seed"""
+    from kmap_amd._toml import dump_toml, load_toml
+    from kmap_amd.kmer_count import _preproc
+    from kmap_amd.motif_discovery import _scan_motif
+    g = golden("scan2.npz")
+    src = GOLD / "scan2"
+    fa, noise, res = tmp_path / "scan2.fa", tmp_path / "noise_kmers.txt", tmp_path / "res"
+    shutil.copyfile(src / "scan2.fa", fa)
+    shutil.copyfile(src / "noise_kmers.txt", noise)
+    res.mkdir()
+    cfg = load_toml(src / "config.toml")
+    assert cfg["general"]["repetitive_mode"] is True
+    cfg["general"]["input_fasta_file"], cfg["general"]["res_dir"] = str(fa), str(res)
+    cfg["motif_discovery"]["noise_kmer_file"] = str(noise)
+    dump_toml(cfg, res / "config.toml")
+    _preproc(str(fa), str(res))
+    np.random.seed(9)
+    _scan_motif(str(res))
+    for k in range(6, 10):
+        with open(res / "kmer_count" / f"k{k}.pkl", "rb") as fh:
+            kk, u, c = pickle.load(fh)
+        np.testing.assert_array_equal(u, g[f"k{k}_uniq"])
+        np.testing.assert_array_equal(c, g[f"k{k}_cnt"])
+        assert u.dtype == g[f"k{k}_uniq"].dtype and c.dtype == g[f"k{k}_cnt"].dtype
+    for f in ("candidate_conseq.csv", "final_conseq.txt", "final_conseq.info.csv", "final.motif_occurence.csv", "sample_kmers.tsv"):
+        assert (res / f).read_text() == (src / f).read_text(), f
+    with open(res / "sample_kmers.pkl", "rb") as fh:
+        skh, scnt, slab, conseqs = pickle.load(fh)
+    np.testing.assert_array_equal(skh, g["samp_kh"])
+    np.testing.assert_array_equal(scnt, g["samp_cnts"])
+    np.testing.assert_array_equal(slab, g["samp_label"])
+    assert list(conseqs) == [str(c) for c in g["samp_conseqs"]]
+    with open(res / "sample_kmer_hamdist_mat.pkl", "rb") as fh:
+        klen, mat, lab = pickle.load(fh)
+    assert klen == int(g["hamdist_kmer_len"]) and mat.dtype == np.int64
+    np.testing.assert_array_equal(mat, g["hamdist_mat_u8"])
+    np.testing.assert_array_equal(lab, g["hamdist_label"])
