@@ -69,39 +69,35 @@ def cpu_baseline(kh, lab, target_s=12.0):
             "sample": f"{rows2} of {n} rows x {n} cols (oracle ko_hamdist_rows, OpenMP, {dt:.1f} s)"}
 
 
-def embed_dist_leg(dist, torch, kh, lab, n, out_d, iters=(20, 120)):
-    """Row-sharded embedding of the same N sampled k-mers on all ranks (kmap_amd.distributed): per-iteration time from
-    the difference of two runs (setup = D, neighbour selection, sums cancels).  Errors are reported, not raised: a rank
-    that failed sets a flag that every rank sees before anyone enters the next collective-bearing phase."""
+def embed_dist_leg(dist, torch, kh, lab, n, out_d, iters=100):
+    """Sharded embedding of the same N sampled k-mers on all ranks (kmap_amd.distributed): wall time of the iteration loop
+    alone (device-synchronised on both sides, max over ranks), after a short run that absorbs one-time costs.  Errors are
+    reported, not raised: a rank that failed sets a flag that every rank sees before anyone enters the next phase."""
     from kmap_amd.distributed import kmap_from_kmers_distributed
     out_d.free()
-    res, err = {}, ""
+    err, loop_s = "", 0.0
     flag = torch.zeros(1, dtype=torch.int32, device="cuda")
-    times = []
-    for it in iters:
+    for it in (3, iters):
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()):
             break
         dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        tr = {}
         try:
-            kmap_from_kmers_distributed(kh, np.ones(n, np.int64), lab, ["A" * K, "C" * K], K, n_max_iter=it, random_seed=7)
+            kmap_from_kmers_distributed(kh, np.ones(n, np.int64), lab, ["A" * K, "C" * K], K, n_max_iter=it, random_seed=7, trace=tr)
+            loop_s = tr["loop_s"]
         except Exception as e:   # noqa: BLE001
             err = f"{type(e).__name__}: {e}"[:300]
             flag.fill_(1)
-        torch.cuda.synchronize()
-        times.append(time.perf_counter() - t0)
     dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-    if int(flag.item()) or len(times) < 2:
+    if int(flag.item()):
         return {"error": err or "another rank failed"}
-    t = torch.tensor(times, dtype=torch.float64, device="cuda")
+    t = torch.tensor([loop_s], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    t = t.tolist()
-    res = {"n_kmers": n, "mode": "default (FAST above N = 16384)", "iterations": list(iters), "wall_s": t,
-           "ms_per_iteration": (t[1] - t[0]) / (iters[1] - iters[0]) * 1e3, "setup_s": t[0] - iters[0] * (t[1] - t[0]) / (iters[1] - iters[0]),
-           "collectives_per_iteration": 2}
-    return res
+    cyc = os.environ.get("KMAP_DIST_CYCLIC", "1") != "0" and n >= 16384
+    return {"n_kmers": n, "mode": "FAST, each unordered pair once, cyclic 256-row blocks per rank" if cyc else "FAST, contiguous row blocks",
+            "iterations": iters, "loop_s": float(t.item()), "ms_per_iteration": float(t.item()) / iters * 1e3,
+            "collectives_per_iteration": 2}
 
 
 def main():

@@ -280,6 +280,13 @@ typedef struct kmap_embed kmap_embed;
 #define KMAP_EMBED_SEQ 1       /* one lane per row, j ascending, no FMA: the reference's f32 order */
 int kmap_embed_create(kmap_embed **e, int64_t n, int64_t row0, int64_t nrows, int n_best, float learning_rate,
                       int mode);
+/* FAST mode sharded over `world` ranks with each unordered pair evaluated once: rank r owns the 256-row blocks
+ * I = r, r + world, ... (cyclic: the upper-triangle work of a block shrinks with I).  Its probability rows are passed block
+ * after block (local block b = rows [256 (r + world b), +256) of the matrix; kmap_embed_cyclic_blocks gives their number).
+ * kmap_embed_forces then writes partial gradients for ALL points (rows and columns the rank touched) into grad_dev -- the
+ * ranks' buffers are summed by the all-reduce (a true sum here, unlike the row-sharded sessions' concatenation). */
+int kmap_embed_create_cyclic(kmap_embed **e, int64_t n, int world, int rank, int n_best, float learning_rate);
+int64_t kmap_embed_cyclic_blocks(int64_t n, int world, int rank);
 int kmap_embed_destroy(kmap_embed *e);
 int kmap_embed_set_prob_f32(kmap_embed *e, const float *p_rows_dev, int64_t ld);       /* device rows */
 int kmap_embed_set_prob_lut(kmap_embed *e, const uint16_t *sums_rows_dev, int64_t ld, const float *lut,

@@ -104,6 +104,8 @@ _SIGS = {
     "kmap_cross_entropy_f32": (i32, [vp, vp, i64, vp]),
     "kmap_gradient_loss_f32": (i32, [vp, vp, vp, i64, vp]),
     "kmap_embed_create": (i32, [P(vp), i64, i64, i64, i32, f32, i32]),
+    "kmap_embed_create_cyclic": (i32, [P(vp), i64, i32, i32, i32, f32]),
+    "kmap_embed_cyclic_blocks": (i64, [i64, i32, i32]),
     "kmap_embed_destroy": (i32, [vp]),
     "kmap_embed_set_prob_f32": (i32, [vp, vp, i64]),
     "kmap_embed_set_prob_lut": (i32, [vp, vp, i64, vp, i32]),

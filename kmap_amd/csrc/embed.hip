@@ -541,15 +541,18 @@ template <bool LUTSRC>
 __global__ __launch_bounds__(KMAP_WAVE *SY_WAVES) void forces_sym_kernel(ProbSrc src, const float *__restrict__ Y, int64_t n,
                                                                          float *__restrict__ rowpart,
                                                                          float *__restrict__ colpart,
-                                                                         double *__restrict__ loss_part, int64_t nJ) {
+                                                                         double *__restrict__ loss_part, int64_t nJ, int world,
+                                                                         int rank) {
     extern __shared__ __attribute__((aligned(16))) float lut_s[];
     if (LUTSRC) {
         for (int t = threadIdx.x; t < src.lut_len && t < F_LUT_LDS; t += blockDim.x) lut_s[t] = src.lut[t];
         __syncthreads();
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t I = blockIdx.y, J = (int64_t)blockIdx.x * SY_WAVES + wave;
-    const int64_t part_idx = I * (gridDim.x * SY_WAVES) + J;
+    // blockIdx.y = local row block; global row block I (cyclic over the ranks).  Probability rows and column partials are
+    // indexed by the local block, row partials by the global row.
+    const int64_t Il = blockIdx.y, I = (int64_t)rank + (int64_t)world * Il, J = (int64_t)blockIdx.x * SY_WAVES + wave;
+    const int64_t part_idx = Il * (gridDim.x * SY_WAVES) + J;
     double wave_loss = 0.0;
     if (J < nJ && sy_tile_live(I, J)) {
         const float *X = Y, *Yy = Y + n;
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(KMAP_WAVE *SY_WAVES) void forces_sym_kernel(ProbSrc
                     if (!CHECK || (j0 + F_CPL - 1 > gi && j0 < n)) {   // this lane has at least one column right of the diagonal
                         float p[F_CPL];
                         if (LUTSRC) {
-                            const uint16_t *row = src.ps + gi * src.ld + j0;
+                            const uint16_t *row = src.ps + (Il * SY_R + (gi - I * SY_R)) * src.ld + j0;
                             if (vec_ok) {
                                 const u32x4 w = *reinterpret_cast<const u32x4 *>(row);
                                 const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
@@ -595,7 +598,7 @@ __global__ __launch_bounds__(KMAP_WAVE *SY_WAVES) void forces_sym_kernel(ProbSrc
                                 for (int c = 0; c < F_CPL; ++c) p[c] = (j0 + c < n) ? lut_s[row[c]] : 0.0f;
                             }
                         } else {
-                            const float *row = src.pf + gi * src.ld + j0;
+                            const float *row = src.pf + (Il * SY_R + (gi - I * SY_R)) * src.ld + j0;
 #pragma unroll
                             for (int c = 0; c < F_CPL; ++c) p[c] = (j0 + c < n) ? row[c] : 0.0f;
                         }
@@ -643,8 +646,8 @@ __global__ __launch_bounds__(KMAP_WAVE *SY_WAVES) void forces_sym_kernel(ProbSrc
 #pragma unroll
         for (int c = 0; c < F_CPL; ++c) {
             if (j0 + c < n) {
-                colpart[(I * 2 + 0) * n + j0 + c] = cgx[c];
-                colpart[(I * 2 + 1) * n + j0 + c] = cgy[c];
+                colpart[(Il * 2 + 0) * n + j0 + c] = cgx[c];
+                colpart[(Il * 2 + 1) * n + j0 + c] = cgy[c];
             }
         }
         for (int o = 32; o > 0; o >>= 1) wave_loss += __shfl_down(wave_loss, o);
@@ -654,9 +657,12 @@ __global__ __launch_bounds__(KMAP_WAVE *SY_WAVES) void forces_sym_kernel(ProbSrc
 
 // G[c][i] = sum_J rowpart[J][c][i] (tiles right of i's row block) + sum_I colpart[I][c][i] (row blocks above / at i)
 __global__ __launch_bounds__(BLK) void sym_reduce_kernel(const float *__restrict__ rowpart, const float *__restrict__ colpart,
-                                                         int64_t n, int64_t nI, int64_t nJ, float *__restrict__ G) {
+                                                         int64_t n, int64_t n_lblocks, int64_t nJ, int world, int rank,
+                                                         float *__restrict__ G) {
     // 8 lanes per output element (a one-lane walk over ~300 partials is latency-bound: 113 us at N = 50 k): lane l adds the
-    // partials l, l+8, ... in order, then the 8 lane sums are combined in a fixed butterfly -- deterministic, no atomics
+    // partials l, l+8, ... in order, then the 8 lane sums are combined in a fixed butterfly -- deterministic, no atomics.
+    // Sharded: row partials exist only for the rows of this rank's blocks, column partials for its local blocks; the ranks'
+    // G buffers are then summed by the all-reduce.
     constexpr int SPLIT = 8;
     const int64_t t = ((int64_t)blockIdx.x * BLK + threadIdx.x) / SPLIT;
     const int l = threadIdx.x & (SPLIT - 1);
@@ -665,10 +671,11 @@ __global__ __launch_bounds__(BLK) void sym_reduce_kernel(const float *__restrict
         const int c = (int)(t / n);
         const int64_t i = t % n;
         const int64_t Ii = i / SY_R, Ji = i / SY_C;
-        for (int64_t J = l; J < nJ; J += SPLIT)
-            if (sy_tile_live(Ii, J)) g += rowpart[(J * 2 + c) * n + i];
-        for (int64_t I = l; I < nI; I += SPLIT)
-            if (sy_tile_live(I, Ji)) g += colpart[(I * 2 + c) * n + i];
+        if (Ii % world == rank)
+            for (int64_t J = l; J < nJ; J += SPLIT)
+                if (sy_tile_live(Ii, J)) g += rowpart[(J * 2 + c) * n + i];
+        for (int64_t b = l; b < n_lblocks; b += SPLIT)
+            if (sy_tile_live((int64_t)rank + (int64_t)world * b, Ji)) g += colpart[(b * 2 + c) * n + i];
     }
     g += __shfl_xor(g, 1);
     g += __shfl_xor(g, 2);
@@ -972,11 +979,15 @@ struct kmap_embed {
     float *rowpart = nullptr, *colpart = nullptr;
     int64_t symI = 0, symJ = 0;
     bool sym = false;
+    // symmetric FAST path sharded over ranks: rank r owns the 256-row blocks I = r, r + world, ... (cyclic: the upper-triangle
+    // work per block shrinks with I); its probability rows are stored block after block (local block b = I / world)
+    int world = 1, rank = 0;
+    int64_t n_lblocks = 0;
 };
 
 namespace {
 int n_force_blocks(const kmap_embed *e) {
-    if (e->sym) return (int)(e->symI * (((e->symJ + SY_WAVES - 1) / SY_WAVES) * SY_WAVES));
+    if (e->sym) return (int)(e->n_lblocks * (((e->symJ + SY_WAVES - 1) / SY_WAVES) * SY_WAVES));
     if (e->mode == KMAP_EMBED_SEQ) return (int)((e->nrows + SQ_ROWS * SQ_WAVES - 1) / (SQ_ROWS * SQ_WAVES));
     return (int)((e->nrows + F_RPW * F_WAVES - 1) / (F_RPW * F_WAVES));
 }
@@ -1068,8 +1079,27 @@ int kmap_knn_smooth_f32(const float *D, const int32_t *nb, int64_t n, int n_nb, 
 }
 
 // ---- session ---------------------------------------------------------------------------------
+static int embed_create_impl(kmap_embed **out, int64_t n, int64_t row0, int64_t nrows, int n_best, float learning_rate,
+                             int mode, int world, int rank);
+
 int kmap_embed_create(kmap_embed **out, int64_t n, int64_t row0, int64_t nrows, int n_best, float learning_rate,
                       int mode) {
+    return embed_create_impl(out, n, row0, nrows, n_best, learning_rate, mode, 1, 0);
+}
+
+int64_t kmap_embed_cyclic_blocks(int64_t n, int world, int rank) {
+    if (n <= 0 || world <= 0 || rank < 0 || rank >= world) return 0;
+    const int64_t nI = (n + SY_R - 1) / SY_R;
+    return nI > rank ? (nI - rank + world - 1) / world : 0;
+}
+
+int kmap_embed_create_cyclic(kmap_embed **out, int64_t n, int world, int rank, int n_best, float learning_rate) {
+    KMAP_REQUIRE(world >= 1 && rank >= 0 && rank < world, "embed_create_cyclic: bad world / rank");
+    return embed_create_impl(out, n, 0, n, n_best, learning_rate, KMAP_EMBED_FAST, world, rank);
+}
+
+static int embed_create_impl(kmap_embed **out, int64_t n, int64_t row0, int64_t nrows, int n_best, float learning_rate,
+                             int mode, int world, int rank) {
     KMAP_REQUIRE(out, "embed_create: null");
     KMAP_REQUIRE(n > 0 && row0 >= 0 && nrows >= 0 && row0 + nrows <= n, "embed_create: bad row range");
     KMAP_REQUIRE(n < ((int64_t)1 << 31) - 64, "embed_create: n too large");
@@ -1080,8 +1110,12 @@ int kmap_embed_create(kmap_embed **out, int64_t n, int64_t row0, int64_t nrows, 
     {   // symmetric FAST kernel: single-GPU all-rows sessions (KMAP_EMBED_SYM=0 switches it off for A/B runs)
         const char *env = getenv("KMAP_EMBED_SYM");
         e->sym = (mode == KMAP_EMBED_FAST) && row0 == 0 && nrows == n && n >= 16384 && !(env && env[0] == '0');   // below ~16k the tall tiles leave CUs idle
+        if (world > 1) e->sym = true;                       // the cyclic creator always runs the symmetric kernel
         e->symI = (n + SY_R - 1) / SY_R;
         e->symJ = (n + SY_C - 1) / SY_C;
+        e->world = world;
+        e->rank = rank;
+        e->n_lblocks = kmap_embed_cyclic_blocks(n, world, rank);
     }
     e->n_part = n_force_blocks(e) > 0 ? n_force_blocks(e) : 1;
     hipError_t err = hipSuccess;
@@ -1096,7 +1130,7 @@ int kmap_embed_create(kmap_embed **out, int64_t n, int64_t row0, int64_t nrows, 
     A((void **)&e->lut_dev, F_LUT_LDS * 4);
     if (e->sym) {
         A((void **)&e->rowpart, (size_t)e->symJ * 2 * n * 4);
-        A((void **)&e->colpart, (size_t)e->symI * 2 * n * 4);
+        A((void **)&e->colpart, (size_t)(e->n_lblocks ? e->n_lblocks : 1) * 2 * n * 4);
     }
     if (err != hipSuccess) {
         kmap_set_error("embed_create: %s", hipGetErrorString(err));
@@ -1183,10 +1217,10 @@ int kmap_embed_forces(kmap_embed *e, float *grad_dev_2xn, double *loss_dev, void
     const bool lut = e->src.ps != nullptr;
     const size_t lds = lut ? (((size_t)e->src.lut_len * 4 + 15) & ~(size_t)15) : 16;
     if (e->sym) {
-        dim3 grid((unsigned)((e->symJ + SY_WAVES - 1) / SY_WAVES), (unsigned)e->symI);
-        if (lut) forces_sym_kernel<true><<<grid, KMAP_WAVE * SY_WAVES, lds, st>>>(e->src, e->Y, e->n, e->rowpart, e->colpart, e->loss_part, e->symJ);
-        else forces_sym_kernel<false><<<grid, KMAP_WAVE * SY_WAVES, lds, st>>>(e->src, e->Y, e->n, e->rowpart, e->colpart, e->loss_part, e->symJ);
-        sym_reduce_kernel<<<(unsigned)((2 * e->n * 8 + BLK - 1) / BLK), BLK, 0, st>>>(e->rowpart, e->colpart, e->n, e->symI, e->symJ, G);
+        dim3 grid((unsigned)((e->symJ + SY_WAVES - 1) / SY_WAVES), (unsigned)e->n_lblocks);
+        if (lut) forces_sym_kernel<true><<<grid, KMAP_WAVE * SY_WAVES, lds, st>>>(e->src, e->Y, e->n, e->rowpart, e->colpart, e->loss_part, e->symJ, e->world, e->rank);
+        else forces_sym_kernel<false><<<grid, KMAP_WAVE * SY_WAVES, lds, st>>>(e->src, e->Y, e->n, e->rowpart, e->colpart, e->loss_part, e->symJ, e->world, e->rank);
+        sym_reduce_kernel<<<(unsigned)((2 * e->n * 8 + BLK - 1) / BLK), BLK, 0, st>>>(e->rowpart, e->colpart, e->n, e->n_lblocks, e->symJ, e->world, e->rank, G);
     } else if (e->mode == KMAP_EMBED_SEQ) {
         if (lut) forces_seq_kernel<true><<<nblk, KMAP_WAVE * SQ_WAVES, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
         else forces_seq_kernel<false><<<nblk, KMAP_WAVE * SQ_WAVES, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);

@@ -1,12 +1,19 @@
 """Row-sharded multi-GPU execution of the Hamming / smoothing / embedding stages (one process per GPU,
 torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).
 
-Sharding: every rank holds all N hashes (<= 1.6 MB) and owns a contiguous block of rows of
-the N x N problem.  The Hamming matrix and the neighbour sums need no data-path collective; the embedding
-loop exchanges, per iteration, the 2 x N gradient (each rank fills only its rows; sum = concatenation, exact)
-and one float64 loss partial.  Best-list / early-stop / jitter logic then runs redundantly and identically on
-every rank (apply kernel), so no further broadcast is needed.
+Sharding: every rank holds all N hashes (<= 1.6 MB) and owns row blocks of the N x N problem.  The
+Hamming matrix and the neighbour sums need no data-path collective; the embedding loop exchanges, per iteration, the
+2 x N gradient and one float64 loss partial (two all-reduces).  Two layouts:
+  * SEQ, and FAST below N = 16384: one contiguous row block per rank, every rank evaluates all columns of its rows and
+    fills only its rows of the gradient (sum = concatenation, exact);
+  * FAST from N = 16384: the symmetric kernel -- each unordered pair once -- with the 256-row blocks dealt out cyclically
+    (rank r owns blocks r, r + world, ...: the upper-triangle work of a block shrinks with its index); a rank's gradient
+    buffer then holds partial sums for all points and the all-reduce is a true sum.
+Best-list / early-stop / jitter logic runs redundantly and identically on every rank (apply kernel), so no further
+broadcast is needed.
 """
+import os
+
 import numpy as np
 
 
@@ -81,15 +88,32 @@ def kmap_from_kmers_distributed(samp_kh, samp_cnts, samp_label, conseq_list, kme
         parts = [None] * world
         dist.all_gather_object(parts, nb_local)
         nb = np.concatenate(parts)
-    res = vz.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, kmer_len, lens, nb, n_neighbour, row0=row0, nrows=nrows)
-    sums_d, lds = res if res is not None else vz.knn_sums_dev(D_d.ptr, ldd, nb, n, n_neighbour, row0=row0, nrows=nrows)
+    # FAST at N >= 16384: symmetric kernel, each unordered pair once; rank r owns the 256-row blocks r, r + world, ...
+    # (cyclic), its gradient buffer holds partial sums for ALL points and the all-reduce adds the ranks' buffers.
+    # Otherwise: contiguous row blocks, every rank evaluates all columns of its rows (SEQ keeps the reference's row order).
+    cyclic = (mode == vz.EMBED_FAST and n >= 16384 and world > 1 and os.environ.get("KMAP_DIST_CYCLIC", "1") != "0")
+    if cyclic:
+        blocks = vz.cyclic_blocks(n, world, rank)
+        lds = (n + 127) & ~127
+        blk_bytes = vz.CYCLIC_BLOCK_ROWS * lds * 2
+        sums_d = _ffi.DeviceBuffer(max(len(blocks), 1) * blk_bytes)
+        for b, (r0, nr) in enumerate(blocks):
+            dst = sums_d.ptr + b * blk_bytes
+            if vz.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, kmer_len, lens, nb, n_neighbour, row0=r0, nrows=nr, out=dst) is None:
+                vz.knn_sums_dev(D_d.ptr, ldd, nb, n, n_neighbour, row0=r0, nrows=nr, out=dst)
+    else:
+        res = vz.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, kmer_len, lens, nb, n_neighbour, row0=row0, nrows=nrows)
+        sums_d, lds = res if res is not None else vz.knn_sums_dev(D_d.ptr, ldd, nb, n, n_neighbour, row0=row0, nrows=nrows)
     if isinstance(nb, _ffi.DeviceBuffer):
         nb.free()
     for b in (D_d, kh_d, lab_d):
         b.free()
     lut = vz.hd_prob_lut(kmer_len, n_neighbour, n_neighbour * n_neighbour * kmer_len)
     ld_data, placeholders = vz._init_draws(n, n_best_result, random_seed)      # same seed -> same draws on every rank
-    sess = vz.EmbedSession(n, n_best_result, learning_rate, mode, row0=row0, nrows=nrows)
+    if cyclic:
+        sess = vz.EmbedSession(n, n_best_result, learning_rate, vz.EMBED_FAST, cyclic=(world, rank))
+    else:
+        sess = vz.EmbedSession(n, n_best_result, learning_rate, mode, row0=row0, nrows=nrows)
     try:
         sess.set_prob_lut(sums_d, lds, lut)
         sess.set_coords(ld_data, placeholders)

@@ -92,21 +92,36 @@ def _is_small_int_matrix(m):
     return np.issubdtype(m.dtype, np.integer) and m.size > 0 and m.min() >= 0 and m.max() <= 255
 
 
-def knn_sums_dev(D_dev_ptr, ldd, nb, n, n_nb, row0=0, nrows=None, stream=None):
-    """Device: integer neighbour sums of rows [row0,row0+nrows) -> DeviceBuffer of uint16 [nrows x lds]."""
+def knn_sums_dev(D_dev_ptr, ldd, nb, n, n_nb, row0=0, nrows=None, stream=None, out=None):
+    """Device: integer neighbour sums of rows [row0,row0+nrows) -> DeviceBuffer of uint16 [nrows x lds]
+    (out: device address of a caller-owned block to fill instead; the returned buffer is then None)."""
     nrows = n - row0 if nrows is None else nrows
     lds = (n + 127) & ~127
     own = not isinstance(nb, _ffi.DeviceBuffer)
     nb_d = _ffi.DeviceBuffer.from_numpy(np.ascontiguousarray(nb, np.int32)) if own else nb
-    sums_d = _ffi.DeviceBuffer(max(nrows, 1) * lds * 2)
-    check(_ffi.lib().kmap_knn_sums_u8_dev(D_dev_ptr, ldd, nb_d.ptr, n, n_nb, row0, nrows, sums_d.ptr, lds, stream))
+    sums_d = _ffi.DeviceBuffer(max(nrows, 1) * lds * 2) if out is None else None
+    check(_ffi.lib().kmap_knn_sums_u8_dev(D_dev_ptr, ldd, nb_d.ptr, n, n_nb, row0, nrows, sums_d.ptr if out is None else out, lds,
+                                          stream))
     _ffi.sync(stream)
     if own:
         nb_d.free()
     return sums_d, lds
 
 
-def knn_sums_kmers_dev(kh_dev_ptr, lab_dev_ptr, n, kmer_len, conseq_lens, nb, n_nb, row0=0, nrows=None, stream=None):
+CYCLIC_BLOCK_ROWS = 256   # row block of the symmetric FAST kernel (SY_R in csrc/embed.hip)
+
+
+def cyclic_blocks(n, world, rank):
+    """global row ranges [(row0, nrows), ...] of the 256-row blocks rank, rank + world, ... (EmbedSession(cyclic=...))"""
+    nb = int(_ffi.lib().kmap_embed_cyclic_blocks(n, world, rank))
+    out = []
+    for b in range(nb):
+        r0 = (rank + world * b) * CYCLIC_BLOCK_ROWS
+        out.append((r0, min(CYCLIC_BLOCK_ROWS, n - r0)))
+    return out
+
+
+def knn_sums_kmers_dev(kh_dev_ptr, lab_dev_ptr, n, kmer_len, conseq_lens, nb, n_nb, row0=0, nrows=None, stream=None, out=None):
     """Same sums as knn_sums_dev but from the k-mers themselves (base-count profiles, csrc/knn_profile.hip): no matrix is
     read.  Returns None when the profile kernel does not cover the request (k > 16, more than 4 short consensuses)."""
     nrows = n - row0 if nrows is None else nrows
@@ -114,14 +129,16 @@ def knn_sums_kmers_dev(kh_dev_ptr, lab_dev_ptr, n, kmer_len, conseq_lens, nb, n_
     clen = np.ascontiguousarray(conseq_lens, dtype=np.int32)
     own = not isinstance(nb, _ffi.DeviceBuffer)
     nb_d = _ffi.DeviceBuffer.from_numpy(np.ascontiguousarray(nb, np.int32)) if own else nb
-    sums_d = _ffi.DeviceBuffer(max(nrows, 1) * lds * 2)
+    sums_d = _ffi.DeviceBuffer(max(nrows, 1) * lds * 2) if out is None else None
+    dst = sums_d.ptr if out is None else out              # out: device address of a caller-owned [nrows x lds] uint16 block
     fn = _ffi.lib().kmap_knn_sums_kmers_u32_dev if get_hash_dtype(kmer_len) == np.uint32 else _ffi.lib().kmap_knn_sums_kmers_u64_dev
     rc = fn(kh_dev_ptr, lab_dev_ptr, n, kmer_len, ptr(clen) if len(clen) else None, len(clen), nb_d.ptr, n_nb, row0, nrows,
-            sums_d.ptr, lds, stream)
+            dst, lds, stream)
     if own:
         nb_d.free()
     if rc == -4:                      # KMAP_E_UNSUP
-        sums_d.free()
+        if sums_d is not None:
+            sums_d.free()
         return None
     check(rc)
     _ffi.sync(stream)
@@ -201,10 +218,15 @@ def gradient_loss_taichi(hd_prob_mat, ld_prob_mat, ld_data, debug=False):
 class EmbedSession:
     """Owns a kmap_embed handle (coordinates, probabilities, snapshots and loop state in HBM)."""
 
-    def __init__(self, n, n_best=10, learning_rate=0.01, mode=EMBED_FAST, row0=0, nrows=None):
+    def __init__(self, n, n_best=10, learning_rate=0.01, mode=EMBED_FAST, row0=0, nrows=None, cyclic=None):
+        """cyclic=(world, rank): FAST session that owns the 256-row blocks rank, rank + world, ... and evaluates every
+        unordered pair once (multi-GPU; the probability rows are passed block after block, see cyclic_blocks)."""
         h = _ffi.vp()
         nrows = n - row0 if nrows is None else nrows
-        check(_ffi.lib().kmap_embed_create(C.byref(h), n, row0, nrows, n_best, learning_rate, mode))
+        if cyclic is not None:
+            check(_ffi.lib().kmap_embed_create_cyclic(C.byref(h), n, int(cyclic[0]), int(cyclic[1]), n_best, learning_rate))
+        else:
+            check(_ffi.lib().kmap_embed_create(C.byref(h), n, row0, nrows, n_best, learning_rate, mode))
         self._h, self.n, self.n_best = h.value, n, n_best
         self._keep = []
 
@@ -287,9 +309,12 @@ def _init_draws(n_data, n_best_result, random_seed):
 def _run_loop(sess, n_max_iter, step_fn=None, debug=False, trace=None):
     """Drive the device loop in segments; jitter normals are pre-drawn from numpy's global stream in
     order, and the stream is left exactly where the reference would leave it (one draw per jitter hit)."""
+    import time
     rng_state = np.random.get_state()
     pool = np.zeros(0, np.float64)
     info = sess.state()
+    _ffi.sync()
+    t_loop = time.perf_counter()
     while info["iters"] < n_max_iter and not info["stopped"]:
         seg = min(_SEGMENT, n_max_iter - info["iters"])
         if len(pool) - info["jitter_used"] < 2 * seg:
@@ -302,10 +327,13 @@ def _run_loop(sess, n_max_iter, step_fn=None, debug=False, trace=None):
         info = sess.state()
         if debug:
             print(f"i_iter= {info['iters']} loss= {info['last_loss']}")
+    _ffi.sync()
+    t_loop = time.perf_counter() - t_loop
     np.random.set_state(rng_state)
     if info["jitter_used"]:
         np.random.normal(0, 0.01, info["jitter_used"])
     if trace is not None:
+        trace["loop_s"] = t_loop                    # wall time of the iterations alone (device-synchronised on both sides)
         trace["losses"] = sess.losses()
         trace["state"] = info
         trace["last_coords"] = sess.coords()

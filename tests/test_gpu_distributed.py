@@ -162,3 +162,48 @@ def test_visualize_kmers_cli_under_torchrun(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append((res / "low_dim_data.tsv").read_text())
     assert outs[0] == outs[1] and outs[0].count("\n") == int(cnts.sum()) + 1
+
+
+def _cyclic_worker(rank, world, port, out_dir, n, iters):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    import kmap_amd.visualization as V
+    from kmap_amd.distributed import kmap_from_kmers_distributed
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(3)
+        kh = rng.integers(0, 4 ** K, size=n, dtype=np.uint64)
+        lab = np.sort(rng.integers(0, 3, size=n)).astype(np.int64)
+        tr = {}
+        best, _ = kmap_from_kmers_distributed(kh, np.ones(n, np.int64), lab, ["ACGTACGT", "ACGTAC"], K, n_max_iter=iters,
+                                              random_seed=SEED, mode=V.EMBED_FAST, trace=tr)
+        np.savez(Path(out_dir) / f"cyc_rank{rank}.npz", best=best, last=tr["last_coords"], losses=tr["losses"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cyclic_symmetric_shards_match_single_gpu(tmp_path):
+    """FAST at N >= 16384 under torch.distributed: the ranks own cyclic 256-row blocks and evaluate each unordered pair once;
+    the all-reduced gradient equals the single-GPU symmetric kernel's up to the order of the partial sums."""
+    import torch.multiprocessing as mp
+    import kmap_amd.visualization as V
+    n, iters = 16384 + 3 * 256 + 77, 6            # 68 row blocks, the last one ragged; odd split over 3 ranks
+    mp.spawn(_cyclic_worker, args=(3, _free_port(), str(tmp_path), n, iters), nprocs=3, join=True)
+    r = [np.load(tmp_path / f"cyc_rank{i}.npz") for i in range(3)]
+    for i in (1, 2):                              # identical state machines on every rank
+        np.testing.assert_array_equal(r[0]["last"], r[i]["last"])
+        np.testing.assert_array_equal(r[0]["losses"], r[i]["losses"])
+    rng = np.random.default_rng(3)
+    kh = rng.integers(0, 4 ** K, size=n, dtype=np.uint64)
+    lab = np.sort(rng.integers(0, 3, size=n)).astype(np.int64)
+    tr = {}
+    V.kmap_from_kmers(kh, np.ones(n, np.int64), lab, ["ACGTACGT", "ACGTAC"], K, n_max_iter=iters, random_seed=SEED,
+                      mode=V.EMBED_FAST, trace=tr)
+    np.testing.assert_allclose(r[0]["losses"], tr["losses"], rtol=2e-6)
+    # FAST sums are order-dependent in the last bits and the first steps from a random start are violent (the loss falls
+    # 100x in one step), so a handful of coordinates drift to ~1e-4 of the embedding's extent within 6 iterations
+    scale = np.abs(tr["last_coords"]).max()
+    diff = np.abs(r[0]["last"] - tr["last_coords"])
+    assert diff.max() <= 5e-4 * scale and np.quantile(diff, 0.99) <= 2e-5 * scale
