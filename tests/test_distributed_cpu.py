@@ -96,3 +96,83 @@ def test_two_rank_embedding_protocol_matches_single_process(tmp_path):
     u = np.load(ROOT / "tests" / "golden" / "umap_n96.npz")
     np.testing.assert_allclose(r0["ld"], u["coords"][n_iter - 1], rtol=0, atol=1e-5)
     np.testing.assert_allclose(r0["losses"], u["losses"][:n_iter], rtol=2e-6)
+
+
+class CyclicOracleSession:
+    """Stand-in for EmbedSession(cyclic=(world, rank)): the rank evaluates each unordered pair (i < j) whose row i lies in
+    one of its cyclic 256-row blocks and writes partial gradients for BOTH points; the all-reduce then is a true sum."""
+
+    def __init__(self, p, ld, blocks, lr, grad_np, loss_np):
+        from oracle import oracle as O
+        self.O, self.p, self.ld, self.lr = O, p, ld.copy(), lr
+        self.g, self.l = grad_np, loss_np
+        n = p.shape[0]
+        own = np.zeros(n, bool)
+        for r0, nr in blocks:
+            own[r0:r0 + nr] = True
+        self.mask = own[:, None] & (np.arange(n)[None, :] > np.arange(n)[:, None])
+        self.losses, self.prev = [], np.inf
+
+    def forces(self, gp, lp):
+        O, p = self.O, self.p
+        q = O.cal_ld_prob_mat(self.ld).astype(np.float64)
+        t = np.where(self.mask, (q / (1 - q)) * (p - q), 0.0)
+        for c in (0, 1):
+            d = self.ld[c][:, None].astype(np.float64) - self.ld[c][None, :]
+            f = t * d
+            self.g[c] = (f.sum(axis=1) - f.sum(axis=0)).astype(np.float32)   # row side minus column side
+        ce = -(p * np.log(q) + (1 - p) * np.log(1 - q))
+        self.l[0] = np.where(self.mask, ce, 0.0).sum()
+
+    def apply(self, gp, lp):
+        cur = np.float32(2.0 * self.l[0])
+        self.losses.append(cur)
+        self.prev = cur
+        self.ld += (-(4.0 * self.g) * self.lr)
+
+
+def _cyclic_worker(rank, world, port, n_iter, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from kmap_amd.distributed import DistEmbedLoop
+    from kmap_amd.visualization import cyclic_blocks
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 600                                                 # three 256-row blocks: 256, 256, 88
+        rng = np.random.default_rng(4)
+        p = rng.random((n, n)) * 0.9 + 0.05
+        p = np.triu(p, 1)
+        p = (p + p.T).astype(np.float32)
+        ld = (rng.standard_normal((2, n)) * 3).astype(np.float32)
+        blocks = cyclic_blocks(n, world, rank)
+        grad_t = torch.zeros((2, n), dtype=torch.float32)
+        loss_t = torch.zeros(1, dtype=torch.float64)
+        sess = CyclicOracleSession(p, ld, blocks, 0.0005, grad_t.numpy(), loss_t.numpy())   # small steps: no chaotic amplification
+        loop = DistEmbedLoop(sess, grad_t, loss_t, dist if world > 1 else None)
+        loop.step(n_iter)
+        np.savez(Path(out_dir) / f"cyc{rank}_of{world}.npz", ld=sess.ld, losses=np.array(sess.losses, np.float32),
+                 blocks=np.array(blocks).reshape(-1, 2))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_cyclic_block_protocol_matches_single_process(tmp_path):
+    """the cyclic symmetric layout (FAST from N = 16384 in the product): block dealing, partial gradients for all points, the
+    all-reduce as a true sum -- two and three ranks (one of them with a single ragged block) against one process"""
+    import torch.multiprocessing as mp
+    n_iter = 6
+    for world in (1, 2, 3):
+        mp.spawn(_cyclic_worker, args=(world, _free_port(), n_iter, str(tmp_path)), nprocs=world, join=True)
+    single = np.load(tmp_path / "cyc0_of1.npz")
+    assert single["blocks"].tolist() == [[0, 256], [256, 256], [512, 88]]
+    two = [np.load(tmp_path / f"cyc{r}_of2.npz") for r in range(2)]
+    assert two[0]["blocks"].tolist() == [[0, 256], [512, 88]] and two[1]["blocks"].tolist() == [[256, 256]]
+    for world in (2, 3):
+        rs = [np.load(tmp_path / f"cyc{r}_of{world}.npz") for r in range(world)]
+        for r in rs[1:]:
+            np.testing.assert_array_equal(rs[0]["ld"], r["ld"])        # every rank holds the same iterate
+            np.testing.assert_array_equal(rs[0]["losses"], r["losses"])
+        np.testing.assert_allclose(rs[0]["losses"], single["losses"], rtol=1e-6)
+        np.testing.assert_allclose(rs[0]["ld"], single["ld"], rtol=0, atol=1e-4 * np.abs(single["ld"]).max())
