@@ -8,6 +8,7 @@
 // compaction that applies the reverse-complement merge on the fly.  A uint32 bin wraps exactly
 // like the reference's int64 -> int32 cast of np.unique counts.
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -542,8 +543,16 @@ int kmap_counts_fetch(kmap_counts *c, void *uniq_out, void *cnt_out) {
         uint32_t *tmp = (uint32_t *)malloc(n * 4);
         KMAP_REQUIRE(tmp, "counts_fetch: host malloc");
         hipError_t e = hipMemcpy(tmp, c->cnt, n * 4, hipMemcpyDeviceToHost);
-        if (e == hipSuccess)
-            for (size_t i = 0; i < n; ++i) ((int64_t *)cnt_out)[i] = (int64_t)tmp[i];
+        if (e == hipSuccess) {   // widen uint32 -> int64 on several host threads (10^9 entries at k = 16)
+            const unsigned nt = n > ((size_t)1 << 22) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nt; ++t)
+                pool.emplace_back([=]() {
+                    const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
+                    for (size_t i = lo; i < hi; ++i) ((int64_t *)cnt_out)[i] = (int64_t)tmp[i];
+                });
+            for (auto &th : pool) th.join();
+        }
         free(tmp);
         KMAP_CHECK_HIP(e);
     }
