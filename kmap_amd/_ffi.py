@@ -213,6 +213,17 @@ class DeviceBuffer:
             pass
 
 
+class DeviceView(DeviceBuffer):
+    """Non-owning alias of device memory someone else owns (a torch tensor, a slice of a DeviceBuffer): same `.ptr` /
+    `.to_numpy` interface, `free()` only drops the alias.  `keep` holds a reference to the owner."""
+
+    def __init__(self, dev_ptr, nbytes, keep=None):   # noqa: super().__init__ would allocate
+        self.ptr, self.nbytes, self._keep = int(dev_ptr), int(nbytes), keep
+
+    def free(self):
+        self.ptr, self._keep = None, None
+
+
 def sync(stream=None):
     check(lib().kmap_stream_sync(stream))
 

@@ -1,8 +1,9 @@
 """`kmap` command line: the three verbs of the reference's CLI that sit on the GPU hot path
 (reference cli.py:9-36, kmer_count.py:70-101, motif_discovery.py:29-53, visualization.py:18-33),
 with the same option names, plus `ex_hamball` (motif_discovery.py:74-108; Hamming-ball extraction on the GPU).  The
-and `check_motif_co_occurence` (motif_discovery.py:111-178; data only).  The reference's plotting / alignment verbs
-(draw_logo, align_conseq, extract_motif_locations, plot_network) are out of scope here."""
+reference's plotting / alignment / reporting verbs (draw_logo, align_conseq, extract_motif_locations, plot_network,
+check_motif_co_occurence) are out of scope here.  `scan_motif` and `visualize_kmers` shard over the
+GPUs of a node when launched through `python -m torch.distributed.run --nproc-per-node G -m kmap_amd <verb> ...`."""
 import click
 
 from . import __version__
@@ -57,17 +58,3 @@ def visualize_kmers(res_dir, debug=False):
 def ex_hamball(res_dir, conseq, return_type, output_file, max_ham_dist=-1):
     from .reports import _ex_hamball
     _ex_hamball(res_dir, conseq, return_type, output_file, max_ham_dist)
-
-
-@cli.command(name="check_motif_co_occurence")
-@click.option("--input_fasta_file", type=str, required=True, help="Input FASTA file")
-@click.option("--motif1", type=str, required=True, help="First motif sequence")
-@click.option("--motif2", type=str, required=True, help="Second motif sequence")
-@click.option("--max_ham_dist1", type=int, required=True, help="Maximum Hamming distance for the first motif")
-@click.option("--max_ham_dist2", type=int, required=True, help="Maximum Hamming distance for the second motif")
-@click.option("--output_dir", type=str, required=True, help="Output directory")
-@click.option("--revcom_mode", type=bool, default=True, required=False, help="Reverse complement mode")
-def check_motif_co_occurence(input_fasta_file, motif1, motif2, max_ham_dist1, max_ham_dist2, output_dir, revcom_mode=True):
-    from .motif_discovery import check_motif_co_occurence as _run
-    co, dist, _, info = _run(input_fasta_file, motif1, motif2, max_ham_dist1, max_ham_dist2, output_dir, revcom_mode)
-    print(f"co-occurrence matrix:\n{co}\nmedian |distance|: {dist[0][1]}  {info}")

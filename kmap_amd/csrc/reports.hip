@@ -233,8 +233,8 @@ int kmap_pos_density(const int32_t *hits, const int64_t *offs, const int32_t *po
 // members), per-label weight sums / prefix sums / searches run on the device, and only the sampled entries come back.
 namespace {
 struct LabTab {
-    uint64_t cons[32], rccons[32];
-    int32_t clen[32], radius[32];
+    uint64_t cons[63], rccons[63];
+    int32_t clen[63], radius[63];
     int n;
 };
 
@@ -333,7 +333,7 @@ extern "C" {
 int kmap_label_kmers_dev(void *uniq_dev, int64_t n, int k, int n_cons, const uint64_t *cons_kh, const int32_t *cons_len,
                          const int32_t *cons_radius, int radius_k, int revcom_mode, uint8_t *label_dev, void *stream) {
     KMAP_REQUIRE(k > 0 && k < 32 && n >= 0, "label_kmers: bad k / n");
-    KMAP_REQUIRE(n_cons > 0 && n_cons <= 32 && cons_kh && cons_len && cons_radius, "label_kmers: 1..32 consensuses");
+    KMAP_REQUIRE(n_cons > 0 && n_cons <= 63 && cons_kh && cons_len && cons_radius, "label_kmers: 1..63 consensuses");
     if (n == 0) return KMAP_OK;
     KMAP_REQUIRE(uniq_dev && label_dev, "label_kmers: null pointer");
     LabTab t;

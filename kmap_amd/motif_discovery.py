@@ -31,7 +31,7 @@ DENSE_PKL_MAX_N = 16384
 # above this many unique k-mers find_motif stops fetching the count arrays every trial: the top_k candidates come from
 # the device (largest count, then lowest index) instead of np.argpartition (whose tie order is numpy-specific anyway)
 TOPK_DEVICE_MIN = 4_000_000
-SAMPLE_ON_DEVICE = True      # sample_disp_kmer: keep tables above TOPK_DEVICE_MIN on the device (False: numpy formulation)
+TOPK_DEVICE_MAX_K = 16       # kmap_counts_topk keeps 16 candidates per thread; a larger top_k takes the host path at any size
 
 STAGE_TIMES = {}   # cumulative wall-clock per stage of the last runs (tools/e2e.py, bench.py report it)
 
@@ -68,6 +68,8 @@ class DeviceSeq:
         self.n_seq = len(self.borders_host)
         self.borders = _ffi.DeviceBuffer.from_numpy(self.borders_host)
         self.read_len = (self.borders_host[:, 1] - self.borders_host[:, 0]).astype(np.int64)
+        # the reads scan() results cover: these reads here; ALL reads for a read-sharded DistDeviceSeq (distributed.py)
+        self.out_n_seq, self.out_read_len = self.n_seq, self.read_len
         self.groups = int(_ffi.lib().kmap_packed_groups(self.n))
         self.codes = _ffi.DeviceBuffer(self.groups * 4)
         self.inval_orig = _ffi.DeviceBuffer(self.groups * 2)
@@ -188,7 +190,7 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
         else:
             dev_seq.count(dc, kmer_len, dedupe=not rep_mode, merge_revcom=merge_revcom_mode)   # first round
             uniq_kh_arr, uniq_kh_cnt_arr = None, None
-        big = dc.n_uniq > TOPK_DEVICE_MIN
+        big = dc.n_uniq > TOPK_DEVICE_MIN and top_k <= TOPK_DEVICE_MAX_K
         writer = None
         if save_kmer_cnt_flag and kmer_cnt_pkl_file and not Path(kmer_cnt_pkl_file).exists():
             if uniq_kh_arr is None:
@@ -247,7 +249,7 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
             cons = [consensus_kh, revcom_hash(consensus_kh, kmer_len)] if merge_revcom_mode else [consensus_kh]
             dev_seq.mask(kmer_len, np.array(cons), np.array([max_ham_dist] * len(cons)))
             dev_seq.count(dc, kmer_len, dedupe=False, merge_revcom=merge_revcom_mode)   # later rounds: no dedupe (:695)
-            big = dc.n_uniq > TOPK_DEVICE_MIN
+            big = dc.n_uniq > TOPK_DEVICE_MIN and top_k <= TOPK_DEVICE_MAX_K
             uniq_kh_arr, uniq_kh_cnt_arr = None, None
         if writer is not None:
             writer.join()
@@ -263,7 +265,7 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
 
 
 # ---- motif occurrence (reference motif_discovery.py:1396-1477) -------------------------------------------
-def scan_motif_occurence(dev_seq: DeviceSeq, conseq_list, motif_def_dict, revcom_mode=True):
+def scan_motif_occurence(dev_seq: DeviceSeq, conseq_list, motif_def_dict, revcom_mode=True, subsample=True):
     """Per consensus: (hits_per_read int32[n_seq], positions int32[sum]) after the reference's >20-hit random
     subsample (np.random.choice in read order, then consensus order -- the reference's draw order)."""
     per = []
@@ -271,7 +273,7 @@ def scan_motif_occurence(dev_seq: DeviceSeq, conseq_list, motif_def_dict, revcom
         k = len(conseq)
         hits, pos = dev_seq.scan(k, kmer2hash(conseq), motif_def_dict[k].max_ham_dist, revcom_mode)
         per.append([hits, pos])
-    big = [(int(r), c) for c, (hits, _) in enumerate(per) for r in np.nonzero(hits > 20)[0]]
+    big = [(int(r), c) for c, (hits, _) in enumerate(per) for r in np.nonzero(hits > 20)[0]] if subsample else []
     if big:
         offs = [np.concatenate([[0], np.cumsum(h, dtype=np.int64)]) for h, _ in per]
         keep = [np.ones(len(p), bool) for _, p in per]
@@ -289,24 +291,27 @@ def scan_motif_occurence(dev_seq: DeviceSeq, conseq_list, motif_def_dict, revcom
 
 
 def gen_motif_occurence_file(conseq_list: List[str], motif_def_dict: dict, input_fasta_file, output_file, revcom_mode=True,
-                             dev_seq: DeviceSeq = None):
+                             dev_seq: DeviceSeq = None, write=True):
     """seq_ind;loc,loc;...;seq_len for every read with a hit.  With `dev_seq` the resident read array is
-    scanned (it is the encoding of the same FASTA); otherwise the FASTA is encoded and uploaded here."""
+    scanned (it is the encoding of the same FASTA); otherwise the FASTA is encoded and uploaded here.
+    write=False: scan only (the ranks of a read-sharded run that do not own the output files)."""
     own = dev_seq is None
     if own:
         assert Path(input_fasta_file).exists()
         arr, borders = encode_fasta(str(input_fasta_file))
         dev_seq = DeviceSeq(arr, borders)
     try:
-        per = scan_motif_occurence(dev_seq, conseq_list, motif_def_dict, revcom_mode)
+        per = scan_motif_occurence(dev_seq, conseq_list, motif_def_dict, revcom_mode, subsample=write)
         header = "seq_ind;" + ";".join(f"motif_{i}_{c}" for i, c in enumerate(conseq_list)) + ";seq_len"
         n_cons = len(conseq_list)
         hits_ptrs = (C.c_void_p * max(n_cons, 1))(*[h.ctypes.data for h, _ in per])
         pos_keep = [np.ascontiguousarray(p, np.int32) if len(p) else np.zeros(1, np.int32) for _, p in per]
         pos_ptrs = (C.c_void_p * max(n_cons, 1))(*[p.ctypes.data for p in pos_keep])
         rows = _ffi.i64(0)
-        check(_ffi.lib().kmap_write_occurrence_csv(str(output_file).encode(), header.encode(), dev_seq.n_seq, n_cons,
-                                                   hits_ptrs, pos_ptrs, ptr(dev_seq.read_len), C.byref(rows)))
+        if write:
+            assert all(len(h) == dev_seq.out_n_seq for h, _ in per)
+            check(_ffi.lib().kmap_write_occurrence_csv(str(output_file).encode(), header.encode(), dev_seq.out_n_seq, n_cons,
+                                                       hits_ptrs, pos_ptrs, ptr(dev_seq.out_read_len), C.byref(rows)))
         return per
     finally:
         if own:
@@ -326,180 +331,185 @@ def get_user_motif_occurence_file(input_fasta_file, conseq_list: List[str], max_
     return gen_motif_occurence_file(conseq_list, motif_def_dict, input_fasta_file, output_file, revcom_mode)
 
 
-def check_motif_co_occurence(input_fasta_file: str, motif1: str, motif2: str, max_ham_dist1: int, max_ham_dist2: int,
-                             output_dir: str, revcom_mode: bool):
-    """`kmap check_motif_co_occurence` without its figures (reference motif_discovery.py:155-178): writes
-    user_motif_occurence.csv and returns (co-occurrence matrix, median-distance matrix, distance lists, info string)."""
-    assert Path(input_fasta_file).exists()
-    out = Path(output_dir)
-    out.mkdir(parents=True, exist_ok=True)
-    occurence_file = out / "user_motif_occurence.csv"
-    get_user_motif_occurence_file(Path(input_fasta_file), [motif1, motif2], [max_ham_dist1, max_ham_dist2], occurence_file,
-                                  revcom_mode)
-    co_occur_mat, loc_dist_mat, loc_dist_dict = get_motif_co_occurence_mat(occurence_file, 2)
-    info_str = ""
-    if np.any(co_occur_mat):
-        co_occur_freq = co_occur_mat[0][1] * 2 / (co_occur_mat[0][0] + co_occur_mat[1][1])
-        info_str = f"co_occur_freq={co_occur_freq * 100:.2f}%"
-    return co_occur_mat, loc_dist_mat, loc_dist_dict, info_str
-
-
 from .reports import (Occurrence, get_motif_seq_num, get_motif_pos_density, get_motif_co_occurence_mat,   # noqa: E402,F401
                       write_co_occurence_mat, write_co_occurence_dist_arr, ex_hamball_kh_arr, cal_cnt_mat, _ex_hamball)
 
 
 # ---- sampling (reference motif_discovery.py:812-921) -------------------------------------------------------
-def sample_disp_kmer(conseq_list: List[str], kmer_len: int, motif_def_dict: dict, kmer_count_dir: Path, n_total_sample=5000,
-                     n_motif_kmer=2500, revcom_mode=True):
-    conseq_list = [s for s in conseq_list if 2 < len(s) <= kmer_len]
-    assert len(conseq_list) > 0
-    assert all(len(a) >= len(b) for a, b in zip(conseq_list, conseq_list[1:]))
-    with open(Path(kmer_count_dir) / f"k{kmer_len}.pkl", "rb") as fh:
-        res_list = pickle.load(fh)
-    assert res_list[0] == kmer_len
-    uniq_kh_arr, uniq_kh_cnt_arr = res_list[1], res_list[2]
+class _LabelledTable:
+    """The counted k-mers of one k resident on the device with a label per entry (csrc/reports.hip: label_kernel).
+    Semantics of the reference's labelling (motif_discovery.py:846-883): distance of a k-mer to consensus c = its first
+    len(c) bases against c, or -- reverse-complement mode -- its last len(c) bases against rc(c) if that is strictly
+    smaller; a distance above c's own radius counts as k; label = first consensus at the minimum, or the noise label
+    n_conseq when the minimum exceeds the radius of k; members matched through the reverse complement are re-oriented."""
 
-    sampling_flag = True
-    # the reference's builtin sum() over numpy scalars == a sum wrapped to the count dtype; np.sum is O(n) in C
-    n_seq_total = _wrap_total(int(uniq_kh_cnt_arr.sum(dtype=np.int64)), kmer_len)
-    if n_total_sample > n_seq_total:
-        warnings.warn(f"The number of samples n_sample={n_total_sample} is larger than the original "
-                      f"data n_seq={n_seq_total}, process and return original data.")
-        sampling_flag = False
-
-    n_conseq, n_uniq = len(conseq_list), len(uniq_kh_arr)
-    big = n_uniq > TOPK_DEVICE_MIN
-    if big and sampling_flag and n_conseq <= 32 and SAMPLE_ON_DEVICE:
-        return _sample_disp_kmer_dev(uniq_kh_arr, uniq_kh_cnt_arr, conseq_list, kmer_len, motif_def_dict, n_total_sample,
-                                     n_motif_kmer, revcom_mode)
-    # distances are <= kmer_len < 32: a narrow matrix gives the same min/argmin and fits 1e9 unique k-mers in memory
-    ham_dist_mat = np.zeros((n_conseq, n_uniq), dtype=np.uint8 if big else int)
-    rc_flag_mat = np.zeros((n_conseq, n_uniq), dtype=bool)
-    for i, conseq in enumerate(conseq_list):
-        conseq_kh = kmer2hash(conseq)
-        dist_arr = cal_hamming_dist_head(uniq_kh_arr, conseq_kh, kmer_len, len(conseq))
-        if revcom_mode:
-            rc_conseq_kh = revcom_hash(conseq_kh, len(conseq))
-            assert conseq_kh <= rc_conseq_kh
-            rc_dist_arr = cal_hamming_dist_tail(uniq_kh_arr, rc_conseq_kh, kmer_len, len(conseq))
-            rc_flag_mat[i] = rc_dist_arr < dist_arr
-            dist_arr = np.minimum(dist_arr, rc_dist_arr)
-        ham_dist_mat[i] = dist_arr
-    for i, conseq in enumerate(conseq_list):
-        ham_dist_mat[i][ham_dist_mat[i] > motif_def_dict[len(conseq)].max_ham_dist] = kmer_len
-    min_dist_arr = np.min(ham_dist_mat, axis=0)
-    label_arr = np.argmin(ham_dist_mat, axis=0)
-    label_arr[min_dist_arr > motif_def_dict[kmer_len].max_ham_dist] = n_conseq
-
-    if revcom_mode:   # align Hamming-ball members with their consensus
-        for i in range(n_conseq):
-            members = np.where(label_arr == i)[0]
-            flip = members[rc_flag_mat[i][members]]
-            if len(flip):
-                uniq_kh_arr[flip] = get_revcom_hash_arr(uniq_kh_arr[flip], kmer_len)
-    if not sampling_flag:
-        return uniq_kh_arr, uniq_kh_cnt_arr, label_arr, conseq_list
-
-    sample_cnt_arr = np.bincount(label_arr, weights=uniq_kh_cnt_arr)
-    motif_weights = sample_cnt_arr[:-1] / sum(sample_cnt_arr[:-1])
-    sample_cnt_arr[:-1] = np.around(n_motif_kmer * motif_weights)
-    sample_cnt_arr[-1] = n_total_sample - sum(sample_cnt_arr[0:-1])
-    sample_cnt_arr = sample_cnt_arr.astype(int)
-    assert len(sample_cnt_arr) == n_conseq + 1
-
-    samp_inds, samp_cnts = [], []
-    for c in range(n_conseq + 1):
-        c_inds = np.where(label_arr == c)[0]
-        ws = uniq_kh_cnt_arr[c_inds]
-        ws_total = _wrap_total(int(ws.sum(dtype=np.int64)), kmer_len)
-        if len(c_inds) > TOPK_DEVICE_MIN:
-            # np.random.multinomial walks every category with one binomial draw each (minutes for 1e9 categories):
-            # draw the same multinomial distribution by inverse CDF instead (global legacy RNG, different draws)
-            cdf = np.cumsum(ws, dtype=np.float64)
-            hits = np.searchsorted(cdf, np.random.random_sample(int(sample_cnt_arr[c])) * cdf[-1], side="right")
-            sel, tmp = np.unique(np.minimum(hits, len(ws) - 1), return_counts=True)
-            samp_inds.append(c_inds[sel])
-            samp_cnts.append(tmp)
-            continue
-        ws = ws / ws_total
-        tmpcnts = np.random.multinomial(sample_cnt_arr[c], ws, size=1).squeeze()   # global legacy RNG, as the reference
-        samp_inds.append(c_inds[tmpcnts > 0])
-        samp_cnts.append(tmpcnts[tmpcnts > 0])
-    samp_inds = np.concatenate(samp_inds)
-    samp_cnts = np.concatenate(samp_cnts)
-    return uniq_kh_arr[samp_inds], samp_cnts, label_arr[samp_inds], conseq_list
-
-
-def _sample_disp_kmer_dev(uniq_kh_arr, uniq_kh_cnt_arr, conseq_list, kmer_len, motif_def_dict, n_total_sample, n_motif_kmer,
-                          revcom_mode):
-    """sample_disp_kmer for k-mer tables above TOPK_DEVICE_MIN entries: the table stays on the device (labels, re-orientation,
-    per-label weight sums, prefix sums and searches are kernels), only the sampled entries come back.  Draws the same random
-    numbers in the same order as the host formulation above (np.random.multinomial for labels up to TOPK_DEVICE_MIN members,
-    inverse CDF beyond), so both give identical samples."""
-    lib = _ffi.lib()
-    n, n_conseq = len(uniq_kh_arr), len(conseq_list)
-    hd, cd = get_hash_dtype(kmer_len), get_cnt_dtype(kmer_len)
-    u_d = _ffi.DeviceBuffer.from_numpy(np.ascontiguousarray(uniq_kh_arr, hd))
-    c_d = _ffi.DeviceBuffer.from_numpy(np.ascontiguousarray(uniq_kh_cnt_arr, cd))
-    lab_d, scratch_d, excl_d = _ffi.DeviceBuffer(n), _ffi.DeviceBuffer(n * 4), _ffi.DeviceBuffer((n + 1) * 8)
-    cnt64 = int(cd == np.int64)
-    try:
-        cons = np.array([int(kmer2hash(s)) for s in conseq_list], np.uint64)
+    def __init__(self, uniq_kh_arr, uniq_kh_cnt_arr, conseq_list, kmer_len, motif_def_dict, revcom_mode):
+        self.k, self.n, self.n_lab = kmer_len, len(uniq_kh_arr), len(conseq_list) + 1
+        self.hd, self.cd = get_hash_dtype(kmer_len), get_cnt_dtype(kmer_len)
+        self.cnt64 = int(self.cd == np.int64)
+        if self.n_lab > 64:
+            raise ValueError(f"sample_disp_kmer: {self.n_lab - 1} consensus sequences; the device labelling handles at most 63")
+        self._bufs = []
+        self.u_d = self._dev(np.ascontiguousarray(uniq_kh_arr, self.hd))
+        self.c_d = self._dev(np.ascontiguousarray(uniq_kh_cnt_arr, self.cd))
+        self.lab_d = self._dev(nbytes=max(self.n, 1))
+        self.w32_d = self._dev(nbytes=max(self.n, 1) * 4)
+        self.excl_d = self._dev(nbytes=(self.n + 1) * 8)
+        kh = [int(kmer2hash(s)) for s in conseq_list]
+        if revcom_mode:   # consensuses are stored as the smaller of (hash, revcom hash), like the reference asserts (:857)
+            assert all(h <= int(revcom_hash(h, len(s))) for h, s in zip(kh, conseq_list))
+        cons = np.array(kh, np.uint64)
         lens = np.array([len(s) for s in conseq_list], np.int32)
         rads = np.array([motif_def_dict[len(s)].max_ham_dist for s in conseq_list], np.int32)
-        if revcom_mode:
-            for s in conseq_list:
-                assert kmer2hash(s) <= revcom_hash(kmer2hash(s), len(s))
-        check(lib.kmap_label_kmers_dev(u_d.ptr, n, kmer_len, n_conseq, ptr(cons), ptr(lens), ptr(rads),
-                                       int(motif_def_dict[kmer_len].max_ham_dist), int(bool(revcom_mode)), lab_d.ptr, None))
-        wsum, members = np.zeros(n_conseq + 1, np.int64), np.zeros(n_conseq + 1, np.int64)
-        check(lib.kmap_label_sums_dev(lab_d.ptr, c_d.ptr, cnt64, n, n_conseq + 1, ptr(wsum), ptr(members)))
+        if self.n:
+            check(_ffi.lib().kmap_label_kmers_dev(self.u_d.ptr, self.n, kmer_len, len(conseq_list), ptr(cons), ptr(lens), ptr(rads),
+                                                  int(motif_def_dict[kmer_len].max_ham_dist), int(bool(revcom_mode)),
+                                                  self.lab_d.ptr, None))
 
-        sample_cnt_arr = wsum.astype(np.float64)                       # np.bincount(label_arr, weights=uniq_kh_cnt_arr)
-        motif_weights = sample_cnt_arr[:-1] / sum(sample_cnt_arr[:-1])
-        sample_cnt_arr[:-1] = np.around(n_motif_kmer * motif_weights)
-        sample_cnt_arr[-1] = n_total_sample - sum(sample_cnt_arr[0:-1])
-        sample_cnt_arr = sample_cnt_arr.astype(int)
+    def _dev(self, arr=None, nbytes=None):
+        b = _ffi.DeviceBuffer.from_numpy(arr) if arr is not None and len(arr) else _ffi.DeviceBuffer(nbytes or 16)
+        self._bufs.append(b)
+        return b
 
-        samp_inds, samp_cnts = [], []
-        for c in range(n_conseq + 1):
-            m = int(members[c])
-            if m > TOPK_DEVICE_MIN:                                    # inverse CDF over the integer prefix sums
-                check(lib.kmap_label_prefix_dev(lab_d.ptr, c_d.ptr, cnt64, n, c, scratch_d.ptr, excl_d.ptr, None))
-                total = float(wsum[c])
-                x = np.random.random_sample(int(sample_cnt_arr[c])) * total
-                targets = np.minimum(np.floor(x).astype(np.int64), int(wsum[c]) - 1)
-                hits = np.empty(len(targets), np.int64)
-                check(lib.kmap_prefix_search_dev(excl_d.ptr, n, ptr(targets), len(targets), ptr(hits)))
-                sel, tmp = np.unique(hits, return_counts=True)
-                samp_inds.append(sel)
-                samp_cnts.append(tmp)
-                continue
-            c_inds = np.empty(m, np.int64)
-            if m:
-                check(lib.kmap_label_prefix_dev(lab_d.ptr, None, 0, n, c, scratch_d.ptr, excl_d.ptr, None))
-                check(lib.kmap_label_members_dev(lab_d.ptr, excl_d.ptr, n, c, m, ptr(c_inds)))
-            ws = np.empty(m, cd)
-            check(lib.kmap_gather_dev(c_d.ptr, np.dtype(cd).itemsize, ptr(c_inds), m, ptr(ws)))
-            ws = ws / _wrap_total(int(ws.sum(dtype=np.int64)), kmer_len)
-            tmpcnts = np.random.multinomial(sample_cnt_arr[c], ws, size=1).squeeze()
-            samp_inds.append(c_inds[tmpcnts > 0])
-            samp_cnts.append(tmpcnts[tmpcnts > 0])
-        samp_inds = np.concatenate(samp_inds)
-        samp_cnts = np.concatenate(samp_cnts)
-        out_kh, out_lab = np.empty(len(samp_inds), hd), np.empty(len(samp_inds), np.uint8)
-        check(lib.kmap_gather_dev(u_d.ptr, np.dtype(hd).itemsize, ptr(samp_inds), len(samp_inds), ptr(out_kh)))
-        check(lib.kmap_gather_dev(lab_d.ptr, 1, ptr(samp_inds), len(samp_inds), ptr(out_lab)))
-        return out_kh, samp_cnts, out_lab.astype(np.int64), conseq_list
-    finally:
-        for b in (u_d, c_d, lab_d, scratch_d, excl_d):
+    def label_totals(self):
+        """(sum of counts, number of members) per label, int64[n_lab] each"""
+        wsum, members = np.zeros(self.n_lab, np.int64), np.zeros(self.n_lab, np.int64)
+        if self.n:
+            check(_ffi.lib().kmap_label_sums_dev(self.lab_d.ptr, self.c_d.ptr, self.cnt64, self.n, self.n_lab, ptr(wsum), ptr(members)))
+        return wsum, members
+
+    def member_indices(self, c, m):
+        """ascending table indices of label c's m members"""
+        idx = np.empty(m, np.int64)
+        if m:
+            check(_ffi.lib().kmap_label_prefix_dev(self.lab_d.ptr, None, 0, self.n, c, self.w32_d.ptr, self.excl_d.ptr, None))
+            check(_ffi.lib().kmap_label_members_dev(self.lab_d.ptr, self.excl_d.ptr, self.n, c, m, ptr(idx)))
+        return idx
+
+    def _take(self, buf, dtype, idx):
+        out = np.empty(len(idx), dtype)
+        check(_ffi.lib().kmap_gather_dev(buf.ptr, np.dtype(dtype).itemsize, ptr(np.ascontiguousarray(idx, np.int64)), len(idx), ptr(out)))
+        return out
+
+    def counts_at(self, idx):
+        return self._take(self.c_d, self.cd, idx)
+
+    def kmers_at(self, idx):
+        return self._take(self.u_d, self.hd, idx)
+
+    def labels_at(self, idx):
+        return self._take(self.lab_d, np.uint8, idx).astype(np.int64)
+
+    def cdf_pick(self, c, total, n_draw):
+        """n_draw inverse-CDF picks over label c's counts: index of the member whose cumulative count interval holds
+        floor(u * total), u ~ np.random.random_sample (global legacy stream)."""
+        check(_ffi.lib().kmap_label_prefix_dev(self.lab_d.ptr, self.c_d.ptr, self.cnt64, self.n, c, self.w32_d.ptr, self.excl_d.ptr, None))
+        u = np.random.random_sample(n_draw) * float(total)
+        targets = np.minimum(np.floor(u).astype(np.int64), total - 1)
+        hit = np.empty(n_draw, np.int64)
+        check(_ffi.lib().kmap_prefix_search_dev(self.excl_d.ptr, self.n, ptr(targets), n_draw, ptr(hit)))
+        return hit
+
+    def whole_table(self):
+        """(re-oriented k-mers, labels int64) of every entry"""
+        return self.u_d.to_numpy(self.hd, (self.n,)), self.lab_d.to_numpy(np.uint8, (self.n,)).astype(np.int64)
+
+    def close(self):
+        for b in self._bufs:
             b.free()
+        self._bufs = []
+
+
+def _label_quota(label_weight, n_total_sample, n_motif_kmer):
+    """How many of the n_total_sample draws each label gets (reference :893-897): the motif labels share n_motif_kmer in
+    proportion to their k-mer mass (rounded half-to-even by np.around), the noise label takes the remainder.  All quantities
+    are integer-valued float64, so the order of the sums does not matter."""
+    mass = np.asarray(label_weight, np.float64)
+    share = mass[:-1] / mass[:-1].sum()
+    quota = np.empty(len(mass), np.float64)
+    quota[:-1] = np.around(n_motif_kmer * share)
+    quota[-1] = n_total_sample - quota[:-1].sum()
+    return quota.astype(int)
+
+
+def sample_disp_kmer(conseq_list: List[str], kmer_len: int, motif_def_dict: dict, kmer_count_dir: Path, n_total_sample=5000,
+                     n_motif_kmer=2500, revcom_mode=True):
+    """Drop-in for the reference's sample_disp_kmer (motif_discovery.py:812-921): labels every counted k-mer of `kmer_len` by
+    its nearest consensus and draws a labelled multinomial sample -> (k-mer hashes, sample counts, labels, consensus list).
+    The table is labelled on the device whatever its size; the host only makes the random draws, in the reference's order and
+    from the same global np.random stream (one np.random.multinomial per label over the members' normalised counts), so the
+    sample equals the reference's for a given seed.  Labels with more than TOPK_DEVICE_MIN members are drawn by inverse CDF
+    instead (np.random.multinomial walks every category: minutes at 1e9 members) -- a documented deviation in the random
+    draws, not in the distribution, for tables the reference cannot process."""
+    conseq_list = [s for s in conseq_list if 2 < len(s) <= kmer_len]
+    assert len(conseq_list) > 0
+    assert all(len(a) >= len(b) for a, b in zip(conseq_list, conseq_list[1:]))   # longest first, as merge_consensus_seqs emits
+    with open(Path(kmer_count_dir) / f"k{kmer_len}.pkl", "rb") as fh:
+        k_pkl, uniq_kh_arr, uniq_kh_cnt_arr = pickle.load(fh)
+    assert k_pkl == kmer_len
+
+    tab = _LabelledTable(uniq_kh_arr, uniq_kh_cnt_arr, conseq_list, kmer_len, motif_def_dict, revcom_mode)
+    try:
+        label_weight, label_members = tab.label_totals()
+        # the reference compares against the builtin sum() of numpy scalars, i.e. a total wrapped to the count dtype
+        n_seq_total = _wrap_total(int(label_weight.sum()), kmer_len)
+        if n_total_sample > n_seq_total:
+            warnings.warn(f"The number of samples n_sample={n_total_sample} is larger than the original "
+                          f"data n_seq={n_seq_total}, process and return original data.")
+            kh_all, lab_all = tab.whole_table()
+            return kh_all, uniq_kh_cnt_arr, lab_all, conseq_list
+
+        quota = _label_quota(label_weight, n_total_sample, n_motif_kmer)
+        picked, picked_cnt = [], []
+        for c, n_draw in enumerate(quota):
+            m = int(label_members[c])
+            if m > TOPK_DEVICE_MIN:
+                where, times = np.unique(tab.cdf_pick(c, int(label_weight[c]), int(n_draw)), return_counts=True)
+            else:
+                members = tab.member_indices(c, m)
+                w = tab.counts_at(members)
+                prob = w / _wrap_total(int(w.sum(dtype=np.int64)), kmer_len)      # builtin sum() of count-dtype scalars
+                draw = np.random.multinomial(n_draw, prob, size=1).squeeze()
+                where, times = members[draw > 0], draw[draw > 0]
+            picked.append(where)
+            picked_cnt.append(times)
+        picked, picked_cnt = np.concatenate(picked), np.concatenate(picked_cnt)
+        return tab.kmers_at(picked), picked_cnt, tab.labels_at(picked), conseq_list
+    finally:
+        tab.close()
 
 
 # ---- `kmap scan_motif` (reference motif_discovery.py:187-486) ------------------------------------------------
 def _scan_motif(res_dir: str, debug=False):
+    """`kmap scan_motif`.  Under `python -m torch.distributed.run --nproc-per-node G -m kmap_amd scan_motif ...` the reads are
+    sharded over the G ranks (contiguous read ranges, distributed.make_dist_device_seq): per-read dedupe, masking and the
+    occurrence scans are local to a rank, the 4^k-bin histograms are all-reduced (so every rank takes the same find_motif
+    decisions) and the scan hits are all-gathered; rank 0 owns every output file and the np.random draws."""
+    from .visualization import _dist_context
+    dist, rank, owns_group = _dist_context()
+    _scan_motif_impl(res_dir, debug, dist, rank)
+    if dist is not None:            # success path only (a failing rank re-raises and the launcher tears the job down)
+        dist.barrier()
+        if owns_group:
+            dist.destroy_process_group()
+
+
+def _scan_motif_impl(res_dir, debug, dist, rank):
     from ._toml import load_toml
     res = Path(res_dir)
+    lead = rank == 0                # owner of the output files
+
+    def exists(path):
+        """does the file exist -- rank 0's answer on every rank, so that all ranks take the same branch (the branches below
+        contain collectives, and rank 0 creates the files while the others may still be checking)"""
+        if dist is None:
+            return Path(path).exists()
+        import torch
+        from .distributed import _coll_device
+        t = torch.tensor([int(Path(path).exists())], dtype=torch.int64, device=_coll_device(dist))
+        dist.broadcast(t, 0)
+        return bool(t.item())
+
     config_file_path = res / FileNameDict["config_file"]
     motif_def_file_path = res / FileNameDict["motif_def_file"]
     proc_fasta_file_path = res / FileNameDict["processed_fasta_file"]
@@ -522,26 +532,33 @@ def _scan_motif(res_dir: str, debug=False):
             boarder_mat = pickle.load(fh)
     n_all_seq = len(boarder_mat)
 
+    def resident(arr):
+        if dist is None:
+            return DeviceSeq(arr, boarder_mat)
+        from .distributed import make_dist_device_seq
+        return make_dist_device_seq(arr, boarder_mat, dist)
+
     # the occurrence scans read the ORIGINAL reads (the reference re-parses the FASTA for them)
     with _stage("upload"):
-        scan_seq = DeviceSeq(seq_np_arr, boarder_mat)
+        scan_seq = resident(seq_np_arr)
+    count_seq = scan_seq
     if md["noise_kmer_file"] != "None":
         assert Path(md["noise_kmer_file"]).exists()
         with open(Path(md["noise_kmer_file"]), "r") as fh:
             noise = [ln.strip() for ln in fh if ln.strip()]
         if noise:
             seq_np_arr = mask_ham_ball(seq_np_arr, motif_def_dict, noise, [0 for _ in noise])
-    count_seq = DeviceSeq(seq_np_arr, boarder_mat) if md["noise_kmer_file"] != "None" else scan_seq
+        count_seq = resident(seq_np_arr)
 
     top_k, n_trial = md["top_k"], md["n_trial"]
     save_kmer_cnt_flag = md["save_kmer_cnt_flag"]
     input_fasta_file = Path(config_dict["general"]["input_fasta_file"])
     candidate_conseq_list = []
-    if save_kmer_cnt_flag:
+    if save_kmer_cnt_flag and lead:
         (res / FileNameDict["kmer_count_dir"]).mkdir(exist_ok=True)
 
     candidate_conseq_file = res / FileNameDict["candidate_conseq_file"]
-    if candidate_conseq_file.exists():
+    if exists(candidate_conseq_file):
         print(f"{candidate_conseq_file} already exist, re-use it.")
     else:
         occ_flag = md["store_conseq_occur_info_flag"]
@@ -553,10 +570,13 @@ def _scan_motif(res_dir: str, debug=False):
             count_seq.reset()
             d = motif_def_dict[kmer_len]
             kmer_cnt_file = res / FileNameDict["kmer_count_dir"] / f"k{kmer_len}.pkl"
+            # sharded: every rank loads a cached k{k}.pkl if rank 0 sees one, otherwise all count and only rank 0 saves
+            cached = exists(kmer_cnt_file) if (dist is not None and save_kmer_cnt_flag) else False   # collective: every rank calls it
+            save_here = save_kmer_cnt_flag and (dist is None or lead or cached)
             with _stage("find_motif"), _stage(f"find_motif_k{kmer_len}"):
                 consensus_kh_dict = find_motif(None, kmer_len, d.max_ham_dist, d.p_uniform, d.ratio_mu, d.ratio_std,
                                                d.ratio_cutoff, top_k, n_trial, revcom_mode, rep_mode,
-                                               save_kmer_cnt_flag=save_kmer_cnt_flag, kmer_cnt_pkl_file=kmer_cnt_file,
+                                               save_kmer_cnt_flag=save_here, kmer_cnt_pkl_file=kmer_cnt_file,
                                                boarder_pkl_file=boarder_pkl_file, debug=debug, dev_seq=count_seq)
             tmp_list = [hash2kmer(kh, kmer_len) for kh in consensus_kh_dict]
             per = None
@@ -564,8 +584,11 @@ def _scan_motif(res_dir: str, debug=False):
                 occ_file = res / FileNameDict["kmer_count_dir"] / f"k{kmer_len}.motif_occurence.csv"
                 with _stage("occurrence_per_k"):
                     per = gen_motif_occurence_file(tmp_list, motif_def_dict, input_fasta_file, occ_file, revcom_mode,
-                                                   dev_seq=scan_seq)
+                                                   dev_seq=scan_seq, write=lead)
             for i, kmer_seq in enumerate(tmp_list):
+                candidate_conseq_list.append(kmer_seq)
+                if not lead:
+                    continue
                 kh = kmer2hash(kmer_seq)
                 prop, ratio, log10_p = consensus_kh_dict[get_hash_dtype(kmer_len)(kh)]
                 row = (f"{kmer_len},{kh},{kmer_seq},{reverse_complement(kmer_seq)},{prop:0.8f},"
@@ -575,21 +598,24 @@ def _scan_motif(res_dir: str, debug=False):
                     row += (f",{n_motif_seq},{n_all_seq},{float(n_motif_seq) / n_all_seq:0.4f},{n_occ},"
                             f"{float(n_occ) / n_motif_seq:0.2f}")
                 lines.append(row)
-                candidate_conseq_list.append(kmer_seq)
         print(f"kmer counting finished for k={min_k}...{max_k}. Candidate consensus sequences generated.")
-        write_lines(lines, candidate_conseq_file)
+        if lead:
+            write_lines(lines, candidate_conseq_file)
 
     final_conseq_file = res / FileNameDict["final_conseq_file"]
-    if final_conseq_file.exists():
+    if exists(final_conseq_file):
         with open(final_conseq_file, "r") as fh:
             final_conseq_list = fh.read().splitlines()
         print(f"{final_conseq_file} already exist, re-use it.")
     else:
         final_conseq_list = merge_consensus_seqs(candidate_conseq_list)
-        write_lines(final_conseq_list, final_conseq_file)
+        if lead:
+            write_lines(final_conseq_list, final_conseq_file)
 
     final_conseq_info_file = res / FileNameDict["final_conseq_info_file"]
-    if final_conseq_info_file.exists():
+    if not lead:
+        pass
+    elif final_conseq_info_file.exists():
         print(f"{final_conseq_info_file} already exist, re-use it.")
     else:
         with open(final_conseq_file, "r") as fh:
@@ -613,8 +639,13 @@ def _scan_motif(res_dir: str, debug=False):
     occurence_file = res / FileNameDict["motif_occurence_file"]
     with _stage("occurrence_final"):
         per_final = gen_motif_occurence_file(final_conseq_list, motif_def_dict, input_fasta_file, occurence_file, revcom_mode,
-                                             dev_seq=scan_seq)
-    occ = Occurrence.from_per(per_final, scan_seq.read_len)   # the consumers below use the hit list, not the CSV
+                                             dev_seq=scan_seq, write=lead)
+    if not lead:                    # everything below is host-side reporting / sampling on the hit list and the k{k}.pkl tables
+        if count_seq is not scan_seq:
+            count_seq.close()
+        scan_seq.close()
+        return
+    occ = Occurrence.from_per(per_final, scan_seq.out_read_len)   # the consumers below use the hit list, not the CSV
 
     # the reference also draws pdf figures in these branches (motif_discovery.py:364-425); only the data files are produced
     if md["motif_pos_density_flag"]:

@@ -471,21 +471,24 @@ def _dist_context():
     return dist, dist.get_rank(), owns
 
 
-def _visualize_kmers(res_dir: str, debug=False, mode=None):
+def _visualize_kmers(res_dir: str, debug=False, mode=None, neighbor_inds_mat=None):
     """reference visualization.py:36-87: config.toml + sample_kmer_hamdist_mat.pkl -> low_dim_data.tsv.
     Under a torch.distributed launch the compact hand-off is embedded row-sharded over all ranks (rank 0 writes the file);
-    a dense int64 matrix (N <= 16384) is embedded by rank 0 alone."""
+    a dense int64 matrix (N <= 16384) is embedded by rank 0 alone.
+    neighbor_inds_mat: optional (N, n_neighbour) neighbour table replacing the selection (np.argpartition's choice among
+    ties is numpy / ISA specific; parity tests inject the table the reference run used)."""
     dist, rank, owns_group = _dist_context()
-    try:
-        return _visualize_kmers_impl(res_dir, debug, mode, dist, rank)
-    finally:
-        if dist is not None:
-            dist.barrier()
-            if owns_group:
-                dist.destroy_process_group()
+    out = _visualize_kmers_impl(res_dir, debug, mode, dist, rank, neighbor_inds_mat)
+    # success path only: a rank that raised must not park in a barrier its peers may never reach -- it re-raises, exits
+    # non-zero and the launcher tears the other ranks down
+    if dist is not None:
+        dist.barrier()
+        if owns_group:
+            dist.destroy_process_group()
+    return out
 
 
-def _visualize_kmers_impl(res_dir, debug, mode, dist, rank):
+def _visualize_kmers_impl(res_dir, debug, mode, dist, rank, neighbor_inds_mat=None):
     from ._toml import load_toml
     cfg_path = Path(res_dir) / FileNameDict["config_file"]
     assert cfg_path.exists()
@@ -509,17 +512,18 @@ def _visualize_kmers_impl(res_dir, debug, mode, dist, rank):
             ld_data, _ = kmap_from_kmers_distributed(samp_kh, samp_cnts, samp_label, conseq_list, kmer_len,
                                                      n_neighbour=vz["n_neighbour"], n_max_iter=vz["n_max_iter"],
                                                      learning_rate=vz["learning_rate"], n_best_result=vz["n_best_result"],
-                                                     random_seed=random_seed, mode=mode)
+                                                     random_seed=random_seed, mode=mode, neighbor_inds_mat=neighbor_inds_mat)
         else:
             ld_data, _ = kmap_from_kmers(samp_kh, samp_cnts, samp_label, conseq_list, kmer_len, n_neighbour=vz["n_neighbour"],
                                          n_max_iter=vz["n_max_iter"], learning_rate=vz["learning_rate"],
-                                         n_best_result=vz["n_best_result"], random_seed=random_seed, debug=debug, mode=mode)
+                                         n_best_result=vz["n_best_result"], random_seed=random_seed, debug=debug, mode=mode,
+                                         neighbor_inds_mat=neighbor_inds_mat)
     elif rank != 0:
         return None      # dense hand-off: rank 0 embeds alone
     else:
         ld_data = kmap(hamdist_mat, kmer_len, n_neighbour=vz["n_neighbour"], n_max_iter=vz["n_max_iter"],
                        learning_rate=vz["learning_rate"], n_best_result=vz["n_best_result"], random_seed=random_seed,
-                       debug=debug, mode=mode)
+                       debug=debug, mode=mode, neighbor_inds_mat=neighbor_inds_mat)
     if rank != 0:
         return ld_data
     lines = ["x\ty\tlabel"]

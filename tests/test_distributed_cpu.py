@@ -176,3 +176,47 @@ def test_cyclic_block_protocol_matches_single_process(tmp_path):
             np.testing.assert_array_equal(rs[0]["losses"], r["losses"])
         np.testing.assert_allclose(rs[0]["losses"], single["losses"], rtol=1e-6)
         np.testing.assert_allclose(rs[0]["ld"], single["ld"], rtol=0, atol=1e-4 * np.abs(single["ld"]).max())
+
+
+def _gather_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from kmap_amd.distributed import all_gather_concat, broadcast_seed, read_partition
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(100 + rank)
+        # scan-hit shaped payloads: per-read counts (length known from the read partition) and ragged position lists
+        borders = np.zeros((1003, 2), np.int64)
+        lens = [read_partition(borders, world, r)[1] for r in range(world)]
+        hits = rng.integers(0, 5, size=lens[rank]).astype(np.int32)
+        pos = rng.integers(0, 1 << 20, size=int(hits.sum()) if rank != 1 else 0).astype(np.int32)   # rank 1: no hits at all
+        nb = rng.integers(0, 1003, size=(lens[rank], 20)).astype(np.int32)
+        got = {"hits": all_gather_concat(dist, hits, lens), "pos": all_gather_concat(dist, pos), "nb": all_gather_concat(dist, nb, lens),
+               "u16": all_gather_concat(dist, (hits * 1000).astype(np.uint16)),
+               "seed_none": broadcast_seed(dist, None), "seed_given": broadcast_seed(dist, 41),
+               "mine_hits": hits, "mine_pos": pos, "mine_nb": nb}
+        np.savez(Path(out_dir) / f"gather{rank}.npz", **got)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_all_gather_concat_and_seed_broadcast(tmp_path):
+    """the tensor collectives that replaced all_gather_object: ragged arrays (incl. an empty one) concatenate in rank order
+    with dtype and trailing shape intact; a "default" seed becomes one shared seed, a given seed is left alone"""
+    import torch.multiprocessing as mp
+    world = 3
+    mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    rs = [np.load(tmp_path / f"gather{r}.npz") for r in range(world)]
+    for key, mine in (("hits", "mine_hits"), ("pos", "mine_pos"), ("nb", "mine_nb")):
+        want = np.concatenate([r[mine] for r in rs])
+        for r in rs:
+            np.testing.assert_array_equal(r[key], want)
+            assert r[key].dtype == want.dtype and r[key].shape == want.shape
+    assert rs[0]["nb"].shape == (1003, 20) and len(rs[1]["mine_pos"]) == 0
+    want16 = np.concatenate([(r["mine_hits"] * 1000).astype(np.uint16) for r in rs])
+    for r in rs:
+        np.testing.assert_array_equal(r["u16"], want16)
+        assert r["u16"].dtype == np.uint16
+        assert int(r["seed_none"]) == int(rs[0]["seed_none"]) and 0 <= int(r["seed_none"]) < 2 ** 32
+        assert int(r["seed_given"]) == 41

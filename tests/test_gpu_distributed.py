@@ -32,7 +32,8 @@ def _worker(rank, world, port, mode, out_dir):
         kh, cnts, lab, conseqs = _inputs()
         tr = {}
         best, _ = kmap_from_kmers_distributed(kh, cnts, lab, conseqs, K, n_max_iter=ITERS, random_seed=SEED, mode=mode, trace=tr)
-        np.savez(Path(out_dir) / f"m{mode}_rank{rank}.npz", best=best, last=tr["last_coords"], losses=tr["losses"])
+        np.savez(Path(out_dir) / f"m{mode}_rank{rank}.npz", best=best, last=tr["last_coords"], losses=tr["losses"],
+                 d_rows=tr["hbm"]["d_rows"])
     finally:
         dist.destroy_process_group()
 
@@ -51,6 +52,7 @@ def test_two_ranks_one_gpu_equals_single(tmp_path, mode):
     r0, r1 = np.load(tmp_path / f"m{mode}_rank0.npz"), np.load(tmp_path / f"m{mode}_rank1.npz")
     np.testing.assert_array_equal(r0["last"], r1["last"])
     np.testing.assert_array_equal(r0["losses"], r1["losses"])
+    assert int(r0["d_rows"]) == 751 and int(r1["d_rows"]) == 750      # each rank computed only its rows of D (N^2 / G bytes)
     kh, cnts, lab, conseqs = _inputs()
     tr = {}
     best, _ = V.kmap_from_kmers(kh, cnts, lab, conseqs, K, n_max_iter=ITERS, random_seed=SEED, mode=mode, trace=tr)
@@ -207,3 +209,118 @@ def test_cyclic_symmetric_shards_match_single_gpu(tmp_path):
     scale = np.abs(tr["last_coords"]).max()
     diff = np.abs(r[0]["last"] - tr["last_coords"])
     assert diff.max() <= 5e-4 * scale and np.quantile(diff, 0.99) <= 2e-5 * scale
+
+
+def _seed_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from kmap_amd.distributed import kmap_from_kmers_distributed
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        kh, cnts, lab, conseqs = _inputs()
+        tr = {}
+        best, _ = kmap_from_kmers_distributed(kh, cnts, lab, conseqs, K, n_max_iter=8, random_seed=None, mode=1, trace=tr)
+        np.savez(Path(out_dir) / f"seed_rank{rank}.npz", best=best, last=tr["last_coords"], losses=tr["losses"], seed=tr["seed"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_default_seed_is_shared_by_all_ranks(tmp_path):
+    """random_seed = "default" (None: OS entropy in the reference): rank 0 draws the seed and broadcasts it, so every rank
+    starts from the same coordinates / placeholders / jitter stream and the state machines stay identical."""
+    import torch.multiprocessing as mp
+    mp.spawn(_seed_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "seed_rank0.npz"), np.load(tmp_path / "seed_rank1.npz")
+    assert int(r0["seed"]) == int(r1["seed"])
+    np.testing.assert_array_equal(r0["last"], r1["last"])
+    np.testing.assert_array_equal(r0["best"], r1["best"])
+    np.testing.assert_array_equal(r0["losses"], r1["losses"])
+    assert np.isfinite(r0["losses"]).all() and len(r0["losses"]) == 8
+
+
+def _occ_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from kmap_amd import synth
+    from kmap_amd.distributed import make_dist_device_seq
+    from kmap_amd.kmer_count import _pkg_file, init_motif_def_dict
+    from kmap_amd.motif_discovery import gen_motif_occurence_file
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seq, borders = synth.synth_reads(20011, 90, 6)
+        ds = make_dist_device_seq(seq, borders, dist)
+        mdd = init_motif_def_dict(_pkg_file("default_motif_def_table.csv"))
+        np.random.seed(3)
+        gen_motif_occurence_file(["AATCGATAGC", "CCTACGTA", "AAAAAA"], mdd, None, Path(out_dir) / f"occ_rank{rank}.csv", True,
+                                 dev_seq=ds, write=(rank == 0))
+        ds.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_occurrence_csv_from_read_sharded_seq(tmp_path):
+    """gen_motif_occurence_file on a read-sharded DistDeviceSeq (3 ranks, uneven shards) writes the single-GPU file: the
+    gathered hits are paired with the GLOBAL read count / read lengths."""
+    import torch.multiprocessing as mp
+    from kmap_amd import synth
+    from kmap_amd.kmer_count import _pkg_file, init_motif_def_dict
+    from kmap_amd.motif_discovery import DeviceSeq, gen_motif_occurence_file
+    mp.spawn(_occ_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    assert not (tmp_path / "occ_rank1.csv").exists() and not (tmp_path / "occ_rank2.csv").exists()
+    seq, borders = synth.synth_reads(20011, 90, 6)
+    ds = DeviceSeq(seq, borders)
+    np.random.seed(3)
+    gen_motif_occurence_file(["AATCGATAGC", "CCTACGTA", "AAAAAA"], init_motif_def_dict(_pkg_file("default_motif_def_table.csv")),
+                             None, tmp_path / "single.csv", True, dev_seq=ds)
+    ds.close()
+    got, want = (tmp_path / "occ_rank0.csv").read_text(), (tmp_path / "single.csv").read_text()
+    assert got == want and got.count("\n") > 5000
+
+
+def test_scan_motif_cli_under_torchrun(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m kmap_amd scan_motif` (reads sharded over two ranks that share
+    the test box's GPU, gloo): every output file equals the single-process verb's, a second (cached) run re-uses them."""
+    import pickle
+    import subprocess
+    from kmap_amd import synth
+    seq, borders = synth.synth_reads(40_001, 60, 12)
+    outs = {}
+    for tag in ("single", "dist"):
+        res = tmp_path / tag
+        res.mkdir()
+        over = {"kmer_count": {"min_k": 6, "max_k": 9},
+                "motif_discovery": {"motif_pos_density_flag": False, "motif_co_occurence_flag": False, "gen_hamball_flag": False,
+                                    "n_total_sample": 400, "n_motif_sample": 200},
+                "visualization": {"gen_fig_flag": False, "random_seed": 7, "n_max_iter": 10}}
+        synth.write_res_dir(res, seq, borders, over)
+        env = dict(os.environ, PYTHONPATH=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        seeded = "import sys, numpy as np; np.random.seed(123); from kmap_amd.motif_discovery import _scan_motif; _scan_motif(sys.argv[1])"
+        if tag == "single":
+            cmd = [sys.executable, "-c", seeded, str(res)]
+        else:
+            env.update(KMAP_DIST_BACKEND="gloo", KMAP_DIST_SAME_GPU="1")
+            (tmp_path / "seeded_scan.py").write_text(seeded + "\n")
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                   "--master-port", str(_free_port()), str(tmp_path / "seeded_scan.py"), str(res)]
+        for attempt in range(2 if tag == "dist" else 1):       # second pass: every branch takes its "already exist" path
+            r = subprocess.run(cmd, env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stderr[-3000:]
+        files = {}
+        for f in sorted(res.rglob("*")):
+            if f.is_file() and f.name not in ("input.bin.pkl", "input.seqboarder.bin.pkl", "config.toml"):
+                files[str(f.relative_to(res))] = f.read_bytes()
+        outs[tag] = files
+    assert sorted(outs["single"]) == sorted(outs["dist"]) and len(outs["single"]) >= 12
+    for name, blob in outs["single"].items():
+        if name.endswith(".pkl"):
+            a, b = pickle.loads(blob), pickle.loads(outs["dist"][name])
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(np.asarray(x, dtype=object) if isinstance(x, list) else x,
+                                              np.asarray(y, dtype=object) if isinstance(y, list) else y, err_msg=name)
+        else:
+            assert blob == outs["dist"][name], name
+    assert len((tmp_path / "dist" / "final_conseq.txt").read_text().split()) >= 1

@@ -16,12 +16,11 @@ def _lines(p):
         return fh.read().splitlines()
 
 
-@pytest.fixture(scope="module")
-def run_dir(tmp_path_factory):
+def _run_c1(tmp):
+    """preproc + scan_motif of tests/test.fa with the reference run's config, seeded like gen_golden.py"""
     from kmap_amd._toml import dump_toml, load_toml
     from kmap_amd.kmer_count import _preproc
     from kmap_amd.motif_discovery import _scan_motif
-    tmp = tmp_path_factory.mktemp("c1")
     fa = tmp / "test.fa"
     shutil.copyfile(GOLD / "test.fa", fa)
     res = tmp / "res"
@@ -34,6 +33,11 @@ def run_dir(tmp_path_factory):
     np.random.seed(123)                                              # gen_golden.py seeds the same way
     _scan_motif(str(res))
     return res
+
+
+@pytest.fixture(scope="module")
+def run_dir(tmp_path_factory):
+    return _run_c1(tmp_path_factory.mktemp("c1"))
 
 
 def test_preproc_arrays(run_dir, golden):
@@ -193,79 +197,160 @@ def test_c5_shape_scan_and_count_vs_oracle(motif_defs):
 
 
 def test_visualize_kmers_c1(run_dir, golden):
-    """visualize_kmers on the C1 result directory: low_dim_data.tsv equals the golden trace's best snapshot
-    printed with the reference's %3.3f format (the file contract is 1e-3 granular)."""
-    from kmap_amd._toml import dump_toml, load_toml
+    """visualize_kmers on the C1 result directory, with the neighbour table of the reference run injected (np.argpartition's
+    choice among ties differs between hosts): low_dim_data.tsv equals the golden trace's best snapshot printed with the
+    reference's %3.3f format (the file contract is 1e-3 granular)."""
+    from kmap_amd._toml import load_toml
     from kmap_amd.visualization import _visualize_kmers
     u = golden("umap_n300.npz")
     cfg = load_toml(run_dir / "config.toml")
     assert cfg["visualization"]["random_seed"] == int(u["seed"]) and cfg["visualization"]["n_max_iter"] == int(u["n_iter"])
-    ld = _visualize_kmers(str(run_dir))
-    # np.argpartition on this host may pick other tie members than on the host that made the fixture, so the
-    # strict comparison is only made when the neighbour choice coincides
+    ld = _visualize_kmers(str(run_dir), neighbor_inds_mat=u["nb"])
     with open(run_dir / "sample_kmer_hamdist_mat.pkl", "rb") as fh:
         _, mat, labels = pickle.load(fh)
     rows = _lines(run_dir / "low_dim_data.tsv")
     assert rows[0] == "x\ty\tlabel" and len(rows) == 301
     assert [int(r.split("\t")[2]) for r in rows[1:]] == [int(x) for x in labels]
-    if np.array_equal(np.argpartition(mat, 20, axis=1)[:, :20], u["nb"]):
-        np.testing.assert_allclose(ld, u["final"], rtol=0, atol=1e-5)
-        want = [f"{x:3.3f}\t{y:3.3f}\t{int(l)}" for x, y, l in zip(u["final"][0], u["final"][1], labels)]
-        mism = sum(a != b for a, b in zip(rows[1:], want))
-        assert mism <= 3    # a coordinate within 1e-5 of a rounding boundary may print differently
+    np.testing.assert_allclose(ld, u["final"], rtol=0, atol=1e-5)
+    want = [f"{x:3.3f}\t{y:3.3f}\t{int(l)}" for x, y, l in zip(u["final"][0], u["final"][1], labels)]
+    mism = sum(a != b for a, b in zip(rows[1:], want))
+    assert mism <= 3    # a coordinate within 1e-5 of a rounding boundary may print differently
 
 
-def test_sample_disp_kmer_device_path(run_dir, golden, motif_defs, monkeypatch):
-    """sample_disp_kmer with the k-mer table kept on the device (tables above TOPK_DEVICE_MIN entries):
-    (a) tests/test.fa, all labels small enough for np.random.multinomial: device path == numpy formulation (the one the
-        pipeline test above pins to the reference's sample_kmers.pkl);
-    (b) random table, low threshold: device path == numpy formulation (inverse CDF for big labels, multinomial for small)."""
+def test_compact_handoff_equals_dense(run_dir, golden, tmp_path, monkeypatch):
+    """above DENSE_PKL_MAX_N sampled k-mers scan_motif writes [kmer_len, None, labels] instead of the int64
+    N x N matrix and visualize_kmers rebuilds the matrix on the device from sample_kmers.pkl.  With the threshold patched to
+    0 the same C1 run must hand over the same labels and produce the same low_dim_data.tsv as the dense pickle (SEQ mode,
+    the reference run's neighbour table injected), i.e. the golden embedding."""
+    from kmap_amd import motif_discovery as MD
+    from kmap_amd.visualization import EMBED_SEQ, _visualize_kmers
+    u = golden("umap_n300.npz")
+    monkeypatch.setattr(MD, "DENSE_PKL_MAX_N", 0)
+    res = _run_c1(tmp_path)
+    with open(res / "sample_kmer_hamdist_mat.pkl", "rb") as fh:
+        klen, mat, labels = pickle.load(fh)
+    with open(run_dir / "sample_kmer_hamdist_mat.pkl", "rb") as fh:
+        klen_d, mat_d, labels_d = pickle.load(fh)
+    assert mat is None and mat_d is not None and klen == klen_d
+    np.testing.assert_array_equal(labels, labels_d)
+    assert (res / "sample_kmers.pkl").read_bytes() == (run_dir / "sample_kmers.pkl").read_bytes()
+    dense = _visualize_kmers(str(run_dir), mode=EMBED_SEQ, neighbor_inds_mat=u["nb"])
+    compact = _visualize_kmers(str(res), mode=EMBED_SEQ, neighbor_inds_mat=u["nb"])
+    np.testing.assert_array_equal(compact, dense)          # same device arithmetic from either hand-off
+    assert (res / "low_dim_data.tsv").read_text() == (run_dir / "low_dim_data.tsv").read_text()
+    np.testing.assert_allclose(compact, u["final"], rtol=0, atol=1e-5)
+
+
+def test_device_topk_tie_rule(motif_defs, monkeypatch):
+    """Tables above TOPK_DEVICE_MIN unique k-mers take their top_k candidates from kmap_counts_topk: largest count first, ties
+    by the LOWEST table index.  That is a documented deviation from the reference's np.argpartition(cnt, -top_k)[-top_k:]
+    (motif_discovery.py:661), whose choice among equal counts at the top_k boundary is an artefact of numpy's introselect.
+    Tie-heavy table: counts 9, 9, then a plateau of 7s crossing the boundary.  Expected: the two 9s and the three lowest-index
+    7s.  np.argpartition returns the same multiset of counts but whichever three 7s introselect leaves in the tail."""
+    from kmap_amd.kmer_count import DeviceCounts
+    from kmap_amd._ffi import check, lib, ptr
+    k = 9
+    rng = np.random.default_rng(5)
+    u = np.sort(rng.choice(4 ** k, size=5000, replace=False)).astype(np.uint32)
+    c = rng.integers(1, 6, size=5000).astype(np.int32)
+    sevens = np.array([40, 41, 700, 1200, 2500, 2501, 3900, 4999])
+    c[sevens] = 7
+    c[[1234, 77]] = 9
+    dc = DeviceCounts()
+    check(lib().kmap_counts_load(dc._h, ptr(u), ptr(c), len(u), k))
+    dc.k, dc.n_uniq = k, len(u)
+    idx, kh, cnt = dc.topk(5)
+    assert list(cnt) == [9, 9, 7, 7, 7]
+    assert list(idx) == [77, 1234, 40, 41, 700]
+    np.testing.assert_array_equal(kh, u[[77, 1234, 40, 41, 700]])
+    ref_pick = set(np.argpartition(c, -5)[-5:].tolist())
+    assert {77, 1234} <= ref_pick and len(ref_pick & set(sevens.tolist())) == 3     # same multiset of counts ...
+    dc.close()
+
+
+def _inverse_cdf_reference(uniq, cnt, lab, quota, big_min, k):
+    """test-local numpy statement of the sampling rule of sample_disp_kmer given labels: np.random.multinomial over the
+    normalised counts for labels with <= big_min members (the reference's draw), inverse CDF by np.searchsorted on the
+    cumulative counts for larger labels (the product's documented rule for tables the reference cannot process)"""
+    inds, cnts = [], []
+    for c, n_draw in enumerate(quota):
+        ci = np.where(lab == c)[0]
+        ws = cnt[ci]
+        if len(ci) > big_min:
+            cdf = np.cumsum(ws, dtype=np.float64)
+            hits = np.searchsorted(cdf, np.floor(np.random.random_sample(int(n_draw)) * cdf[-1]), side="right")
+            sel, t = np.unique(np.minimum(hits, len(ws) - 1), return_counts=True)
+            inds.append(ci[sel])
+            cnts.append(t)
+            continue
+        t = np.random.multinomial(n_draw, ws / sum(ws), size=1).squeeze()
+        inds.append(ci[t > 0])
+        cnts.append(t[t > 0])
+    return np.concatenate(inds), np.concatenate(cnts)
+
+
+def test_sample_disp_kmer_vs_oracle(run_dir, golden, motif_defs, monkeypatch):
+    """sample_disp_kmer (table labelled on the device, host draws only):
+    (a) tests/test.fa: == the oracle's numpy restatement of the reference (which the pipeline test pins to the reference's
+        sample_kmers.pkl), and the whole-table return when more samples are asked for than k-mers exist;
+    (b) random tables, low TOPK_DEVICE_MIN: labels / re-orientation == oracle, draws == the inverse-CDF rule above."""
     import pickle
+    import warnings
     from kmap_amd import motif_discovery as MD
     from kmap_amd.kmer_count import init_motif_def_dict
+    from oracle import oracle as O
     s = golden("scan_testfa.npz")
     conseqs = [str(c) for c in s["samp_conseqs"]]
     k = int(s["hamdist_kmer_len"])
     mdd = init_motif_def_dict(GOLD / "scan_testfa" / "motif_def_table.csv")
+    r_of = {kk: d.max_ham_dist for kk, d in mdd.items()}
     with open(run_dir / "kmer_count" / f"k{k}.pkl", "rb") as fh:
-        n_uniq = len(pickle.load(fh)[1])
-    monkeypatch.setattr(MD, "TOPK_DEVICE_MIN", n_uniq - 1)
-    outs = []
-    for on_dev in (True, False):                               # False: numpy formulation == the reference (test above)
-        monkeypatch.setattr(MD, "SAMPLE_ON_DEVICE", on_dev)
-        np.random.seed(123)
-        outs.append(MD.sample_disp_kmer(conseqs, k, mdd, run_dir / "kmer_count", n_total_sample=300, n_motif_kmer=150))
-    for a, b in zip(outs[0][:3], outs[1][:3]):
+        _, u, c = pickle.load(fh)
+    np.random.seed(123)
+    got = MD.sample_disp_kmer(conseqs, k, mdd, run_dir / "kmer_count", n_total_sample=300, n_motif_kmer=150)
+    np.random.seed(123)
+    want = O.sample_disp_kmer(conseqs, k, r_of, u, c, n_total_sample=300, n_motif_kmer=150)
+    for a, b in zip(got[:3], want[:3]):
         np.testing.assert_array_equal(a, b)
         assert a.dtype == b.dtype
-    assert outs[0][2].dtype == np.int64 and len(outs[0][0]) > 100
+    assert got[2].dtype == np.int64 and len(got[0]) > 100 and list(got[3]) == list(want[3])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = MD.sample_disp_kmer(conseqs, k, mdd, run_dir / "kmer_count", n_total_sample=10 ** 9, n_motif_kmer=150)
+        want = O.sample_disp_kmer(conseqs, k, r_of, u, c, n_total_sample=10 ** 9, n_motif_kmer=150)
+    for a, b in zip(got[:3], want[:3]):
+        np.testing.assert_array_equal(a, b)
+        assert a.dtype == b.dtype
 
     rng = np.random.default_rng(77)
     for kk, cons_list in ((10, ["AATCGATAGC", "ACCTACGT"]), (16, ["AACCGGTTAACCGGTA", "ACGTTGCA", "AAGGCCTTAA"])):
         hi = 4 ** kk
         ball = []
-        for c in cons_list:                                   # plant members around every consensus (both strands)
-            base = int(MD.kmer2hash(c)) << (2 * (kk - len(c)))
+        for cs in cons_list:                                   # plant members around every consensus (both strands)
+            base = int(MD.kmer2hash(cs)) << (2 * (kk - len(cs)))
             ball += [base ^ int(rng.integers(0, 4)) << (2 * int(rng.integers(0, kk))) for _ in range(400)]
         u = np.unique(np.concatenate([rng.integers(0, hi, size=60_000, dtype=np.uint64), np.array(ball, np.uint64)]))
         u = u.astype(MD.get_hash_dtype(kk))
         c = rng.integers(1, 50, size=len(u)).astype(MD.get_cnt_dtype(kk))
-        d = tmp = run_dir.parent / f"samp_k{kk}"
+        d = run_dir.parent / f"samp_k{kk}"
         (d / "kc").mkdir(parents=True, exist_ok=True)
         with open(d / "kc" / f"k{kk}.pkl", "wb") as fh:
             pickle.dump([kk, u, c], fh)
-        mdd2 = init_motif_def_dict(GOLD / "scan_testfa" / "motif_def_table.csv")
+        ordered = sorted(cons_list, key=len, reverse=True)
         monkeypatch.setattr(MD, "TOPK_DEVICE_MIN", 500)
-        outs = []
-        for on_dev in (True, False):
-            monkeypatch.setattr(MD, "SAMPLE_ON_DEVICE", on_dev)
-            np.random.seed(5)
-            outs.append(MD.sample_disp_kmer(sorted(cons_list, key=len, reverse=True), kk, mdd2, d / "kc", n_total_sample=4000,
-                                            n_motif_kmer=2000))
-        for a, b in zip(outs[0][:3], outs[1][:3]):
-            np.testing.assert_array_equal(a, b)
-            assert a.dtype == b.dtype
-        assert outs[0][2].max() == len(cons_list) and int(outs[0][1].sum()) == 4000
+        np.random.seed(5)
+        got = MD.sample_disp_kmer(ordered, kk, mdd, d / "kc", n_total_sample=4000, n_motif_kmer=2000)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ou, oc, olab, _ = O.sample_disp_kmer(ordered, kk, r_of, u, c, n_total_sample=10 ** 12)   # labels + re-orientation only
+        quota = MD._label_quota(np.bincount(olab, weights=oc, minlength=len(ordered) + 1), 4000, 2000)
+        np.random.seed(5)
+        inds, cnts = _inverse_cdf_reference(ou, oc, olab, quota, 500, kk)
+        np.testing.assert_array_equal(got[0], ou[inds])
+        np.testing.assert_array_equal(got[1], cnts)
+        np.testing.assert_array_equal(got[2], olab[inds])
+        assert got[0].dtype == ou.dtype and got[2].dtype == np.int64
+        assert got[2].max() == len(cons_list) and int(got[1].sum()) == 4000
 
 
 def test_genome_like_input_vs_oracle(motif_defs):

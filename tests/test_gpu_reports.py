@@ -149,13 +149,10 @@ def test_scan_motif_report_branches(R, golden, tmp_path):
 
 
 def test_user_motif_occurence_file(golden, tmp_path):
-    """get_user_motif_occurence_file / check_motif_co_occurence on tests/test.fa == the reference's file (incl. the
+    """get_user_motif_occurence_file (occurrence scan with user-given radii) on tests/test.fa == the reference's file (incl. the
     per-length radius override: the last consensus of a length decides)"""
     from kmap_amd import motif_discovery as MD
     np.random.seed(321)
     MD.get_user_motif_occurence_file(GOLD / "test.fa", ["AATCGATAGC", "CCTACGTA", "GGGGGGGG"], [3, 1, 2],
                                      tmp_path / "u.csv", True)
     assert (tmp_path / "u.csv").read_text() == (RGOLD / "user_motif_occurence.csv").read_text()
-    co, dist, dd, info = MD.check_motif_co_occurence(str(GOLD / "test.fa"), "CAATCGATAGC", "ACCTACGTA", 2, 2, str(tmp_path / "co"), True)
-    assert (tmp_path / "co" / "user_motif_occurence.csv").exists() and co.shape == (2, 2) and info.startswith("co_occur_freq=")
-    assert co[0, 1] == len(dd[(0, 1)]) == co[1, 0]
