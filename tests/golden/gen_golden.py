@@ -15,7 +15,7 @@ are stored (as .npz / text data files).
 Groups: ops (G2-G5 operator vectors), scan (G1,G6-G8 pipeline on tests/test.fa),
 embed (G9,G10 smoothing + umap traces), report (occurrence-file consumers and Hamming-ball
 extraction: position density, co-occurrence matrices, count matrices), occ20 (occurrence rows with the
-> 20-hit random subsample).
+> 20-hit random subsample), earlystop (umap runs that end by the early-stop rule).
 """
 import os
 import pickle
@@ -375,6 +375,41 @@ def gen_embed():
              coords=np.array(snaps, dtype=np.float32), jitter_hits=np.array(jit), final=final)
 
 
+def gen_earlystop():
+    """umap runs of the reference that END BY THE EARLY-STOP RULE (visualization.py:310-311) before n_max_iter: sub-matrices of
+    the N=300 matrix with a large learning rate, so that every pair reaches the q clip and the loss becomes exactly constant.
+    The loss steps before the floor are ~1e-5 relative (>> the 1e-7 stop threshold), which makes the stop iteration robust to
+    last-bit differences of the loss."""
+    z = np.load(HERE / "scan_testfa.npz", allow_pickle=False)
+    D = z["hamdist_mat_u8"].astype(np.int64)
+    k = int(z["hamdist_kmer_len"])
+    n_nb = 20
+    out = {"kmer_len": np.array(k), "n_nb": np.array(n_nb)}
+    for tag, sub, lr, seed, n_iter in (("a", 32, 16.0, 1, 500), ("b", 48, 16.0, 1, 50)):
+        idx = np.arange(0, 300, 300 // sub)[:sub]
+        Dm = D[np.ix_(idx, idx)]
+        losses = []
+        o_ce = vz.cross_entropy_taichi
+
+        def ce(hd, ldp, im):
+            v = o_ce(hd, ldp, im)
+            losses.append(v)
+            return v
+
+        vz.cross_entropy_taichi = ce
+        try:
+            final = vz.kmap(Dm, k, n_neighbour=n_nb, n_max_iter=n_iter, learning_rate=lr, n_best_result=10, random_seed=seed,
+                            debug=False)
+        finally:
+            vz.cross_entropy_taichi = o_ce
+        assert len(losses) < n_iter, "this case is meant to stop early"
+        nbm = np.argpartition(Dm, n_nb, axis=1)[:, :n_nb].astype(np.int32)
+        print(f"  earlystop {tag}: N={sub} lr={lr} stopped after {len(losses)} of {n_iter} iterations, last losses {losses[-3:]}")
+        out.update({f"{tag}_D": Dm.astype(np.uint8), f"{tag}_nb": nbm, f"{tag}_seed": np.array(seed), f"{tag}_lr": np.array(lr),
+                    f"{tag}_n_max_iter": np.array(n_iter), f"{tag}_losses": np.array(losses, dtype=np.float32), f"{tag}_final": final})
+    save("umap_earlystop.npz", **out)
+
+
 def _synthetic_occurrence_file(path, rng, n_reads=400, n_motif=4):
     """An occurrence CSV in the reference's format with 4 motifs, multi-hit cells (up to 20 sorted locations), empty
     cells and varying read lengths -- input data for the consumers, written by this script (not by the reference)."""
@@ -594,7 +629,8 @@ def gen_occ20():
 
 
 if __name__ == "__main__":
-    groups = sys.argv[1:] or ["ops", "scan", "embed", "report", "occ20", "scan2"]
+    groups = sys.argv[1:] or ["ops", "scan", "embed", "report", "occ20", "scan2", "earlystop"]
     for g in groups:
         print(f"[{g}]")
-        {"ops": gen_ops, "scan": gen_scan, "embed": gen_embed, "report": gen_report, "occ20": gen_occ20, "scan2": gen_scan2}[g]()
+        {"ops": gen_ops, "scan": gen_scan, "embed": gen_embed, "report": gen_report, "occ20": gen_occ20, "scan2": gen_scan2,
+         "earlystop": gen_earlystop}[g]()

@@ -201,6 +201,34 @@ def test_early_stop_and_zero_iters(V):
     assert len(tr["losses"]) == 3 and tr["state"]["iters"] == 3
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_early_stop_golden(V, golden, tag):
+    """Runs of the reference that end by its early-stop rule |loss - prev| < 1e-7 |loss| (visualization.py:310-311) before
+    n_max_iter (tests/golden/umap_earlystop.npz: N = 32 stopping after 145 of 500 iterations, N = 48 after 5 of 50; large
+    learning rate, every pair ends at the q clip so the loss becomes exactly constant).  The HIP loop (SEQ mode, the run's
+    neighbour table injected) must raise `stopped` at the same iteration, log the same losses and return the same snapshot
+    (the first iterate at the minimum loss).  Coordinates are O(1e2..1e3) here (learning rate 16), so the 1e-5 bound is taken
+    relative to their extent."""
+    u = golden("umap_earlystop.npz")
+    D, want_losses, want_final = u[f"{tag}_D"].astype(np.int64), u[f"{tag}_losses"], u[f"{tag}_final"]
+    tr = {}
+    final = V.kmap(D, int(u["kmer_len"]), n_neighbour=int(u["n_nb"]), n_max_iter=int(u[f"{tag}_n_max_iter"]),
+                   learning_rate=float(u[f"{tag}_lr"]), random_seed=int(u[f"{tag}_seed"]), debug=False, mode=V.EMBED_SEQ,
+                   neighbor_inds_mat=u[f"{tag}_nb"], trace=tr)
+    assert tr["state"]["stopped"] is True
+    assert tr["state"]["iters"] == len(want_losses) < int(u[f"{tag}_n_max_iter"])
+    np.testing.assert_allclose(tr["losses"], want_losses, rtol=2e-6)
+    assert tr["losses"][-1] == tr["losses"][-2]                      # the rule fired on an exactly repeated loss
+    scale = float(np.abs(want_final).max())
+    np.testing.assert_allclose(final, want_final, rtol=0, atol=1e-5 * max(scale, 1.0))
+    # FAST mode takes the same decision on this robust case (loss steps before the floor are ~1e-5 relative)
+    tr2 = {}
+    V.kmap(D, int(u["kmer_len"]), n_neighbour=int(u["n_nb"]), n_max_iter=int(u[f"{tag}_n_max_iter"]),
+           learning_rate=float(u[f"{tag}_lr"]), random_seed=int(u[f"{tag}_seed"]), debug=False, mode=V.EMBED_FAST,
+           neighbor_inds_mat=u[f"{tag}_nb"], trace=tr2)
+    assert tr2["state"]["stopped"] is True and abs(tr2["state"]["iters"] - len(want_losses)) <= 2
+
+
 def test_fast_vs_seq_at_default_size(V):
     """N = 5000 (the reference's default n_total_sample), k = 8: FAST tracks SEQ's loss curve (see default_mode() for why trajectories are not compared digit by digit); the loss decreases; best snapshot has the lowest logged loss."""
     from oracle import oracle as O

@@ -231,6 +231,18 @@ def test_umap_trace(golden, tag):
     np.testing.assert_allclose(final, u["final"], rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_umap_early_stop(golden, tag):
+    """the reference's early-stop rule (visualization.py:310-311): runs that ended before n_max_iter"""
+    u = golden("umap_earlystop.npz")
+    tr = {}
+    final = O.kmap(u[f"{tag}_D"].astype(np.int64), int(u["kmer_len"]), n_neighbour=int(u["n_nb"]), n_max_iter=int(u[f"{tag}_n_max_iter"]),
+                   learning_rate=float(u[f"{tag}_lr"]), random_seed=int(u[f"{tag}_seed"]), nb=u[f"{tag}_nb"], trace=tr)
+    assert len(tr["losses"]) == len(u[f"{tag}_losses"]) < int(u[f"{tag}_n_max_iter"])
+    np.testing.assert_allclose(np.array(tr["losses"], np.float32), u[f"{tag}_losses"], rtol=2e-6)
+    np.testing.assert_allclose(final, u[f"{tag}_final"], rtol=0, atol=1e-5 * max(1.0, float(np.abs(u[f"{tag}_final"]).max())))
+
+
 # ---- report consumers (SURVEY 8(f) rows 3-4): oracle and host logic vs the reference's outputs -----------------------
 from pathlib import Path  # noqa: E402
 
