@@ -656,23 +656,27 @@ __global__ __launch_bounds__(KMAP_WAVE *SY_WAVES) void forces_sym_kernel(ProbSrc
 }
 
 // =================================================================================================
-// FAST forces, symmetric form, second generation (u16 sums + LUT source).  Same tiling, partial buffers and loss layout as
-// forces_sym_kernel; what changes is the instruction stream of the tiles that lie entirely right of the diagonal (all but
-// ~1 % of the work at N = 50 k), which PMC passes showed VALU-issue bound with 55 % of the wave-cycles parked on loads:
-//   * rows go in groups of four; the four 16-byte loads of group g+1 are in flight while group g is evaluated (the old kernel
+// FAST forces, symmetric form, second generation (u16 sums + LUT source).  Same partial buffers and loss layout as
+// forces_sym_kernel, other work split and instruction stream.  PMC passes of the first kernel (profiles/r02_pmc*.json) showed
+// 75 % VALU issue utilisation at ~23 VALU instructions per pair, 55 % of the wave-cycles parked on loads, and only ~2.4 waves
+// per wave slot over the whole launch (9.8 k waves of 256 rows x 512 columns on 4096 slots: a long tail).  Here:
+//   * a block = one 256-row x 512-column tile, its four waves take one 64-row block each (4x finer work units, 39 k waves);
+//     the waves' column-side sums meet in LDS, so the column partials stay one slice per 256-row block;
+//   * rows go in groups of S2_G; the 16-byte sums loads of group g+1 are in flight while group g is evaluated (the old kernel
 //     loaded, waited, gathered, waited, computed -- per row);
 //   * all per-pair arithmetic on column PAIRS as v_pk_{add,mul,fma}_f32 (two pairs per issue slot): with m = d2c (1 + d2c),
-//     r = 1/m:  q = r d2c,  q/(1-q) = r + q,  1-q = 1 - q   (13 issue slots per pair incl. the two 8-cycle transcendentals,
-//     instead of ~23);
-//   * LUT byte offsets by one SDWA shift per pair (v_lshlrev_b32_sdwa picks the 16-bit half and scales it by 4);
-//   * the eight row-side partial sums of a group (gx, gy of 4 rows) are reduced together: transposed through a 2-KiB per-wave
-//     LDS scratch (8 ds_write, 2 ds_read_b128, 7 adds, 3 DPP steps) instead of 2 x 6 DPP steps per row.
-// Tiles that touch the diagonal or the right / bottom edge take the masked generic path (the old kernel's arithmetic).
+//     r = 1/m:  q = r d2c,  q/(1-q) = r + q  (~16 issue slots per pair incl. the two 8-cycle transcendentals, down from ~25);
+//   * LUT byte offsets by one SDWA shift per pair (v_lshlrev_b32_sdwa picks the 16-bit half and scales it by 4), the LUT at LDS
+//     address 0 so that the shift result is the ds_read address;
+//   * the row-side partial sums of a group (gx, gy of S2_G rows) are reduced together: transposed through a per-wave LDS
+//     scratch (ds_write per value, one ds_read_b128 per lane, a few adds, DPP row shifts) instead of 2 x 6 DPP steps per row.
+// Row blocks that touch the diagonal or the right / bottom edge take the masked generic path (the first kernel's arithmetic).
 // =================================================================================================
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int S2_G = 4;                        // rows per group
+constexpr int S2_G = 2;                        // rows per group
 constexpr int S2_TSTRIDE = 68;                 // dwords between value types in the transpose scratch (64 lanes + 4: conflict-free)
-constexpr int S2_SCRATCH = 2 * S2_G * S2_TSTRIDE;   // dwords per wave (8 value types)
+constexpr int S2_SCRATCH = 2 * S2_G * S2_TSTRIDE;   // dwords per wave (2 S2_G value types)
+constexpr int S2_CS = 16 * 64;                 // dwords per wave of the column-sum exchange: 16 components x 64 lanes
 
 __device__ __forceinline__ uint32_t lut_off_lo(uint32_t w, uint32_t two) {   // (w & 0xFFFF) << 2
     uint32_t a;
@@ -685,190 +689,215 @@ __device__ __forceinline__ uint32_t lut_off_hi(uint32_t w, uint32_t two) {   // 
     return a;
 }
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// float at an absolute LDS byte address.  The LUT is the kernel's first LDS object and starts at address 0 (checked on entry), so
+// the SDWA result IS the ds_read address: no per-pair add of the (relocated, zero) base of the extern __shared__ symbol.
+__device__ __forceinline__ float lds_f32_at(uint32_t byte_addr) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) float *>(byte_addr);
+}
 
 __global__ __launch_bounds__(KMAP_WAVE *SY_WAVES, 4) void forces_sym2_kernel(ProbSrc src, const float *__restrict__ Y, int64_t n,
-                                                                          float *__restrict__ rowpart, float *__restrict__ colpart,
-                                                                          double *__restrict__ loss_part, int64_t nJ, int world,
-                                                                          int rank, int lut_pad) {
-    extern __shared__ __attribute__((aligned(16))) float lut_s[];   // [lut_pad] LUT, then SY_WAVES transpose scratches
+                                                                             float *__restrict__ rowpart, float *__restrict__ colpart,
+                                                                             double *__restrict__ loss_part, int64_t nJ, int64_t part_ld,
+                                                                             int world, int rank, int lut_pad) {
+    static_assert(SY_WAVES == SY_NRB, "one wave per 64-row block of the tile");
+    extern __shared__ __attribute__((aligned(16))) float lut_s[];   // [lut_pad] LUT | SY_WAVES transpose scratches | column-sum exchange
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // blockIdx.x = column tile J, blockIdx.y = local 256-row block; global row block I (cyclic over the ranks)
+    const int64_t Il = blockIdx.y, I = (int64_t)rank + (int64_t)world * Il, J = blockIdx.x;
+    if (!sy_tile_live(I, J)) {                                      // tile entirely below the diagonal (block-uniform)
+        if (threadIdx.x == 0) loss_part[Il * part_ld + J] = 0.0;
+        return;
+    }
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)lut_s != 0u) __builtin_trap();   // see lds_f32_at
     for (int t = threadIdx.x; t < src.lut_len && t < F_LUT_LDS; t += blockDim.x) lut_s[t] = src.lut[t];
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *scratch = lut_s + lut_pad + wave * S2_SCRATCH;
-    const int64_t Il = blockIdx.y, I = (int64_t)rank + (int64_t)world * Il, J = (int64_t)blockIdx.x * SY_WAVES + wave;
-    const int64_t part_idx = Il * (gridDim.x * SY_WAVES) + J;
+    float *colx = lut_s + lut_pad + SY_WAVES * S2_SCRATCH;          // [wave][component 0..15][lane]
+    const float *X = Y, *Yy = Y + n;
+    const int64_t j0 = J * SY_C + (int64_t)lane * F_CPL;
+    f32x2 cgx[4], cgy[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) cgx[d] = cgy[d] = f32x2{0.0f, 0.0f};
     double wave_loss = 0.0;
-    if (J < nJ && sy_tile_live(I, J)) {
-        const float *X = Y, *Yy = Y + n;
-        const int64_t j0 = J * SY_C + (int64_t)lane * F_CPL;
-        f32x2 xj[4], yj[4], cgx[4], cgy[4];
+    const int64_t r0 = I * SY_R + (int64_t)wave * SY_RB;            // this wave's 64 rows
+    if (r0 < n && (J + 1) * SY_C - 1 > r0) {
+        f32x2 xj[4], yj[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const int64_t ja = (j0 + 2 * d < n) ? j0 + 2 * d : n - 1, jb = (j0 + 2 * d + 1 < n) ? j0 + 2 * d + 1 : n - 1;
             xj[d] = f32x2{X[ja], X[jb]};
             yj[d] = f32x2{Yy[ja], Yy[jb]};
-            cgx[d] = cgy[d] = f32x2{0.0f, 0.0f};
         }
-        const bool full_tile = (J + 1) * SY_C <= n;   // wave-uniform: every lane's 8 columns exist
-        const bool vec_ok = (src.ld % 8 == 0);
-        const uint32_t two = 2;
+        const int nr = (int)((n - r0 < SY_RB) ? n - r0 : SY_RB);
+        const int64_t myrow = (r0 + lane < n) ? r0 + lane : n - 1;
+        float xrv = X[myrow], yrv = Yy[myrow];                      // lane r holds row r's coordinates
+        const uint16_t *rows = src.ps + (Il * SY_R + (int64_t)wave * SY_RB) * src.ld + j0;   // row r of the block: rows + r * ld
         float ce2 = 0.0f;
-        for (int rb = 0; rb < SY_NRB; ++rb) {
-            const int64_t r0 = I * SY_R + (int64_t)rb * SY_RB;
-            if (r0 >= n || !((J + 1) * SY_C - 1 > r0)) break;   // row blocks further down lie entirely below the diagonal
-            const int nr = (int)((n - r0 < SY_RB) ? n - r0 : SY_RB);
-            const int64_t myrow = (r0 + lane < n) ? r0 + lane : n - 1;
-            const float xr = X[myrow], yr = Yy[myrow];
-            const uint16_t *rows = src.ps + (Il * SY_R + (int64_t)rb * SY_RB) * src.ld + j0;   // row r of the block: rows + r * ld
-            // interior: 64 rows, all left of the tile's first column, all 512 columns exist -> no j > i / j < n tests
-            const bool interior = full_tile && vec_ok && nr == SY_RB && (J * SY_C > r0 + nr - 1);
-            if (interior) {
-                u32x4 wn[S2_G];
+        // interior: 64 rows, all left of the tile's first column, all 512 columns exist -> no j > i / j < n tests
+        const bool interior = ((J + 1) * SY_C <= n) && (src.ld % 8 == 0) && nr == SY_RB && (J * SY_C > r0 + nr - 1);
+        if (interior) {
+            const uint32_t two = 2;
+            u32x4 wn[S2_G];
 #pragma unroll
-                for (int a = 0; a < S2_G; ++a) wn[a] = *reinterpret_cast<const u32x4 *>(rows + (int64_t)a * src.ld);
-                // LUT gather of one row's 8 probabilities: one SDWA shift (16-bit half -> byte offset) + one ds_read_b32 per pair
-                auto gather = [&](f32x2(&p2)[4], const u32x4 &w) {
-                    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+            for (int a = 0; a < S2_G; ++a) wn[a] = *reinterpret_cast<const u32x4 *>(rows + (int64_t)a * src.ld);
+#pragma unroll 1
+            for (int g = 0; g < SY_RB / S2_G; ++g) {
+                u32x4 wc[S2_G];
+#pragma unroll
+                for (int a = 0; a < S2_G; ++a) wc[a] = wn[a];
+                if (g + 1 < SY_RB / S2_G) {
+#pragma unroll
+                    for (int a = 0; a < S2_G; ++a)
+                        wn[a] = *reinterpret_cast<const u32x4 *>(rows + (int64_t)((g + 1) * S2_G + a) * src.ld);
+                }
+                float part[2 * S2_G];
+                f32x2 es2 = f32x2{0.0f, 0.0f};
+#pragma unroll
+                for (int a = 0; a < S2_G; ++a) {
+                    const int r = g * S2_G + a;
+                    float xi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xrv), r));
+                    float yi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yrv), r));
+                    const uint32_t ws[4] = {wc[a].x, wc[a].y, wc[a].z, wc[a].w};
+                    f32x2 p2[4];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)   // LUT gather: one SDWA shift (16-bit half -> byte offset) + one ds_read_b32 per pair
+                        p2[d] = f32x2{lds_f32_at(lut_off_lo(ws[d], two)), lds_f32_at(lut_off_hi(ws[d], two))};
+                    f32x2 gx2 = f32x2{0.0f, 0.0f}, gy2 = f32x2{0.0f, 0.0f}, pr2 = f32x2{1.0f, 1.0f};
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
-                        const float plo = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lut_s) + lut_off_lo(ws[d], two));
-                        const float phi = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lut_s) + lut_off_hi(ws[d], two));
-                        p2[d] = f32x2{plo, phi};
-                    }
-                };
-                f32x2 pc[4], pn[4];
-                gather(pc, wn[0]);
-#pragma unroll 1
-                for (int g = 0; g < SY_RB / S2_G; ++g) {
-                    u32x4 wc[S2_G];
-#pragma unroll
-                    for (int a = 0; a < S2_G; ++a) wc[a] = wn[a];
-                    const bool more = g + 1 < SY_RB / S2_G;
-                    if (more) {
-#pragma unroll
-                        for (int a = 0; a < S2_G; ++a)
-                            wn[a] = *reinterpret_cast<const u32x4 *>(rows + (int64_t)((g + 1) * S2_G + a) * src.ld);
-                    }
-                    float part[2 * S2_G];
-                    f32x2 es2 = f32x2{0.0f, 0.0f};
-#pragma unroll
-                    for (int a = 0; a < S2_G; ++a) {
-                        // the next row's gathers are in flight while this row is evaluated (rows are kept apart by scheduling
-                        // barriers: left alone, the scheduler interleaves all four rows and spills)
-                        if (a + 1 < S2_G) gather(pn, wc[a + 1]);
-                        else if (more) gather(pn, wn[0]);          // first row of the next group: loaded a whole group ago
-                        const int r = g * S2_G + a;
-                        const float xi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xr), r));
-                        const float yi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yr), r));
                         const f32x2 xi2 = f32x2{xi, xi}, yi2 = f32x2{yi, yi};
-                        f32x2 gx2 = f32x2{0.0f, 0.0f}, gy2 = f32x2{0.0f, 0.0f}, pr2 = f32x2{1.0f, 1.0f};
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) {
-                            const f32x2 dx = xi2 - xj[d], dy = yi2 - yj[d];
-                            const f32x2 d2 = pk_fma(dx, dx, dy * dy);
-                            const f32x2 d2c = f32x2{__builtin_amdgcn_fmed3f(d2.x, FAST_D2_MIN, FAST_D2_MAX),
-                                                    __builtin_amdgcn_fmed3f(d2.y, FAST_D2_MIN, FAST_D2_MAX)};
-                            const f32x2 m = pk_fma(d2c, d2c, d2c);                       // d2c (1 + d2c)
-                            const f32x2 rr = f32x2{__builtin_amdgcn_rcpf(m.x), __builtin_amdgcn_rcpf(m.y)};
-                            const f32x2 q = rr * d2c;                                    // 1 / (1 + d2c), clipped through d2c
-                            const f32x2 u = rr + q;                                      // q / (1 - q) = 1 / d2c
-                            const f32x2 t = u * (pc[d] - q);
-                            const f32x2 omq = f32x2{1.0f, 1.0f} - q;
-                            gx2 = pk_fma(t, dx, gx2);                                    // row side: + t (y_i - y_j)
-                            gy2 = pk_fma(t, dy, gy2);
-                            cgx[d] = pk_fma(-t, dx, cgx[d]);                             // column side (negation = operand modifier)
-                            cgy[d] = pk_fma(-t, dy, cgy[d]);
-                            const f32x2 lg = f32x2{__builtin_amdgcn_logf(d2c.x), __builtin_amdgcn_logf(d2c.y)};
-                            es2 = pk_fma(pc[d], lg, es2);
-                            pr2 = pr2 * omq;
-                        }
-                        part[2 * a] = gx2.x + gx2.y;
-                        part[2 * a + 1] = gy2.x + gy2.y;
-                        ce2 += __builtin_amdgcn_logf(pr2.x * pr2.y);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) pc[d] = pn[d];
+                        const f32x2 dx = xi2 - xj[d], dy = yi2 - yj[d];
+                        const f32x2 d2 = pk_fma(dx, dx, dy * dy);
+                        const f32x2 d2c = f32x2{__builtin_amdgcn_fmed3f(d2.x, FAST_D2_MIN, FAST_D2_MAX),
+                                                __builtin_amdgcn_fmed3f(d2.y, FAST_D2_MIN, FAST_D2_MAX)};
+                        const f32x2 m = pk_fma(d2c, d2c, d2c);                       // d2c (1 + d2c)
+                        const f32x2 rr = f32x2{__builtin_amdgcn_rcpf(m.x), __builtin_amdgcn_rcpf(m.y)};
+                        const f32x2 q = rr * d2c;                                    // 1 / (1 + d2c), clipped through d2c
+                        const f32x2 u = rr + q;                                      // q / (1 - q) = 1 / d2c
+                        const f32x2 t = u * (p2[d] - q);
+                        const f32x2 omq = f32x2{1.0f, 1.0f} - q;
+                        gx2 = pk_fma(t, dx, gx2);                                    // row side: + t (y_i - y_j)
+                        gy2 = pk_fma(t, dy, gy2);
+                        cgx[d] = pk_fma(-t, dx, cgx[d]);                             // column side (negation = operand modifier)
+                        cgy[d] = pk_fma(-t, dy, cgy[d]);
+                        const f32x2 lg = f32x2{__builtin_amdgcn_logf(d2c.x), __builtin_amdgcn_logf(d2c.y)};
+                        es2 = pk_fma(p2[d], lg, es2);
+                        pr2 = pr2 * omq;
+                        // two column pairs at a time: the empty asm ties their results to the inputs of the next two (row
+                        // coordinates), so only two of the group's independent chains are interleaved -- enough to fill most
+                        // trans / packed-op wait states; left alone the scheduler overlaps all of them and needs > 200 VGPRs.
+                        // The LUT gathers above stay free to issue early.
+                        if (d & 1)
+                            asm volatile("" : "+s"(xi), "+s"(yi), "+v"(xrv), "+v"(yrv), "+v"(gx2), "+v"(gy2), "+v"(es2), "+v"(pr2),
+                                         "+v"(cgx[d]), "+v"(cgy[d]), "+v"(cgx[d - 1]), "+v"(cgy[d - 1]));
                     }
-                    ce2 -= es2.x + es2.y;
-                    // the 8 partial sums of the group, summed over the wave's 64 lanes: value type t to scratch[t][lane], lane L
-                    // then adds the 8 entries [L >> 3][8 (L & 7) ..] and three DPP steps finish the groups of 8 lanes
-#pragma unroll
-                    for (int t = 0; t < 2 * S2_G; ++t) scratch[t * S2_TSTRIDE + lane] = part[t];
-                    __builtin_amdgcn_wave_barrier();
-                    const f32x4 va = *reinterpret_cast<const f32x4 *>(scratch + (lane >> 3) * S2_TSTRIDE + (lane & 7) * 8);
-                    const f32x4 vb = *reinterpret_cast<const f32x4 *>(scratch + (lane >> 3) * S2_TSTRIDE + (lane & 7) * 8 + 4);
-                    __builtin_amdgcn_wave_barrier();
-                    float sred = ((va.x + va.y) + (va.z + va.w)) + ((vb.x + vb.y) + (vb.z + vb.w));
-                    sred = dpp_add<0x111, 0xF>(sred);   // row_shr:1
-                    sred = dpp_add<0x112, 0xF>(sred);   // row_shr:2
-                    sred = dpp_add<0x114, 0xF>(sred);   // row_shr:4 -> lanes 7, 15, 23, ... hold the total of their value type
-                    if ((lane & 7) == 7) {
-                        const int t = lane >> 3;                                 // value type: row t >> 1 of the group, x / y
-                        rowpart[(J * 2 + (t & 1)) * n + r0 + g * S2_G + (t >> 1)] = sred;
-                    }
-                    if ((g & 3) == 3) {
-                        wave_loss += (double)ce2;
-                        ce2 = 0.0f;
-                    }
+                    part[2 * a] = gx2.x + gx2.y;
+                    part[2 * a + 1] = gy2.x + gy2.y;
+                    ce2 += __builtin_amdgcn_logf(pr2.x * pr2.y);
                 }
-            } else {
-                for (int r = 0; r < nr; ++r) {
-                    const int64_t gi = r0 + r;
-                    const float xi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xr), r));
-                    const float yi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yr), r));
-                    float gx = 0.0f, gy = 0.0f;
-                    if (j0 + F_CPL - 1 > gi && j0 < n) {   // this lane has at least one column right of the diagonal
-                        float esum = 0.0f, prod = 1.0f;
+                ce2 -= es2.x + es2.y;
+                // the 2 S2_G partial sums of the group, summed over the wave's 64 lanes: value type t goes to scratch[t][lane],
+                // lane L then adds the S2_E entries [L / S2_L][S2_E (L % S2_L) ..] and DPP row shifts finish the groups of S2_L lanes
+                constexpr int S2_T = 2 * S2_G, S2_L = 64 / S2_T, S2_E = 64 / S2_L;   // value types; lanes per type; entries per lane
 #pragma unroll
-                        for (int c = 0; c < F_CPL; ++c) {
-                            const int64_t j = j0 + c;
-                            const float p = (j < n) ? lut_s[rows[(int64_t)r * src.ld + c]] : 0.0f;
-                            const float xc = (c & 1) ? xj[c >> 1].y : xj[c >> 1].x, yc = (c & 1) ? yj[c >> 1].y : yj[c >> 1].x;
-                            const float dx = xi - xc, dy = yi - yc;
-                            float t, omq, d2c;
-                            fast_core(dx, dy, p, t, omq, d2c);
-                            const float lterm = p * __builtin_amdgcn_logf(d2c);
-                            const bool live = (j > gi) && (j < n);
-                            t = live ? t : 0.0f;
-                            esum += live ? lterm : 0.0f;
-                            prod *= live ? omq : 1.0f;
-                            gx = __builtin_fmaf(t, dx, gx);
-                            gy = __builtin_fmaf(t, dy, gy);
-                            if (c & 1) {
-                                cgx[c >> 1].y = __builtin_fmaf(-t, dx, cgx[c >> 1].y);
-                                cgy[c >> 1].y = __builtin_fmaf(-t, dy, cgy[c >> 1].y);
-                            } else {
-                                cgx[c >> 1].x = __builtin_fmaf(-t, dx, cgx[c >> 1].x);
-                                cgy[c >> 1].x = __builtin_fmaf(-t, dy, cgy[c >> 1].x);
-                            }
+                for (int t = 0; t < S2_T; ++t) scratch[t * S2_TSTRIDE + lane] = part[t];
+                __builtin_amdgcn_wave_barrier();
+                const float *mine = scratch + (lane / S2_L) * S2_TSTRIDE + (lane % S2_L) * S2_E;
+                float sred;
+                if constexpr (S2_E == 8) {
+                    const f32x4 va = *reinterpret_cast<const f32x4 *>(mine), vb = *reinterpret_cast<const f32x4 *>(mine + 4);
+                    sred = ((va.x + va.y) + (va.z + va.w)) + ((vb.x + vb.y) + (vb.z + vb.w));
+                } else {
+                    static_assert(S2_E == 4 || S2_E == 8, "rows per group: 2 or 4");
+                    const f32x4 va = *reinterpret_cast<const f32x4 *>(mine);
+                    sred = (va.x + va.y) + (va.z + va.w);
+                }
+                __builtin_amdgcn_wave_barrier();
+                sred = dpp_add<0x111, 0xF>(sred);   // row_shr:1
+                sred = dpp_add<0x112, 0xF>(sred);   // row_shr:2
+                sred = dpp_add<0x114, 0xF>(sred);   // row_shr:4
+                if constexpr (S2_L == 16) sred = dpp_add<0x118, 0xF>(sred);   // row_shr:8
+                if ((lane % S2_L) == S2_L - 1) {   // the last lane of each group holds the total of its value type
+                    const int t = lane / S2_L;                               // row t >> 1 of the group, x / y
+                    rowpart[(J * 2 + (t & 1)) * n + r0 + g * S2_G + (t >> 1)] = sred;
+                }
+                if (((g + 1) * S2_G) % 16 == 0) {
+                    wave_loss += (double)ce2;
+                    ce2 = 0.0f;
+                }
+            }
+        } else {
+            for (int r = 0; r < nr; ++r) {
+                const int64_t gi = r0 + r;
+                const float xi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xrv), r));
+                const float yi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yrv), r));
+                float gx = 0.0f, gy = 0.0f;
+                if (j0 + F_CPL - 1 > gi && j0 < n) {   // this lane has at least one column right of the diagonal
+                    float esum = 0.0f, prod = 1.0f;
+#pragma unroll
+                    for (int c = 0; c < F_CPL; ++c) {
+                        const int64_t j = j0 + c;
+                        const float p = (j < n) ? lut_s[rows[(int64_t)r * src.ld + c]] : 0.0f;
+                        const float xc = (c & 1) ? xj[c >> 1].y : xj[c >> 1].x, yc = (c & 1) ? yj[c >> 1].y : yj[c >> 1].x;
+                        const float dx = xi - xc, dy = yi - yc;
+                        float t, omq, d2c;
+                        fast_core(dx, dy, p, t, omq, d2c);
+                        const float lterm = p * __builtin_amdgcn_logf(d2c);
+                        const bool live = (j > gi) && (j < n);
+                        t = live ? t : 0.0f;
+                        esum += live ? lterm : 0.0f;
+                        prod *= live ? omq : 1.0f;
+                        gx = __builtin_fmaf(t, dx, gx);
+                        gy = __builtin_fmaf(t, dy, gy);
+                        if (c & 1) {
+                            cgx[c >> 1].y = __builtin_fmaf(-t, dx, cgx[c >> 1].y);
+                            cgy[c >> 1].y = __builtin_fmaf(-t, dy, cgy[c >> 1].y);
+                        } else {
+                            cgx[c >> 1].x = __builtin_fmaf(-t, dx, cgx[c >> 1].x);
+                            cgy[c >> 1].x = __builtin_fmaf(-t, dy, cgy[c >> 1].x);
                         }
-                        ce2 += __builtin_amdgcn_logf(prod) - esum;
                     }
-                    gx = wave_sum_to_lane63(gx);
-                    gy = wave_sum_to_lane63(gy);
-                    if (lane == 63) {
-                        rowpart[(J * 2 + 0) * n + gi] = gx;
-                        rowpart[(J * 2 + 1) * n + gi] = gy;
-                    }
-                    if ((r & 15) == 15) {
-                        wave_loss += (double)ce2;
-                        ce2 = 0.0f;
-                    }
+                    ce2 += __builtin_amdgcn_logf(prod) - esum;
+                }
+                gx = wave_sum_to_lane63(gx);
+                gy = wave_sum_to_lane63(gy);
+                if (lane == 63) {
+                    rowpart[(J * 2 + 0) * n + gi] = gx;
+                    rowpart[(J * 2 + 1) * n + gi] = gy;
+                }
+                if ((r & 15) == 15) {
+                    wave_loss += (double)ce2;
+                    ce2 = 0.0f;
                 }
             }
         }
         wave_loss += (double)ce2;
         wave_loss *= -0.6931471805599453;
-#pragma unroll
-        for (int c = 0; c < F_CPL; ++c) {
-            if (j0 + c < n) {
-                colpart[(Il * 2 + 0) * n + j0 + c] = (c & 1) ? cgx[c >> 1].y : cgx[c >> 1].x;
-                colpart[(Il * 2 + 1) * n + j0 + c] = (c & 1) ? cgy[c >> 1].y : cgy[c >> 1].x;
-            }
-        }
         for (int o = 32; o > 0; o >>= 1) wave_loss += __shfl_down(wave_loss, o);
     }
-    if (lane == 0) loss_part[part_idx] = wave_loss;
+    // column side: the four waves' sums over their 64 rows meet in LDS; one slice per 256-row block leaves the CU
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        colx[(wave * 16 + 2 * d) * 64 + lane] = cgx[d].x;
+        colx[(wave * 16 + 2 * d + 1) * 64 + lane] = cgx[d].y;
+        colx[(wave * 16 + 8 + 2 * d) * 64 + lane] = cgy[d].x;
+        colx[(wave * 16 + 8 + 2 * d + 1) * 64 + lane] = cgy[d].y;
+    }
+    double *wl = reinterpret_cast<double *>(colx + SY_WAVES * S2_CS);
+    if (lane == 0) wl[wave] = wave_loss;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = q * 256 + threadIdx.x;              // output element: x / y component, column of the tile
+        const int cxy = e >> 9, col = e & 511, comp = cxy * 8 + (col & 7), l = col >> 3;
+        float s = colx[(0 * 16 + comp) * 64 + l];
+        s += colx[(1 * 16 + comp) * 64 + l];
+        s += colx[(2 * 16 + comp) * 64 + l];
+        s += colx[(3 * 16 + comp) * 64 + l];
+        const int64_t j = J * SY_C + col;
+        if (j < n) colpart[(Il * 2 + cxy) * n + j] = s;
+    }
+    if (threadIdx.x == 0) loss_part[Il * part_ld + J] = ((wl[0] + wl[1]) + (wl[2] + wl[3]));
 }
 
 // G[c][i] = sum_J rowpart[J][c][i] (tiles right of i's row block) + sum_I colpart[I][c][i] (row blocks above / at i)
@@ -1365,6 +1394,7 @@ static int embed_create_impl(kmap_embed **out, int64_t n, int64_t row0, int64_t 
     KMAP_CHECK_HIP(hipMemcpy(&e->states[0], &s0, sizeof s0, hipMemcpyHostToDevice));
     KMAP_CHECK_HIP(hipMemcpy(&e->states[1], &s0, sizeof s0, hipMemcpyHostToDevice));
     KMAP_CHECK_HIP(hipMemset(e->G, 0, (size_t)2 * n * 4));
+    KMAP_CHECK_HIP(hipMemset(e->loss_part, 0, (size_t)e->n_part * 8));
     *out = e;
     return KMAP_OK;
 }
@@ -1437,8 +1467,10 @@ int kmap_embed_forces(kmap_embed *e, float *grad_dev_2xn, double *loss_dev, void
         static const bool sym2 = [] { const char *v = getenv("KMAP_EMBED_SYM2"); return !(v && v[0] == '0'); }();   // A/B switch
         if (lut && sym2) {
             const int lut_pad = (int)(lds / 4);
-            forces_sym2_kernel<<<grid, KMAP_WAVE * SY_WAVES, lds + (size_t)SY_WAVES * S2_SCRATCH * 4, st>>>(
-                e->src, e->Y, e->n, e->rowpart, e->colpart, e->loss_part, e->symJ, e->world, e->rank, lut_pad);
+            const size_t lds2 = lds + ((size_t)SY_WAVES * S2_SCRATCH + (size_t)SY_WAVES * S2_CS) * 4 + SY_WAVES * 8;
+            const int64_t part_ld = ((e->symJ + SY_WAVES - 1) / SY_WAVES) * SY_WAVES;   // loss partials keep the first kernel's layout
+            forces_sym2_kernel<<<dim3((unsigned)e->symJ, (unsigned)e->n_lblocks), KMAP_WAVE * SY_WAVES, lds2, st>>>(
+                e->src, e->Y, e->n, e->rowpart, e->colpart, e->loss_part, e->symJ, part_ld, e->world, e->rank, lut_pad);
         } else if (lut) forces_sym_kernel<true><<<grid, KMAP_WAVE * SY_WAVES, lds, st>>>(e->src, e->Y, e->n, e->rowpart, e->colpart, e->loss_part, e->symJ, e->world, e->rank);
         else forces_sym_kernel<false><<<grid, KMAP_WAVE * SY_WAVES, lds, st>>>(e->src, e->Y, e->n, e->rowpart, e->colpart, e->loss_part, e->symJ, e->world, e->rank);
         sym_reduce_kernel<<<(unsigned)((2 * e->n * 8 + BLK - 1) / BLK), BLK, 0, st>>>(e->rowpart, e->colpart, e->n, e->n_lblocks, e->symJ, e->world, e->rank, G);
