@@ -1102,19 +1102,27 @@ __global__ __launch_bounds__(KMAP_WAVE *SQ_WAVES) void forces_seq_kernel(ProbSrc
     }
 }
 
-// deterministic reduction of the per-block loss partials into loss_out[0]
-__global__ __launch_bounds__(1024) void reduce_loss_kernel(const double *__restrict__ part, int n_part,
-                                                           double *__restrict__ loss_out) {
-    __shared__ double sh[1024];
+// deterministic reduction of the per-block loss partials: thread t adds part[t], part[t + 256], ... in order, then a fixed tree
+// over the 256 thread sums -- the standalone kernel (multi-GPU path: the partials of a rank are reduced before the all-reduce)
+// and the fused tail kernels below run this same code, so every path sees the same bits
+__device__ __forceinline__ double loss_total_256(const double *__restrict__ part, int n_part, double *sh /* [256] LDS */) {
     double s = 0.0;
-    for (int i = threadIdx.x; i < n_part; i += 1024) s += part[i];
+    for (int i = threadIdx.x; i < n_part; i += BLK) s += part[i];
     sh[threadIdx.x] = s;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
+    for (int o = BLK / 2; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) loss_out[0] = sh[0];
+    const double total = sh[0];
+    __syncthreads();
+    return total;
+}
+__global__ __launch_bounds__(BLK) void reduce_loss_kernel(const double *__restrict__ part, int n_part,
+                                                          double *__restrict__ loss_out) {
+    __shared__ double sh[BLK];
+    const double t = loss_total_256(part, n_part, sh);
+    if (threadIdx.x == 0) loss_out[0] = t;
 }
 
 // =================================================================================================
@@ -1128,42 +1136,54 @@ struct LoopState {
     int n_best;
     float prev_loss;        // `loss` of the reference loop (inf before the first iteration)
     float last_loss;
+    float worst_loss;       // = best_loss[n_best - 1], worst_slot = best_slot[n_best - 1]: with the fields above, all a non-leader
+    int worst_slot;         //   thread reads (40 bytes instead of the whole 560-byte record)
     float best_loss[MAX_BEST];   // ascending (bisect.insort_right order)
     int best_slot[MAX_BEST];     // snapshot buffer holding that entry
 };
 
-__global__ __launch_bounds__(BLK) void apply_kernel(LoopState *__restrict__ states, int cur, float *__restrict__ Y,
-                                                    const float *__restrict__ G, const double *__restrict__ loss_sum,
-                                                    float *__restrict__ snaps, int64_t n, float lr,
-                                                    const double *__restrict__ normals, int n_normals,
-                                                    float *__restrict__ loss_log, int64_t loss_log_cap) {
-    const LoopState st = states[cur];   // every block reads the same, already complete state
-    const int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x;
-    const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
-    if (st.stopped) {
-        if (leader) states[cur ^ 1] = st;
+// what one reference iteration decides from the loss (visualization.py:303-311), identical in every thread
+struct StepDecision {
+    float loss;
+    int slot;               // snapshot buffer that takes the iterate if `insert`
+    bool halted, insert, stop;
+};
+__device__ __forceinline__ StepDecision step_decide(const LoopState *__restrict__ st, double loss_total) {
+    StepDecision d;
+    d.halted = st->stopped != 0;
+    d.loss = (float)(2.0 * loss_total);                                  // np.sum(ce) * 2 (visualization.py:176)
+    d.insert = d.loss < st->worst_loss;                                  // :303 (false for NaN)
+    d.stop = fabsf(st->prev_loss - d.loss) < 1e-7f * fabsf(d.loss);      // :310
+    d.slot = st->worst_slot;
+    return d;
+}
+// one coordinate (not point 0 / 1, which the leader owns): snapshot, then the gradient step
+__device__ __forceinline__ void step_element(const StepDecision &d, int64_t idx, float g_raw, float *__restrict__ Y,
+                                             float *__restrict__ snaps, int64_t n, float lr) {
+    const float y = Y[idx];
+    if (d.insert) snaps[(int64_t)d.slot * 2 * n + idx] = y;             // snapshot of the iterate that produced `loss`
+    if (!d.stop) {
+        const float g = 4.0f * g_raw;                                    // gradient_loss_taichi returns 4.0 * ret (:145)
+        Y[idx] = y + (-g * lr);                                          // ld_data += (-grad_loss * learning_rate) (:316)
+    }
+}
+// the leader thread: loop record (best list, stop flag, loss log) and points 0 / 1 incl. add_jitter.  gsp = raw gradient of
+// x0, x1, y0, y1
+__device__ void step_leader(LoopState *__restrict__ states, int cur, const StepDecision &d, float *__restrict__ Y, const float (&gsp)[4],
+                            float *__restrict__ snaps, int64_t n, float lr, const double *__restrict__ normals,
+                            const int *__restrict__ n_normals_dev, float *__restrict__ loss_log, int64_t loss_log_cap) {
+    const LoopState st = states[cur];
+    if (d.halted) {
+        states[cur ^ 1] = st;
         return;
     }
-    const float loss = (float)(2.0 * loss_sum[0]);   // np.sum(ce) * 2 (visualization.py:176)
-    const int nb = st.n_best;
-    const bool insert = loss < st.best_loss[nb - 1];                    // :303 (false for NaN)
-    const bool stop = fabsf(st.prev_loss - loss) < 1e-7f * fabsf(loss); // :310
-    const int slot = st.best_slot[nb - 1];
-    const bool special = (idx == 0 || idx == 1 || idx == n || idx == n + 1);   // owned by the leader (jitter)
-    if (idx < 2 * n && !special) {
-        const float y = Y[idx];
-        if (insert) snaps[(int64_t)slot * 2 * n + idx] = y;             // snapshot of the iterate that produced `loss`
-        if (!stop) {
-            const float g = 4.0f * G[idx];                              // gradient_loss_taichi returns 4.0 * ret (:145)
-            Y[idx] = y + (-g * lr);                                     // ld_data += (-grad_loss * learning_rate) (:316)
-        }
-    }
-    if (!leader) return;
+    const int nb = st.n_best, slot = d.slot;
+    const float loss = d.loss;
     LoopState ns = st;
     ns.iters = st.iters + 1;
     ns.last_loss = loss;
     if (st.iters < loss_log_cap) loss_log[st.iters] = loss;
-    if (insert) {   // best_res_list[:-1] then bisect.insort_right by loss (:304-308)
+    if (d.insert) {   // best_res_list[:-1] then bisect.insort_right by loss (:304-308)
         int pos = 0;
         while (pos < nb - 1 && !(st.best_loss[pos] > loss)) ++pos;
         for (int t = nb - 1; t > pos; --t) {
@@ -1172,22 +1192,23 @@ __global__ __launch_bounds__(BLK) void apply_kernel(LoopState *__restrict__ stat
         }
         ns.best_loss[pos] = loss;
         ns.best_slot[pos] = slot;
+        ns.worst_loss = ns.best_loss[nb - 1];
+        ns.worst_slot = ns.best_slot[nb - 1];
+        for (int p = 0; p < 2 && p < n; ++p)
+            for (int c = 0; c < 2; ++c) snaps[(int64_t)slot * 2 * n + (int64_t)c * n + p] = Y[(int64_t)c * n + p];
     }
-    if (insert)
-        for (int d = 0; d < 2 && d < n; ++d)
-            for (int c = 0; c < 2; ++c) snaps[(int64_t)slot * 2 * n + (int64_t)c * n + d] = Y[(int64_t)c * n + d];
-    if (stop) {
+    if (d.stop) {
         ns.stopped = 1;
     } else {
         ns.prev_loss = loss;
+        const int n_normals = *n_normals_dev;
         // update + add_jitter for points 0 and 1 (visualization.py:179-196 indexes the 2 x N array as N x 2,
-        // so `ld_data[:, d]` is the (x_d, y_d) pair of point d)
-        for (int d = 0; d < 2 && d < n; ++d) {
+        // so `ld_data[:, p]` is the (x_p, y_p) pair of point p)
+        for (int p = 0; p < 2 && p < n; ++p) {
             float v[2];
             for (int c = 0; c < 2; ++c) {
-                const int64_t id = (int64_t)c * n + d;
-                const float g = 4.0f * G[id];
-                v[c] = Y[id] + (-g * lr);
+                const float g = 4.0f * gsp[2 * c + p];
+                v[c] = Y[(int64_t)c * n + p] + (-g * lr);
             }
             const int lo_i = (v[1] < v[0]) ? 1 : 0;                     // argsort of two values (stable)
             const float diff = v[1 - lo_i] - v[lo_i];                   // np.diff of the sorted pair
@@ -1196,10 +1217,76 @@ __global__ __launch_bounds__(BLK) void apply_kernel(LoopState *__restrict__ stat
                 ns.jitter_used += 1;
                 v[lo_i] = (float)((double)v[lo_i] + nrm);               // f32 array element += f64 draw
             }
-            for (int c = 0; c < 2; ++c) Y[(int64_t)c * n + d] = v[c];
+            for (int c = 0; c < 2; ++c) Y[(int64_t)c * n + p] = v[c];
         }
     }
     states[cur ^ 1] = ns;
+}
+
+// apply with the gradient in memory.  FUSED_LOSS: the block first reduces the force kernel's loss partials itself (single-GPU
+// step: forces -> this kernel); otherwise the total comes from loss_in[0] (multi-GPU: after the all-reduce)
+template <bool FUSED_LOSS>
+__global__ __launch_bounds__(BLK) void apply_kernel(LoopState *__restrict__ states, int cur, float *__restrict__ Y,
+                                                    const float *__restrict__ G, const double *__restrict__ loss_in, int n_part,
+                                                    float *__restrict__ snaps, int64_t n, float lr,
+                                                    const double *__restrict__ normals, const int *__restrict__ n_normals_dev,
+                                                    float *__restrict__ loss_log, int64_t loss_log_cap) {
+    __shared__ double sh[FUSED_LOSS ? BLK : 1];
+    const double total = FUSED_LOSS ? loss_total_256(loss_in, n_part, sh) : loss_in[0];
+    const StepDecision d = step_decide(&states[cur], total);   // every block reads the same, already complete record
+    const int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    const bool special = (idx == 0 || idx == 1 || idx == n || idx == n + 1);   // owned by the leader (jitter)
+    if (!d.halted && idx < 2 * n && !special) step_element(d, idx, G[idx], Y, snaps, n, lr);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float gsp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int c = 0; c < 2; ++c)
+            for (int p = 0; p < 2 && p < n; ++p) gsp[2 * c + p] = G[(int64_t)c * n + p];
+        step_leader(states, cur, d, Y, gsp, snaps, n, lr, normals, n_normals_dev, loss_log, loss_log_cap);
+    }
+}
+
+// symmetric FAST kernel, single GPU: the sum of the row / column partials (sym_reduce_kernel's order: 8 lanes per element, lane l
+// adds partials l, l + 8, ..., fixed butterfly) fused with apply -- the gradient never goes to memory.  The first four 8-lane
+// groups of block 0 take x0, x1, y0, y1 and hand them to the leader through LDS; the other groups take the remaining 2N - 4
+// coordinates in order.
+__global__ __launch_bounds__(BLK) void sym_apply_kernel(LoopState *__restrict__ states, int cur, float *__restrict__ Y,
+                                                        const float *__restrict__ rowpart, const float *__restrict__ colpart,
+                                                        int64_t n_lblocks, int64_t nJ, const double *__restrict__ loss_sum,
+                                                        float *__restrict__ snaps, int64_t n, float lr,
+                                                        const double *__restrict__ normals, const int *__restrict__ n_normals_dev,
+                                                        float *__restrict__ loss_log, int64_t loss_log_cap) {
+    constexpr int SPLIT = 8;
+    __shared__ float gsp_s[4];
+    const StepDecision d = step_decide(&states[cur], loss_sum[0]);
+    const int64_t grp = ((int64_t)blockIdx.x * BLK + threadIdx.x) / SPLIT;
+    const int l = threadIdx.x & (SPLIT - 1);
+    // group -> coordinate index: 0..3 -> x0, x1, y0, y1; 4.. -> the others in order
+    int64_t idx;
+    if (grp < 4) idx = (grp >> 1) * n + (grp & 1);
+    else idx = (grp - 4 < n - 2) ? grp - 4 + 2 : grp - 4 + 4;
+    const bool live = idx < 2 * n && (grp >= 4 || (grp & 1) < n);
+    float g = 0.0f;
+    if (live && !d.halted) {
+        const int c = (int)(idx / n);
+        const int64_t i = idx % n;
+        const int64_t Ii = i / SY_R, Ji = i / SY_C;
+        for (int64_t J = l; J < nJ; J += SPLIT)
+            if (sy_tile_live(Ii, J)) g += rowpart[(J * 2 + c) * n + i];
+        for (int64_t b = l; b < n_lblocks; b += SPLIT)
+            if (sy_tile_live(b, Ji)) g += colpart[(b * 2 + c) * n + i];
+    }
+    g += __shfl_xor(g, 1);
+    g += __shfl_xor(g, 2);
+    g += __shfl_xor(g, 4);
+    if (blockIdx.x == 0) {   // block-uniform
+        if (grp < 4 && l == 0) gsp_s[grp] = g;
+        __syncthreads();
+    }
+    if (live && !d.halted && grp >= 4 && l == 0) step_element(d, idx, g, Y, snaps, n, lr);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float gsp[4] = {gsp_s[0], gsp_s[1], gsp_s[2], gsp_s[3]};
+        step_leader(states, cur, d, Y, gsp, snaps, n, lr, normals, n_normals_dev, loss_log, loss_log_cap);
+    }
 }
 
 }  // namespace
@@ -1228,9 +1315,22 @@ struct kmap_embed {
     // work per block shrinks with I); its probability rows are stored block after block (local block b = I / world)
     int world = 1, rank = 0;
     int64_t n_lblocks = 0;
+    // jitter normals: fixed-capacity device buffer + device-resident count, so that the kernel arguments of an iteration never
+    // change between launches (a captured hipGraph stays valid when the host refills the pool)
+    int *n_normals_dev = nullptr;
+    int normals_cap = 0;
+    // two iterations (both parities of the double-buffered loop record) captured as one hipGraph and replayed by kmap_embed_step
+    hipGraphExec_t gexec = nullptr;
+    hipStream_t gstream = nullptr;
+    int graph_cur = 0;
+    bool graph_failed = false;
 };
 
 namespace {
+void drop_graph(kmap_embed *e) {   // kernel arguments changed: the captured iterations are stale
+    if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
+    e->gexec = nullptr;
+}
 int n_force_blocks(const kmap_embed *e) {
     if (e->sym) return (int)(e->n_lblocks * (((e->symJ + SY_WAVES - 1) / SY_WAVES) * SY_WAVES));
     if (e->mode == KMAP_EMBED_SEQ) return (int)((e->nrows + SQ_ROWS * SQ_WAVES - 1) / (SQ_ROWS * SQ_WAVES));
@@ -1373,6 +1473,7 @@ static int embed_create_impl(kmap_embed **out, int64_t n, int64_t row0, int64_t 
     A((void **)&e->loss_sum, 8);
     A((void **)&e->states, 2 * sizeof(LoopState));
     A((void **)&e->lut_dev, F_LUT_LDS * 4);
+    A((void **)&e->n_normals_dev, 16);
     if (e->sym) {
         A((void **)&e->rowpart, (size_t)e->symJ * 2 * n * 4);
         A((void **)&e->colpart, (size_t)(e->n_lblocks ? e->n_lblocks : 1) * 2 * n * 4);
@@ -1391,18 +1492,23 @@ static int embed_create_impl(kmap_embed **out, int64_t n, int64_t row0, int64_t 
         s0.best_loss[b] = INFINITY;
         s0.best_slot[b] = b;
     }
+    s0.worst_loss = INFINITY;
+    s0.worst_slot = n_best - 1;
     KMAP_CHECK_HIP(hipMemcpy(&e->states[0], &s0, sizeof s0, hipMemcpyHostToDevice));
     KMAP_CHECK_HIP(hipMemcpy(&e->states[1], &s0, sizeof s0, hipMemcpyHostToDevice));
     KMAP_CHECK_HIP(hipMemset(e->G, 0, (size_t)2 * n * 4));
     KMAP_CHECK_HIP(hipMemset(e->loss_part, 0, (size_t)e->n_part * 8));
+    KMAP_CHECK_HIP(hipMemset(e->n_normals_dev, 0, 16));
     *out = e;
     return KMAP_OK;
 }
 
 int kmap_embed_destroy(kmap_embed *e) {
     if (!e) return KMAP_OK;
+    if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
+    if (e->gstream) (void)hipStreamDestroy(e->gstream);
     void *ptrs[] = {e->Y, e->G, e->snaps, e->loss_log, e->loss_part, e->loss_sum, e->states, e->lut_dev, e->normals,
-                    e->rowpart, e->colpart};
+                    e->rowpart, e->colpart, e->n_normals_dev};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete e;
@@ -1413,6 +1519,7 @@ int kmap_embed_set_prob_f32(kmap_embed *e, const float *p_rows_dev, int64_t ld) 
     KMAP_REQUIRE(e && p_rows_dev && ld >= e->n, "embed_set_prob_f32: bad arguments");
     e->src = ProbSrc{p_rows_dev, nullptr, nullptr, ld, 0};
     e->have_prob = true;
+    drop_graph(e);
     return KMAP_OK;
 }
 
@@ -1422,6 +1529,7 @@ int kmap_embed_set_prob_lut(kmap_embed *e, const uint16_t *sums_rows_dev, int64_
     KMAP_CHECK_HIP(hipMemcpy(e->lut_dev, lut, (size_t)lut_len * 4, hipMemcpyHostToDevice));
     e->src = ProbSrc{nullptr, sums_rows_dev, e->lut_dev, ld, lut_len};
     e->have_prob = true;
+    drop_graph(e);
     return KMAP_OK;
 }
 
@@ -1439,27 +1547,27 @@ int kmap_embed_set_coords(kmap_embed *e, const float *coords_2xn, const float *p
 int kmap_embed_set_jitter(kmap_embed *e, const double *normals, int n_normals) {
     KMAP_REQUIRE(e && n_normals >= 0 && (n_normals == 0 || normals), "embed_set_jitter: bad arguments");
     KMAP_CHECK_HIP(hipDeviceSynchronize());
-    if (e->normals) KMAP_CHECK_HIP(hipFree(e->normals));
-    e->normals = nullptr;
-    e->n_normals = 0;
-    if (n_normals) {
-        KMAP_CHECK_HIP(hipMalloc((void **)&e->normals, (size_t)n_normals * 8));
-        KMAP_CHECK_HIP(hipMemcpy(e->normals, normals, (size_t)n_normals * 8, hipMemcpyHostToDevice));
-        e->n_normals = n_normals;
+    if (n_normals > e->normals_cap) {           // grow geometrically: the pointer (a kernel argument) rarely changes
+        int cap = e->normals_cap ? e->normals_cap : 8192;
+        while (cap < n_normals) cap *= 2;
+        if (e->normals) KMAP_CHECK_HIP(hipFree(e->normals));
+        e->normals = nullptr;
+        e->normals_cap = 0;
+        KMAP_CHECK_HIP(hipMalloc((void **)&e->normals, (size_t)cap * 8));
+        e->normals_cap = cap;
+        drop_graph(e);
     }
+    if (n_normals) KMAP_CHECK_HIP(hipMemcpy(e->normals, normals, (size_t)n_normals * 8, hipMemcpyHostToDevice));
+    KMAP_CHECK_HIP(hipMemcpy(e->n_normals_dev, &n_normals, 4, hipMemcpyHostToDevice));
+    e->n_normals = n_normals;
     return KMAP_OK;
 }
 
-int kmap_embed_forces(kmap_embed *e, float *grad_dev_2xn, double *loss_dev, void *stream) {
-    KMAP_REQUIRE(e && e->have_prob && e->have_coords, "embed_forces: probabilities/coordinates not set");
-    hipStream_t st = as_stream(stream);
-    float *G = grad_dev_2xn ? grad_dev_2xn : e->G;
-    double *L = loss_dev ? loss_dev : e->loss_sum;
+namespace {
+// the force kernel of the session (+ the row / column partial sum into G for the symmetric kernels when `reduce_sym`);
+// loss partials go to e->loss_part
+int launch_forces(kmap_embed *e, float *G, bool reduce_sym, hipStream_t st) {
     const int nblk = n_force_blocks(e);
-    if (nblk == 0) {
-        KMAP_CHECK_HIP(hipMemsetAsync(L, 0, 8, st));
-        return KMAP_OK;
-    }
     const bool lut = e->src.ps != nullptr;
     const size_t lds = lut ? (((size_t)e->src.lut_len * 4 + 15) & ~(size_t)15) : 16;
     if (e->sym) {
@@ -1473,7 +1581,8 @@ int kmap_embed_forces(kmap_embed *e, float *grad_dev_2xn, double *loss_dev, void
                 e->src, e->Y, e->n, e->rowpart, e->colpart, e->loss_part, e->symJ, part_ld, e->world, e->rank, lut_pad);
         } else if (lut) forces_sym_kernel<true><<<grid, KMAP_WAVE * SY_WAVES, lds, st>>>(e->src, e->Y, e->n, e->rowpart, e->colpart, e->loss_part, e->symJ, e->world, e->rank);
         else forces_sym_kernel<false><<<grid, KMAP_WAVE * SY_WAVES, lds, st>>>(e->src, e->Y, e->n, e->rowpart, e->colpart, e->loss_part, e->symJ, e->world, e->rank);
-        sym_reduce_kernel<<<(unsigned)((2 * e->n * 8 + BLK - 1) / BLK), BLK, 0, st>>>(e->rowpart, e->colpart, e->n, e->n_lblocks, e->symJ, e->world, e->rank, G);
+        if (reduce_sym)
+            sym_reduce_kernel<<<(unsigned)((2 * e->n * 8 + BLK - 1) / BLK), BLK, 0, st>>>(e->rowpart, e->colpart, e->n, e->n_lblocks, e->symJ, e->world, e->rank, G);
     } else if (e->mode == KMAP_EMBED_SEQ) {
         if (lut) forces_seq_kernel<true><<<nblk, KMAP_WAVE * SQ_WAVES, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
         else forces_seq_kernel<false><<<nblk, KMAP_WAVE * SQ_WAVES, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
@@ -1481,7 +1590,73 @@ int kmap_embed_forces(kmap_embed *e, float *grad_dev_2xn, double *loss_dev, void
         if (lut) forces_fast_kernel<true><<<nblk, KMAP_WAVE * F_WAVES, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
         else forces_fast_kernel<false><<<nblk, KMAP_WAVE * F_WAVES, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
     }
-    reduce_loss_kernel<<<1, 1024, 0, st>>>(e->loss_part, nblk, L);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+
+// one single-GPU iteration with the fused tails: forces -> apply<loss reduction fused> (2 launches), or for the symmetric
+// kernels forces -> loss reduction -> partial sums + apply (3 launches instead of 4; the gradient never goes to memory)
+int launch_iteration(kmap_embed *e, hipStream_t st) {
+    KMAP_TRY(launch_forces(e, e->G, false, st));
+    const int nblk = n_force_blocks(e);
+    if (e->sym) {
+        reduce_loss_kernel<<<1, BLK, 0, st>>>(e->loss_part, nblk, e->loss_sum);
+        sym_apply_kernel<<<(unsigned)(((2 * e->n + 4) * 8 + BLK - 1) / BLK), BLK, 0, st>>>(
+            e->states, e->cur, e->Y, e->rowpart, e->colpart, e->n_lblocks, e->symJ, e->loss_sum, e->snaps, e->n, e->lr, e->normals,
+            e->n_normals_dev, e->loss_log, e->loss_log_cap);
+    } else {
+        apply_kernel<true><<<(unsigned)((2 * e->n + BLK - 1) / BLK), BLK, 0, st>>>(e->states, e->cur, e->Y, e->G, e->loss_part, nblk, e->snaps,
+                                                                                  e->n, e->lr, e->normals, e->n_normals_dev,
+                                                                                  e->loss_log, e->loss_log_cap);
+    }
+    KMAP_CHECK_HIP(hipGetLastError());
+    e->cur ^= 1;
+    return KMAP_OK;
+}
+
+// capture two iterations (parities cur, cur ^ 1) into a graph; any failure switches graph replay off for the session
+bool ensure_graph(kmap_embed *e) {
+    if (e->graph_failed) return false;
+    if (e->gexec) return true;
+    // opt-in (KMAP_EMBED_GRAPH=1): measured on ROCm 7.2 / MI355X, replaying the captured pair of iterations is SLOWER than
+    // launching the same 2-3 kernels directly (N = 50 k FAST 0.958 vs 0.882 ms / iteration, N = 5 k SEQ 0.175 vs 0.163, FAST 0.047 vs
+    // 0.041): the launches are already queued ahead of the GPU, and the graph adds per-node dispatch cost
+    static const bool on = [] { const char *v = getenv("KMAP_EMBED_GRAPH"); return v && v[0] == '1'; }();
+    if (!on) { e->graph_failed = true; return false; }
+    if (!e->gstream && hipStreamCreateWithFlags(&e->gstream, hipStreamNonBlocking) != hipSuccess) { e->graph_failed = true; return false; }
+    hipGraph_t graph = nullptr;
+    const int cur0 = e->cur;
+    bool ok = hipStreamBeginCapture(e->gstream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+        ok = launch_iteration(e, e->gstream) == KMAP_OK && launch_iteration(e, e->gstream) == KMAP_OK;
+        ok = (hipStreamEndCapture(e->gstream, &graph) == hipSuccess) && ok && graph;
+    }
+    e->cur = cur0;                                   // captured, not executed
+    if (ok) ok = hipGraphInstantiate(&e->gexec, graph, nullptr, nullptr, 0) == hipSuccess;
+    if (graph) (void)hipGraphDestroy(graph);
+    if (!ok) {
+        (void)hipGetLastError();
+        e->gexec = nullptr;
+        e->graph_failed = true;
+        return false;
+    }
+    e->graph_cur = cur0;
+    return true;
+}
+}  // namespace
+
+int kmap_embed_forces(kmap_embed *e, float *grad_dev_2xn, double *loss_dev, void *stream) {
+    KMAP_REQUIRE(e && e->have_prob && e->have_coords, "embed_forces: probabilities/coordinates not set");
+    hipStream_t st = as_stream(stream);
+    float *G = grad_dev_2xn ? grad_dev_2xn : e->G;
+    double *L = loss_dev ? loss_dev : e->loss_sum;
+    const int nblk = n_force_blocks(e);
+    if (nblk == 0) {
+        KMAP_CHECK_HIP(hipMemsetAsync(L, 0, 8, st));
+        return KMAP_OK;
+    }
+    KMAP_TRY(launch_forces(e, G, true, st));
+    reduce_loss_kernel<<<1, BLK, 0, st>>>(e->loss_part, nblk, L);
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;
 }
@@ -1492,19 +1667,33 @@ int kmap_embed_apply(kmap_embed *e, const float *grad_dev_2xn, const double *los
     const float *G = grad_dev_2xn ? grad_dev_2xn : e->G;
     const double *L = loss_dev ? loss_dev : e->loss_sum;
     const unsigned grid = (unsigned)((2 * e->n + BLK - 1) / BLK);
-    apply_kernel<<<grid, BLK, 0, st>>>(e->states, e->cur, e->Y, G, L, e->snaps, e->n, e->lr, e->normals, e->n_normals,
-                                       e->loss_log, e->loss_log_cap);
+    apply_kernel<false><<<grid, BLK, 0, st>>>(e->states, e->cur, e->Y, G, L, 0, e->snaps, e->n, e->lr, e->normals, e->n_normals_dev,
+                                              e->loss_log, e->loss_log_cap);
     KMAP_CHECK_HIP(hipGetLastError());
     e->cur ^= 1;
     return KMAP_OK;
 }
 
 int kmap_embed_step(kmap_embed *e, int n_iter, void *stream) {
-    KMAP_REQUIRE(e && e->row0 == 0 && e->nrows == e->n, "embed_step: single-GPU convenience needs all rows local");
-    for (int it = 0; it < n_iter; ++it) {
-        KMAP_TRY(kmap_embed_forces(e, nullptr, nullptr, stream));
-        KMAP_TRY(kmap_embed_apply(e, nullptr, nullptr, stream));
+    KMAP_REQUIRE(e && e->row0 == 0 && e->nrows == e->n && e->world == 1, "embed_step: single-GPU convenience needs all rows local");
+    KMAP_REQUIRE(e->have_prob && e->have_coords, "embed_step: probabilities/coordinates not set");
+    hipStream_t st = as_stream(stream);
+    int it = 0;
+    if (n_iter >= 4 && ensure_graph(e)) {
+        if (e->cur != e->graph_cur && it < n_iter) {   // realign the parity the graph was captured at
+            KMAP_TRY(launch_iteration(e, st));
+            ++it;
+        }
+        for (; it + 2 <= n_iter; it += 2) {
+            if (hipGraphLaunch(e->gexec, st) != hipSuccess) {   // e.g. a stream the runtime cannot launch graphs into
+                (void)hipGetLastError();
+                drop_graph(e);
+                e->graph_failed = true;
+                break;
+            }
+        }
     }
+    for (; it < n_iter; ++it) KMAP_TRY(launch_iteration(e, st));
     return KMAP_OK;
 }
 
@@ -1630,7 +1819,7 @@ int kmap_cross_entropy_f32(const float *p_nxn, const float *q_nxn, int64_t n, fl
     KMAP_CHECK_HIP(hipMemcpy(dp.p, p_nxn, (size_t)n * n * 4, hipMemcpyHostToDevice));
     KMAP_CHECK_HIP(hipMemcpy(dq.p, q_nxn, (size_t)n * n * 4, hipMemcpyHostToDevice));
     ce_rows_kernel<<<(unsigned)n, BLK>>>(dp.as<float>(), dq.as<float>(), n, dpart.as<double>());
-    reduce_loss_kernel<<<1, 1024>>>(dpart.as<double>(), (int)n, dsum.as<double>());
+    reduce_loss_kernel<<<1, BLK>>>(dpart.as<double>(), (int)n, dsum.as<double>());
     KMAP_CHECK_HIP(hipGetLastError());
     double s = 0.0;
     KMAP_CHECK_HIP(hipMemcpy(&s, dsum.p, 8, hipMemcpyDeviceToHost));
