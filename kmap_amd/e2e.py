@@ -17,7 +17,16 @@ CONFIGS = {
 }
 
 
-def run_e2e(config="C2", mode="default", min_k=6, max_k=9, iters=None, keep=False, quiet=True, reports=False):
+def synth_config_reads(config):
+    """(seq uint8 array, borders) of a config's seeded synthetic reads"""
+    from . import synth
+    c = CONFIGS[config]
+    return synth.synth_reads(c["n_reads"], c["read_len"], c["seed"])
+
+
+def run_e2e(config="C2", mode="default", min_k=6, max_k=9, iters=None, keep=False, quiet=True, reports=False, reads=None):
+    """reads: (seq, borders) from synth_config_reads(config) to re-use across runs (not consumed); keep=True leaves the result
+    directory in place and returns its path as "res_dir"."""
     import contextlib
     import io
     from . import motif_discovery as md, synth, visualization as vz
@@ -31,7 +40,7 @@ def run_e2e(config="C2", mode="default", min_k=6, max_k=9, iters=None, keep=Fals
     vz.STAGE_TIMES.clear()
     t = {}
     t0 = time.perf_counter()
-    seq, borders = synth.synth_reads(c["n_reads"], c["read_len"], c["seed"])
+    seq, borders = reads if reads is not None else synth.synth_reads(c["n_reads"], c["read_len"], c["seed"])
     t["synth_s"] = time.perf_counter() - t0
     res = Path(tempfile.mkdtemp(prefix=f"kmap_{config}_"))
     over = {"kmer_count": {"min_k": min_k, "max_k": max_k},
@@ -58,7 +67,7 @@ def run_e2e(config="C2", mode="default", min_k=6, max_k=9, iters=None, keep=Fals
         stages = dict(md.STAGE_TIMES)
         stages.update({"viz_" + k: v for k, v in vz.STAGE_TIMES.items()})
         return {"config": config, "mode": mode, **c, "k_range": [min_k, max_k], "final_conseq": finals,
-                "n_embedded": len(rows) - 1, "times": t, "stages": stages}
+                "n_embedded": len(rows) - 1, "times": t, "stages": stages, "res_dir": str(res) if keep else None}
     finally:
         if prev_mode is None:
             os.environ.pop("KMAP_EMBED_MODE", None)
