@@ -1,0 +1,246 @@
+"""BASELINE.json's configurations at their FULL sizes on one MI355X (C3: 10 M x 150 bp reads, N = 50 000 sampled k-mers; C4: N =
+200 000; C5: 50 M x 300 bp reads, k = 14, radius 5).  An O(reads) / O(N^2) CPU recount is not feasible inside a test, so every
+stage is checked by size-independent properties plus the CPU oracle on sampled reads / rows:
+  counting   additivity over disjoint read sets (the histogram is linear, the revcom merge too), closed-form totals, and the
+             oracle's counts on sampled sub-slices;
+  masking    the masked array on sampled read chunks == the oracle's mask_input (masking never leaves a read);
+  scan       per-read hits of >= 10^4 sampled reads == the oracle's ko_scan_read;
+  Hamming    sampled rows == the oracle's rows, symmetry, zero diagonal;
+  embedding  one force evaluation at N = 50 000: symmetric FAST kernel vs the reference-order SEQ kernel."""
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+K = 8
+
+
+def _dense(u, c, k):
+    d = np.zeros(4 ** k, np.int64)
+    d[u.astype(np.int64)] = c
+    return d
+
+
+@pytest.fixture(scope="module")
+def c3_reads():
+    from kmap_amd.e2e import synth_config_reads
+    return synth_config_reads("C3")            # 10 M x 150 bp, seed 2 (1.51e9 positions)
+
+
+@pytest.fixture(scope="module")
+def c3_dev(c3_reads):
+    from kmap_amd.motif_discovery import DeviceSeq
+    ds = DeviceSeq(*c3_reads)
+    yield ds
+    ds.close()
+
+
+def _slice_reads(seq, borders, r0, r1):
+    lo, hi = int(borders[r0, 0]), int(borders[r1 - 1, 1]) + 1
+    return np.ascontiguousarray(seq[lo:hi]), borders[r0:r1] - lo
+
+
+def test_c3_counting_full_size(c3_reads, c3_dev):
+    from kmap_amd.kmer_count import DeviceCounts
+    from kmap_amd.motif_discovery import DeviceSeq
+    from oracle import oracle as O
+    seq, borders = c3_reads
+    n_reads, read_len = len(borders), int(borders[0, 1] - borders[0, 0])
+    dc = DeviceCounts()
+    full = {}
+    for dedupe in (False, True):
+        c3_dev.count(dc, K, dedupe=dedupe, merge_revcom=True)
+        u, c = dc.fetch()
+        assert len(np.unique(u)) == len(u) and c.min() > 0
+        full[dedupe] = _dense(u, c, K)
+    # closed form: no N in the synthetic reads -> every window counts once, palindromic 8-mers twice (merge_revcom doubles them)
+    c3_dev.count(dc, K, dedupe=False, merge_revcom=False)
+    u0, c0 = dc.fetch()
+    assert int(c0.sum()) == n_reads * (read_len - K + 1)
+    pal = np.array([int(O.revcom_hash(int(h), K)) == int(h) for h in u0])
+    assert int(full[False].sum()) == int(c0.sum()) + int(c0[pal].sum())
+    assert np.all(full[True] <= full[False]) and full[True].sum() < full[False].sum()
+    # additivity over 8 disjoint read slices (uneven cuts), both modes
+    cuts = [0, 1_000_003, 2_345_678, 3_999_999, 5_000_000, 6_543_210, 8_000_001, 9_123_456, n_reads]
+    acc = {False: np.zeros(4 ** K, np.int64), True: np.zeros(4 ** K, np.int64)}
+    for a, b in zip(cuts, cuts[1:]):
+        s, bd = _slice_reads(seq, borders, a, b)
+        ds = DeviceSeq(s, bd)
+        for dedupe in (False, True):
+            ds.count(dc, K, dedupe=dedupe, merge_revcom=True)
+            acc[dedupe] += _dense(*dc.fetch(), K)
+        ds.close()
+    for dedupe in (False, True):
+        np.testing.assert_array_equal(acc[dedupe], full[dedupe])
+    # the oracle on sampled sub-slices (k = 8 and the partitioned k = 14 path)
+    for a, k in ((777_777, 8), (9_400_000, 8), (4_200_000, 14)):
+        s, bd = _slice_reads(seq, borders, a, a + 40_000)
+        ds = DeviceSeq(s, bd)
+        for dedupe in (False, True):
+            ds.count(dc, k, dedupe=dedupe, merge_revcom=True)
+            u, c = dc.fetch()
+            ou, oc = O.count_kmers(s, bd, k, rep_mode=not dedupe, revcom_mode=True)
+            np.testing.assert_array_equal(u, ou)
+            np.testing.assert_array_equal(c, oc)
+        ds.close()
+    dc.close()
+
+
+def test_c3_masking_full_size(c3_reads, c3_dev):
+    from kmap_amd.kmer_count import kmer2hash, revcom_hash
+    from oracle import oracle as O
+    seq, borders = c3_reads
+    cons = int(kmer2hash("CCTACGTA"))
+    ck = np.array([cons, int(revcom_hash(cons, K))], np.uint64)
+    c3_dev.reset()
+    c3_dev.mask(K, ck, np.array([2, 2]))
+    got = c3_dev.download()
+    c3_dev.reset()
+    assert got.shape == seq.shape
+    changed = got != seq
+    assert np.all(got[changed] == 255) and 0.005 < changed.mean() < 0.5           # only ever turns bases into 255
+    rng = np.random.default_rng(1)
+    for a in rng.integers(0, len(borders) - 5000, size=6):
+        lo, hi = int(borders[a, 0]), int(borders[a + 5000 - 1, 1]) + 1
+        want = O.mask_input(seq[lo:hi].copy(), K, ck, np.array([2, 2]))
+        np.testing.assert_array_equal(got[lo:hi], want)
+
+
+def _check_scan(seq, borders, hits, pos, k, cons, radius, sample):
+    from oracle import oracle as O
+    offs = np.concatenate([[0], np.cumsum(hits, dtype=np.int64)])
+    buf, md = np.empty(int(borders[0, 1] - borders[0, 0]) + 1, np.int32), C.c_int(0)
+    L = O.lib()
+    n_hit = 0
+    for i in sample:
+        st, en = int(borders[i, 0]), int(borders[i, 1])
+        m = L.ko_scan_read(np.ascontiguousarray(seq[st:en]), en - st, k, cons, radius, 1, buf, C.byref(md))
+        assert hits[i] == m, (i, hits[i], m)
+        np.testing.assert_array_equal(pos[offs[i]:offs[i + 1]], buf[:m])
+        n_hit += m > 0
+    return n_hit
+
+
+def test_c3_scan_full_size(c3_reads, c3_dev):
+    from kmap_amd.kmer_count import kmer2hash
+    seq, borders = c3_reads
+    rng = np.random.default_rng(2)
+    sample = np.concatenate([[0, len(borders) - 1], rng.integers(0, len(borders), size=12_000)])
+    for conseq, radius in (("CCTACGTA", 2), ("ATCGATA", 1)):
+        hits, pos = c3_dev.scan(len(conseq), kmer2hash(conseq), radius, True)
+        assert len(hits) == len(borders) and int(hits.sum()) == len(pos)
+        frac = np.count_nonzero(hits) / len(hits)
+        assert 0.2 < frac < 0.99                                                   # 40 % of the reads carry each planted motif, chance hits on top
+        assert _check_scan(seq, borders, hits, pos, len(conseq), int(kmer2hash(conseq)), radius, sample) > 3000
+
+
+def test_c5_scan_full_size():
+    """BASELINE config C5: k = 14, max_ham_dist = 5 Hamming-ball scan over 50 M x 300 bp reads (1.505e10 positions)."""
+    from kmap_amd import synth
+    from kmap_amd.kmer_count import kmer2hash
+    from kmap_amd.motif_discovery import DeviceSeq
+    motif = "AGGACCTACGTACA"
+    seq, borders = synth.synth_reads(50_000_000, 300, 3, motifs=(motif, "AATCGATAGC"))
+    assert len(seq) == 15_050_000_000
+    ds = DeviceSeq(seq, borders)
+    hits, pos = ds.scan(14, kmer2hash(motif), 5, True)
+    ds.close()
+    assert len(hits) == 50_000_000 and int(hits.sum(dtype=np.int64)) == len(pos)
+    assert np.count_nonzero(hits) > 0.4 * len(hits)                                # radius 5 of 14: most reads have a nearest hit
+    rng = np.random.default_rng(3)
+    sample = np.concatenate([[0, len(borders) - 1], rng.integers(0, len(borders), size=12_000)])
+    assert _check_scan(seq, borders, hits, pos, 14, int(kmer2hash(motif)), 5, sample) > 4000
+
+
+def _pipeline_like_sample(n, seed):
+    """n expanded 8-mers with the C3 hand-over's structure: label 0 around CCTACGTA (full length), label 1 around ATCGATA (a
+    7-mer: its pairs are compared on 7 bases), noise label 2; sorted by label, with duplicates."""
+    from kmap_amd.kmer_count import kmer2hash
+    rng = np.random.default_rng(seed)
+    parts, labs = [], []
+    for lab, (core, m) in enumerate((("CCTACGTA", n // 3), ("ATCGATAC", n // 6))):
+        base = int(kmer2hash(core))
+        kh = np.full(m, base, np.uint64)
+        for _ in range(2):                                                          # up to two substitutions
+            pos, val = rng.integers(0, K, size=m), rng.integers(0, 4, size=m).astype(np.uint64)
+            sh = (2 * pos).astype(np.uint64)
+            kh = (kh & ~(np.uint64(3) << sh)) | (val << sh)
+        parts.append(kh)
+        labs.append(np.full(m, lab))
+    rest = n - sum(len(p) for p in parts)
+    parts.append(rng.integers(0, 4 ** K, size=rest, dtype=np.uint64))
+    labs.append(np.full(rest, 2))
+    return np.concatenate(parts).astype(np.uint32), np.concatenate(labs).astype(np.int32), [8, 7]
+
+
+def test_c4_hamming_full_size():
+    """BASELINE config C4's matrix on ONE GPU: N = 200 000 (4e10 pairs, 40 GB of uint8): sampled rows == oracle, symmetric."""
+    from kmap_amd import _ffi
+    from kmap_amd.hamdist import hamdist_matrix_dev, pitch_for
+    from oracle import oracle as O
+    n = 200_000
+    kh, lab, lens = _pipeline_like_sample(n, 4)
+    ld = pitch_for(n)
+    kh_d, lab_d, D_d = _ffi.DeviceBuffer.from_numpy(kh), _ffi.DeviceBuffer.from_numpy(lab), _ffi.DeviceBuffer(n * ld)
+    hamdist_matrix_dev(kh_d.ptr, lab_d.ptr, n, K, lens, D_d.ptr, ld)
+    _ffi.sync()
+    rng = np.random.default_rng(5)
+    rows = np.unique(np.concatenate([[0, 1, n // 3 - 1, n // 3, n // 2 - 1, n // 2, n - 1], rng.integers(0, n, size=120)]))
+    got = np.stack([D_d.to_numpy(np.uint8, (n,), offset=int(r) * ld) for r in rows])
+    for b in (D_d, kh_d, lab_d):
+        b.free()
+    want = np.empty((1, n), np.uint8)
+    kh64, cl = np.ascontiguousarray(kh, np.uint64), np.ascontiguousarray(lens, np.int32)
+    for g, r in zip(got, rows):
+        O.lib().ko_hamdist_rows(kh64, lab, n, K, cl, len(cl), int(r), 1, want)
+        np.testing.assert_array_equal(g, want[0])
+    sub = got[:, rows]                                                              # D[rows][:, rows]
+    np.testing.assert_array_equal(sub, sub.T)
+    assert np.all(np.diag(sub) == 0) and got.max() <= K
+
+
+def test_c3_embedding_force_evaluation_full_size():
+    """N = 50 000 with the hand-over's label structure: the symmetric FAST kernel (the C3 default) against the SEQ kernel (the
+    reference's summation order) on one force evaluation -- loss to 2e-6, gradient to 2e-5 of its scale -- and 20 FAST
+    iterations that keep lowering the loss."""
+    from kmap_amd import _ffi, visualization as V
+    from kmap_amd.hamdist import hamdist_matrix_dev, pitch_for
+    n = 50_000
+    kh, lab, lens = _pipeline_like_sample(n, 6)
+    ldd = pitch_for(n)
+    kh_d, lab_d, D_d = _ffi.DeviceBuffer.from_numpy(kh), _ffi.DeviceBuffer.from_numpy(lab), _ffi.DeviceBuffer(n * ldd)
+    hamdist_matrix_dev(kh_d.ptr, lab_d.ptr, n, K, lens, D_d.ptr, ldd)
+    nb_d = V.knn_select_dev(D_d.ptr, ldd, n, 20)
+    sums_d, lds = V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, K, lens, nb_d, 20)
+    # the profile-based sums == the matrix-based sums on sampled rows
+    chk_d, _ = V.knn_sums_dev(D_d.ptr, ldd, nb_d, n, 20, row0=12_345, nrows=64)
+    np.testing.assert_array_equal(sums_d.to_numpy(np.uint16, (64, lds), offset=12_345 * lds * 2)[:, :n], chk_d.to_numpy(np.uint16, (64, lds))[:, :n])
+    for b in (chk_d, D_d, nb_d, kh_d, lab_d):
+        b.free()
+    lut = V.hd_prob_lut(K, 20, 400 * K)
+    coords = np.random.default_rng(7).standard_normal((2, n)).astype(np.float32)
+    outs = {}
+    for tag, mode in (("seq", V.EMBED_SEQ), ("fast", V.EMBED_FAST)):
+        sess = V.EmbedSession(n, 10, 0.01, mode)
+        _ffi.check(_ffi.lib().kmap_embed_set_prob_lut(sess._h, sums_d.ptr, lds, _ffi.ptr(lut), len(lut)))
+        sess.set_coords(coords)
+        g_d, l_d = _ffi.DeviceBuffer(2 * n * 4), _ffi.DeviceBuffer(8)
+        g_d.zero()
+        sess.forces(g_d.ptr, l_d.ptr)
+        _ffi.sync()
+        outs[tag] = (g_d.to_numpy(np.float32, (2, n)), float(l_d.to_numpy(np.float64, (1,))[0]))
+        if tag == "fast":
+            sess.set_jitter(np.random.default_rng(8).normal(0, 0.01, 4096))
+            sess.step(20)
+            losses = sess.losses()
+            assert len(losses) == 20 and np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+        sess.close()
+    sums_d.free()
+    (gs, ls), (gf, lf) = outs["seq"], outs["fast"]
+    assert abs(lf - ls) <= 2e-6 * abs(ls)
+    np.testing.assert_allclose(gf, gs, rtol=0, atol=2e-5 * np.abs(gs).max())
