@@ -120,6 +120,15 @@ int kmap_counts_run_hashes_dev(kmap_counts *c, const void *hash_dev, int64_t n, 
 int kmap_counts_load(kmap_counts *c, const void *uniq, const void *cnt, int64_t n_uniq, int k);
 /* uniq_out: uint32[n_uniq] (k<16) or uint64[n_uniq]; cnt_out: int32 (k<16) or int64 */
 int kmap_counts_fetch(kmap_counts *c, void *uniq_out, void *cnt_out);
+/* the same copy on a caller-chosen stream through pinned staging buffers (conversion on host threads): lets a background host
+ * thread drain a finished table (multi-GB at k >= 14) while the default stream keeps counting into another handle */
+int kmap_counts_fetch_stream(kmap_counts *c, void *uniq_out, void *cnt_out, void *stream);
+/* elements [first, first + count) of one array of the table in the reference's dtype: which = 0 unique hashes, 1 counts */
+int kmap_counts_fetch_range(kmap_counts *c, int which, int64_t first, int64_t count, void *out, void *stream);
+/* device addresses of the resident table (uniq uint32 for k < 16 else uint64; cnt uint32 whatever k; counts > 2^32 wrap like the
+ * histogram bins); valid until the next count / load / destroy on the handle.  Lets sample_disp_kmer (motif_discovery.py:812-921)
+ * label a multi-GB table where it lies instead of re-reading k{k}.pkl */
+int kmap_counts_table_dev(kmap_counts *c, void **uniq_dev, void **cnt_dev, int64_t *n_uniq);
 int kmap_counts_total(kmap_counts *c, int64_t *total);          /* sum of counts */
 /* the top_k (<= 16) most frequent k-mers: largest count first, ties by lowest index (np.argpartition's tie order,
  * motif_discovery.py:661, is numpy-specific; this rule is used when the arrays are too large to fetch per trial).

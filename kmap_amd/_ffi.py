@@ -62,6 +62,9 @@ _SIGS = {
     "kmap_counts_run_hashes_dev": (i32, [vp, vp, i64, i32, i32, P(i64), vp]),
     "kmap_counts_load": (i32, [vp, vp, vp, i64, i32]),
     "kmap_counts_fetch": (i32, [vp, vp, vp]),
+    "kmap_counts_fetch_stream": (i32, [vp, vp, vp, vp]),
+    "kmap_counts_table_dev": (i32, [vp, P(vp), P(vp), P(i64)]),
+    "kmap_counts_fetch_range": (i32, [vp, i32, i64, i64, vp, vp]),
     "kmap_counts_total": (i32, [vp, P(i64)]),
     "kmap_hamball_extract": (i32, [vp, vp, i64, i32, u64, i32, i32, vp, vp, P(i64), vp]),
     "kmap_pos_density": (i32, [vp, vp, vp, vp, i64, i32, vp, i32, f64, vp]),

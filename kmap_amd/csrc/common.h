@@ -41,7 +41,7 @@ static inline hipStream_t as_stream(void *s) { return (hipStream_t)s; }
 // stack, sub-sector (4-byte) stores from workgroups on different XCDs into stream-ordered pool
 // memory were observed to be lost (only one XCD's bytes of each 32-byte sector survived), while the
 // same kernels on hipMalloc memory are correct.  Work that uses a slot is ordered by its stream.
-enum { KMAP_SLOT_A = 0, KMAP_SLOT_B = 1, KMAP_SLOT_C = 2, KMAP_SLOT_D = 3, KMAP_SLOT_HASH = 4, KMAP_SLOT_PART = 5 };
+enum { KMAP_SLOT_A = 0, KMAP_SLOT_B = 1, KMAP_SLOT_C = 2, KMAP_SLOT_D = 3, KMAP_SLOT_HASH = 4, KMAP_SLOT_PART = 5, KMAP_SLOT_BINS = 6 };
 int kmap_scratch(void **ptr, size_t bytes, hipStream_t stream, int slot);
 
 // RAII device scratch buffer for the blocking host-pointer entry points

@@ -8,7 +8,9 @@
 // compaction that applies the reverse-complement merge on the fly.  A uint32 bin wraps exactly
 // like the reference's int64 -> int32 cast of np.unique counts.
 #include <algorithm>
+#include <mutex>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -331,19 +333,18 @@ static uint64_t host_revcom(uint64_t h, int k, int narrow) {
 
 namespace {
 
+// The 4^k-bin histogram is transient (one count call, or hist -> all-reduce -> finish in the sharded flow), so all handles of a
+// device share ONE table from the scratch arena instead of owning one each: a fresh handle per k and per find_motif round paid
+// ~1 s of hipMalloc / hipFree for the 16-GiB table at k = 16.  (Counting is single-threaded per device, like the arena.)
 int ensure_bins(kmap_counts *c, size_t n_bins) {
-    if (c->bins_cap < n_bins) {
-        if (c->bins) KMAP_CHECK_HIP(hipFree(c->bins));
-        c->bins = nullptr;
-        c->bins_cap = 0;
-        hipError_t e = hipMalloc((void **)&c->bins, n_bins * 4);
-        if (e != hipSuccess) {
-            kmap_set_error("counts: cannot allocate %zu-bin histogram (%.1f GiB): %s", n_bins, n_bins * 4.0 / (1 << 30),
-                           hipGetErrorString(e));
-            return KMAP_E_NOMEM;
-        }
-        c->bins_cap = n_bins;
+    void *p = nullptr;
+    const int rc = kmap_scratch(&p, n_bins * 4, (hipStream_t) nullptr, KMAP_SLOT_BINS);
+    if (rc != KMAP_OK) {
+        kmap_set_error("counts: cannot allocate %zu-bin histogram (%.1f GiB)", n_bins, n_bins * 4.0 / (1 << 30));
+        return rc;
     }
+    c->bins = (uint32_t *)p;
+    c->bins_cap = n_bins;
     return KMAP_OK;
 }
 
@@ -462,8 +463,7 @@ int kmap_counts_destroy(kmap_counts *c) {
     if (!c) return KMAP_OK;
     if (c->uniq) (void)hipFree(c->uniq);
     if (c->cnt) (void)hipFree(c->cnt);
-    if (c->bins) (void)hipFree(c->bins);
-    delete c;
+    delete c;   // the histogram table belongs to the scratch arena
     return KMAP_OK;
 }
 
@@ -557,6 +557,151 @@ int kmap_counts_fetch(kmap_counts *c, void *uniq_out, void *cnt_out) {
         KMAP_CHECK_HIP(e);
     }
     return KMAP_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// device -> host copy of n elements through two pinned staging buffers on `st`, converted on host threads while the next chunk is
+// in flight: SRC (device element) -> DST (host element), e.g. uint32 -> int64.  A plain hipMemcpy into pageable numpy memory runs
+// at ~16 GB/s and, on the null stream, would also serialise with the kernels of the trials that follow; this path keeps the
+// transfer on its own stream (SDMA next to the kernels) and reaches the host-side memory bandwidth.
+// pinned staging buffers are kept in a process-wide free list (hipHostMalloc costs ~75 ms per 256 MiB: more than the whole copy
+// of a 1-GB table); concurrent fetches (two TableSaver threads) each take their own pair
+constexpr size_t STAGE_BYTES = (size_t)256 << 20;
+std::mutex g_stage_mu;
+std::vector<void *> g_stage_free;
+struct StagePair {
+    void *buf[2] = {nullptr, nullptr};
+    StagePair() {
+        std::lock_guard<std::mutex> lk(g_stage_mu);
+        for (int b = 0; b < 2; ++b) {
+            if (!g_stage_free.empty()) {
+                buf[b] = g_stage_free.back();
+                g_stage_free.pop_back();
+            } else if (hipHostMalloc(&buf[b], STAGE_BYTES, hipHostMallocDefault) != hipSuccess) {
+                buf[b] = nullptr;
+            }
+        }
+    }
+    bool ok() const { return buf[0] && buf[1]; }
+    ~StagePair() {
+        std::lock_guard<std::mutex> lk(g_stage_mu);
+        for (int b = 0; b < 2; ++b)
+            if (buf[b]) g_stage_free.push_back(buf[b]);
+    }
+};
+
+template <typename SRC, typename DST>
+int staged_fetch(DST *dst, const SRC *src_dev, size_t n, hipStream_t st) {
+    if (n == 0) return KMAP_OK;
+    StagePair sp;                                                 // two pinned 256-MiB buffers from the process-wide pool
+    if (!sp.ok()) {
+        kmap_set_error("counts_fetch: pinned staging allocation failed");
+        return KMAP_E_NOMEM;
+    }
+    const size_t chunk = STAGE_BYTES / sizeof(SRC);               // elements per chunk
+    SRC *stage[2] = {(SRC *)sp.buf[0], (SRC *)sp.buf[1]};
+    const unsigned nt = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    hipError_t err = hipSuccess;
+    size_t off = 0;
+    int b = 0;
+    size_t len = std::min(chunk, n);
+    err = hipMemcpyAsync(stage[0], src_dev, len * sizeof(SRC), hipMemcpyDeviceToHost, st);
+    while (err == hipSuccess && off < n) {
+        err = hipStreamSynchronize(st);                           // chunk `b` has landed
+        if (err != hipSuccess) break;
+        const size_t next_off = off + len, next_len = next_off < n ? std::min(chunk, n - next_off) : 0;
+        if (next_len) err = hipMemcpyAsync(stage[b ^ 1], src_dev + next_off, next_len * sizeof(SRC), hipMemcpyDeviceToHost, st);
+        try {
+            std::vector<std::thread> pool;
+            const SRC *sp = stage[b];
+            DST *dp = dst + off;
+            for (unsigned t = 0; t < nt; ++t)
+                pool.emplace_back([=]() {
+                    const size_t lo = len * t / nt, hi = len * (t + 1) / nt;
+                    // the destination may be an unaligned view into a memory-mapped pickle file (TableSaver): byte-wise typed stores
+                    typedef DST __attribute__((aligned(1))) DSTu;
+                    DSTu *du = (DSTu *)dp;
+                    if (std::is_same<SRC, DST>::value) memcpy((void *)(dp + lo), (const void *)(sp + lo), (hi - lo) * sizeof(SRC));
+                    else for (size_t i = lo; i < hi; ++i) du[i] = (DST)sp[i];
+                });
+            for (auto &th : pool) th.join();
+        } catch (...) {                                           // thread creation failed: convert on this thread
+            typedef DST __attribute__((aligned(1))) DSTu;
+            DSTu *du = (DSTu *)(dst + off);
+            for (size_t i = 0; i < len; ++i) du[i] = (DST)stage[b][i];
+        }
+        off = next_off;
+        len = next_len;
+        b ^= 1;
+    }
+    if (err != hipSuccess) (void)hipStreamSynchronize(st);
+    KMAP_CHECK_HIP(err);
+    return KMAP_OK;
+}
+
+// uint64 keys that fit 32 bits (k = 16): narrowed on the device so that half the bytes cross PCIe
+__global__ __launch_bounds__(256) void narrow_keys_kernel(const uint64_t *__restrict__ in, int64_t n, uint32_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)in[i];
+}
+}  // namespace
+
+extern "C" {
+
+/* device addresses of the resident table (uniq: uint32 for k < 16 else uint64; cnt: uint32 whatever k), valid until the next
+ * count / load / destroy on this handle */
+int kmap_counts_table_dev(kmap_counts *c, void **uniq_dev, void **cnt_dev, int64_t *n_uniq) {
+    KMAP_REQUIRE(c && c->k > 0 && uniq_dev && cnt_dev && n_uniq, "counts_table_dev: nothing counted yet / null output");
+    *uniq_dev = c->uniq;
+    *cnt_dev = (void *)c->cnt;
+    *n_uniq = c->n_uniq;
+    return KMAP_OK;
+}
+
+/* kmap_counts_fetch on a caller-chosen stream (so that a background host thread can drain a finished table while the null
+ * stream keeps counting into ANOTHER handle): pinned staging, conversion on host threads.  Blocks until the arrays are complete. */
+int kmap_counts_fetch_stream(kmap_counts *c, void *uniq_out, void *cnt_out, void *stream) {
+    KMAP_REQUIRE(c && c->k > 0, "counts_fetch: nothing counted yet");
+    if (c->n_uniq == 0) return KMAP_OK;
+    KMAP_REQUIRE(uniq_out && cnt_out, "counts_fetch: null output");
+    hipStream_t st = as_stream(stream);
+    const size_t n = (size_t)c->n_uniq;
+    if (c->narrow) {
+        KMAP_TRY((staged_fetch<uint32_t, uint32_t>((uint32_t *)uniq_out, (const uint32_t *)c->uniq, n, st)));
+        KMAP_TRY((staged_fetch<uint32_t, uint32_t>((uint32_t *)cnt_out, c->cnt, n, st)));   // uint32 bits == int32 wrap
+    } else {
+        if (c->k <= 16) {
+            DevBuf k32;
+            KMAP_TRY(k32.alloc(n * 4));
+            narrow_keys_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((const uint64_t *)c->uniq, (int64_t)n, k32.as<uint32_t>());
+            KMAP_CHECK_HIP(hipGetLastError());
+            KMAP_TRY((staged_fetch<uint32_t, uint64_t>((uint64_t *)uniq_out, k32.as<uint32_t>(), n, st)));
+        } else {
+            KMAP_TRY((staged_fetch<uint64_t, uint64_t>((uint64_t *)uniq_out, (const uint64_t *)c->uniq, n, st)));
+        }
+        KMAP_TRY((staged_fetch<uint32_t, int64_t>((int64_t *)cnt_out, c->cnt, n, st)));
+    }
+    return KMAP_OK;
+}
+
+/* a range of one array of the table, converted to the reference's dtype: which = 0 the unique hashes (uint32 for k < 16, uint64
+ * otherwise), which = 1 the counts (int32 / int64).  Same stream / staging path as kmap_counts_fetch_stream; lets a writer
+ * stream a multi-GB table to a file chunk by chunk without holding it in host memory. */
+int kmap_counts_fetch_range(kmap_counts *c, int which, int64_t first, int64_t count, void *out, void *stream) {
+    KMAP_REQUIRE(c && c->k > 0 && (which == 0 || which == 1), "counts_fetch_range: nothing counted yet / bad selector");
+    KMAP_REQUIRE(first >= 0 && count >= 0 && first + count <= c->n_uniq, "counts_fetch_range: range outside the table");
+    if (count == 0) return KMAP_OK;
+    KMAP_REQUIRE(out, "counts_fetch_range: null output");
+    hipStream_t st = as_stream(stream);
+    const size_t n = (size_t)count;
+    if (which == 0) {
+        if (c->narrow) return staged_fetch<uint32_t, uint32_t>((uint32_t *)out, (const uint32_t *)c->uniq + first, n, st);
+        return staged_fetch<uint64_t, uint64_t>((uint64_t *)out, (const uint64_t *)c->uniq + first, n, st);
+    }
+    if (c->narrow) return staged_fetch<uint32_t, uint32_t>((uint32_t *)out, c->cnt + first, n, st);   // uint32 bits == int32 wrap
+    return staged_fetch<uint32_t, int64_t>((int64_t *)out, c->cnt + first, n, st);
 }
 
 int kmap_counts_total(kmap_counts *c, int64_t *total) {

@@ -172,10 +172,15 @@ class DeviceCounts:
         self.k, self.n_uniq = k, nu.value
         return self.n_uniq
 
-    def fetch(self):
+    def fetch(self, stream=None):
+        """(unique hashes, counts) as the reference's numpy arrays.  stream: a non-default stream handle -> the copy runs there
+        through pinned staging buffers (a background thread can then drain this table while the default stream keeps working)."""
         u = np.empty(self.n_uniq, get_hash_dtype(self.k))
         c = np.empty(self.n_uniq, get_cnt_dtype(self.k))
-        check(_ffi.lib().kmap_counts_fetch(self._h, ptr(u), ptr(c)))
+        if stream is None:
+            check(_ffi.lib().kmap_counts_fetch(self._h, ptr(u), ptr(c)))
+        else:
+            check(_ffi.lib().kmap_counts_fetch_stream(self._h, ptr(u), ptr(c), stream))
         return u, c
 
     def total(self):

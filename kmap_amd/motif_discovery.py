@@ -31,6 +31,7 @@ DENSE_PKL_MAX_N = 16384
 # above this many unique k-mers find_motif stops fetching the count arrays every trial: the top_k candidates come from
 # the device (largest count, then lowest index) instead of np.argpartition (whose tie order is numpy-specific anyway)
 TOPK_DEVICE_MIN = 4_000_000
+SAVE_ASYNC_MIN = 4_000_000   # tables above this many unique k-mers are fetched + pickled by a background TableSaver
 TOPK_DEVICE_MAX_K = 16       # kmap_counts_topk keeps 16 candidates per thread; a larger top_k takes the host path at any size
 
 STAGE_TIMES = {}   # cumulative wall-clock per stage of the last runs (tools/e2e.py, bench.py report it)
@@ -157,6 +158,102 @@ def merge_consensus_seqs(conseq_list: List[str]) -> List[str]:
     return finals
 
 
+# ---- k{k}.pkl writer for multi-GB tables ----------------------------------------------------------------
+class _PickleLayout:
+    """write() sink for a dry run of pickle.Pickler(protocol=5): records where the pickler would put the large array payloads
+    (it hands them to write() one call each, without copying) and keeps the small pieces, without touching the payload bytes."""
+
+    def __init__(self, big_min=1 << 16):       # the C pickler writes payloads of >= 64 KiB (its frame size target) directly
+        self.pos, self.small, self.big, self.big_min = 0, [], [], big_min
+
+    def write(self, data):
+        n = memoryview(data).nbytes
+        if n >= self.big_min:
+            self.big.append((self.pos, n))
+        else:
+            self.small.append((self.pos, bytes(data)))
+        self.pos += n
+        return n
+
+
+class TableSaver:
+    """Background save of one k's count table as k{k}.pkl = pickle([k, uniq, cnt]) while the caller goes on counting into
+    another handle.  The table is streamed from a DeviceCounts handle that nobody writes any more: a dry run of the real
+    pickler over untouched np.empty arrays of the right shape gives the byte layout (where the two array payloads go, and the
+    small pieces around them); the payloads are then fetched chunk by chunk -- own stream, pinned staging, conversion to the
+    reference's dtypes on host threads, the next chunk in flight while the current one is written -- and written in place.
+    The file is byte for byte what pickle.dump writes, without ever holding the 15 GB of a k = 16 table (C3) in host memory
+    (fetching it whole, pickling and freeing it cost 2.5 s; measured alternatives: os.pwrite from several threads -- no gain,
+    one inode lock; filling a memory-mapped file -- 4x slower, page faults through overlayfs).
+    join() re-raises a failure on the caller's thread; the handle (the table resident in HBM) stays usable until close()."""
+    CHUNK_BYTES = 128 << 20
+
+    def __init__(self, dc, kmer_len, path, device=None):
+        import threading
+        self.dc, self.k, self.path, self.err = dc, kmer_len, path, None
+        self._dev = device
+        self._t = threading.Thread(target=self._run)
+        self._t.start()
+
+    def _run(self):
+        import time
+        from concurrent.futures import ThreadPoolExecutor
+        try:
+            t0 = time.perf_counter()
+            lib = _ffi.lib()
+            if self._dev is not None:
+                check(lib.kmap_set_device(self._dev))              # HIP's current device is per thread
+            n, dts = self.dc.n_uniq, (get_hash_dtype(self.k), get_cnt_dtype(self.k))
+            lay = _PickleLayout()
+            pickle.Pickler(lay, protocol=5).dump([self.k, np.empty(n, dts[0]), np.empty(n, dts[1])])   # layout only: pages never touched
+            if [b for _, b in lay.big] != [n * np.dtype(d).itemsize for d in dts]:
+                u, c = self.dc.fetch()                             # small table (payloads inside a frame): plain dump
+                with open(self.path, "wb") as fh:
+                    pickle.dump([self.k, u, c], fh, protocol=5)
+                return
+            st = _ffi.vp()
+            check(lib.kmap_stream_create(C.byref(st)))
+            pool = ThreadPoolExecutor(1)
+
+            def fetch(which, first, count, buf):
+                if self._dev is not None:
+                    check(lib.kmap_set_device(self._dev))
+                check(lib.kmap_counts_fetch_range(self.dc._h, which, first, count, buf.ctypes.data, st.value))
+                return buf[:count]
+            try:
+                pieces = sorted([(pos, None, b) for pos, b in lay.small] + [(pos, i, None) for i, (pos, _) in enumerate(lay.big)])
+                with open(self.path, "wb") as fh:
+                    for pos, which, small in pieces:
+                        assert fh.tell() == pos
+                        if which is None:
+                            fh.write(small)
+                            continue
+                        step = self.CHUNK_BYTES // np.dtype(dts[which]).itemsize
+                        bufs = [np.empty(min(step, n), dts[which]) for _ in range(2)]
+                        nxt = pool.submit(fetch, which, 0, min(step, n), bufs[0])
+                        for i, first in enumerate(range(0, n, step)):
+                            cur = nxt.result()
+                            if first + step < n:
+                                nxt = pool.submit(fetch, which, first + step, min(step, n - first - step), bufs[(i + 1) & 1])
+                            fh.write(memoryview(cur))
+                    assert fh.tell() == lay.pos
+            finally:
+                pool.shutdown()
+                lib.kmap_stream_destroy(st.value)
+            STAGE_TIMES[f"bg_save_k{self.k}"] = time.perf_counter() - t0    # background: overlaps the main thread's stages
+        except BaseException as e:   # noqa: BLE001 -- re-raised by join()
+            self.err = e
+
+    def join(self):
+        self._t.join()
+        if self.err is not None:
+            raise self.err
+
+    def close(self):
+        self._t.join()
+        self.dc.close()
+
+
 # ---- find_motif (reference motif_discovery.py:594-702) -----------------------------------------------
 def _wrap_total(total, k):
     """`sum(uniq_kh_cnt_arr)` in the reference accumulates numpy scalars of the count dtype: int32 wrap for k<16."""
@@ -165,9 +262,25 @@ def _wrap_total(total, k):
 
 def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_std, ratio_cutoff, top_k=5, n_trial=10,
                merge_revcom_mode=True, rep_mode=False, save_kmer_cnt_flag=True, kmer_cnt_pkl_file: Path = None,
-               boarder_pkl_file: Path = None, debug=False, dev_seq: DeviceSeq = None) -> dict:
+               boarder_pkl_file: Path = None, debug=False, dev_seq: DeviceSeq = None, table_savers: dict = None,
+               counts_pool: list = None) -> dict:
     """Greedy motif discovery for one k.  Drop-in signature; `dev_seq` (optional) is an already uploaded
-    DeviceSeq whose working copy is masked in place (then seq_np_arr is not touched)."""
+    DeviceSeq whose working copy is masked in place (then seq_np_arr is not touched).
+    table_savers (optional dict): for tables above TOPK_DEVICE_MIN unique k-mers the background TableSaver of k{k}.pkl is left
+    in table_savers[kmer_len] instead of being joined here -- the caller joins / closes it (scan_motif: at its end, so that the
+    multi-GB fetch + pickle overlaps the following k and the occurrence scans, and sample_disp_kmer can re-use the resident table).
+    counts_pool (optional list): DeviceCounts handles to re-use and to hand back (their arrays keep their capacity: a fresh handle
+    per k re-allocates multi-GB buffers)."""
+
+    def take():
+        return counts_pool.pop() if counts_pool else DeviceCounts()
+
+    def give(h):
+        if counts_pool is not None:
+            counts_pool.append(h)
+        else:
+            h.close()
+
     from scipy.stats import norm
     if boarder_pkl_file:
         assert Path(boarder_pkl_file).exists()
@@ -176,7 +289,8 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
         with open(boarder_pkl_file, "rb") as fh:
             boarder_mat = pickle.load(fh)
         dev_seq = DeviceSeq(seq_np_arr, boarder_mat)
-    dc = DeviceCounts()
+    dc = take()
+    saver = None
     try:
         cached = save_kmer_cnt_flag and kmer_cnt_pkl_file and Path(kmer_cnt_pkl_file).exists()
         if cached:
@@ -191,51 +305,41 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
             dev_seq.count(dc, kmer_len, dedupe=not rep_mode, merge_revcom=merge_revcom_mode)   # first round
             uniq_kh_arr, uniq_kh_cnt_arr = None, None
         big = dc.n_uniq > TOPK_DEVICE_MIN and top_k <= TOPK_DEVICE_MAX_K
-        writer = None
-        if save_kmer_cnt_flag and kmer_cnt_pkl_file and not Path(kmer_cnt_pkl_file).exists():
-            if uniq_kh_arr is None:
-                uniq_kh_arr, uniq_kh_cnt_arr = dc.fetch()
-            payload = [kmer_len, uniq_kh_arr, uniq_kh_cnt_arr]
-
-            def _dump(path=kmer_cnt_pkl_file, obj=payload, proto=5 if big else 4):
-                # protocol 5 streams the array buffers straight to the file (no intermediate bytes copy of a multi-GB table);
-                # any Python >= 3.8 pickle.load reads it
-                with open(path, "wb") as fh:
-                    pickle.dump(obj, fh, protocol=proto)
-            if big:   # multi-GB pickle: write it while the trials run on the GPU
-                import threading
-                writer_err = []
-
-                def _dump_bg():
-                    try:
-                        _dump()
-                    except BaseException as e:   # noqa: BLE001 -- re-raised on the caller's thread at join time
-                        writer_err.append(e)
-                writer = threading.Thread(target=_dump_bg)
-                writer.start()
-            else:
-                _dump()
-        elif uniq_kh_arr is None and not big:
-            uniq_kh_arr, uniq_kh_cnt_arr = dc.fetch()
         n_total_kmer = _wrap_total(dc.total(), kmer_len)   # first round only (:648)
+        first = dc                                          # the first-round table (trial 0 reads it)
+        if save_kmer_cnt_flag and kmer_cnt_pkl_file and not Path(kmer_cnt_pkl_file).exists():
+            if dc.n_uniq > SAVE_ASYNC_MIN:
+                # multi-GB table: fetch + pickle on a background thread / stream; the later rounds count into a second handle
+                dev = _ffi.i32(0)
+                check(_ffi.lib().kmap_get_device(C.byref(dev)))
+                _ffi.sync()
+                saver = TableSaver(first, kmer_len, kmer_cnt_pkl_file, device=dev.value)
+                dc = take()
+            else:
+                uniq_kh_arr, uniq_kh_cnt_arr = dc.fetch()
+                with open(kmer_cnt_pkl_file, "wb") as fh:
+                    pickle.dump([kmer_len, uniq_kh_arr, uniq_kh_cnt_arr], fh, protocol=4)
+        elif not big:
+            uniq_kh_arr, uniq_kh_cnt_arr = dc.fetch()
 
         res = {}
+        cur = first
         for i_trial in range(n_trial):
-            if top_k > dc.n_uniq:
+            if top_k > cur.n_uniq:
                 if debug:
-                    print(f"There are only {dc.n_uniq} kmers, while top_k={top_k}.")
+                    print(f"There are only {cur.n_uniq} kmers, while top_k={top_k}.")
                 break
             if big:
-                _, cand_kh, _ = dc.topk(top_k)
+                _, cand_kh, _ = cur.topk(top_k)
                 cand_kh = cand_kh[::-1]                      # ascending counts, like argpartition's tail
             else:
                 if uniq_kh_arr is None:
-                    uniq_kh_arr, uniq_kh_cnt_arr = dc.fetch()
+                    uniq_kh_arr, uniq_kh_cnt_arr = cur.fetch()
                 top_k_inds = np.array(np.argpartition(uniq_kh_cnt_arr, -top_k)[-top_k:])   # same numpy call -> same ties
                 cand_kh = uniq_kh_arr[top_k_inds]
             if len(cand_kh) == 0:
                 break
-            hamball_cnt_arr = dc.hamball_mass(cand_kh, max_ham_dist, merge_revcom_mode)
+            hamball_cnt_arr = cur.hamball_mass(cand_kh, max_ham_dist, merge_revcom_mode)
             if debug:
                 print(f"{i_trial= }")
             best = int(np.argmax(hamball_cnt_arr))
@@ -249,17 +353,24 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
             cons = [consensus_kh, revcom_hash(consensus_kh, kmer_len)] if merge_revcom_mode else [consensus_kh]
             dev_seq.mask(kmer_len, np.array(cons), np.array([max_ham_dist] * len(cons)))
             dev_seq.count(dc, kmer_len, dedupe=False, merge_revcom=merge_revcom_mode)   # later rounds: no dedupe (:695)
+            cur = dc
             big = dc.n_uniq > TOPK_DEVICE_MIN and top_k <= TOPK_DEVICE_MAX_K
             uniq_kh_arr, uniq_kh_cnt_arr = None, None
-        if writer is not None:
-            writer.join()
-            if writer_err:
-                raise writer_err[0]
+        if saver is not None and table_savers is None:
+            saver.join()
         if own:
             seq_np_arr[:] = dev_seq.download()   # the reference mutates its argument
         return res
     finally:
-        dc.close()
+        if saver is None:
+            give(dc)
+        else:
+            if dc is not first:
+                give(dc)
+            if table_savers is not None:
+                table_savers[kmer_len] = saver               # the caller joins (errors surface there) and closes; table stays resident
+            else:
+                saver.close()
         if own:
             dev_seq.close()
 
@@ -343,15 +454,28 @@ class _LabelledTable:
     smaller; a distance above c's own radius counts as k; label = first consensus at the minimum, or the noise label
     n_conseq when the minimum exceeds the radius of k; members matched through the reverse complement are re-oriented."""
 
-    def __init__(self, uniq_kh_arr, uniq_kh_cnt_arr, conseq_list, kmer_len, motif_def_dict, revcom_mode):
-        self.k, self.n, self.n_lab = kmer_len, len(uniq_kh_arr), len(conseq_list) + 1
+    def __init__(self, uniq_kh_arr, uniq_kh_cnt_arr, conseq_list, kmer_len, motif_def_dict, revcom_mode, resident=None):
+        """resident: a DeviceCounts handle that still holds this k's table (scan_motif keeps the big ones): the k-mers are copied
+        device to device (labelling re-orients them in place) and the uint32 counts are read where they lie -- no k{k}.pkl
+        load, no upload."""
         self.hd, self.cd = get_hash_dtype(kmer_len), get_cnt_dtype(kmer_len)
-        self.cnt64 = int(self.cd == np.int64)
+        self._bufs = []
+        if resident is not None:
+            up, cp, nu = _ffi.vp(), _ffi.vp(), _ffi.i64(0)
+            check(_ffi.lib().kmap_counts_table_dev(resident._h, C.byref(up), C.byref(cp), C.byref(nu)))
+            self.n = nu.value
+            self.u_d = self._dev(nbytes=max(self.n, 1) * np.dtype(self.hd).itemsize)
+            check(_ffi.lib().kmap_memcpy_d2d(self.u_d.ptr, up.value, self.n * np.dtype(self.hd).itemsize, None))
+            self.c_d = _ffi.DeviceView(cp.value, self.n * 4, keep=resident)
+            self.cnt64, self.c_dev_dtype = 0, np.uint32                  # device counts are uint32 bins whatever k
+        else:
+            self.n = len(uniq_kh_arr)
+            self.u_d = self._dev(np.ascontiguousarray(uniq_kh_arr, self.hd))
+            self.c_d = self._dev(np.ascontiguousarray(uniq_kh_cnt_arr, self.cd))
+            self.cnt64, self.c_dev_dtype = int(self.cd == np.int64), self.cd
+        self.k, self.n_lab = kmer_len, len(conseq_list) + 1
         if self.n_lab > 64:
             raise ValueError(f"sample_disp_kmer: {self.n_lab - 1} consensus sequences; the device labelling handles at most 63")
-        self._bufs = []
-        self.u_d = self._dev(np.ascontiguousarray(uniq_kh_arr, self.hd))
-        self.c_d = self._dev(np.ascontiguousarray(uniq_kh_cnt_arr, self.cd))
         self.lab_d = self._dev(nbytes=max(self.n, 1))
         self.w32_d = self._dev(nbytes=max(self.n, 1) * 4)
         self.excl_d = self._dev(nbytes=(self.n + 1) * 8)
@@ -392,7 +516,7 @@ class _LabelledTable:
         return out
 
     def counts_at(self, idx):
-        return self._take(self.c_d, self.cd, idx)
+        return self._take(self.c_d, self.c_dev_dtype, idx).astype(self.cd)
 
     def kmers_at(self, idx):
         return self._take(self.u_d, self.hd, idx)
@@ -433,7 +557,7 @@ def _label_quota(label_weight, n_total_sample, n_motif_kmer):
 
 
 def sample_disp_kmer(conseq_list: List[str], kmer_len: int, motif_def_dict: dict, kmer_count_dir: Path, n_total_sample=5000,
-                     n_motif_kmer=2500, revcom_mode=True):
+                     n_motif_kmer=2500, revcom_mode=True, resident=None):
     """Drop-in for the reference's sample_disp_kmer (motif_discovery.py:812-921): labels every counted k-mer of `kmer_len` by
     its nearest consensus and draws a labelled multinomial sample -> (k-mer hashes, sample counts, labels, consensus list).
     The table is labelled on the device whatever its size; the host only makes the random draws, in the reference's order and
@@ -444,11 +568,20 @@ def sample_disp_kmer(conseq_list: List[str], kmer_len: int, motif_def_dict: dict
     conseq_list = [s for s in conseq_list if 2 < len(s) <= kmer_len]
     assert len(conseq_list) > 0
     assert all(len(a) >= len(b) for a, b in zip(conseq_list, conseq_list[1:]))   # longest first, as merge_consensus_seqs emits
-    with open(Path(kmer_count_dir) / f"k{kmer_len}.pkl", "rb") as fh:
-        k_pkl, uniq_kh_arr, uniq_kh_cnt_arr = pickle.load(fh)
-    assert k_pkl == kmer_len
+    def load_pkl():
+        with open(Path(kmer_count_dir) / f"k{kmer_len}.pkl", "rb") as fh:
+            k_pkl, u, c = pickle.load(fh)
+        assert k_pkl == kmer_len
+        return u, c
 
-    tab = _LabelledTable(uniq_kh_arr, uniq_kh_cnt_arr, conseq_list, kmer_len, motif_def_dict, revcom_mode)
+    # resident: a TableSaver whose DeviceCounts handle still holds the table of k{kmer_len}.pkl (scan_motif keeps the multi-GB
+    # ones): label it where it lies instead of reading the file back and uploading it
+    if resident is not None:
+        uniq_kh_arr = uniq_kh_cnt_arr = None
+        tab = _LabelledTable(None, None, conseq_list, kmer_len, motif_def_dict, revcom_mode, resident=resident.dc)
+    else:
+        uniq_kh_arr, uniq_kh_cnt_arr = load_pkl()
+        tab = _LabelledTable(uniq_kh_arr, uniq_kh_cnt_arr, conseq_list, kmer_len, motif_def_dict, revcom_mode)
     try:
         label_weight, label_members = tab.label_totals()
         # the reference compares against the builtin sum() of numpy scalars, i.e. a total wrapped to the count dtype
@@ -457,6 +590,9 @@ def sample_disp_kmer(conseq_list: List[str], kmer_len: int, motif_def_dict: dict
             warnings.warn(f"The number of samples n_sample={n_total_sample} is larger than the original "
                           f"data n_seq={n_seq_total}, process and return original data.")
             kh_all, lab_all = tab.whole_table()
+            if uniq_kh_cnt_arr is None:
+                resident.join()
+                uniq_kh_cnt_arr = load_pkl()[1]
             return kh_all, uniq_kh_cnt_arr, lab_all, conseq_list
 
         quota = _label_quota(label_weight, n_total_sample, n_motif_kmer)
@@ -487,14 +623,19 @@ def _scan_motif(res_dir: str, debug=False):
     decisions) and the scan hits are all-gathered; rank 0 owns every output file and the np.random draws."""
     from .visualization import _dist_context
     dist, rank, owns_group = _dist_context()
-    _scan_motif_impl(res_dir, debug, dist, rank)
+    savers = {}     # k -> TableSaver of a multi-GB k{k}.pkl written in the background while the next k is counted
+    try:
+        _scan_motif_impl(res_dir, debug, dist, rank, savers)
+    finally:
+        for sv in savers.values():   # normally joined inside; after an exception: let the writers end, free the tables
+            sv.close()
     if dist is not None:            # success path only (a failing rank re-raises and the launcher tears the job down)
         dist.barrier()
         if owns_group:
             dist.destroy_process_group()
 
 
-def _scan_motif_impl(res_dir, debug, dist, rank):
+def _scan_motif_impl(res_dir, debug, dist, rank, savers):
     from ._toml import load_toml
     res = Path(res_dir)
     lead = rank == 0                # owner of the output files
@@ -557,6 +698,7 @@ def _scan_motif_impl(res_dir, debug, dist, rank):
     if save_kmer_cnt_flag and lead:
         (res / FileNameDict["kmer_count_dir"]).mkdir(exist_ok=True)
 
+    counts_pool = []          # DeviceCounts handles handed from k to k (closed below)
     candidate_conseq_file = res / FileNameDict["candidate_conseq_file"]
     if exists(candidate_conseq_file):
         print(f"{candidate_conseq_file} already exist, re-use it.")
@@ -566,7 +708,12 @@ def _scan_motif_impl(res_dir, debug, dist, rank):
         if occ_flag:
             head += ",n_motif_reads,n_all_reads,motif_reads_prop,motif_occurrence,motif_occurrence_per_motif_read"
         lines = [head]
-        for kmer_len in range(min_k, max_k + 1):
+        # find_motif of one k depends on nothing but the reads, so the k values go in the order that hides the background work
+        # best -- the largest k first: its count table (15 GB of k16.pkl at C3) is then fetched and pickled while every other k is
+        # counted -- and the per-k files, candidate rows and np.random draws (occurrence subsampling) follow in ascending k
+        # exactly as the reference emits them
+        found = {}
+        for kmer_len in sorted(range(min_k, max_k + 1), key=lambda k: (k != max_k, k)):
             count_seq.reset()
             d = motif_def_dict[kmer_len]
             kmer_cnt_file = res / FileNameDict["kmer_count_dir"] / f"k{kmer_len}.pkl"
@@ -574,10 +721,13 @@ def _scan_motif_impl(res_dir, debug, dist, rank):
             cached = exists(kmer_cnt_file) if (dist is not None and save_kmer_cnt_flag) else False   # collective: every rank calls it
             save_here = save_kmer_cnt_flag and (dist is None or lead or cached)
             with _stage("find_motif"), _stage(f"find_motif_k{kmer_len}"):
-                consensus_kh_dict = find_motif(None, kmer_len, d.max_ham_dist, d.p_uniform, d.ratio_mu, d.ratio_std,
-                                               d.ratio_cutoff, top_k, n_trial, revcom_mode, rep_mode,
-                                               save_kmer_cnt_flag=save_here, kmer_cnt_pkl_file=kmer_cnt_file,
-                                               boarder_pkl_file=boarder_pkl_file, debug=debug, dev_seq=count_seq)
+                found[kmer_len] = find_motif(None, kmer_len, d.max_ham_dist, d.p_uniform, d.ratio_mu, d.ratio_std,
+                                             d.ratio_cutoff, top_k, n_trial, revcom_mode, rep_mode,
+                                             save_kmer_cnt_flag=save_here, kmer_cnt_pkl_file=kmer_cnt_file,
+                                             boarder_pkl_file=boarder_pkl_file, debug=debug, dev_seq=count_seq,
+                                             table_savers=savers, counts_pool=counts_pool)
+        for kmer_len in range(min_k, max_k + 1):
+            consensus_kh_dict = found[kmer_len]
             tmp_list = [hash2kmer(kh, kmer_len) for kh in consensus_kh_dict]
             per = None
             if occ_flag:
@@ -598,6 +748,8 @@ def _scan_motif_impl(res_dir, debug, dist, rank):
                     row += (f",{n_motif_seq},{n_all_seq},{float(n_motif_seq) / n_all_seq:0.4f},{n_occ},"
                             f"{float(n_occ) / n_motif_seq:0.2f}")
                 lines.append(row)
+        for h in counts_pool:
+            h.close()
         print(f"kmer counting finished for k={min_k}...{max_k}. Candidate consensus sequences generated.")
         if lead:
             write_lines(lines, candidate_conseq_file)
@@ -687,7 +839,8 @@ def _scan_motif_impl(res_dir, debug, dist, rank):
         with _stage("sample_kmers"):
             samp_kh_arr, samp_cnts, samp_label_arr, conseq_list = sample_disp_kmer(
                 final_conseq_list, kmer_len, motif_def_dict, kmer_count_dir=res / FileNameDict["kmer_count_dir"],
-                n_total_sample=n_total_sample, n_motif_kmer=n_motif_sample, revcom_mode=revcom_mode)
+                n_total_sample=n_total_sample, n_motif_kmer=n_motif_sample, revcom_mode=revcom_mode,
+                resident=savers.get(kmer_len))
         with open(sample_kmer_pkl_file, "wb") as fh:
             pickle.dump([samp_kh_arr, samp_cnts, samp_label_arr, conseq_list], fh)
         kmers = np.array([hash2kmer(kh, kmer_len) for kh in samp_kh_arr])
@@ -708,6 +861,10 @@ def _scan_motif_impl(res_dir, debug, dist, rank):
             with open(res / FileNameDict["sample_kmer_hamdist_mat_file"], "wb") as fh:
                 pickle.dump([kmer_len, hamdist_mat, label_arr], fh)
         print("Hamming distance matrix of sampled kmers are generated.")
+
+    with _stage("join_table_writers"):       # the k{k}.pkl files of the large tables are complete from here on
+        for sv in savers.values():
+            sv.join()
 
     if md["gen_hamball_flag"]:
         out_dir_path = res / FileNameDict["hamball_dir"]

@@ -241,6 +241,32 @@ def test_compact_handoff_equals_dense(run_dir, golden, tmp_path, monkeypatch):
     np.testing.assert_allclose(compact, u["final"], rtol=0, atol=1e-5)
 
 
+def test_scan_motif_background_table_savers(run_dir, tmp_path, monkeypatch):
+    """Large count tables leave find_motif through a background TableSaver (own stream, pinned staging, parallel pickle writer)
+    while the trials go on in a second handle, and sample_disp_kmer labels the table still resident in HBM instead of reading
+    k{k}.pkl back.  With the size threshold patched to 0 every k of the C1 run takes that path: all files must equal the
+    synchronous run's (the pickles array for array)."""
+    from kmap_amd import motif_discovery as MD
+    monkeypatch.setattr(MD, "SAVE_ASYNC_MIN", 0)
+    res = _run_c1(tmp_path)
+    names = sorted(p.relative_to(run_dir) for p in run_dir.rglob("*") if p.is_file() and p.name != "low_dim_data.tsv")
+    assert sorted(p.relative_to(res) for p in res.rglob("*") if p.is_file()) == names and len(names) > 20
+    for rel in names:
+        a, b = run_dir / rel, res / rel
+        if rel.name == "config.toml":
+            continue
+        if rel.suffix == ".pkl":
+            with open(a, "rb") as fa, open(b, "rb") as fb:
+                xa, xb = pickle.load(fa), pickle.load(fb)
+            for u, v in zip(xa, xb):
+                if isinstance(u, np.ndarray):
+                    assert u.dtype == v.dtype
+                np.testing.assert_array_equal(np.asarray(u, dtype=object) if isinstance(u, list) else u,
+                                              np.asarray(v, dtype=object) if isinstance(v, list) else v, err_msg=str(rel))
+        else:
+            assert a.read_bytes() == b.read_bytes(), rel
+
+
 def test_device_topk_tie_rule(motif_defs, monkeypatch):
     """Tables above TOPK_DEVICE_MIN unique k-mers take their top_k candidates from kmap_counts_topk: largest count first, ties
     by the LOWEST table index.  That is a documented deviation from the reference's np.argpartition(cnt, -top_k)[-top_k:]
