@@ -258,6 +258,10 @@ __global__ __launch_bounds__(T_TPB) void hamdist_tile_kernel(const uint32_t *__r
         }
     }
 
+    // do this lane's 16 columns carry one group id (lanes past the last column: no)
+    const uint32_t lane_g = gcol[0] & 0xFFu;
+    const bool lane_uniform = full && gcol[0] == lane_g * 0x01010101u && gcol[1] == gcol[0] && gcol[2] == gcol[0] && gcol[3] == gcol[0];
+
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const int64_t rloc = g * (8 * R) + rho + 8 * j;          // row inside this call's output (wave-uniform)
@@ -278,16 +282,29 @@ __global__ __launch_bounds__(T_TPB) void hamdist_tile_kernel(const uint32_t *__r
                 }
             } else {
                 const uint32_t sh = (uint32_t)gshift.v[rg];
+                const bool w_same = __all(lane_uniform && lane_g == rg), w_none = __all(lane_uniform && lane_g != rg);
+                if (w_same || w_none) {   // whole wave inside / outside the row's group (see the one-hot branch below)
+                    const uint32_t s2 = w_same ? sh : 0u;
 #pragma unroll
-                for (int v = 0; v < COLS_PER_LANE / 4; ++v) {
-                    uint32_t acc = pack_bias<uint32_t>();
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) {
-                        uint32_t xx = a0 ^ nb0[4 * v + cc];
-                        if (((gcol[v] >> (8 * cc)) & 0xFFu) == rg) xx >>= sh;
-                        acc += p2(xx) << (8 * cc);
+                    for (int v = 0; v < COLS_PER_LANE / 4; ++v) {
+                        uint32_t acc = p2((a0 ^ nb0[4 * v]) >> s2) + pack_bias<uint32_t>();
+                        acc += p2((a0 ^ nb0[4 * v + 1]) >> s2) << 8;
+                        acc += p2((a0 ^ nb0[4 * v + 2]) >> s2) << 16;
+                        acc += p2((a0 ^ nb0[4 * v + 3]) >> s2) << 24;
+                        w[v] = acc;
                     }
-                    w[v] = acc;
+                } else {
+#pragma unroll
+                    for (int v = 0; v < COLS_PER_LANE / 4; ++v) {
+                        uint32_t acc = pack_bias<uint32_t>();
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) {
+                            uint32_t xx = a0 ^ nb0[4 * v + cc];
+                            if (((gcol[v] >> (8 * cc)) & 0xFFu) == rg) xx >>= sh;
+                            acc += p2(xx) << (8 * cc);
+                        }
+                        w[v] = acc;
+                    }
                 }
             }
         } else if (rg == 0) {
@@ -306,17 +323,36 @@ __global__ __launch_bounds__(T_TPB) void hamdist_tile_kernel(const uint32_t *__r
             const int clen = k - (int)(gshift.v[rg] >> 1);
             const uint64_t pm = (clen >= 16) ? ~0ull : ((1ull << (4 * clen)) - 1ull);
             const uint32_t p0 = a0 & (uint32_t)pm, p1 = a1 & (uint32_t)(pm >> 32);
+            // labels arrive grouped (sample_disp_kmer emits label after label), so nearly every wave's 1024 columns lie entirely
+            // inside the row's group or entirely outside it: a wave-uniform test picks the row code once (prefix-masked or whole)
+            // and the row runs at the plain rows' 2.75 ops per byte; only the waves on a group boundary select per byte
+            const bool w_same = __all(lane_uniform && lane_g == rg), w_none = __all(lane_uniform && lane_g != rg);
+            if (w_same || w_none) {
+                const uint32_t e0 = w_same ? p0 : a0, e1 = w_same ? p1 : a1;
 #pragma unroll
-            for (int v = 0; v < COLS_PER_LANE / 4; ++v) {
-                uint32_t acc = 0;
+                for (int v = 0; v < COLS_PER_LANE / 4; ++v) {
+                    uint32_t acc = 0;
 #pragma unroll
-                for (int cc = 3; cc >= 0; --cc) {
-                    const bool same = ((gcol[v] >> (8 * cc)) & 0xFFu) == rg;
-                    uint32_t d = bcnt((same ? p0 : a0) & nb0[4 * v + cc], 0u);
-                    if constexpr (CW == 2) d = bcnt((same ? p1 : a1) & nb1[4 * v + cc], d);
-                    acc = (acc << 8) | d;
+                    for (int cc = 3; cc >= 0; --cc) {
+                        uint32_t d = bcnt(e0 & nb0[4 * v + cc], 0u);
+                        if constexpr (CW == 2) d = bcnt(e1 & nb1[4 * v + cc], d);
+                        acc = (acc << 8) | d;
+                    }
+                    w[v] = acc;
                 }
-                w[v] = acc;
+            } else {
+#pragma unroll
+                for (int v = 0; v < COLS_PER_LANE / 4; ++v) {
+                    uint32_t acc = 0;
+#pragma unroll
+                    for (int cc = 3; cc >= 0; --cc) {
+                        const bool same = ((gcol[v] >> (8 * cc)) & 0xFFu) == rg;
+                        uint32_t d = bcnt((same ? p0 : a0) & nb0[4 * v + cc], 0u);
+                        if constexpr (CW == 2) d = bcnt((same ? p1 : a1) & nb1[4 * v + cc], d);
+                        acc = (acc << 8) | d;
+                    }
+                    w[v] = acc;
+                }
             }
         }
         uint8_t *orow = out + rloc * ld + col0;
