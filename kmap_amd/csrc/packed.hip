@@ -11,6 +11,7 @@
 // Kernels: pack / unpack, hash materialisation, histogram (LDS-privatised passes or global atomics) straight from the
 // packed stream, Hamming-ball mask (flag + coverage), and the per-read occurrence scan.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "counts_internal.h"
@@ -99,20 +100,27 @@ __global__ __launch_bounds__(BLK) void unpack_kernel(const uint32_t *__restrict_
 }
 
 // ---- hash materialisation (one thread per group, 16 hashes, 64/128 contiguous bytes out) -------------------------
+// skip bits of per-read de-duplication (dedupe_skip_packed_kernel): word w covers positions 32w .. 32w+31, position 32w+j in bit
+// 31-j; a set bit = "the k-mer starting here already occurred in its read".  Group g's 16 bits, window i in bit 15-i:
+__device__ __forceinline__ uint32_t skip16_of(const uint32_t *__restrict__ skip, int64_t g) {
+    return skip ? ((skip[g >> 1] >> ((g & 1) ? 0 : 16)) & 0xFFFFu) : 0u;
+}
+
 template <typename H, bool WIDE>
 __global__ __launch_bounds__(BLK) void hash_packed_kernel(const uint32_t *__restrict__ codes, const uint16_t *__restrict__ inval,
-                                                          int64_t n, int k, H *__restrict__ out) {
+                                                          int64_t n, int k, H *__restrict__ out, const uint32_t *__restrict__ skip) {
     const int64_t g = (int64_t)blockIdx.x * BLK + threadIdx.x;
     const int64_t p0 = g * 16;
     if (p0 >= n) return;
     const Win w = load_win(codes, inval, g);
     const uint64_t kmask = low_mask<uint64_t>(k);
+    const uint32_t sk = skip16_of(skip, g);
     H hs[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         bool bad;
         const uint64_t h = win_hash<WIDE>(w, i, k, kmask, bad);
-        hs[i] = bad ? (H)~(H)0 : (H)h;
+        hs[i] = (bad || ((sk >> (15 - i)) & 1u)) ? (H)~(H)0 : (H)h;
     }
     if (p0 + 16 <= n && ((uintptr_t)out % 16) == 0) {
         u32x4 *o = reinterpret_cast<u32x4 *>(out + p0);
@@ -136,7 +144,8 @@ constexpr int HP_TPB = 1024;
 template <bool WIDE, bool LDSMODE>
 __global__ __launch_bounds__(LDSMODE ? HP_TPB : BLK) void hist_packed_kernel(const uint32_t *__restrict__ codes,
                                                                              const uint16_t *__restrict__ inval, int64_t n,
-                                                                             int k, uint64_t bin0, uint32_t *__restrict__ bins) {
+                                                                             int k, uint64_t bin0, uint32_t *__restrict__ bins,
+                                                                             const uint32_t *__restrict__ skip) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lb[];
     if (LDSMODE) {
         for (int b = threadIdx.x; b < HP_BINS; b += blockDim.x) lb[b] = 0;
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(LDSMODE ? HP_TPB : BLK) void hist_packed_kernel(con
                 bad |= bad << step;
                 have += step;
             }
-            const uint32_t bad16 = (uint32_t)(bad >> 32);          // windows 0..15 in bits 15..0
+            const uint32_t bad16 = (uint32_t)(bad >> 32) | skip16_of(skip, g);   // windows 0..15 in bits 15..0 (+ per-read duplicates)
             const uint32_t hi = (uint32_t)(w.t0 >> 32), lo = (uint32_t)w.t0;
             const uint32_t b0 = (uint32_t)bin0;
             const int sh = 32 - 2 * k;
@@ -171,11 +180,12 @@ __global__ __launch_bounds__(LDSMODE ? HP_TPB : BLK) void hist_packed_kernel(con
             }
             continue;
         }
+        const uint32_t sk = skip16_of(skip, g);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             bool bad;
             const uint64_t h = win_hash<WIDE>(w, i, k, kmask, bad);
-            if (bad) continue;
+            if (bad || ((sk >> (15 - i)) & 1u)) continue;
             if (LDSMODE) {
                 const uint64_t a = h - bin0;
                 if (a < (uint64_t)HP_BINS) atomicAdd(&lb[a], 1u);
@@ -191,6 +201,99 @@ __global__ __launch_bounds__(LDSMODE ? HP_TPB : BLK) void hist_packed_kernel(con
             if (c) atomicAdd(&bins[bin0 + b], c);
         }
     }
+}
+
+// ---- per-read de-duplication as skip bits (remove_duplicate_hash_per_seq, kmer_count.py:743-760, fused with counting) -----------
+// The reference invalidates every repeated hash of a read before counting; only the COUNTS are used afterwards, so which of the
+// equal windows survives does not matter.  One wave per read: the windows are hashed straight from the packed codes, 64 at a
+// time, and inserted into a per-wave open-addressing set in LDS with one atomicCAS per probe -- the lane whose CAS claims an
+// empty slot owns the k-mer, a lane that finds its own key there is a duplicate.  The duplicates leave as one bit per position
+// (ballot -> two 32-bit words per step; words that straddle a read border are shared with the neighbouring read's wave and are
+// ORed atomically, the others are plain stores into the zeroed array), which the histogram / hash kernels OR into their
+// invalid-window masks.  No 4-8 B/position hash array is written, de-duplicated in place and read back any more.
+constexpr int DS_CAP = 512;             // longest read handled here (longer ones: the hash-array path of kmer_ops.hip)
+constexpr int DS_SLOTS = 2 * DS_CAP;
+constexpr int DS_WAVES = 4;
+template <bool K64>
+__global__ __launch_bounds__(KMAP_WAVE *DS_WAVES) void dedupe_skip_packed_kernel(const uint32_t *__restrict__ codes,
+                                                                                 const uint16_t *__restrict__ inval, int64_t n,
+                                                                                 const int64_t *__restrict__ borders, int64_t n_seq,
+                                                                                 int k, uint32_t *__restrict__ skip) {
+    typedef typename std::conditional<K64, unsigned long long, unsigned int>::type K;
+    __shared__ K keys[DS_WAVES][DS_SLOTS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t s = (int64_t)blockIdx.x * DS_WAVES + wave;
+    if (s >= n_seq) return;
+    int64_t st = borders[2 * s], en = borders[2 * s + 1];
+    if (st < 0) st = 0;
+    if (en > n) en = n;
+    const int64_t L = en - st;
+    if (L <= 1 || L > DS_CAP) return;       // a read of one window has no duplicate; longer reads never get here (host check)
+    int T = 64;
+    while (T < 2 * L) T <<= 1;
+    K *kt = keys[wave];
+    const K EMPTY = (K)~(K)0;               // never a valid hash (k <= 15 in 32 bits, k = 16 in 64 bits)
+    for (int t = lane; t < T; t += 64) kt[t] = EMPTY;
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t kmask = low_mask<uint64_t>(k);
+    // three 64-position steps per batch: their window loads are issued together (a wave is latency-bound otherwise: one
+    // dependent global load per step and only a few steps per read)
+    constexpr int NB = 3;
+    for (int64_t pb = st & ~(int64_t)31; pb < en; pb += 64 * NB) {
+        Win w[NB];
+        bool act[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            const int64_t p = pb + 64 * c + lane;
+            act[c] = p >= st && p < en;
+            if (act[c]) w[c] = load_win(codes, inval, p >> 4);
+        }
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            const int64_t p0 = pb + 64 * c;
+            if (p0 >= en) break;                                          // wave-uniform
+            const int64_t p = p0 + lane;
+            bool dup = false;
+            if (act[c]) {
+                bool bad;
+                const uint64_t h = win_hash<false>(w[c], (int)(p & 15), k, kmask, bad);   // k <= 16: the window lies in groups g, g+1
+                if (!bad) {
+                    uint64_t x = h * 0x9E3779B97F4A7C15ull;
+                    int slot = (int)((x ^ (x >> 29)) & (uint64_t)(T - 1));
+                    for (;;) {
+                        const K prev = atomicCAS(&kt[slot], EMPTY, (K)h);
+                        if (prev == EMPTY) break;
+                        if (prev == (K)h) { dup = true; break; }
+                        slot = (slot + 1) & (T - 1);
+                    }
+                }
+            }
+            const unsigned long long m = __ballot(dup);
+            if (lane < 2) {
+                const uint32_t bits = __builtin_bitreverse32(lane ? (uint32_t)(m >> 32) : (uint32_t)m);   // lane l of the half -> bit 31-l
+                if (bits) {
+                    const int64_t w0 = p0 + 32 * lane;                    // first position of this word
+                    if (w0 < st || w0 + 32 > en) atomicOr(&skip[w0 >> 5], bits);   // shared with a neighbouring read
+                    else skip[w0 >> 5] = bits;
+                }
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(BLK) void max_read_len_kernel(const int64_t *__restrict__ borders, int64_t n_seq, int64_t n,
+                                                           unsigned long long *__restrict__ out) {
+    unsigned long long m = 0;
+    for (int64_t s = (int64_t)blockIdx.x * BLK + threadIdx.x; s < n_seq; s += (int64_t)gridDim.x * BLK) {
+        int64_t st = borders[2 * s], en = borders[2 * s + 1];
+        if (st < 0) st = 0;
+        if (en > n) en = n;
+        if (en - st > (int64_t)m) m = (unsigned long long)(en - st);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long t = __shfl_down(m, o);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
 // ---- Hamming-ball mask on the packed stream (mask_input, kmer_count.py:580-610) ---------------------------------------
@@ -608,12 +711,39 @@ int kmap_hash_kmers_packed_dev(const uint32_t *codes_dev, const uint16_t *inval_
     if (n == 0) return KMAP_OK;
     const unsigned g = grid_for((n + 15) >> 4, BLK);
     hipStream_t st = as_stream(stream);
-    if (k < 16) hash_packed_kernel<uint32_t, false><<<g, BLK, 0, st>>>(codes_dev, inval_dev, n, k, (uint32_t *)out_dev);
-    else if (k == 16) hash_packed_kernel<uint64_t, false><<<g, BLK, 0, st>>>(codes_dev, inval_dev, n, k, (uint64_t *)out_dev);
-    else hash_packed_kernel<uint64_t, true><<<g, BLK, 0, st>>>(codes_dev, inval_dev, n, k, (uint64_t *)out_dev);
+    if (k < 16) hash_packed_kernel<uint32_t, false><<<g, BLK, 0, st>>>(codes_dev, inval_dev, n, k, (uint32_t *)out_dev, nullptr);
+    else if (k == 16) hash_packed_kernel<uint64_t, false><<<g, BLK, 0, st>>>(codes_dev, inval_dev, n, k, (uint64_t *)out_dev, nullptr);
+    else hash_packed_kernel<uint64_t, true><<<g, BLK, 0, st>>>(codes_dev, inval_dev, n, k, (uint64_t *)out_dev, nullptr);
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;
 }
+
+namespace {
+// skip bits of the per-read de-duplication for k <= 16; *skip_out stays null when some read is longer than DS_CAP (the caller
+// then takes the hash-array path, which handles any length)
+int dedupe_skip_bits(const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n, const int64_t *borders_dev, int64_t n_seq, int k,
+                     hipStream_t st, uint32_t **skip_out) {
+    *skip_out = nullptr;
+    static const bool on = [] { const char *e = getenv("KMAP_DEDUPE_SKIP"); return !(e && e[0] == '0'); }();   // A/B switch
+    if (!on || n_seq == 0 || n == 0) return KMAP_OK;
+    const size_t words = (size_t)((n + 31) >> 5) + 4;
+    uint32_t *skip = nullptr;
+    KMAP_TRY(kmap_scratch((void **)&skip, words * 4 + 16, st, KMAP_SLOT_C));
+    unsigned long long *mx = (unsigned long long *)(skip + ((words + 1) & ~(size_t)1));
+    KMAP_CHECK_HIP(hipMemsetAsync(skip, 0, words * 4 + 16, st));
+    max_read_len_kernel<<<1024, BLK, 0, st>>>(borders_dev, n_seq, n, mx);
+    unsigned long long max_len = 0;
+    KMAP_CHECK_HIP(hipMemcpyAsync(&max_len, mx, 8, hipMemcpyDeviceToHost, st));
+    KMAP_CHECK_HIP(hipStreamSynchronize(st));
+    if (max_len > (unsigned long long)DS_CAP) return KMAP_OK;
+    const unsigned grid = (unsigned)((n_seq + DS_WAVES - 1) / DS_WAVES);
+    if (k == 16) dedupe_skip_packed_kernel<true><<<grid, KMAP_WAVE * DS_WAVES, 0, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, skip);
+    else dedupe_skip_packed_kernel<false><<<grid, KMAP_WAVE * DS_WAVES, 0, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, skip);
+    KMAP_CHECK_HIP(hipGetLastError());
+    *skip_out = skip;
+    return KMAP_OK;
+}
+}  // namespace
 
 // fills c->bins (zeroed first) with the k-mer histogram of the packed reads; k <= 16
 int kmap_counts_hist_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n,
@@ -622,9 +752,13 @@ int kmap_counts_hist_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const
     KMAP_REQUIRE(k > 0 && k <= 16, "counts_hist_packed: k=%d needs the sort path (no histogram)", k);
     KMAP_REQUIRE(n >= 0 && codes_dev && inval_dev, "counts_hist_packed: bad input");
     hipStream_t st = as_stream(stream);
+    uint32_t *skip = nullptr;   // per-read duplicates as one bit per position (first find_motif round), or null
     if (dedupe_per_read) {
-        // per-read dedupe (first round only) works on a materialised hash array
         KMAP_REQUIRE(n_seq == 0 || borders_dev, "counts_hist_packed: dedupe needs borders");
+        KMAP_TRY(dedupe_skip_bits(codes_dev, inval_dev, n, borders_dev, n_seq, k, st, &skip));
+    }
+    if (dedupe_per_read && !skip) {
+        // reads longer than the LDS set allows: per-read dedupe on a materialised hash array (any length)
         void *hash = nullptr;
         KMAP_TRY(kmap_scratch(&hash, (size_t)(n ? n : 1) * (k < 16 ? 4 : 8), st, KMAP_SLOT_HASH));
         KMAP_TRY(kmap_hash_kmers_packed_dev(codes_dev, inval_dev, n, k, hash, stream));
@@ -636,7 +770,8 @@ int kmap_counts_hist_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const
         // 11 <= k <= 15: materialise the hashes once (4 B/position) and take the bucket-partitioned histogram
         void *hash = nullptr;
         KMAP_TRY(kmap_scratch(&hash, (size_t)n * 4, st, KMAP_SLOT_HASH));
-        KMAP_TRY(kmap_hash_kmers_packed_dev(codes_dev, inval_dev, n, k, hash, stream));
+        hash_packed_kernel<uint32_t, false><<<grid_for((n + 15) >> 4, BLK), BLK, 0, st>>>(codes_dev, inval_dev, n, k, (uint32_t *)hash, skip);
+        KMAP_CHECK_HIP(hipGetLastError());
         return kmap_counts_part_hist_u32(c, (const uint32_t *)hash, n, k, st);
     }
     KMAP_TRY(kmap_counts_prepare_bins(c, k, st));
@@ -652,11 +787,11 @@ int kmap_counts_hist_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const
             }
             for (size_t p = 0; p < passes; ++p)
                 hist_packed_kernel<false, true><<<256, HP_TPB, HP_BINS * 4, st>>>(codes_dev, inval_dev, n, k,
-                                                                                  (uint64_t)p * HP_BINS, c->bins);
+                                                                                  (uint64_t)p * HP_BINS, c->bins, skip);
         } else {
             int64_t g = ((n + 15) / 16 + BLK - 1) / BLK;
             if (g > 256 * 16) g = 256 * 16;
-            hist_packed_kernel<false, false><<<(unsigned)g, BLK, 16, st>>>(codes_dev, inval_dev, n, k, 0, c->bins);
+            hist_packed_kernel<false, false><<<(unsigned)g, BLK, 16, st>>>(codes_dev, inval_dev, n, k, 0, c->bins, skip);
         }
         KMAP_CHECK_HIP(hipGetLastError());
     }
