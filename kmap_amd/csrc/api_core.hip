@@ -50,6 +50,20 @@ int kmap_scratch(void **ptr, size_t bytes, hipStream_t stream, int slot) {
     return KMAP_OK;
 }
 
+int kmap_allow_lds(const void *kernel, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, int> done;     // (kernel, device) -> bytes granted
+    int dev = 0;
+    KMAP_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    int &have = done[std::make_pair(kernel, dev)];
+    if (have < bytes) {
+        KMAP_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        have = bytes;
+    }
+    return KMAP_OK;
+}
+
 extern "C" {
 
 int kmap_version(void) { return 1000 * 0 + 1; }

@@ -415,12 +415,7 @@ int hist_hashes(kmap_counts *c, const H *hash_dev, int64_t n, int k, hipStream_t
     if (n > 0) {
         const size_t passes = (n_bins + HL_BINS - 1) / HL_BINS;
         if (sizeof(H) == 4 && passes <= 32 && n >= (1 << 20) && ((uintptr_t)hash_dev % 16) == 0) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)hist_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   HL_BINS * 4));
-                attr_set = true;
-            }
+            KMAP_TRY(kmap_allow_lds((const void *)hist_lds_kernel, HL_BINS * 4));
             for (size_t p = 0; p < passes; ++p)
                 hist_lds_kernel<<<256, HL_TPB, HL_BINS * 4, st>>>((const uint32_t *)hash_dev, n, (uint32_t)(p * HL_BINS),
                                                                  c->bins);
@@ -546,12 +541,17 @@ int kmap_counts_fetch(kmap_counts *c, void *uniq_out, void *cnt_out) {
         if (e == hipSuccess) {   // widen uint32 -> int64 on several host threads (10^9 entries at k = 16)
             const unsigned nt = n > ((size_t)1 << 22) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
             std::vector<std::thread> pool;
-            for (unsigned t = 0; t < nt; ++t)
-                pool.emplace_back([=]() {
+            size_t done_to = 0;                                     // entries [0, done_to) are covered by started threads
+            try {
+                for (unsigned t = 0; t < nt; ++t) {
                     const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
-                    for (size_t i = lo; i < hi; ++i) ((int64_t *)cnt_out)[i] = (int64_t)tmp[i];
-                });
+                    pool.emplace_back([=]() { for (size_t i = lo; i < hi; ++i) ((int64_t *)cnt_out)[i] = (int64_t)tmp[i]; });
+                    done_to = hi;
+                }
+            } catch (...) {                                         // no exception may cross the C ABI: finish on this thread
+            }
             for (auto &th : pool) th.join();
+            for (size_t i = done_to; i < n; ++i) ((int64_t *)cnt_out)[i] = (int64_t)tmp[i];
         }
         free(tmp);
         KMAP_CHECK_HIP(e);

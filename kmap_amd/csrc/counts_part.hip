@@ -167,20 +167,12 @@ int kmap_counts_part_hist_u32(kmap_counts *c, const uint32_t *hash_dev, int64_t 
     part_init_cursor_kernel<<<NBK / 256, 256, 0, st>>>(goff, cursor);
     int64_t tiles = (n + PT_TILE - 1) / PT_TILE;
     if (tiles > 1024) tiles = 1024;
-    static bool sc_attr = false;
-    if (!sc_attr) {
-        KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)part_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PT_TILE * 4));
-        sc_attr = true;
-    }
+    KMAP_TRY(kmap_allow_lds((const void *)part_scatter_kernel, PT_TILE * 4));
     part_scatter_kernel<<<(unsigned)tiles, PS_TPB, (size_t)PT_TILE * 4, st>>>(hash_dev, n, shift, cursor, keys);
     const uint32_t bins_per_bucket = (uint32_t)(n_bins >> PB);
     const uint32_t sub = bins_per_bucket < (uint32_t)PH_BINS ? bins_per_bucket : (uint32_t)PH_BINS;
     const int passes = (int)(bins_per_bucket / sub);
-    static bool attr_set = false;
-    if (!attr_set) {
-        KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)part_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PH_BINS * 4));
-        attr_set = true;
-    }
+    KMAP_TRY(kmap_allow_lds((const void *)part_hist_kernel, PH_BINS * 4));
     part_hist_kernel<<<(unsigned)(NBK * passes), PH_TPB, (size_t)sub * 4, st>>>(keys, goff, bins_per_bucket, passes, sub, c->bins);
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;

@@ -217,12 +217,7 @@ template <int R, typename MT, typename IT>
 int launch_knn_rows(const uint8_t *D_dev, int64_t ldd, const int32_t *nb_dev, const IT *nbT, int64_t n, int n_nb, int64_t row0,
                     int64_t nrows, uint16_t *sums_dev, int64_t lds, int64_t mpitch, hipStream_t st) {
     const size_t bytes = (size_t)R * mpitch * sizeof(MT);
-    static bool attr_set = false;
-    if (!attr_set) {
-        KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)knn_sums_rows_kernel<R, MT, IT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           150 * 1024));
-        attr_set = true;
-    }
+    KMAP_TRY(kmap_allow_lds((const void *)knn_sums_rows_kernel<R, MT, IT>, 150 * 1024));
     const int64_t groups = (nrows + R - 1) / R;
     const int64_t grid = groups < 2048 ? groups : 2048;
     knn_sums_rows_kernel<R, MT, IT><<<(unsigned)grid, KNN_TPB, bytes, st>>>(D_dev, ldd, nb_dev, nbT, n, n_nb, row0, nrows, sums_dev,
@@ -1381,12 +1376,7 @@ int kmap_knn_sums_u8_dev(const uint8_t *D_dev, int64_t ldd, const int32_t *nb_de
     int64_t chunk = (n + 15) & ~(int64_t)15;
     if (chunk > KNN_CHUNK_MAX) chunk = KNN_CHUNK_MAX;
     const size_t lds_bytes = (size_t)chunk * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)knn_sums_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           KNN_CHUNK_MAX * 2));
-        attr_set = true;
-    }
+    KMAP_TRY(kmap_allow_lds((const void *)knn_sums_kernel, KNN_CHUNK_MAX * 2));
     int64_t grid = nrows < 2048 ? nrows : 2048;
     knn_sums_kernel<<<(unsigned)grid, KNN_TPB, lds_bytes, st>>>(D_dev, ldd, nb_dev, nbT, n, n_nb, row0, nrows, sums_dev,
                                                                 lds, (int)chunk);

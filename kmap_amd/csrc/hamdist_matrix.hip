@@ -380,12 +380,8 @@ int launch_tile(const uint32_t *c0, const uint32_t *c1, const uint8_t *gid, cons
     const int64_t groups = (nrows + 8 * R - 1) / (8 * R);
     KMAP_REQUIRE(groups <= 65535, "hamdist_matrix: nrows too large for one launch (%lld)", (long long)nrows);
     const dim3 blocks((unsigned)(8 * cb), (unsigned)groups);
-    static bool attr_set = false;   // per instantiation; both store policies at once
-    if (!attr_set) {
-        KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)hamdist_tile_kernel<CW, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)hamdist_tile_kernel<CW, R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    KMAP_TRY(kmap_allow_lds((const void *)hamdist_tile_kernel<CW, R, true>, 160 * 1024));
+    KMAP_TRY(kmap_allow_lds((const void *)hamdist_tile_kernel<CW, R, false>, 160 * 1024));
     if (nt)
         hamdist_tile_kernel<CW, R, true><<<blocks, T_TPB, lds_bytes, st>>>(c0, c1, gid, gshift, k, n, row0, nrows, out, ld, cb, inv, shift);
     else

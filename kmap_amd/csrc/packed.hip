@@ -779,12 +779,7 @@ int kmap_counts_hist_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const
         const size_t n_bins = (size_t)1 << (2 * k);
         const size_t passes = (n_bins + HP_BINS - 1) / HP_BINS;
         if (passes <= 32 && n >= (1 << 16)) {   // k <= 10: 32 passes x 0.375 B/position still beat scattered device atomics
-            static bool attr_set = false;
-            if (!attr_set) {
-                KMAP_CHECK_HIP(hipFuncSetAttribute((const void *)hist_packed_kernel<false, true>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, HP_BINS * 4));
-                attr_set = true;
-            }
+            KMAP_TRY(kmap_allow_lds((const void *)hist_packed_kernel<false, true>, HP_BINS * 4));
             for (size_t p = 0; p < passes; ++p)
                 hist_packed_kernel<false, true><<<256, HP_TPB, HP_BINS * 4, st>>>(codes_dev, inval_dev, n, k,
                                                                                   (uint64_t)p * HP_BINS, c->bins, skip);
