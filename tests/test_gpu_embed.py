@@ -355,3 +355,33 @@ def test_knn_sums_from_kmers_equals_matrix_sums(V, n, k, lens):
     blk_d, lds3 = V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, k, lens, nb, n_nb, row0=r0, nrows=nr)
     np.testing.assert_array_equal(blk_d.to_numpy(np.uint16, (nr, lds3))[:, :n], want[r0:r0 + nr])
     assert V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, k, [max(1, k - 1)] * 5, nb, n_nb) is None   # 5 short consensuses
+
+
+def test_graph_replay_switch_gives_the_same_run(V, golden):
+    """KMAP_EMBED_GRAPH=1 replays a captured pair of iterations (opt-in: measured slower than direct launches on this stack);
+    the switch is read once per process, so the graph run is a child process.  Same losses, same best snapshot, bit for bit."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, sys.argv[1]); import kmap_amd.visualization as V\n"
+        "u = np.load(sys.argv[1] + '/tests/golden/umap_n96.npz')\n"
+        "tr = {}\n"
+        "best = V.kmap(u['D'].astype(np.int64), int(u['kmer_len']), n_max_iter=41, random_seed=int(u['seed']), debug=False,\n"
+        "              mode=int(sys.argv[3]), neighbor_inds_mat=u['nb'], trace=tr)\n"
+        "np.savez(sys.argv[2], best=best, losses=tr['losses'], last=tr['last_coords'])\n")
+    with tempfile.TemporaryDirectory() as td:
+        for mode in (V.EMBED_SEQ, V.EMBED_FAST):
+            outs = []
+            for graph in ("0", "1"):
+                out = os.path.join(td, f"g{graph}_{mode}.npz")
+                env = dict(os.environ, KMAP_EMBED_GRAPH=graph)
+                r = subprocess.run([sys.executable, "-c", code, str(root), out, str(mode)], env=env, capture_output=True, text=True, timeout=600)
+                assert r.returncode == 0, r.stderr[-2000:]
+                outs.append(np.load(out))
+            for key in ("best", "losses", "last"):
+                np.testing.assert_array_equal(outs[0][key], outs[1][key])
+            assert len(outs[0]["losses"]) == 41
