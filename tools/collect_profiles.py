@@ -29,8 +29,8 @@ for t in ("write", "fetch"):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
-        k = r["Kernel_Name"]
-        k = k.split("<")[0].replace("void ", "").strip() if k.startswith("void") else k.split("(")[0].strip()
+        k = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+        k = k.split("<")[0].split("(")[0].strip()
         agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in agg.items():
         out["kernels"].setdefault(k, {})[c + "_KB_mean"] = sum(v) / len(v)
@@ -41,4 +41,7 @@ if hk:
     d["hbm_bytes_per_launch"] = (2 * d.get("FETCH_SIZE_KB_mean", 0) + d.get("WRITE_SIZE_KB_mean", 0)) * 1024
     d["algorithmic_bytes_per_launch"] = 50000 * 50000 + 5 * 50000
 json.dump(out, open(dst / f"{tag}_bench_pmc.json", "w"), indent=1)
+for name, to in (("pmc_summary.json", f"{tag}_pmc.json"), ("pmc_summary.txt", f"{tag}_pmc.txt")):
+    if (src / name).exists():
+        shutil.copyfile(src / name, dst / to)
 print(sorted(p.name for p in dst.iterdir()))

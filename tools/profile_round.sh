@@ -12,4 +12,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/bench_pmc_fetch -- python
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e2e_trace -- python3 $R/tools/e2e.py --config C3 --mode fast --iters 100 > $OUT/e2e_trace.json 2> $OUT/e2e_trace.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/embed_trace -- python3 $R/tools/bench_embed.py --n 50000 --iters 10 > $OUT/embed_trace.txt 2> $OUT/embed_trace.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scan_trace -- python3 $R/tools/bench_scan.py --reps 5 > $OUT/scan_trace.json 2> $OUT/scan_trace.err
+# counters for every kernel DESIGN.md calls "bound by ..." (C3 pipeline + SEQ micro-benchmark, four PMC passes)
+bash $R/tools/pmc_round.sh round > $OUT/pmc_round.log 2>&1 || true
+python3 $R/tools/pmc_summary.py $R/gpurun_out/pmc_round $OUT/pmc_summary.json > $OUT/pmc_summary.txt 2>&1 || true
 ls $OUT
