@@ -1097,9 +1097,8 @@ __global__ __launch_bounds__(KMAP_WAVE *SQ_WAVES) void forces_seq_kernel(ProbSrc
     }
 }
 
-// deterministic reduction of the per-block loss partials: thread t adds part[t], part[t + 256], ... in order, then a fixed tree
-// over the 256 thread sums -- the standalone kernel (multi-GPU path: the partials of a rank are reduced before the all-reduce)
-// and the fused tail kernels below run this same code, so every path sees the same bits
+// deterministic reduction of the per-block loss partials inside the fused apply kernel (every block computes the same total):
+// thread t adds part[t], part[t + 256], ... in order, then a fixed tree over the 256 thread sums
 __device__ __forceinline__ double loss_total_256(const double *__restrict__ part, int n_part, double *sh /* [256] LDS */) {
     double s = 0.0;
     for (int i = threadIdx.x; i < n_part; i += BLK) s += part[i];
@@ -1113,11 +1112,21 @@ __device__ __forceinline__ double loss_total_256(const double *__restrict__ part
     __syncthreads();
     return total;
 }
-__global__ __launch_bounds__(BLK) void reduce_loss_kernel(const double *__restrict__ part, int n_part,
-                                                          double *__restrict__ loss_out) {
-    __shared__ double sh[BLK];
-    const double t = loss_total_256(part, n_part, sh);
-    if (threadIdx.x == 0) loss_out[0] = t;
+// standalone reduction (symmetric kernels: ~2 10^4 partials; multi-GPU: a rank's partials before the all-reduce): 1024 threads,
+// thread t adds part[t], part[t + 1024], ... in order, then a fixed tree (a 256-thread block took 30 us on 19 600 partials)
+constexpr int RL_TPB = 1024;
+__global__ __launch_bounds__(RL_TPB) void reduce_loss_kernel(const double *__restrict__ part, int n_part,
+                                                             double *__restrict__ loss_out) {
+    __shared__ double sh[RL_TPB];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n_part; i += RL_TPB) s += part[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = RL_TPB / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_out[0] = sh[0];
 }
 
 // =================================================================================================
@@ -1590,7 +1599,7 @@ int launch_iteration(kmap_embed *e, hipStream_t st) {
     KMAP_TRY(launch_forces(e, e->G, false, st));
     const int nblk = n_force_blocks(e);
     if (e->sym) {
-        reduce_loss_kernel<<<1, BLK, 0, st>>>(e->loss_part, nblk, e->loss_sum);
+        reduce_loss_kernel<<<1, RL_TPB, 0, st>>>(e->loss_part, nblk, e->loss_sum);
         sym_apply_kernel<<<(unsigned)(((2 * e->n + 4) * 8 + BLK - 1) / BLK), BLK, 0, st>>>(
             e->states, e->cur, e->Y, e->rowpart, e->colpart, e->n_lblocks, e->symJ, e->loss_sum, e->snaps, e->n, e->lr, e->normals,
             e->n_normals_dev, e->loss_log, e->loss_log_cap);
@@ -1646,7 +1655,7 @@ int kmap_embed_forces(kmap_embed *e, float *grad_dev_2xn, double *loss_dev, void
         return KMAP_OK;
     }
     KMAP_TRY(launch_forces(e, G, true, st));
-    reduce_loss_kernel<<<1, BLK, 0, st>>>(e->loss_part, nblk, L);
+    reduce_loss_kernel<<<1, RL_TPB, 0, st>>>(e->loss_part, nblk, L);
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;
 }
@@ -1809,7 +1818,7 @@ int kmap_cross_entropy_f32(const float *p_nxn, const float *q_nxn, int64_t n, fl
     KMAP_CHECK_HIP(hipMemcpy(dp.p, p_nxn, (size_t)n * n * 4, hipMemcpyHostToDevice));
     KMAP_CHECK_HIP(hipMemcpy(dq.p, q_nxn, (size_t)n * n * 4, hipMemcpyHostToDevice));
     ce_rows_kernel<<<(unsigned)n, BLK>>>(dp.as<float>(), dq.as<float>(), n, dpart.as<double>());
-    reduce_loss_kernel<<<1, BLK>>>(dpart.as<double>(), (int)n, dsum.as<double>());
+    reduce_loss_kernel<<<1, RL_TPB>>>(dpart.as<double>(), (int)n, dsum.as<double>());
     KMAP_CHECK_HIP(hipGetLastError());
     double s = 0.0;
     KMAP_CHECK_HIP(hipMemcpy(&s, dsum.p, 8, hipMemcpyDeviceToHost));
