@@ -351,8 +351,10 @@ def main():
     n = int(round(N_BASE * math.sqrt(world) / 16)) * 16
     reads, first, res_dir = None, None, None
     if rank == 0:
+        os.environ["KMAP_DIST_DISABLE"] = "1"       # rank 0 runs the pipeline on its own GPU; the verbs must not join the process group
         reads = synth_config_reads("C3")
         first = run_e2e("C3", "default", reads=reads, keep=True)
+        os.environ.pop("KMAP_DIST_DISABLE")
         res_dir = first["res_dir"]
         kh, lab, lens, conseqs = pipeline_sample(res_dir, n)
     else:

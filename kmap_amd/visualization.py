@@ -454,7 +454,7 @@ def _dist_context():
     KMAP_DIST_BACKEND / KMAP_DIST_SAME_GPU exist for rehearsals on a one-GPU box (gloo, every rank on GPU 0)."""
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 or os.environ.get("KMAP_DIST_DISABLE") == "1":   # KMAP_DIST_DISABLE=1: this rank runs the verb on its own
         return None, 0, False
     import torch
     import torch.distributed as dist

@@ -165,3 +165,15 @@ def test_hamdist_pitch_rule():
         ld = pitch_for(n)
         assert ld >= n and ld % 4096 == 0 and (ld // 4096) % 2 == 1 and ld - n < 2 * 4096
     assert pitch_for(50_000) == 53_248
+
+
+def test_dist_context_can_be_disabled(monkeypatch):
+    """bench.py's rank 0 runs the C3 pipeline on its own while the other ranks wait: KMAP_DIST_DISABLE=1 keeps the verbs out of the
+    process group (found by a 2-rank rehearsal: rank 0's scan_motif joined collectives nobody else entered)"""
+    from kmap_amd.visualization import _dist_context
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("KMAP_DIST_DISABLE", "1")
+    assert _dist_context() == (None, 0, False)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.delenv("KMAP_DIST_DISABLE")
+    assert _dist_context() == (None, 0, False)
