@@ -324,3 +324,65 @@ def test_scan_motif_cli_under_torchrun(tmp_path):
         else:
             assert blob == outs["dist"][name], name
     assert len((tmp_path / "dist" / "final_conseq.txt").read_text().split()) >= 1
+
+
+def _nccl_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import pickle
+    import torch
+    import torch.distributed as dist
+    from kmap_amd import synth
+    from kmap_amd.distributed import all_gather_concat, broadcast_seed, kmap_from_kmers_distributed, make_dist_device_seq
+    from kmap_amd.kmer_count import DeviceCounts, kmer2hash
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        kh, cnts, lab, conseqs = _inputs()
+        tr = {}
+        best, _ = kmap_from_kmers_distributed(kh, cnts, lab, conseqs, K, n_max_iter=ITERS, random_seed=SEED, mode=1, trace=tr)
+        out = {"best": best, "losses": tr["losses"], "seed": broadcast_seed(dist, None),
+               "cat": all_gather_concat(dist, np.arange(7, dtype=np.uint16).reshape(-1, 1))}
+        seq, borders = synth.synth_reads(20_003, 75, 4)
+        ds = make_dist_device_seq(seq, borders, dist)
+        dc = DeviceCounts()
+        ds.count(dc, 9, dedupe=True, merge_revcom=True)
+        out["counts"] = dc.fetch()
+        out["scan"] = ds.scan(8, kmer2hash("ATCGATAG"), 2, True)
+        dc.close()
+        ds.close()
+        with open(Path(out_dir) / "nccl.pkl", "wb") as fh:
+            pickle.dump(out, fh)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank(tmp_path):
+    """The collectives' DEVICE-tensor code paths (backend "nccl" = RCCL: all_gather_into_tensor of the neighbour table on the
+    GPU, histogram all-reduce on library-owned memory, device-staged all_gather_concat, seed broadcast) with a one-rank process
+    group on the test box's single GPU -- the multi-rank tests above run over gloo, which takes the host-tensor branches."""
+    import pickle
+    import torch.multiprocessing as mp
+    import kmap_amd.visualization as V
+    from kmap_amd import synth
+    from kmap_amd.kmer_count import DeviceCounts, kmer2hash
+    from kmap_amd.motif_discovery import DeviceSeq
+    mp.spawn(_nccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    with open(tmp_path / "nccl.pkl", "rb") as fh:
+        got = pickle.load(fh)
+    kh, cnts, lab, conseqs = _inputs()
+    tr = {}
+    best, _ = V.kmap_from_kmers(kh, cnts, lab, conseqs, K, n_max_iter=ITERS, random_seed=SEED, mode=1, trace=tr)
+    np.testing.assert_array_equal(got["best"], best)
+    np.testing.assert_array_equal(got["losses"], tr["losses"])
+    assert got["seed"] is None and got["cat"].dtype == np.uint16 and got["cat"].shape == (7, 1)   # one rank: the seed stays "default"
+    seq, borders = synth.synth_reads(20_003, 75, 4)
+    ds, dc = DeviceSeq(seq, borders), DeviceCounts()
+    ds.count(dc, 9, dedupe=True, merge_revcom=True)
+    u, c = dc.fetch()
+    np.testing.assert_array_equal(got["counts"][0], u)
+    np.testing.assert_array_equal(got["counts"][1], c)
+    hits, pos = ds.scan(8, kmer2hash("ATCGATAG"), 2, True)
+    np.testing.assert_array_equal(got["scan"][0], hits)
+    np.testing.assert_array_equal(got["scan"][1], pos)
+    dc.close()
+    ds.close()
