@@ -21,6 +21,8 @@ int kmap_counts_prepare_bins(kmap_counts *c, int k, hipStream_t st);
 int kmap_counts_finish_hist(kmap_counts *c, int k, int merge, int64_t *n_uniq, hipStream_t st);
 int kmap_counts_hist_hashes(kmap_counts *c, const void *hash_dev, int64_t n, int k, hipStream_t st);
 int kmap_counts_reserve_bins(kmap_counts *c, int k);   // allocation only (the partitioned histogram writes every bin)
-// 11 <= k <= 15, uint32 hashes: bucket-partitioned histogram without global atomics (counts_part.hip)
+// 11 <= k <= 16, hashes as uint32: bucket-partitioned histogram without global atomics (counts_part.hip); k = 16: the valid
+// windows of the all-T 16-mer (hash 0xFFFFFFFF = the uint32 invalid marker) are counted aside and added with part_add_bin
 bool kmap_counts_part_applies(int k, int64_t n);
 int kmap_counts_part_hist_u32(kmap_counts *c, const uint32_t *hash_dev, int64_t n, int k, hipStream_t st);
+int kmap_counts_part_add_bin(kmap_counts *c, size_t bin, const unsigned long long *extra_dev, hipStream_t st);

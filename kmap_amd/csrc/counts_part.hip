@@ -1,4 +1,4 @@
-// counts_part.hip -- partitioned histogram for 11 <= k <= 15 (uint32 hashes).
+// counts_part.hip -- partitioned histogram for 11 <= k <= 16 (hashes as uint32).
 //
 // A 4^k-bin table (16 MiB .. 4 GiB) does not fit LDS, and device-scope atomics into it run at ~20 G updates/s (74 ms for
 // 1.5e9 k-mers, random bins: every update is a read-modify-write of a DRAM sector).  Instead:
@@ -7,6 +7,10 @@
 //   fetch-add per non-empty bucket per tile, LDS cursors) -> a bucket-ordered key array (4 B per valid k-mer);
 //   (4) one block per (bucket, 32768-bin range): stream the bucket's keys, LDS histogram of the range, plain coalesced stores
 //   of the LDS bins into the table.  Every bin of the table is written exactly once (no memset, no global atomics).
+// k = 15, 16: one bucket level would need 32 / 128 range passes over every bucket's keys in step (4) (41 ms at k = 15; k = 16
+// used device atomics into the 16-GiB table: 112 ms).  A second level splits every bucket into S = 32 / 128 sub-buckets of 32768
+// bins with the same tile-staged counting sort, run on 32768-key tiles that never cross a bucket border; step (4) is then one
+// pass per sub-bucket.
 // The table then goes through the usual compaction / reverse-complement merge (counts.hip).
 #include <stdlib.h>
 
@@ -138,11 +142,124 @@ __global__ __launch_bounds__(PH_TPB) void part_hist_kernel(const uint32_t *__res
     uint32_t *dst = table + (size_t)bucket * bins_per_bucket + r0;
     for (uint32_t j = threadIdx.x; j < sub; j += PH_TPB) dst[j] = lb[j];
 }
+// ---- second level: tiles of <= 32768 keys inside one first-level bucket ---------------------------------------------------
+constexpr int P2_MAX = 128;        // sub-buckets per bucket (k = 16); 32 at k = 15
+__global__ void part2_ntiles_kernel(const uint64_t *__restrict__ goff, uint32_t *__restrict__ ntile) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < NBK) ntile[b] = (uint32_t)((goff[b + 1] - goff[b] + PT_TILE - 1) / PT_TILE);
+}
+// tile -> (bucket, key range); tile_off[NBK] = number of tiles.  One thread searches, the block reads the result from LDS.
+struct TileRange {
+    uint32_t bucket;
+    uint64_t lo, hi;
+};
+__device__ __forceinline__ TileRange find_tile(const uint64_t *__restrict__ tile_off, const uint64_t *__restrict__ goff, uint64_t tile,
+                                               TileRange *sh) {
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = NBK;                          // largest b with tile_off[b] <= tile
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (tile_off[mid] <= tile) lo = mid;
+            else hi = mid;
+        }
+        TileRange r;
+        r.bucket = (uint32_t)lo;
+        r.lo = goff[lo] + (tile - tile_off[lo]) * PT_TILE;
+        r.hi = r.lo + PT_TILE < goff[lo + 1] ? r.lo + PT_TILE : goff[lo + 1];
+        *sh = r;
+    }
+    __syncthreads();
+    const TileRange r = *sh;
+    __syncthreads();
+    return r;
+}
+__global__ __launch_bounds__(PS_TPB) void part2_count_kernel(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ goff,
+                                                             const uint64_t *__restrict__ tile_off, int shift2, int S,
+                                                             uint32_t *__restrict__ gcount2) {
+    __shared__ uint32_t cnt[P2_MAX];
+    __shared__ TileRange tr;
+    const uint64_t n_tiles = tile_off[NBK];
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const TileRange r = find_tile(tile_off, goff, tile, &tr);
+        if ((int)threadIdx.x < S) cnt[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint64_t i = r.lo + threadIdx.x; i < r.hi; i += PS_TPB) atomicAdd(&cnt[(keys[i] >> shift2) & (uint32_t)(S - 1)], 1u);
+        __syncthreads();
+        if ((int)threadIdx.x < S && cnt[threadIdx.x]) atomicAdd(&gcount2[(size_t)r.bucket * S + threadIdx.x], cnt[threadIdx.x]);
+        __syncthreads();
+    }
+}
+__global__ void part2_init_cursor_kernel(const uint64_t *__restrict__ goff2, int64_t m, unsigned long long *__restrict__ cursor2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) cursor2[i] = goff2[i];
+}
+// the tile-staged counting sort of part_scatter_kernel with S sub-buckets inside one bucket
+__global__ __launch_bounds__(PS_TPB) void part2_scatter_kernel(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ goff,
+                                                               const uint64_t *__restrict__ tile_off, int shift2, int S,
+                                                               unsigned long long *__restrict__ cursor2, uint32_t *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sorted[];      // PT_TILE entries
+    __shared__ uint32_t cnt[P2_MAX], loff[P2_MAX];
+    __shared__ unsigned long long base[P2_MAX];
+    __shared__ TileRange tr;
+    const uint64_t n_tiles = tile_off[NBK];
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const TileRange r = find_tile(tile_off, goff, tile, &tr);
+        if ((int)threadIdx.x < S) cnt[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t v[PS_PER];
+        bool live[PS_PER];
+#pragma unroll
+        for (int j = 0; j < PS_PER; ++j) {
+            const uint64_t i = r.lo + (uint64_t)j * PS_TPB + threadIdx.x;
+            live[j] = i < r.hi;
+            v[j] = live[j] ? keys[i] : 0u;
+            if (live[j]) atomicAdd(&cnt[(v[j] >> shift2) & (uint32_t)(S - 1)], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {                       // exclusive scan of the S <= 128 counts by the first wave (two per lane)
+            const int lane = threadIdx.x;
+            const uint32_t c0 = (2 * lane < S) ? cnt[2 * lane] : 0u, c1 = (2 * lane + 1 < S) ? cnt[2 * lane + 1] : 0u;
+            uint32_t inc = c0 + c1;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+            }
+            const uint32_t e0 = inc - c0 - c1, e1 = e0 + c0;
+            if (2 * lane < S) {
+                loff[2 * lane] = e0;
+                base[2 * lane] = c0 ? atomicAdd(&cursor2[(size_t)r.bucket * S + 2 * lane], (unsigned long long)c0) : 0ull;
+            }
+            if (2 * lane + 1 < S) {
+                loff[2 * lane + 1] = e1;
+                base[2 * lane + 1] = c1 ? atomicAdd(&cursor2[(size_t)r.bucket * S + 2 * lane + 1], (unsigned long long)c1) : 0ull;
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < S) cnt[threadIdx.x] = loff[threadIdx.x];      // running cursor of the sub-bucket inside the tile
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PS_PER; ++j)
+            if (live[j]) sorted[atomicAdd(&cnt[(v[j] >> shift2) & (uint32_t)(S - 1)], 1u)] = v[j];
+        __syncthreads();
+        const uint32_t n_keys = (uint32_t)(r.hi - r.lo);
+        for (uint32_t p = threadIdx.x; p < n_keys; p += PS_TPB) {
+            const uint32_t key = sorted[p];
+            const uint32_t sb = (key >> shift2) & (uint32_t)(S - 1);
+            out[base[sb] + (p - loff[sb])] = key;                              // consecutive p of a sub-bucket -> consecutive addresses
+        }
+        __syncthreads();
+    }
+}
+// k = 16: the all-T 16-mer's hash is 0xFFFFFFFF = the uint32 invalid marker; the hash kernel counts its valid windows aside and
+// this adds them to their bin
+__global__ void part_add_bin_kernel(uint32_t *__restrict__ table, size_t bin, const unsigned long long *__restrict__ extra) {
+    table[bin] += (uint32_t)*extra;
+}
 }  // namespace
 
 bool kmap_counts_part_applies(int k, int64_t n) {
     static const int on = [] { const char *e = getenv("KMAP_COUNT_PART"); return e ? atoi(e) : 1; }();
-    return on && k >= 11 && k <= 15 && n >= ((int64_t)1 << 20);
+    return on && k >= 11 && k <= 16 && n >= ((int64_t)1 << 20);
 }
 
 // bins of c <- histogram of the valid (!= 0xFFFFFFFF) hashes; the whole table is written (no prior memset needed)
@@ -173,7 +290,42 @@ int kmap_counts_part_hist_u32(kmap_counts *c, const uint32_t *hash_dev, int64_t 
     const uint32_t sub = bins_per_bucket < (uint32_t)PH_BINS ? bins_per_bucket : (uint32_t)PH_BINS;
     const int passes = (int)(bins_per_bucket / sub);
     KMAP_TRY(kmap_allow_lds((const void *)part_hist_kernel, PH_BINS * 4));
+    static const int two_level = [] { const char *e = getenv("KMAP_COUNT_PART2"); return e ? atoi(e) : 1; }();   // A/B switch
+    if (k >= 15 && two_level && passes <= P2_MAX) {
+        // second level: S = passes sub-buckets of 32768 bins per bucket; keys re-sorted tile by tile inside their bucket
+        const int S = passes, shift2 = 15;                           // sub-bucket = bits [15, 15 + log2 S) of the hash
+        uint32_t *gcount2 = nullptr, *keys2 = nullptr, *ntile = nullptr;
+        uint64_t *goff2 = nullptr, *tile_off = nullptr;
+        unsigned long long *cursor2 = nullptr;
+        const size_t m = (size_t)NBK * S;
+        void *aux = nullptr;
+        KMAP_TRY(kmap_scratch(&aux, (m + 1) * 8 + m * 8 + ((size_t)NBK + 1) * 8 + m * 4 + (size_t)NBK * 4, st, KMAP_SLOT_B));
+        goff2 = reinterpret_cast<uint64_t *>(aux);
+        cursor2 = reinterpret_cast<unsigned long long *>(goff2 + m + 1);
+        tile_off = reinterpret_cast<uint64_t *>(cursor2 + m);
+        gcount2 = reinterpret_cast<uint32_t *>(tile_off + NBK + 1);
+        ntile = gcount2 + m;
+        KMAP_TRY(kmap_scratch((void **)&keys2, (size_t)n * 4, st, KMAP_SLOT_HASH));   // the hash array is dead: its slot takes the re-sorted keys
+        KMAP_CHECK_HIP(hipMemsetAsync(gcount2, 0, m * 4, st));
+        part2_ntiles_kernel<<<NBK / 256, 256, 0, st>>>(goff, ntile);
+        KMAP_TRY(exclusive_scan_u32(ntile, NBK, tile_off, st));
+        part2_count_kernel<<<2048, PS_TPB, 0, st>>>(keys, goff, tile_off, shift2, S, gcount2);
+        KMAP_TRY(exclusive_scan_u32(gcount2, (int64_t)m, goff2, st));
+        part2_init_cursor_kernel<<<(unsigned)((m + 255) / 256), 256, 0, st>>>(goff2, (int64_t)m, cursor2);
+        KMAP_TRY(kmap_allow_lds((const void *)part2_scatter_kernel, PT_TILE * 4));
+        part2_scatter_kernel<<<1024, PS_TPB, (size_t)PT_TILE * 4, st>>>(keys, goff, tile_off, shift2, S, cursor2, keys2);
+        // one pass per sub-bucket: "bucket" = sub-bucket index, 32768 bins each
+        part_hist_kernel<<<(unsigned)m, PH_TPB, (size_t)PH_BINS * 4, st>>>(keys2, goff2, (uint32_t)PH_BINS, 1, (uint32_t)PH_BINS, c->bins);
+        KMAP_CHECK_HIP(hipGetLastError());
+        return KMAP_OK;
+    }
     part_hist_kernel<<<(unsigned)(NBK * passes), PH_TPB, (size_t)sub * 4, st>>>(keys, goff, bins_per_bucket, passes, sub, c->bins);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+
+int kmap_counts_part_add_bin(kmap_counts *c, size_t bin, const unsigned long long *extra_dev, hipStream_t st) {
+    part_add_bin_kernel<<<1, 1, 0, st>>>(c->bins, bin, extra_dev);
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;
 }

@@ -108,7 +108,8 @@ __device__ __forceinline__ uint32_t skip16_of(const uint32_t *__restrict__ skip,
 
 template <typename H, bool WIDE>
 __global__ __launch_bounds__(BLK) void hash_packed_kernel(const uint32_t *__restrict__ codes, const uint16_t *__restrict__ inval,
-                                                          int64_t n, int k, H *__restrict__ out, const uint32_t *__restrict__ skip) {
+                                                          int64_t n, int k, H *__restrict__ out, const uint32_t *__restrict__ skip,
+                                                          unsigned long long *__restrict__ all_ones) {
     const int64_t g = (int64_t)blockIdx.x * BLK + threadIdx.x;
     const int64_t p0 = g * 16;
     if (p0 >= n) return;
@@ -116,12 +117,18 @@ __global__ __launch_bounds__(BLK) void hash_packed_kernel(const uint32_t *__rest
     const uint64_t kmask = low_mask<uint64_t>(k);
     const uint32_t sk = skip16_of(skip, g);
     H hs[16];
+    uint32_t n_ones = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         bool bad;
         const uint64_t h = win_hash<WIDE>(w, i, k, kmask, bad);
-        hs[i] = (bad || ((sk >> (15 - i)) & 1u)) ? (H)~(H)0 : (H)h;
+        const bool drop = bad || ((sk >> (15 - i)) & 1u);
+        hs[i] = drop ? (H)~(H)0 : (H)h;
+        // 16-mers as uint32 (partitioned counting): the all-T k-mer's hash IS the invalid marker -- its valid windows are counted
+        // aside (all_ones) and leave the array as invalid
+        if (all_ones && !drop && (H)h == (H)~(H)0) ++n_ones;
     }
+    if (n_ones) atomicAdd(all_ones, (unsigned long long)n_ones);
     if (p0 + 16 <= n && ((uintptr_t)out % 16) == 0) {
         u32x4 *o = reinterpret_cast<u32x4 *>(out + p0);
         if constexpr (sizeof(H) == 4) {
@@ -711,9 +718,9 @@ int kmap_hash_kmers_packed_dev(const uint32_t *codes_dev, const uint16_t *inval_
     if (n == 0) return KMAP_OK;
     const unsigned g = grid_for((n + 15) >> 4, BLK);
     hipStream_t st = as_stream(stream);
-    if (k < 16) hash_packed_kernel<uint32_t, false><<<g, BLK, 0, st>>>(codes_dev, inval_dev, n, k, (uint32_t *)out_dev, nullptr);
-    else if (k == 16) hash_packed_kernel<uint64_t, false><<<g, BLK, 0, st>>>(codes_dev, inval_dev, n, k, (uint64_t *)out_dev, nullptr);
-    else hash_packed_kernel<uint64_t, true><<<g, BLK, 0, st>>>(codes_dev, inval_dev, n, k, (uint64_t *)out_dev, nullptr);
+    if (k < 16) hash_packed_kernel<uint32_t, false><<<g, BLK, 0, st>>>(codes_dev, inval_dev, n, k, (uint32_t *)out_dev, nullptr, nullptr);
+    else if (k == 16) hash_packed_kernel<uint64_t, false><<<g, BLK, 0, st>>>(codes_dev, inval_dev, n, k, (uint64_t *)out_dev, nullptr, nullptr);
+    else hash_packed_kernel<uint64_t, true><<<g, BLK, 0, st>>>(codes_dev, inval_dev, n, k, (uint64_t *)out_dev, nullptr, nullptr);
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;
 }
@@ -766,13 +773,27 @@ int kmap_counts_hist_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const
         else KMAP_TRY(kmap_dedupe_per_read_u64_dev((uint64_t *)hash, n, borders_dev, n_seq, stream));
         return kmap_counts_hist_hashes(c, hash, n, k, st);
     }
-    if (k < 16 && kmap_counts_part_applies(k, n)) {
-        // 11 <= k <= 15: materialise the hashes once (4 B/position) and take the bucket-partitioned histogram
+    if (kmap_counts_part_applies(k, n)) {
+        // 11 <= k <= 16: materialise the hashes once (4 B/position, 16-mers too) and take the bucket-partitioned histogram
         void *hash = nullptr;
-        KMAP_TRY(kmap_scratch(&hash, (size_t)n * 4, st, KMAP_SLOT_HASH));
-        hash_packed_kernel<uint32_t, false><<<grid_for((n + 15) >> 4, BLK), BLK, 0, st>>>(codes_dev, inval_dev, n, k, (uint32_t *)hash, skip);
+        KMAP_TRY(kmap_scratch(&hash, (size_t)n * 4 + 16, st, KMAP_SLOT_HASH));
+        unsigned long long *all_ones = nullptr;
+        if (k == 16) {
+            void *cnt8 = nullptr;
+            KMAP_TRY(kmap_scratch(&cnt8, 64, st, KMAP_SLOT_D));
+            all_ones = (unsigned long long *)cnt8;
+            KMAP_CHECK_HIP(hipMemsetAsync(all_ones, 0, 8, st));
+        }
+        hash_packed_kernel<uint32_t, false><<<grid_for((n + 15) >> 4, BLK), BLK, 0, st>>>(codes_dev, inval_dev, n, k, (uint32_t *)hash, skip, all_ones);
         KMAP_CHECK_HIP(hipGetLastError());
-        return kmap_counts_part_hist_u32(c, (const uint32_t *)hash, n, k, st);
+        if (k == 16) {   // the scan inside the partitioned path re-uses slot D: move the count next to the hash array first
+            unsigned long long *keep = (unsigned long long *)((char *)hash + (((size_t)n * 4 + 7) & ~(size_t)7));
+            KMAP_CHECK_HIP(hipMemcpyAsync(keep, all_ones, 8, hipMemcpyDeviceToDevice, st));
+            all_ones = keep;
+        }
+        KMAP_TRY(kmap_counts_part_hist_u32(c, (const uint32_t *)hash, n, k, st));
+        if (k == 16) KMAP_TRY(kmap_counts_part_add_bin(c, (size_t)0xFFFFFFFFu, all_ones, st));
+        return KMAP_OK;
     }
     KMAP_TRY(kmap_counts_prepare_bins(c, k, st));
     if (n > 0) {

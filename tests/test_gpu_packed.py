@@ -182,3 +182,35 @@ def test_counting_full_size_properties(env):
         ds.reset()
     dc.close()
     ds.close()
+
+
+@pytest.mark.parametrize("k", [15, 16])
+def test_two_level_partitioned_counts_vs_oracle(env, k):
+    """k = 15 / 16 above 2^20 positions: bucket partition + second level (32 / 128 sub-buckets of 32768 bins per bucket, keys
+    re-sorted tile by tile inside their bucket) == the oracle, with and without per-read dedupe and revcom merge.  The reads
+    hold long poly-T / poly-A stretches: at k = 16 the all-T 16-mer's hash 0xFFFFFFFF is the uint32 invalid marker and is
+    counted aside; repeats and N bases exercise dedupe and invalid windows."""
+    _ffi, DeviceCounts, DeviceSeq, O = env
+    rng = np.random.default_rng(1000 + k)
+    seq, borders = synth(rng, 9000, 100, 220, p_n=0.002)
+    assert len(seq) > (1 << 20)
+    for r in range(0, 9000, 37):                       # poly-T / poly-A / tandem-repeat reads
+        st, en = borders[r]
+        seq[st:en] = (3, 0, 3)[r % 3] if r % 3 != 2 else seq[st:en]
+        if r % 3 == 2:
+            seq[st:en] = np.resize(np.array([0, 1, 2, 3, 3, 3], np.uint8), en - st)
+    ds, dc = DeviceSeq(seq, borders), DeviceCounts()
+    for dedupe in (False, True):
+        for merge in (True, False):
+            ds.count(dc, k, dedupe=dedupe, merge_revcom=merge)
+            u, c = dc.fetch()
+            ou, oc = O.count_kmers(seq, borders, k, rep_mode=not dedupe, revcom_mode=merge)
+            np.testing.assert_array_equal(u, ou)
+            np.testing.assert_array_equal(c, oc)
+            assert u.dtype == ou.dtype and c.dtype == oc.dtype
+    if k == 16:
+        ds.count(dc, k, dedupe=False, merge_revcom=False)
+        u, c = dc.fetch()
+        assert u[-1] == 0xFFFFFFFF and c[-1] > 1000        # the all-T 16-mer is present and counted
+    dc.close()
+    ds.close()
