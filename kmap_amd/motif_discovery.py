@@ -401,11 +401,36 @@ def scan_motif_occurence(dev_seq: DeviceSeq, conseq_list, motif_def_dict, revcom
     return per
 
 
+class _BackgroundCall:
+    """A native call (GIL released) on its own thread; join() re-raises its failure on the caller's thread."""
+
+    def __init__(self, fn):
+        import threading
+        self.err = None
+
+        def run():
+            try:
+                fn()
+            except BaseException as e:   # noqa: BLE001 -- re-raised by join()
+                self.err = e
+        self._t = threading.Thread(target=run)
+        self._t.start()
+
+    def join(self):
+        self._t.join()
+        if self.err is not None:
+            raise self.err
+
+    close = join
+
+
 def gen_motif_occurence_file(conseq_list: List[str], motif_def_dict: dict, input_fasta_file, output_file, revcom_mode=True,
-                             dev_seq: DeviceSeq = None, write=True):
+                             dev_seq: DeviceSeq = None, write=True, writers: list = None):
     """seq_ind;loc,loc;...;seq_len for every read with a hit.  With `dev_seq` the resident read array is
     scanned (it is the encoding of the same FASTA); otherwise the FASTA is encoded and uploaded here.
-    write=False: scan only (the ranks of a read-sharded run that do not own the output files)."""
+    write=False: scan only (the ranks of a read-sharded run that do not own the output files).
+    writers (optional list): the CSV is formatted and written by a background thread appended to the list (the caller joins it;
+    scan_motif: while the next k is counted and scanned) instead of before returning."""
     own = dev_seq is None
     if own:
         assert Path(input_fasta_file).exists()
@@ -418,11 +443,18 @@ def gen_motif_occurence_file(conseq_list: List[str], motif_def_dict: dict, input
         hits_ptrs = (C.c_void_p * max(n_cons, 1))(*[h.ctypes.data for h, _ in per])
         pos_keep = [np.ascontiguousarray(p, np.int32) if len(p) else np.zeros(1, np.int32) for _, p in per]
         pos_ptrs = (C.c_void_p * max(n_cons, 1))(*[p.ctypes.data for p in pos_keep])
-        rows = _ffi.i64(0)
         if write:
             assert all(len(h) == dev_seq.out_n_seq for h, _ in per)
-            check(_ffi.lib().kmap_write_occurrence_csv(str(output_file).encode(), header.encode(), dev_seq.out_n_seq, n_cons,
-                                                       hits_ptrs, pos_ptrs, ptr(dev_seq.out_read_len), C.byref(rows)))
+            n_out, read_len = dev_seq.out_n_seq, dev_seq.out_read_len
+
+            def emit(keep=(per, pos_keep, hits_ptrs, pos_ptrs, read_len)):     # the arrays stay alive with the closure
+                rows = _ffi.i64(0)
+                check(_ffi.lib().kmap_write_occurrence_csv(str(output_file).encode(), header.encode(), n_out, n_cons,
+                                                           hits_ptrs, pos_ptrs, ptr(read_len), C.byref(rows)))
+            if writers is not None:
+                writers.append(_BackgroundCall(emit))
+            else:
+                emit()
         return per
     finally:
         if own:
@@ -627,12 +659,21 @@ def _scan_motif(res_dir: str, debug=False):
     try:
         _scan_motif_impl(res_dir, debug, dist, rank, savers)
     finally:
-        for sv in savers.values():   # normally joined inside; after an exception: let the writers end, free the tables
-            sv.close()
+        for sv in _flat(savers):     # normally joined inside; after an exception: let the writers end, free the tables
+            try:
+                sv.close()
+            except BaseException:    # noqa: BLE001 -- a writer's failure already surfaced through join(), or the run is failing anyway
+                pass
     if dist is not None:            # success path only (a failing rank re-raises and the launcher tears the job down)
         dist.barrier()
         if owns_group:
             dist.destroy_process_group()
+
+
+def _flat(savers):
+    """background jobs of a scan_motif run: k -> TableSaver, "occurrence" -> [CSV writers]"""
+    for v in savers.values():
+        yield from (v if isinstance(v, list) else [v])
 
 
 def _scan_motif_impl(res_dir, debug, dist, rank, savers):
@@ -734,7 +775,7 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
                 occ_file = res / FileNameDict["kmer_count_dir"] / f"k{kmer_len}.motif_occurence.csv"
                 with _stage("occurrence_per_k"):
                     per = gen_motif_occurence_file(tmp_list, motif_def_dict, input_fasta_file, occ_file, revcom_mode,
-                                                   dev_seq=scan_seq, write=lead)
+                                                   dev_seq=scan_seq, write=lead, writers=savers.setdefault("occurrence", []))
             for i, kmer_seq in enumerate(tmp_list):
                 candidate_conseq_list.append(kmer_seq)
                 if not lead:
@@ -791,7 +832,7 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
     occurence_file = res / FileNameDict["motif_occurence_file"]
     with _stage("occurrence_final"):
         per_final = gen_motif_occurence_file(final_conseq_list, motif_def_dict, input_fasta_file, occurence_file, revcom_mode,
-                                             dev_seq=scan_seq, write=lead)
+                                             dev_seq=scan_seq, write=lead, writers=savers.setdefault("occurrence", []))
     if not lead:                    # everything below is host-side reporting / sampling on the hit list and the k{k}.pkl tables
         if count_seq is not scan_seq:
             count_seq.close()
@@ -862,8 +903,8 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
                 pickle.dump([kmer_len, hamdist_mat, label_arr], fh)
         print("Hamming distance matrix of sampled kmers are generated.")
 
-    with _stage("join_table_writers"):       # the k{k}.pkl files of the large tables are complete from here on
-        for sv in savers.values():
+    with _stage("join_table_writers"):       # the k{k}.pkl files of the large tables and the occurrence CSVs are complete from here on
+        for sv in _flat(savers):
             sv.join()
 
     if md["gen_hamball_flag"]:
