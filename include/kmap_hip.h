@@ -176,6 +176,14 @@ int kmap_scan_run_packed_dev(kmap_scan *s, const uint32_t *codes_dev, const uint
                              const int64_t *borders_dev, int64_t n_seq, int k, uint64_t cons, int radius, int revcom,
                              int64_t *total_hits, void *stream);
 int kmap_scan_fetch(kmap_scan *s, int32_t *hits_per_read, int8_t *min_dist, int32_t *positions);
+/* the last run's results without (or before) a fetch: the two numbers scan_motif's candidate table needs of a hit list --
+ * reads with a hit (get_motif_seq_num, motif_discovery.py:1345-1393) and the largest per-read hit count (> 20 triggers the
+ * reference's subsampling, :1466-1469) -- and a fetch on the caller's stream, for worker threads that write the occurrence
+ * CSV while the launching thread goes on (the handle keeps the lists until its next run) */
+int kmap_scan_summary(kmap_scan *s, int64_t *reads_with_hits, int32_t *max_hits, void *stream);
+int kmap_scan_fetch_stream(kmap_scan *s, int32_t *hits_per_read, int32_t *positions, void *stream);
+/* hit counts as bytes (narrowed on the device; for lists whose summary max_hits <= 255, larger counts saturate) */
+int kmap_scan_fetch_stream_u8(kmap_scan *s, uint8_t *hits_u8, int32_t *positions, void *stream);
 
 /* host-side writer of the occurrence table (gen_motif_occurence_file motif_discovery.py:1396-1419):
  * rows "seq_ind;loc,loc;...;seq_len" for every read with at least one hit; per consensus c the arrays
@@ -184,6 +192,10 @@ int kmap_scan_fetch(kmap_scan *s, int32_t *hits_per_read, int8_t *min_dist, int3
  * formatting dominates at 10^7 reads. */
 int kmap_write_occurrence_csv(const char *path, const char *header, int64_t n_seq, int n_cons,
                               const int32_t *const *hits, const int32_t *const *pos, const int64_t *read_len,
+                              int64_t *rows_written);
+/* the same file from byte-sized hit counts (kmap_scan_fetch_stream_u8) */
+int kmap_write_occurrence_csv_u8(const char *path, const char *header, int64_t n_seq, int n_cons,
+                              const uint8_t *const *hits, const int32_t *const *pos, const int64_t *read_len,
                               int64_t *rows_written);
 
 /* ---- consumers of the counts / the hit list -------------------------------------------

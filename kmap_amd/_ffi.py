@@ -93,7 +93,11 @@ _SIGS = {
     "kmap_scan_destroy": (i32, [vp]),
     "kmap_scan_run_dev": (i32, [vp, vp, i64, vp, i64, i32, u64, i32, i32, P(i64), vp]),
     "kmap_scan_fetch": (i32, [vp, vp, vp, vp]),
+    "kmap_scan_fetch_stream": (i32, [vp, vp, vp, vp]),
+    "kmap_scan_fetch_stream_u8": (i32, [vp, vp, vp, vp]),
+    "kmap_scan_summary": (i32, [vp, P(i64), P(i32), vp]),
     "kmap_write_occurrence_csv": (i32, [C.c_char_p, C.c_char_p, i64, i32, vp, vp, vp, P(i64)]),
+    "kmap_write_occurrence_csv_u8": (i32, [C.c_char_p, C.c_char_p, i64, i32, vp, vp, vp, P(i64)]),
     "kmap_fasta_open": (i32, [C.c_char_p, P(vp), P(i64), P(i64)]),
     "kmap_fasta_read": (i32, [vp, vp, vp]),
     "kmap_fasta_close": (i32, [vp]),

@@ -5,6 +5,8 @@
 // the hits, ballot-ordered compaction of the positions at the read's minimum distance.
 //
 // Roofline: HBM-bound, 1 B per array position + sparse hit output.
+#include <algorithm>
+
 #include "common.h"
 #include "scan_util.h"
 
@@ -93,6 +95,35 @@ __global__ __launch_bounds__(KMAP_WAVE *SC_WAVES) void scan_kernel(const uint8_t
     }
 }
 
+__global__ __launch_bounds__(256) void scan_summary_kernel(const int32_t *__restrict__ hits, int64_t n_seq,
+                                                           unsigned long long *__restrict__ stat) {
+    unsigned long long cnt = 0, mx = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_seq; i += (int64_t)gridDim.x * 256) {
+        const int32_t h = hits[i];
+        cnt += h > 0;
+        mx = (unsigned long long)h > mx && h > 0 ? (unsigned long long)h : mx;
+    }
+    for (int o = 32; o; o >>= 1) {
+        cnt += __shfl_down(cnt, o);
+        const unsigned long long m2 = __shfl_down(mx, o);
+        mx = m2 > mx ? m2 : mx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (cnt) atomicAdd(&stat[0], cnt);
+        if (mx) atomicMax(&stat[1], mx);
+    }
+}
+
+// thread = 4 reads: int32 hit counts -> bytes (saturating)
+__global__ __launch_bounds__(256) void narrow_hits_kernel(const int32_t *__restrict__ hits, int64_t n_seq, uint8_t *__restrict__ out) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    for (int j = 0; j < 4; ++j)
+        if (i + j < n_seq) {
+            const int32_t h = hits[i + j];
+            out[i + j] = (uint8_t)(h < 0 ? 0 : h > 255 ? 255 : h);
+        }
+}
+
 }  // namespace
 
 #include "scan_internal.h"
@@ -169,6 +200,56 @@ int kmap_scan_run_dev(kmap_scan *s, const uint8_t *seq_dev, int64_t n, const int
     KMAP_CHECK_HIP(hipGetLastError());
     s->total = (int64_t)total;
     if (total_hits) *total_hits = (int64_t)total;
+    return KMAP_OK;
+}
+
+// fetch of the last run's lists on a stream of the caller's (a worker thread's own non-blocking stream: the copies then neither
+// wait for nor hold up the launching thread's null-stream work).  The lists must be complete: call kmap_scan_summary first
+// (it synchronises behind the kernels that write them); the handle must not run again before this returns.
+int kmap_scan_fetch_stream(kmap_scan *s, int32_t *hits_per_read, int32_t *positions, void *stream) {
+    KMAP_REQUIRE(s, "scan_fetch_stream: null handle");
+    hipStream_t st = as_stream(stream);
+    if (s->n_seq && hits_per_read)
+        KMAP_CHECK_HIP(hipMemcpyAsync(hits_per_read, s->hits, (size_t)s->n_seq * 4, hipMemcpyDeviceToHost, st));
+    if (s->total && positions)
+        KMAP_CHECK_HIP(hipMemcpyAsync(positions, s->pos, (size_t)s->total * 4, hipMemcpyDeviceToHost, st));
+    KMAP_CHECK_HIP(hipStreamSynchronize(st));
+    return KMAP_OK;
+}
+
+// what gen_motif_occurence_file's caller needs of a hit list without fetching it: reads with >= 1 hit, largest hit count
+int kmap_scan_summary(kmap_scan *s, int64_t *reads_with_hits, int32_t *max_hits, void *stream) {
+    KMAP_REQUIRE(s && reads_with_hits && max_hits, "scan_summary: null");
+    *reads_with_hits = 0;
+    *max_hits = 0;
+    if (s->n_seq == 0) return KMAP_OK;
+    hipStream_t st = as_stream(stream);
+    unsigned long long *stat = reinterpret_cast<unsigned long long *>(s->offs);   // offs is dead once the positions are written
+    KMAP_CHECK_HIP(hipMemsetAsync(stat, 0, 16, st));
+    scan_summary_kernel<<<(unsigned)std::min<int64_t>((s->n_seq + 2047) / 2048, 2048), 256, 0, st>>>(s->hits, s->n_seq, stat);
+    KMAP_CHECK_HIP(hipGetLastError());
+    unsigned long long host[2] = {0, 0};
+    KMAP_CHECK_HIP(hipMemcpyAsync(host, stat, 16, hipMemcpyDeviceToHost, st));
+    KMAP_CHECK_HIP(hipStreamSynchronize(st));
+    *reads_with_hits = (int64_t)host[0];
+    *max_hits = (int32_t)host[1];
+    return KMAP_OK;
+}
+
+// the same with the hit counts narrowed to bytes on the device first (staged in the handle's dead offset array): for lists
+// whose kmap_scan_summary max_hits is <= 255 -- larger counts would saturate at 255
+int kmap_scan_fetch_stream_u8(kmap_scan *s, uint8_t *hits_u8, int32_t *positions, void *stream) {
+    KMAP_REQUIRE(s, "scan_fetch_stream_u8: null handle");
+    hipStream_t st = as_stream(stream);
+    if (s->n_seq && hits_u8) {
+        uint8_t *stage = reinterpret_cast<uint8_t *>(s->offs) + 64;
+        narrow_hits_kernel<<<(unsigned)((s->n_seq + 1023) / 1024), 256, 0, st>>>(s->hits, s->n_seq, stage);
+        KMAP_CHECK_HIP(hipGetLastError());
+        KMAP_CHECK_HIP(hipMemcpyAsync(hits_u8, stage, (size_t)s->n_seq, hipMemcpyDeviceToHost, st));
+    }
+    if (s->total && positions)
+        KMAP_CHECK_HIP(hipMemcpyAsync(positions, s->pos, (size_t)s->total * 4, hipMemcpyDeviceToHost, st));
+    KMAP_CHECK_HIP(hipStreamSynchronize(st));
     return KMAP_OK;
 }
 

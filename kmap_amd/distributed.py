@@ -251,6 +251,7 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None):
 
     class DistDeviceSeq(DeviceSeq):
         first_read, n_local_reads, n_all_reads = r0, nr, len(borders)
+        scan_lazy = None        # hit lists are all-gathered through the host: no device-resident variant
 
         def count(self, dc, k, dedupe, merge_revcom, use_work=True):
             if k > 16:

@@ -88,6 +88,15 @@ def hash2kmer(hashkey, k: int) -> str:
     return "".join(_BASES[(hk >> (2 * (k - 1 - i))) & 3] for i in range(k))
 
 
+def hashes2kmers(hash_arr, k: int) -> np.ndarray:
+    """hash2kmer for a whole array: numpy '<U{k}' strings"""
+    h = np.asarray(hash_arr, dtype=np.uint64).reshape(-1, 1)
+    shifts = (2 * np.arange(k - 1, -1, -1, dtype=np.uint64)).reshape(1, -1)
+    codes = ((h >> shifts) & np.uint64(3)).astype(np.uint8)
+    letters = np.frombuffer(b"ACGT", dtype="S1")[codes]
+    return letters.view(f"S{k}").reshape(-1).astype(f"U{k}") if k else np.array([""] * len(h))
+
+
 def revcom_hash(in_hash, kmer_len: int):
     dt = get_hash_dtype(kmer_len)
     com = ((1 << (2 * kmer_len)) - 1 - int(in_hash)) % (1 << (8 * np.dtype(dt).itemsize))
@@ -255,6 +264,8 @@ def mask_input(seq_np_arr: np.ndarray, kmer_len: int, consensus_kh_arr, max_hamb
     """In place: overwrite every occurrence of the consensuses' Hamming balls with 255
     (reference kmer_count.py:580-610)."""
     assert seq_np_arr.dtype == np.uint8 and seq_np_arr.flags.c_contiguous
+    if not seq_np_arr.flags.writeable:
+        raise ValueError("mask_input works in place and needs a writeable array (copy a memory-mapped input first)")
     cons = np.ascontiguousarray(consensus_kh_arr, dtype=np.uint64)
     rad = np.ascontiguousarray(max_hamball_dist_arr, dtype=np.int32)
     assert len(cons) == len(rad)
@@ -402,6 +413,129 @@ def encode_fasta_py(fasta_file):
     starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64) if len(parts) else np.zeros(0, np.int64)
     arr = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
     return arr, np.stack([starts, starts + lens - 1], axis=1).astype(int) if len(parts) else np.zeros((0, 2), int)
+
+
+class _BlobAt(Exception):
+    def __init__(self, offset, nbytes):
+        self.offset, self.nbytes = offset, nbytes
+
+
+class _OpReader:
+    """file wrapper for pickletools.genops that stops at the first large bytes payload instead of reading it"""
+
+    def __init__(self, fh, big):
+        self.fh, self.big = fh, big
+
+    def read(self, n):
+        if n >= self.big:
+            raise _BlobAt(self.fh.tell(), n)
+        return self.fh.read(n)
+
+    def readline(self):
+        return self.fh.readline()
+
+    def tell(self):
+        return self.fh.tell()
+
+
+_SKIP_OPS = ("PROTO", "FRAME", "MEMOIZE", "BINPUT", "LONG_BINPUT")
+_INT_OPS = ("BININT", "BININT1", "BININT2", "LONG1")
+
+
+def locate_pickled_array(path, min_bytes=1 << 20):
+    """Where the data of a pickled ndarray sits inside its file: (offset, dtype, shape), or None when the file is anything but
+    ONE C-ordered, little-endian / byte-sized, non-object ndarray pickled with protocol 3 or 4 (what `pickle.dump(arr, fh)` of the
+    reference's preproc writes, kmer_count.py:333) whose >= min_bytes payload is one in-band bytes object.  The op stream around
+    the payload is matched strictly; any deviation returns None and the caller unpickles the ordinary way."""
+    import os
+    import pickletools
+    ops = []
+    with open(path, "rb") as fh:
+        try:
+            for op, arg, _ in pickletools.genops(_OpReader(fh, min_bytes)):
+                if op.name not in _SKIP_OPS:
+                    ops.append((op.name, arg))
+            return None                                           # no large payload at all
+        except _BlobAt as b:
+            offset, nbytes = b.offset, b.nbytes
+        except Exception:                                         # noqa: BLE001 -- not a pickle we understand
+            return None
+        size = os.fstat(fh.fileno()).st_size
+        if offset + nbytes > size or size - (offset + nbytes) > 16:
+            return None
+        fh.seek(offset + nbytes)
+        try:
+            tail = [op.name for op, _, _ in pickletools.genops(fh.read()) if op.name not in _SKIP_OPS]
+        except Exception:                                         # noqa: BLE001
+            return None
+    if tail != ["TUPLE", "BUILD", "STOP"]:
+        return None
+    names = [n for n, _ in ops]
+    # ... MARK 1 <shape tuple> <dtype global> str NEWFALSE NEWTRUE TUPLE3 REDUCE MARK 3 order NONE NONE NONE -1 -1 0 TUPLE BUILD NEWFALSE | payload
+    want_tail = ["TUPLE3", "REDUCE", "MARK", "INT", "STR", "NONE", "NONE", "NONE", "INT", "INT", "INT", "TUPLE", "BUILD", "NEWFALSE"]
+    kinds = ["INT" if n in _INT_OPS else "STR" if n in ("SHORT_BINUNICODE", "BINUNICODE") else n for n in names]
+    if len(kinds) < len(want_tail) + 12 or kinds[-len(want_tail):] != want_tail:
+        return None
+    state = [a for (n, a), kd in zip(ops[-len(want_tail):], want_tail) if kd in ("INT", "STR")]
+    if state[0] != 3 or state[1] not in ("|", "<") or state[2:] != [-1, -1, 0]:
+        return None
+    i = len(ops) - len(want_tail)
+    if kinds[i - 3:i] != ["STR", "NEWFALSE", "NEWTRUE"]:
+        return None
+    dtype_str = ops[i - 3][1]
+    i -= 3
+    if kinds[i - 1] == "GLOBAL" and ops[i - 1][1] == "numpy dtype":
+        i -= 1
+    elif kinds[i - 1] == "STACK_GLOBAL" and kinds[i - 2] == "STR" and ops[i - 2][1] == "dtype":
+        i -= 3                                                    # module name (string or memo reference), "dtype", STACK_GLOBAL
+    else:
+        return None
+    shape = []
+    if kinds[i - 1] in ("TUPLE1", "TUPLE2", "TUPLE3"):
+        nd = int(kinds[i - 1][-1])
+        dims = ops[i - 1 - nd:i - 1]
+        i -= 1 + nd
+    else:
+        return None                                               # 0-d and > 3-d arrays: not the input files
+    if any(n not in _INT_OPS for n, _ in dims):
+        return None
+    shape = tuple(int(a) for _, a in dims)
+    if kinds[i - 2:i] != ["MARK", "INT"] or ops[i - 1][1] != 1:
+        return None
+    head = " ".join(str(a) for _, a in ops[:i - 2] if isinstance(a, str))
+    if "_reconstruct" not in head or "ndarray" not in head or "multiarray" not in head:
+        return None
+    try:
+        dt = np.dtype(dtype_str)
+    except TypeError:
+        return None
+    if dt.hasobject or dt.itemsize * int(np.prod(shape, dtype=np.int64)) != nbytes:
+        return None
+    return offset, dt, shape
+
+
+def load_array_pickle(path, min_bytes=64 << 20):
+    """The ndarray a pickle file holds.  Large plain arrays (locate_pickled_array) come back as a READ-ONLY view of a private
+    memory map of the file -- no 1.5-GB copy through `pickle.load` at C3 (0.27 s + 0.11 s to free it); the upload then DMAs
+    straight from the page cache.  Everything else is unpickled normally."""
+    import mmap
+    import os
+    loc = None
+    try:
+        if os.path.getsize(path) >= min_bytes:
+            loc = locate_pickled_array(path, min_bytes)
+    except OSError:
+        loc = None
+    if loc is None:
+        with open(path, "rb") as fh:
+            return pickle.load(fh)
+    offset, dt, shape = loc
+    if offset % dt.itemsize:                                      # an unaligned view would be legal numpy but a trap for native readers
+        with open(path, "rb") as fh:
+            return pickle.load(fh)
+    with open(path, "rb") as fh:
+        mm = mmap.mmap(fh.fileno(), 0, flags=mmap.MAP_PRIVATE, prot=mmap.PROT_READ)
+    return np.frombuffer(mm, dt, count=int(np.prod(shape, dtype=np.int64)), offset=offset).reshape(shape)
 
 
 def proc_input(input_fasta_file: str, res_dir=".", out_bin_file_name: str = "input.bin.pkl",

@@ -10,7 +10,10 @@ sample_kmer_hamdist_mat.pkl) and the caching rules of the reference are kept.  P
 skipped with a notice.
 """
 import ctypes as C
+import os
 import pickle
+import sys
+import time
 import warnings
 from pathlib import Path
 from typing import List
@@ -22,7 +25,7 @@ from ._ffi import check, ptr
 from .hamdist import _convert_to_block_arr, cal_samp_kmer_hamdist_mat  # noqa: F401  (re-exported, reference names)
 from .kmer_count import (DeviceCounts, FileNameDict, cal_hamming_dist_head, cal_hamming_dist_tail, encode_fasta,
                          gen_motif_def_dict, get_cnt_dtype, get_hash_dtype, get_revcom_hash_arr, hash2kmer, init_motif_def_dict,
-                         kmer2hash,
+                         hashes2kmers, kmer2hash, load_array_pickle,
                          mask_ham_ball, revcom_hash, reverse_complement)
 
 # int64 N x N pickle is kept up to this many sampled k-mers (2 GiB); above it scan_motif writes the compact
@@ -81,6 +84,8 @@ class DeviceSeq:
         raw.free()                      # the uint8 array does not stay on the device
         self.reset()
         self._scan = None
+        import threading
+        self._lazy_lock, self._lazy_free, self._lazy_all = threading.Lock(), [], []     # scan handles of scan_lazy()
 
     def reset(self):
         """restore the unmasked reads (reference motif_discovery.py:263): n/8 bytes"""
@@ -123,12 +128,108 @@ class DeviceSeq:
         check(_ffi.lib().kmap_scan_fetch(self._scan, ptr(hits), None, ptr(pos)))   # per-read minimum distances stay on the device
         return hits, pos
 
+    def scan_lazy(self, k, consensus_kh, radius, revcom):
+        """scan() whose hit list stays in HBM, inside its scan handle, until someone asks for it: `ScanHits.n_reads_hit / .total /
+        .max_hits` are known at once (what scan_motif's candidate table needs), the two arrays are fetched on first use -- by the
+        background CSV writer in scan_motif, off the critical path.  Handles rotate: a fetched (or dropped) ScanHits hands its
+        handle back, so a run allocates a handful of result buffers once instead of one set per consensus."""
+        with self._lazy_lock:
+            h = self._lazy_free.pop() if self._lazy_free else None
+        if h is None:
+            hv = _ffi.vp()
+            check(_ffi.lib().kmap_scan_create(C.byref(hv)))
+            h = hv.value
+            self._lazy_all.append(h)
+        tot, nhit, mx = _ffi.i64(0), _ffi.i64(0), _ffi.i32(0)
+        check(_ffi.lib().kmap_scan_run_packed_dev(h, self.codes.ptr, self.inval_orig.ptr, self.n, self.borders.ptr,
+                                                  self.n_seq, k, int(consensus_kh), int(radius), int(revcom), C.byref(tot), None))
+        check(_ffi.lib().kmap_scan_summary(h, C.byref(nhit), C.byref(mx), None))    # returns once the lists are complete
+        return ScanHits(self, h, self.n_seq, tot.value, nhit.value, mx.value)
+
+    def _lazy_release(self, h):
+        with self._lazy_lock:
+            if self._lazy_all is not None:
+                self._lazy_free.append(h)
+
     def close(self):
         if self._scan:
             _ffi.lib().kmap_scan_destroy(self._scan)
             self._scan = None
+        with self._lazy_lock:
+            handles, self._lazy_all, self._lazy_free = self._lazy_all or [], None, []
+        for h in handles:                 # a ScanHits not fetched by now reports that its sequence is closed
+            _ffi.lib().kmap_scan_destroy(h)
         for b in (self.codes, self.inval_orig, self.inval_work, self.borders):
             b.free()
+
+
+class ScanHits:
+    """One consensus' hit list, resident in HBM (in its scan handle) until first use.  Unpacks like the (hits_per_read, positions)
+    pair scan() returns (`hits, pos = scan_hits` fetches); the summary numbers need no fetch."""
+
+    def __init__(self, owner, handle, n_seq, total, n_reads_hit, max_hits):
+        import threading
+        self._owner, self._handle = owner, handle
+        self.n_seq, self.total, self.n_reads_hit, self.max_hits = n_seq, total, n_reads_hit, max_hits
+        self._host = None
+        self._lock = threading.Lock()
+
+    def host(self):
+        with self._lock:
+            if self._host is None:
+                if self._handle is None:
+                    raise RuntimeError("ScanHits: the list was already handed to a CSV writer (host_u8)")
+                if self._owner._lazy_all is None:
+                    raise RuntimeError("ScanHits: the DeviceSeq was closed before the hit list was fetched")
+                hits, pos = np.empty(self.n_seq, np.int32), np.empty(self.total, np.int32)
+                st = _ffi.vp()
+                check(_ffi.lib().kmap_stream_create(C.byref(st)))      # own stream: neither waits for nor blocks the launching thread
+                try:
+                    check(_ffi.lib().kmap_scan_fetch_stream(self._handle, ptr(hits), ptr(pos), st.value))
+                finally:
+                    _ffi.lib().kmap_stream_destroy(st.value)
+                self._owner._lazy_release(self._handle)
+                self._owner, self._handle = None, None
+                self._host = [hits, pos]
+            return self._host
+
+    @property
+    def unfetched(self):
+        return self._host is None and self._handle is not None
+
+    def host_u8(self):
+        """(hits as uint8, positions) for a list with max_hits <= 255, fetched without keeping the int32 pair; the handle goes
+        back to its sequence, so this is the list's last use"""
+        with self._lock:
+            assert self._host is None and self._handle is not None and self.max_hits <= 255
+            if self._owner._lazy_all is None:
+                raise RuntimeError("ScanHits: the DeviceSeq was closed before the hit list was fetched")
+            hits, pos = np.empty(self.n_seq, np.uint8), np.empty(self.total, np.int32)
+            st = _ffi.vp()
+            check(_ffi.lib().kmap_stream_create(C.byref(st)))
+            try:
+                check(_ffi.lib().kmap_scan_fetch_stream_u8(self._handle, ptr(hits), ptr(pos), st.value))
+            finally:
+                _ffi.lib().kmap_stream_destroy(st.value)
+            self._owner._lazy_release(self._handle)
+            self._owner, self._handle = None, None
+            return hits, pos
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                self._owner._lazy_release(self._handle)
+        except Exception:     # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def __iter__(self):
+        return iter(self.host())
+
+    def __getitem__(self, i):
+        return self.host()[i]
+
+    def __len__(self):
+        return 2
 
 
 # ---- consensus merging (reference motif_discovery.py:533-591) -------------------------------------
@@ -376,29 +477,52 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
 
 
 # ---- motif occurrence (reference motif_discovery.py:1396-1477) -------------------------------------------
-def scan_motif_occurence(dev_seq: DeviceSeq, conseq_list, motif_def_dict, revcom_mode=True, subsample=True):
-    """Per consensus: (hits_per_read int32[n_seq], positions int32[sum]) after the reference's >20-hit random
-    subsample (np.random.choice in read order, then consensus order -- the reference's draw order)."""
+def scan_hit_lists(dev_seq: DeviceSeq, conseq_list, motif_def_dict, revcom_mode=True):
+    """Per consensus the hit list at each read's minimum distance, before any subsampling: ScanHits (resident in HBM) where the
+    sequence offers them, else [hits_per_read int32[n_seq], positions int32[sum]] on the host (read-sharded runs)."""
     per = []
+    lazy = getattr(dev_seq, "scan_lazy", None)
     for conseq in conseq_list:
         k = len(conseq)
-        hits, pos = dev_seq.scan(k, kmer2hash(conseq), motif_def_dict[k].max_ham_dist, revcom_mode)
-        per.append([hits, pos])
-    big = [(int(r), c) for c, (hits, _) in enumerate(per) for r in np.nonzero(hits > 20)[0]] if subsample else []
-    if big:
-        offs = [np.concatenate([[0], np.cumsum(h, dtype=np.int64)]) for h, _ in per]
-        keep = [np.ones(len(p), bool) for _, p in per]
-        newhits = [h.copy() for h, _ in per]
-        for r, c in sorted(big):
-            lo, hi = offs[c][r], offs[c][r + 1]
-            locs = per[c][1][lo:hi]
-            idx = np.random.choice(len(locs), 20, replace=False)        # :1468
-            sel = np.zeros(len(locs), bool)
-            sel[idx] = True                                             # np.sort(locs[idx]): locs ascending already
-            keep[c][lo:hi] = sel
-            newhits[c][r] = 20
-        per = [[newhits[c], per[c][1][keep[c]]] for c in range(len(per))]
+        if lazy is not None:
+            per.append(lazy(k, kmer2hash(conseq), motif_def_dict[k].max_ham_dist, revcom_mode))
+        else:
+            hits, pos = dev_seq.scan(k, kmer2hash(conseq), motif_def_dict[k].max_ham_dist, revcom_mode)
+            per.append([hits, pos])
     return per
+
+
+def needs_draws(per):
+    """does any read carry more than 20 hits of a consensus (the reference then draws 20 of them, motif_discovery.py:1466-1469)"""
+    return any((r.max_hits > 20) if isinstance(r, ScanHits) else bool((r[0] > 20).any()) for r in per)
+
+
+def subsample_hit_lists(per):
+    """the reference's > 20-hit rule: np.random.choice of 20 positions, reads ascending, then consensus order (its draw order);
+    lists without such reads are returned as they are (still in HBM if they were)"""
+    if not needs_draws(per):
+        return per
+    per = [list(r) for r in per]
+    big = [(int(r), c) for c, (hits, _) in enumerate(per) for r in np.nonzero(hits > 20)[0]]
+    offs = [np.concatenate([[0], np.cumsum(h, dtype=np.int64)]) for h, _ in per]
+    keep = [np.ones(len(p), bool) for _, p in per]
+    newhits = [h.copy() for h, _ in per]
+    for r, c in sorted(big):
+        lo, hi = offs[c][r], offs[c][r + 1]
+        locs = per[c][1][lo:hi]
+        idx = np.random.choice(len(locs), 20, replace=False)        # :1468
+        sel = np.zeros(len(locs), bool)
+        sel[idx] = True                                             # np.sort(locs[idx]): locs ascending already
+        keep[c][lo:hi] = sel
+        newhits[c][r] = 20
+    return [[newhits[c], per[c][1][keep[c]]] for c in range(len(per))]
+
+
+def scan_motif_occurence(dev_seq: DeviceSeq, conseq_list, motif_def_dict, revcom_mode=True, subsample=True):
+    """Per consensus: (hits_per_read int32[n_seq], positions int32[sum]) -- or a ScanHits that unpacks to that pair -- after the
+    reference's > 20-hit random subsample."""
+    per = scan_hit_lists(dev_seq, conseq_list, motif_def_dict, revcom_mode)
+    return subsample_hit_lists(per) if subsample else per
 
 
 class _BackgroundCall:
@@ -424,13 +548,38 @@ class _BackgroundCall:
     close = join
 
 
+def write_occurence_file(per, conseq_list, output_file, n_out, read_len, writers: list = None):
+    """the CSV of a (subsampled) hit list; writers (optional list): formatted and written by a background thread appended to the
+    list -- the caller joins it -- instead of before returning.  Lists still resident in HBM are fetched by the writing thread,
+    with byte-sized hit counts (every count is <= 20 there)."""
+    header = "seq_ind;" + ";".join(f"motif_{i}_{c}" for i, c in enumerate(conseq_list)) + ";seq_len"
+    n_cons = len(conseq_list)
+
+    def emit():
+        t0 = time.perf_counter()
+        narrow = bool(per) and all(isinstance(r, ScanHits) and r.unfetched and r.max_hits <= 255 for r in per)
+        host = [r.host_u8() if narrow else tuple(r) for r in per]
+        if os.environ.get("KMAP_IO_TRACE"):
+            print(f"[csv {output_file}] lists fetched in {1e3 * (time.perf_counter() - t0):.1f} ms (start at {t0:.3f})", file=sys.stderr)
+        assert all(len(h) == n_out for h, _ in host)
+        hits_ptrs = (C.c_void_p * max(n_cons, 1))(*[h.ctypes.data for h, _ in host])
+        pos_keep = [np.ascontiguousarray(p, np.int32) if len(p) else np.zeros(1, np.int32) for _, p in host]
+        pos_ptrs = (C.c_void_p * max(n_cons, 1))(*[p.ctypes.data for p in pos_keep])
+        rows = _ffi.i64(0)
+        fn = _ffi.lib().kmap_write_occurrence_csv_u8 if narrow else _ffi.lib().kmap_write_occurrence_csv
+        check(fn(str(output_file).encode(), header.encode(), n_out, n_cons, hits_ptrs, pos_ptrs, ptr(read_len), C.byref(rows)))
+    if writers is not None:
+        writers.append(_BackgroundCall(emit))
+    else:
+        emit()
+
+
 def gen_motif_occurence_file(conseq_list: List[str], motif_def_dict: dict, input_fasta_file, output_file, revcom_mode=True,
                              dev_seq: DeviceSeq = None, write=True, writers: list = None):
     """seq_ind;loc,loc;...;seq_len for every read with a hit.  With `dev_seq` the resident read array is
     scanned (it is the encoding of the same FASTA); otherwise the FASTA is encoded and uploaded here.
     write=False: scan only (the ranks of a read-sharded run that do not own the output files).
-    writers (optional list): the CSV is formatted and written by a background thread appended to the list (the caller joins it;
-    scan_motif: while the next k is counted and scanned) instead of before returning."""
+    writers: see write_occurence_file.  Returns the hit list (entries unpack to (hits_per_read, positions))."""
     own = dev_seq is None
     if own:
         assert Path(input_fasta_file).exists()
@@ -438,23 +587,10 @@ def gen_motif_occurence_file(conseq_list: List[str], motif_def_dict: dict, input
         dev_seq = DeviceSeq(arr, borders)
     try:
         per = scan_motif_occurence(dev_seq, conseq_list, motif_def_dict, revcom_mode, subsample=write)
-        header = "seq_ind;" + ";".join(f"motif_{i}_{c}" for i, c in enumerate(conseq_list)) + ";seq_len"
-        n_cons = len(conseq_list)
-        hits_ptrs = (C.c_void_p * max(n_cons, 1))(*[h.ctypes.data for h, _ in per])
-        pos_keep = [np.ascontiguousarray(p, np.int32) if len(p) else np.zeros(1, np.int32) for _, p in per]
-        pos_ptrs = (C.c_void_p * max(n_cons, 1))(*[p.ctypes.data for p in pos_keep])
+        if own:
+            per = [list(r) for r in per]             # the sequence is closed below: nothing may stay behind in its handles
         if write:
-            assert all(len(h) == dev_seq.out_n_seq for h, _ in per)
-            n_out, read_len = dev_seq.out_n_seq, dev_seq.out_read_len
-
-            def emit(keep=(per, pos_keep, hits_ptrs, pos_ptrs, read_len)):     # the arrays stay alive with the closure
-                rows = _ffi.i64(0)
-                check(_ffi.lib().kmap_write_occurrence_csv(str(output_file).encode(), header.encode(), n_out, n_cons,
-                                                           hits_ptrs, pos_ptrs, ptr(read_len), C.byref(rows)))
-            if writers is not None:
-                writers.append(_BackgroundCall(emit))
-            else:
-                emit()
+            write_occurence_file(per, conseq_list, output_file, dev_seq.out_n_seq, dev_seq.out_read_len, None if own else writers)
         return per
     finally:
         if own:
@@ -707,11 +843,9 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
     rep_mode = config_dict["general"]["repetitive_mode"]
 
     with _stage("load_inputs"):
-        with open(proc_fasta_file_path, "rb") as fh:
-            seq_np_arr = pickle.load(fh)
+        seq_np_arr = load_array_pickle(proc_fasta_file_path)      # large inputs: a read-only view of the mapped file
         boarder_pkl_file = res / FileNameDict["processed_fasta_seqboarder_file"]
-        with open(boarder_pkl_file, "rb") as fh:
-            boarder_mat = pickle.load(fh)
+        boarder_mat = load_array_pickle(boarder_pkl_file)
     n_all_seq = len(boarder_mat)
 
     def resident(arr):
@@ -729,7 +863,7 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
         with open(Path(md["noise_kmer_file"]), "r") as fh:
             noise = [ln.strip() for ln in fh if ln.strip()]
         if noise:
-            seq_np_arr = mask_ham_ball(seq_np_arr, motif_def_dict, noise, [0 for _ in noise])
+            seq_np_arr = mask_ham_ball(np.array(seq_np_arr), motif_def_dict, noise, [0 for _ in noise])   # private copy
         count_seq = resident(seq_np_arr)
 
     top_k, n_trial = md["top_k"], md["n_trial"]
@@ -753,7 +887,9 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
         # best -- the largest k first: its count table (15 GB of k16.pkl at C3) is then fetched and pickled while every other k is
         # counted -- and the per-k files, candidate rows and np.random draws (occurrence subsampling) follow in ascending k
         # exactly as the reference emits them
-        found = {}
+        found, hit_lists, occ_written = {}, {}, set()
+        occ_writers = savers.setdefault("occurrence", [])
+        n_out, out_read_len = scan_seq.out_n_seq, scan_seq.out_read_len
         for kmer_len in sorted(range(min_k, max_k + 1), key=lambda k: (k != max_k, k)):
             count_seq.reset()
             d = motif_def_dict[kmer_len]
@@ -767,15 +903,27 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
                                              save_kmer_cnt_flag=save_here, kmer_cnt_pkl_file=kmer_cnt_file,
                                              boarder_pkl_file=boarder_pkl_file, debug=debug, dev_seq=count_seq,
                                              table_savers=savers, counts_pool=counts_pool)
+            if occ_flag:
+                # the k's occurrence scan right away; if no read needs the > 20-hit draw (np.random: must happen in ascending k),
+                # its CSV writer starts now as well and works while the other k are counted
+                tmp_list = [hash2kmer(kh, kmer_len) for kh in found[kmer_len]]
+                with _stage("occurrence_per_k"):
+                    hit_lists[kmer_len] = scan_hit_lists(scan_seq, tmp_list, motif_def_dict, revcom_mode)
+                    if lead and not needs_draws(hit_lists[kmer_len]):
+                        write_occurence_file(hit_lists[kmer_len], tmp_list, res / FileNameDict["kmer_count_dir"] /
+                                             f"k{kmer_len}.motif_occurence.csv", n_out, out_read_len, occ_writers)
+                        occ_written.add(kmer_len)
         for kmer_len in range(min_k, max_k + 1):
             consensus_kh_dict = found[kmer_len]
             tmp_list = [hash2kmer(kh, kmer_len) for kh in consensus_kh_dict]
             per = None
             if occ_flag:
-                occ_file = res / FileNameDict["kmer_count_dir"] / f"k{kmer_len}.motif_occurence.csv"
-                with _stage("occurrence_per_k"):
-                    per = gen_motif_occurence_file(tmp_list, motif_def_dict, input_fasta_file, occ_file, revcom_mode,
-                                                   dev_seq=scan_seq, write=lead, writers=savers.setdefault("occurrence", []))
+                per = hit_lists.pop(kmer_len)
+                if lead and kmer_len not in occ_written:
+                    with _stage("occurrence_per_k"):
+                        per = subsample_hit_lists(per)
+                        write_occurence_file(per, tmp_list, res / FileNameDict["kmer_count_dir"] /
+                                             f"k{kmer_len}.motif_occurence.csv", n_out, out_read_len, occ_writers)
             for i, kmer_seq in enumerate(tmp_list):
                 candidate_conseq_list.append(kmer_seq)
                 if not lead:
@@ -830,15 +978,22 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
         print("Final consensus sequences generated.")
 
     occurence_file = res / FileNameDict["motif_occurence_file"]
+    want_occ = md["motif_pos_density_flag"] or md["motif_co_occurence_flag"]
     with _stage("occurrence_final"):
-        per_final = gen_motif_occurence_file(final_conseq_list, motif_def_dict, input_fasta_file, occurence_file, revcom_mode,
-                                             dev_seq=scan_seq, write=lead, writers=savers.setdefault("occurrence", []))
+        per_final = scan_motif_occurence(scan_seq, final_conseq_list, motif_def_dict, revcom_mode, subsample=lead)
+        if lead:
+            if want_occ:
+                per_final = [list(r) for r in per_final]       # the report stages below read the lists on this thread
+            write_occurence_file(per_final, final_conseq_list, occurence_file, scan_seq.out_n_seq, scan_seq.out_read_len,
+                                 savers.setdefault("occurrence", []))
     if not lead:                    # everything below is host-side reporting / sampling on the hit list and the k{k}.pkl tables
         if count_seq is not scan_seq:
             count_seq.close()
         scan_seq.close()
         return
-    occ = Occurrence.from_per(per_final, scan_seq.out_read_len)   # the consumers below use the hit list, not the CSV
+    occ = None
+    if want_occ:
+        occ = Occurrence.from_per(per_final, scan_seq.out_read_len)   # the consumers below use the hit list, not the CSV
 
     # the reference also draws pdf figures in these branches (motif_discovery.py:364-425); only the data files are produced
     if md["motif_pos_density_flag"]:
@@ -884,10 +1039,10 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
                 resident=savers.get(kmer_len))
         with open(sample_kmer_pkl_file, "wb") as fh:
             pickle.dump([samp_kh_arr, samp_cnts, samp_label_arr, conseq_list], fh)
-        kmers = np.array([hash2kmer(kh, kmer_len) for kh in samp_kh_arr])
+        kmers = hashes2kmers(samp_kh_arr, kmer_len)
         with open(res / FileNameDict["sample_kmer_txt_file"], "w+") as fh:
-            for kmer, cnt, label in zip(kmers, samp_cnts, samp_label_arr):
-                fh.write(f"{kmer}\t{label}\n" * int(cnt))
+            fh.write("".join(f"{kmer}\t{label}\n" * cnt for kmer, cnt, label in zip(kmers.tolist(), samp_cnts.tolist(),
+                                                                                   samp_label_arr.tolist())))
         print(f"kmers are sampled for visualization. {kmer_len= }, {n_total_sample= }, {n_motif_sample= }")
 
         label_arr = _convert_to_block_arr(samp_label_arr, samp_cnts)

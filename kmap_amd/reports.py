@@ -99,7 +99,10 @@ def _as_occurrence(occ, n_conseq=None) -> Occurrence:
 def get_motif_seq_num(occurence_file_path, motif_index: int):
     """(rows with the motif, total occurrences) -- reference motif_discovery.py:1345-1393"""
     if isinstance(occurence_file_path, list):          # bare hit list from scan_motif_occurence: no container needed
-        hits, pos = occurence_file_path[motif_index]
+        entry = occurence_file_path[motif_index]
+        if hasattr(entry, "n_reads_hit"):               # ScanHits: summary from the device, the list itself is not fetched
+            return int(entry.n_reads_hit), int(entry.total)
+        hits, pos = entry
         return int(np.count_nonzero(hits)), len(pos)    # the positions array holds exactly sum(hits) entries
     hits = _as_occurrence(occurence_file_path).hits[motif_index]
     return int(np.count_nonzero(hits)), int(hits.sum(dtype=np.int64))

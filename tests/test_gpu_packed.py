@@ -142,6 +142,11 @@ def test_packed_scan_vs_oracle(env, k, r):
                 np.testing.assert_array_equal(pos[off:off + m], buf[:m])
                 off += m
             assert off == len(pos)
+            lazy = ds.scan_lazy(k, cons, r, revcom)            # device-resident variant: summary without a fetch, same lists
+            assert (lazy.n_reads_hit, lazy.total, lazy.max_hits) == (int(np.count_nonzero(hits)), len(pos), int(hits.max(initial=0)))
+            h2, p2 = lazy
+            np.testing.assert_array_equal(h2, hits)
+            np.testing.assert_array_equal(p2, pos)
     ds.close()
 
 

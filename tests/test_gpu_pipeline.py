@@ -435,6 +435,53 @@ def test_occurrence_file_with_subsample_golden(tmp_path):
     assert (tmp_path / "o.csv").read_text() == (GOLD / "occ20" / "occ20.motif_occurence.csv").read_text()
 
 
+def test_occurrence_file_lazy_lists_and_background_writer(tmp_path):
+    """the same golden through a resident DeviceSeq: hit lists stay in HBM (ScanHits), the > 20-hit draws fetch them, the CSV is
+    written by a background thread; and a file without such reads goes out with byte-sized hit counts -- equal to the
+    synchronous int32 writer's"""
+    from kmap_amd.kmer_count import encode_fasta, init_motif_def_dict, _pkg_file
+    from kmap_amd.motif_discovery import DeviceSeq, ScanHits, gen_motif_occurence_file, needs_draws, scan_hit_lists
+    mdd = init_motif_def_dict(_pkg_file("default_motif_def_table.csv"))
+    arr, borders = encode_fasta(str(GOLD / "occ20" / "occ20.fa"))
+    ds = DeviceSeq(arr, borders)
+    cons = ["AAAAAAAA", "ACGTACGT", "AACCGGTTAA"]
+    writers = []
+    np.random.seed(77)
+    per = gen_motif_occurence_file(cons, mdd, None, tmp_path / "bg.csv", True, dev_seq=ds, writers=writers)
+    assert len(writers) == 1
+    writers[0].join()
+    assert (tmp_path / "bg.csv").read_text() == (GOLD / "occ20" / "occ20.motif_occurence.csv").read_text()
+    assert all(h.max(initial=0) <= 20 for h, _ in per)
+    lists = scan_hit_lists(ds, cons[1:], mdd, True)                  # no read with > 20 hits of these two
+    assert all(isinstance(r, ScanHits) for r in lists) and not needs_draws(lists)
+    stats = [(r.n_reads_hit, r.total) for r in lists]
+    gen_motif_occurence_file(cons[1:], mdd, None, tmp_path / "u8.csv", True, dev_seq=ds, writers=writers)     # byte counts, background
+    writers[1].join()
+    host = [list(r) for r in lists]                                  # int32 fetch of the other copies
+    assert stats == [(int(np.count_nonzero(h)), len(p)) for h, p in host]
+    from kmap_amd.motif_discovery import write_occurence_file
+    write_occurence_file(host, cons[1:], tmp_path / "i32.csv", ds.out_n_seq, ds.out_read_len)
+    assert (tmp_path / "u8.csv").read_bytes() == (tmp_path / "i32.csv").read_bytes()
+    assert len((tmp_path / "u8.csv").read_text().splitlines()) > 3
+    pending = scan_hit_lists(ds, cons[1:2], mdd, True)[0]
+    ds.close()
+    with pytest.raises(RuntimeError, match="closed before"):         # a list outliving its sequence fails loudly
+        pending.host()
+
+
+def test_scan_motif_deferred_occurrence_path(run_dir, tmp_path, monkeypatch):
+    """scan_motif starts a k's occurrence CSV right after that k's find_motif unless a read needs the > 20-hit draw; then the
+    file waits for its turn in ascending k (np.random order).  Forcing every k down the deferred path must give the same files."""
+    from kmap_amd import motif_discovery as MD
+    monkeypatch.setattr(MD, "needs_draws", lambda per: True)
+    res = _run_c1(tmp_path)
+    names = sorted(p.relative_to(run_dir) for p in run_dir.rglob("*") if p.is_file() and p.name != "low_dim_data.tsv")
+    assert sorted(p.relative_to(res) for p in res.rglob("*") if p.is_file()) == names
+    for rel in names:
+        if rel.suffix in (".csv", ".txt"):
+            assert (run_dir / rel).read_bytes() == (res / rel).read_bytes(), rel
+
+
 def test_second_dataset_repetitive_mode_and_noise_kmers(golden, tmp_path):
     """preproc + scan_motif on a second dataset (tests/golden/scan2: planted motifs, repetitive_mode = true, a noise k-mer
     file masked before counting, k = 6..9) == the files and arrays the reference produced with the same np.random seed"""

@@ -177,3 +177,83 @@ def test_dist_context_can_be_disabled(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "1")
     monkeypatch.delenv("KMAP_DIST_DISABLE")
     assert _dist_context() == (None, 0, False)
+
+
+def test_locate_pickled_array_and_mapped_load(tmp_path):
+    """load_array_pickle maps the payload of a default-protocol ndarray pickle (what preproc writes, reference kmer_count.py:333)
+    and falls back to pickle.load for everything else; either way the values are the pickled ones."""
+    import pickle
+    from kmap_amd.kmer_count import load_array_pickle, locate_pickled_array
+    rng = np.random.default_rng(5)
+    arrays = [rng.integers(0, 256, 3_000_001, dtype=np.uint8), rng.integers(0, 1 << 40, (300_000, 2), dtype=np.int64),
+              rng.integers(0, 1 << 32, 1_000_003, dtype=np.uint32)]
+    for proto in (2, 3, 4, 5, None):
+        for a in arrays:
+            p = tmp_path / "a.pkl"
+            with open(p, "wb") as fh:
+                pickle.dump(a, fh) if proto is None else pickle.dump(a, fh, protocol=proto)
+            loc = locate_pickled_array(p, 1 << 20)
+            if proto in (3, 4, None):
+                off, dt, shape = loc
+                assert dt == a.dtype and shape == a.shape
+                raw = p.read_bytes()[off:off + a.nbytes]
+                assert raw == a.tobytes()
+            else:
+                assert loc is None                      # latin-1 text payload (2) / _frombuffer layout (5): ordinary unpickling
+            b = load_array_pickle(p, 1 << 20)
+            assert b.dtype == a.dtype and b.shape == a.shape and (b == a).all()
+            if loc is not None and loc[0] % a.dtype.itemsize == 0:
+                assert not b.flags.writeable and not b.flags.owndata      # a view of the mapping, not a copy
+    # anything that is not ONE plain C-ordered array is left to pickle
+    for obj in ([arrays[0], arrays[0]], np.asfortranarray(arrays[0][:3_000_000].reshape(2000, 1500)), {"a": arrays[0]},
+                arrays[0][:1000]):
+        p = tmp_path / "o.pkl"
+        with open(p, "wb") as fh:
+            pickle.dump(obj, fh)
+        assert locate_pickled_array(p, 1 << 20) is None
+        back = load_array_pickle(p, 1 << 20)
+        assert type(back) is type(obj)
+    # small files never take the mapped path (default threshold 64 MiB)
+    with open(tmp_path / "s.pkl", "wb") as fh:
+        pickle.dump(arrays[0], fh)
+    assert load_array_pickle(tmp_path / "s.pkl").flags.owndata or load_array_pickle(tmp_path / "s.pkl").flags.writeable
+
+
+def test_hashes2kmers_matches_scalar():
+    from kmap_amd.kmer_count import hash2kmer, hashes2kmers
+    for k in (1, 6, 8, 15, 16, 20, 31):
+        h = np.random.default_rng(k).integers(0, 4 ** k, 500, dtype=np.uint64)
+        a, b = hashes2kmers(h, k), np.array([hash2kmer(x, k) for x in h])
+        assert a.dtype == b.dtype and (a == b).all()
+
+
+@pytest.mark.parametrize("narrow", [False, True])
+def test_occurrence_csv_writer_matches_python_formatting(tmp_path, narrow):
+    """kmap_write_occurrence_csv{,_u8} (host code of the C-ABI library): rows `seq_ind;loc,loc;...;seq_len` for reads with a hit
+    (reference motif_discovery.py:1396-1419), numbers on both sides of the 4- and 8-digit fast paths of the formatter"""
+    import ctypes as C
+    from kmap_amd import _ffi
+    rng = np.random.default_rng(11)
+    n_seq, n_cons = 150_000, 3
+    read_len = rng.choice([7, 150, 9999, 10_000, 123_456, 99_999_999, 100_000_000, 3_000_000_000], n_seq).astype(np.int64)
+    hits, pos = [], []
+    for c in range(n_cons):
+        h = rng.choice([0, 0, 0, 1, 2, 5, 20], n_seq).astype(np.int32)
+        h[rng.integers(0, n_seq, 50)] = 0
+        p = rng.choice([0, 9, 10, 99, 100, 999, 1000, 9999, 10_000, 10_001, 99_999, 12_345_678, 99_999_999, 100_000_000,
+                        2_147_483_647], int(h.sum())).astype(np.int32)
+        hits.append(h.astype(np.uint8) if narrow else h)
+        pos.append(p)
+    header = "seq_ind;" + ";".join(f"motif_{i}_ACGT" for i in range(n_cons)) + ";seq_len"
+    out = tmp_path / "o.csv"
+    rows = _ffi.i64(0)
+    fn = _ffi.lib().kmap_write_occurrence_csv_u8 if narrow else _ffi.lib().kmap_write_occurrence_csv
+    _ffi.check(fn(str(out).encode(), header.encode(), n_seq, n_cons, (C.c_void_p * n_cons)(*[h.ctypes.data for h in hits]),
+                  (C.c_void_p * n_cons)(*[p.ctypes.data for p in pos]), _ffi.ptr(read_len), C.byref(rows)))
+    offs = [np.concatenate([[0], np.cumsum(h, dtype=np.int64)]) for h in hits]
+    want = [header]
+    for i in np.nonzero(np.sum([h > 0 for h in hits], axis=0))[0]:
+        cells = [",".join(str(v) for v in pos[c][offs[c][i]:offs[c][i + 1]]) for c in range(n_cons)]
+        want.append(f"{i};" + ";".join(cells) + f";{read_len[i]}")
+    assert rows.value == len(want) - 1
+    assert out.read_text() == "\n".join(want) + "\n"
