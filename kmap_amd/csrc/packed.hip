@@ -287,6 +287,233 @@ __global__ __launch_bounds__(KMAP_WAVE *DS_WAVES) void dedupe_skip_packed_kernel
         }
     }
 }
+
+// Second kernel, written after the PMC passes on the one above (tools/pmc_dedupe.sh): 349 scalar + 206 vector instructions
+// per read against 18 LDS instructions -- the CU's single scalar unit was the bound (0.86 scalar instructions per clock and
+// CU), not the LDS atomics: wave-uniform values (read index, borders, table size) were computed per lane in 64 bits under
+// divergent loops, and every probe round of the open-addressing set is a dozen mask operations.  (A set without atomics --
+// store, read back, lanes decide who owns the slot -- was built and measured too: 3.3 rounds per 64 windows, 7.5 ms.)
+// Here: * the set is a BITMAP in LDS indexed by the k-mer itself (4^k bits, k <= 8: exact) or by 16 hashed bits (k >= 9),
+//         one returning ds_or per window: the lane that finds its bit clear keeps the k-mer, no probing, no loop;
+//       * hashed mode: a lane that finds its bit set is only a candidate (143 windows in 65 536 bits: ~0.15 false positives
+//         per read).  Candidates are confirmed exactly, one at a time, against all windows of the read up to this step
+//         (recomputed from the packed codes): duplicate iff another window with the same k-mer claimed a bit, or starts earlier;
+//       * waves are persistent (a grid-stride loop over the reads), everything wave-uniform is scalar, positions are 32-bit
+//         offsets from the read's first skip word.
+constexpr int DB_HASH_WORDS = 1024;     // hashed bitmap: 32 768 bits per wave (143 windows: ~0.3 false positives per read)
+constexpr int DB_MAXSTEPS = (DS_CAP + 31 + 63) / 64;
+struct DbRead {                         // a read as the dedupe kernel sees it (all wave-uniform)
+    const uint32_t *crd;                // codes of the group holding the read's first skip word
+    const uint16_t *ird;
+    uint32_t *srd;                      // the read's first skip word
+    int lo, hi;                         // the read's positions as offsets from that word's first position: [lo, hi)
+    int gmax;                           // last group (offset) a window of the read starts in
+    int nsteps;                         // 64-position steps; 0 = nothing to do
+};
+__device__ __forceinline__ DbRead db_read(const uint32_t *codes, const uint16_t *inval, uint32_t *skip, int64_t n, int64_t st, int64_t en) {
+    if (st < 0) st = 0;
+    if (en > n) en = n;
+    const int64_t a0 = st & ~(int64_t)31;
+    DbRead g;
+    g.crd = codes + (a0 >> 4);
+    g.ird = inval + (a0 >> 4);
+    g.srd = skip + (a0 >> 5);
+    g.lo = (int)(st - a0);
+    g.hi = (int)(en - a0);
+    g.gmax = g.hi > 0 ? (g.hi - 1) >> 4 : 0;
+    g.nsteps = en - st <= 1 ? 0 : (g.hi + 63) >> 6;                       // a read of one window has no duplicate
+    return g;
+}
+// the two groups a window starting at offset o needs (lanes behind the read are clamped into the arrays and come out invalid).
+// Raw: nothing may be computed from the loaded registers before the window is used, or the prefetch of the next read turns into
+// a load-and-wait (s_waitcnt sits where the first use is).
+struct DbRaw {
+    uint32_t c0, c1;                    // codes of groups g, g + 1
+    uint16_t f0, f1;                    // their invalid flags
+};
+__device__ __forceinline__ void db_load(const DbRead &g, int o, DbRaw &w) {
+    const int gi = min(o >> 4, g.gmax);
+    w.c0 = g.crd[gi];
+    w.c1 = g.crd[gi + 1];
+    w.f0 = g.ird[gi];
+    w.f1 = g.ird[gi + 1];
+}
+__device__ __forceinline__ bool db_window(const DbRead &g, int o, const DbRaw &w, int k, uint32_t kbits, uint64_t kones, uint32_t &h) {
+    const int i = o & 15;
+    const uint64_t t0 = ((uint64_t)w.c0 << 32) | w.c1;
+    const uint64_t fl = ((uint64_t)w.f0 << 16) | w.f1;                    // 32 invalid flags, position 0 in bit 31
+    h = (uint32_t)((t0 << (2 * i)) >> (64 - 2 * k)) & kbits;              // k <= 16: the window lies in groups g, g + 1
+    const bool bad = ((fl >> (32 - i - k)) & kones) != 0;
+    return o >= g.lo && o < g.hi && !bad;
+}
+
+template <bool EXACT>
+__global__ __launch_bounds__(KMAP_WAVE *DS_WAVES) void dedupe_bitmap_packed_kernel(const uint32_t *__restrict__ codes,
+                                                                                   const uint16_t *__restrict__ inval, int64_t n,
+                                                                                   const int64_t *__restrict__ borders, int64_t n_seq,
+                                                                                   int k, uint32_t *__restrict__ skip, int bw) {
+    extern __shared__ uint4 db_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int per_wave = bw + (EXACT ? 0 : 2 * DB_MAXSTEPS + 2);         // words: bitmap (+ the steps' claim masks)
+    uint32_t *bm = reinterpret_cast<uint32_t *>(db_raw) + (size_t)wave * ((per_wave + 3) & ~3);
+    unsigned long long *claims = reinterpret_cast<unsigned long long *>(bm + bw);
+    const uint32_t kbits = k < 16 ? (1u << (2 * k)) - 1u : ~0u;
+    const uint64_t kones = (1ull << k) - 1ull;
+    const int64_t n_waves = (int64_t)gridDim.x * DS_WAVES;
+    constexpr int NB = 3;
+    int64_t r = (int64_t)blockIdx.x * DS_WAVES + wave;
+    if (r >= n_seq) return;
+    {   // the bitmap is zeroed once; after a read every lane zeroes the words it touched (3 scattered stores instead of bw / 256
+        // 16-byte stores per lane: the LDS pipe is the busiest unit of this kernel)
+        uint4 *b4 = reinterpret_cast<uint4 *>(bm);
+        const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+        for (int t = lane; t < bw / 4; t += 64) b4[t] = zero;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // two-deep software pipeline over the wave's reads: while read i is hashed and inserted, the window loads of read i+1 and
+    // the border load of read i+2 are in flight (one read at a time left ~9000 clocks of exposed latency per read: scalar
+    // load -> window loads -> LDS atomics, with 20 waves per CU)
+    // Borders come through VECTOR loads, 64 reads at a time (lane l holds the borders of the read this wave handles l
+    // iterations into the batch) and reach the scalar registers by v_readlane.  As scalar loads they shared the lgkm counter
+    // with the LDS atomics: every wait for an atomic's result also waited for the border load of two reads ahead (~1 us).
+    auto batch = [&](int64_t b, int64_t &vst, int64_t &ven) {
+        const int64_t rr = r + (b * 64 + lane) * n_waves;
+        vst = 0;
+        ven = 0;
+        if (rr < n_seq) {
+            vst = borders[2 * rr];
+            ven = borders[2 * rr + 1];
+        }
+    };
+    auto lane64 = [](int64_t v, int l) -> int64_t {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), l);
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    int64_t cst, cen, xst, xen;                                           // current and next batch
+    batch(0, cst, cen);
+    batch(1, xst, xen);
+    int64_t it = 0;                                                       // iteration = index into the wave's reads
+    DbRead G = db_read(codes, inval, skip, n, lane64(cst, 0), lane64(cen, 0));
+    DbRaw W[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) db_load(G, c * 64 + lane, W[c]);
+    int64_t rn = r + n_waves;
+    for (;;) {
+        const bool has_next = rn < n_seq;                                 // wave-uniform
+        DbRead Gn = G;
+        DbRaw Wn[NB];
+        if (has_next) {
+            const int l = (int)((it + 1) & 63);
+            if (l == 0) {                                                 // the next read opens a new batch
+                cst = xst;
+                cen = xen;
+                batch((it + 1) / 64 + 1, xst, xen);
+            }
+            Gn = db_read(codes, inval, skip, n, lane64(cst, l), lane64(cen, l));
+        }
+        // always NB loads, on every path (clamped into the read; for the last read they repeat the current one): with a load
+        // count that depends on a branch the compiler waits with vmcnt(0) before the current read's windows are used, i.e. for
+        // the loads just issued
+#pragma unroll
+        for (int c = 0; c < NB; ++c) db_load(Gn, c * 64 + lane, Wn[c]);
+        const int64_t rnn = rn + n_waves;
+        if (G.nsteps) {
+            int touched[NB];                                              // word index per prefetched step, -1 = none
+#pragma unroll
+            for (int c = 0; c < NB; ++c) touched[c] = -1;
+            for (int c0 = 0; c0 < G.nsteps; c0 += NB) {
+                if (c0) {                                                 // reads longer than the prefetched steps
+#pragma unroll
+                    for (int c = 0; c < NB; ++c)
+                        if (c0 + c < G.nsteps) db_load(G, (c0 + c) * 64 + lane, W[c]);
+                }
+                // the batch's atomics go out back to back (steps behind the read: all lanes invalid, nothing issued), then
+                // their results are looked at: one LDS round trip per batch instead of one per step
+                uint32_t h[NB], old[NB], bit[NB];
+                bool valid[NB];
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    valid[c] = db_window(G, (c0 + c) * 64 + lane, W[c], k, kbits, kones, h[c]) && c0 + c < G.nsteps;
+                    const uint32_t idx = EXACT ? h[c] : (h[c] * 0x9E3779B1u) >> 17;
+                    bit[c] = 1u << (idx & 31);
+                    old[c] = 0;
+                    if (valid[c]) old[c] = atomicOr(&bm[idx >> 5], bit[c]);
+                    if (c0 == 0) touched[c] = valid[c] ? (int)(idx >> 5) : -1;
+                }
+                unsigned long long claim[NB];
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    const int cs = c0 + c;
+                    if (cs >= G.nsteps) break;                            // wave-uniform
+                    const bool saw_set = valid[c] && (old[c] & bit[c]);
+                    unsigned long long m = __ballot(saw_set);
+                    if (!EXACT) {
+                        claim[c] = __ballot(valid[c] && !saw_set);
+                        if (G.nsteps > NB && lane == 0) claims[cs] = claim[c];   // long reads: later batches look the masks up in LDS
+                        unsigned long long cand = m;
+                        m = 0;
+                        while (cand) {                                    // scalar loop, rarely entered
+                            const int y = __builtin_ctzll(cand);
+                            cand &= cand - 1;
+                            const uint32_t hc = (uint32_t)__builtin_amdgcn_readlane((int)h[c], y);
+                            const int py = cs * 64 + y;
+                            bool found = false;
+                            for (int c2 = 0; c2 <= cs && !found; ++c2) {
+                                const int o2 = c2 * 64 + lane;
+                                uint32_t h2;
+                                bool v2;
+                                unsigned long long cl2;
+                                if (c2 >= c0) {                           // a step of this batch: still in registers
+                                    const int j = c2 - c0;
+                                    h2 = j == 0 ? h[0] : j == 1 ? h[1] : h[2];
+                                    v2 = j == 0 ? valid[0] : j == 1 ? valid[1] : valid[2];
+                                    cl2 = j == 0 ? claim[0] : j == 1 ? claim[1] : claim[2];
+                                } else {
+                                    DbRaw w2;
+                                    db_load(G, o2, w2);
+                                    v2 = db_window(G, o2, w2, k, kbits, kones, h2);
+                                    cl2 = claims[c2];
+                                }
+                                const bool match = v2 && h2 == hc && o2 != py && (((cl2 >> lane) & 1ull) || o2 < py);
+                                found = __any(match);
+                            }
+                            if (found) m |= 1ull << y;
+                        }
+                    }
+                    if (m) {                                              // wave-uniform
+                        if (lane < 2) {
+                            const uint32_t bits = __builtin_bitreverse32(lane ? (uint32_t)(m >> 32) : (uint32_t)m);   // lane l of the half -> bit 31-l
+                            const int w0 = cs * 64 + 32 * lane;           // first position (offset) of this word
+                            if (bits) {
+                                if (w0 < G.lo || w0 + 32 > G.hi) atomicOr(&G.srd[w0 >> 5], bits);   // shared with a neighbouring read
+                                else G.srd[w0 >> 5] = bits;
+                            }
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (G.nsteps <= NB) {
+#pragma unroll
+                for (int c = 0; c < NB; ++c)
+                    if (touched[c] >= 0) bm[touched[c]] = 0u;
+            } else {                                                      // long read: the whole bitmap
+                uint4 *b4 = reinterpret_cast<uint4 *>(bm);
+                const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+                for (int t = lane; t < bw / 4; t += 64) b4[t] = zero;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (!has_next) break;
+        G = Gn;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) W[c] = Wn[c];
+        rn = rnn;
+        ++it;
+    }
+}
 __global__ __launch_bounds__(BLK) void max_read_len_kernel(const int64_t *__restrict__ borders, int64_t n_seq, int64_t n,
                                                            unsigned long long *__restrict__ out) {
     unsigned long long m = 0;
@@ -744,8 +971,31 @@ int dedupe_skip_bits(const uint32_t *codes_dev, const uint16_t *inval_dev, int64
     KMAP_CHECK_HIP(hipStreamSynchronize(st));
     if (max_len > (unsigned long long)DS_CAP) return KMAP_OK;
     const unsigned grid = (unsigned)((n_seq + DS_WAVES - 1) / DS_WAVES);
-    if (k == 16) dedupe_skip_packed_kernel<true><<<grid, KMAP_WAVE * DS_WAVES, 0, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, skip);
-    else dedupe_skip_packed_kernel<false><<<grid, KMAP_WAVE * DS_WAVES, 0, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, skip);
+    static const bool cas_set = [] { const char *e = getenv("KMAP_DEDUPE_SET"); return e && !strcmp(e, "cas"); }();   // A/B: r02's first kernel
+    if (cas_set) {
+        if (k == 16) dedupe_skip_packed_kernel<true><<<grid, KMAP_WAVE * DS_WAVES, 0, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, skip);
+        else dedupe_skip_packed_kernel<false><<<grid, KMAP_WAVE * DS_WAVES, 0, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, skip);
+    } else {
+        static const int exact_max_k = getenv("KMAP_DEDUPE_EXACT_MAXK") ? atoi(getenv("KMAP_DEDUPE_EXACT_MAXK")) : 8;
+        const bool exact = k <= std::min(8, exact_max_k);                 // 4^k bits fit the per-wave bitmap
+        const int bw = exact ? std::max(4, (int)((1u << (2 * k)) >> 5)) : DB_HASH_WORDS;
+        const int per_wave = (bw + (exact ? 0 : 2 * DB_MAXSTEPS + 2) + 3) & ~3;
+        const size_t lds = (size_t)DS_WAVES * per_wave * 4;
+        // persistent grid = exactly the blocks that are resident at once (one more would run as a second round)
+        int dev = 0, cus = 0, per_cu = 0;
+        KMAP_CHECK_HIP(hipGetDevice(&dev));
+        KMAP_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (exact) KMAP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dedupe_bitmap_packed_kernel<true>, KMAP_WAVE * DS_WAVES, lds));
+        else KMAP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dedupe_bitmap_packed_kernel<false>, KMAP_WAVE * DS_WAVES, lds));
+        static const int per_cu_env = getenv("KMAP_DEDUPE_BLOCKS_PER_CU") ? atoi(getenv("KMAP_DEDUPE_BLOCKS_PER_CU")) : 0;
+        per_cu = std::max(1, std::min(per_cu, (int)((size_t)(156 << 10) / lds)));   // the query says 5 x 32 KiB fit a CU; measured: 4 do (the fifth block runs as a second round, 6.3 -> 8.2 ms)
+        if (per_cu_env > 0) per_cu = per_cu_env;
+        const unsigned pgrid = (unsigned)std::min<int64_t>((n_seq + DS_WAVES - 1) / DS_WAVES, (int64_t)cus * per_cu);
+        static const bool trace = getenv("KMAP_DEDUPE_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "[dedupe] k=%d exact=%d lds=%zu blocks/CU=%d grid=%u\n", k, (int)exact, lds, per_cu, pgrid);
+        if (exact) dedupe_bitmap_packed_kernel<true><<<pgrid, KMAP_WAVE * DS_WAVES, lds, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, skip, bw);
+        else dedupe_bitmap_packed_kernel<false><<<pgrid, KMAP_WAVE * DS_WAVES, lds, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, skip, bw);
+    }
     KMAP_CHECK_HIP(hipGetLastError());
     *skip_out = skip;
     return KMAP_OK;
