@@ -377,25 +377,47 @@ __global__ __launch_bounds__(KMAP_WAVE *DS_WAVES) void dedupe_bitmap_packed_kern
     // Borders come through VECTOR loads, 64 reads at a time (lane l holds the borders of the read this wave handles l
     // iterations into the batch) and reach the scalar registers by v_readlane.  As scalar loads they shared the lgkm counter
     // with the LDS atomics: every wait for an atomic's result also waited for the border load of two reads ahead (~1 us).
-    auto batch = [&](int64_t b, int64_t &vst, int64_t &ven) {
+    // The geometry of a read (db_read: ~45 scalar instructions) is computed here too, by the lane that loaded the borders -- 64
+    // reads per vector instruction -- and travels as three addresses and one packed word: 7 v_readlane + 4 s_bfe per read.
+    struct Batch {
+        uint64_t crd, ird, srd;
+        uint32_t pk;                    // lo | hi << 5 | gmax << 16 | nsteps << 24
+    };
+    auto batch = [&](int64_t b, Batch &B) {
         const int64_t rr = r + (b * 64 + lane) * n_waves;
-        vst = 0;
-        ven = 0;
+        int64_t st = 0, en = 0;
         if (rr < n_seq) {
-            vst = borders[2 * rr];
-            ven = borders[2 * rr + 1];
+            st = borders[2 * rr];
+            en = borders[2 * rr + 1];
         }
+        const DbRead g = db_read(codes, inval, skip, n, st, en);
+        B.crd = (uint64_t)g.crd;
+        B.ird = (uint64_t)g.ird;
+        B.srd = (uint64_t)g.srd;
+        B.pk = (uint32_t)g.lo | ((uint32_t)g.hi << 5) | ((uint32_t)g.gmax << 16) | ((uint32_t)g.nsteps << 24);
     };
-    auto lane64 = [](int64_t v, int l) -> int64_t {
+    auto lane64 = [](uint64_t v, int l) -> uint64_t {
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), l);
-        return (int64_t)(((uint64_t)hi << 32) | lo);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+        return ((uint64_t)hi << 32) | lo;
     };
-    int64_t cst, cen, xst, xen;                                           // current and next batch
-    batch(0, cst, cen);
-    batch(1, xst, xen);
+    auto pick = [&](const Batch &B, int l) -> DbRead {
+        DbRead g;
+        g.crd = reinterpret_cast<const uint32_t *>(lane64(B.crd, l));
+        g.ird = reinterpret_cast<const uint16_t *>(lane64(B.ird, l));
+        g.srd = reinterpret_cast<uint32_t *>(lane64(B.srd, l));
+        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)B.pk, l);
+        g.lo = (int)(pk & 31u);
+        g.hi = (int)((pk >> 5) & 2047u);
+        g.gmax = (int)((pk >> 16) & 255u);
+        g.nsteps = (int)(pk >> 24);
+        return g;
+    };
+    Batch cur, nxt;                                                       // current and next batch of 64 reads
+    batch(0, cur);
+    batch(1, nxt);
     int64_t it = 0;                                                       // iteration = index into the wave's reads
-    DbRead G = db_read(codes, inval, skip, n, lane64(cst, 0), lane64(cen, 0));
+    DbRead G = pick(cur, 0);
     DbRaw W[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) db_load(G, c * 64 + lane, W[c]);
@@ -407,11 +429,10 @@ __global__ __launch_bounds__(KMAP_WAVE *DS_WAVES) void dedupe_bitmap_packed_kern
         if (has_next) {
             const int l = (int)((it + 1) & 63);
             if (l == 0) {                                                 // the next read opens a new batch
-                cst = xst;
-                cen = xen;
-                batch((it + 1) / 64 + 1, xst, xen);
+                cur = nxt;
+                batch((it + 1) / 64 + 1, nxt);
             }
-            Gn = db_read(codes, inval, skip, n, lane64(cst, l), lane64(cen, l));
+            Gn = pick(cur, l);
         }
         // always NB loads, on every path (clamped into the read; for the last read they repeat the current one): with a load
         // count that depends on a branch the compiler waits with vmcnt(0) before the current read's windows are used, i.e. for
