@@ -161,8 +161,34 @@ __global__ __launch_bounds__(LDSMODE ? HP_TPB : BLK) void hist_packed_kernel(con
     const uint64_t kmask = low_mask<uint64_t>(k);
     const int64_t n_groups = (n + 15) >> 4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += stride) {
-        const Win w = load_win(codes, inval, g);
+    // software pipeline: the loads of the thread's NEXT group are issued before the 16 windows of the current one are counted
+    // (raw registers, nothing derived from them before their turn, the same number of loads on every path -- otherwise the
+    // compiler waits for them where they are issued).  Without it every iteration exposed one memory round trip: 360
+    // iterations x ~1.6 us = the 0.59 ms a pass took, at 50 % VALU utilisation and 75 % of the wave-cycles waiting (PMC).
+    const int64_t g_first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t g_last = n_groups - 1;
+    uint32_t nc0 = 0, nc1 = 0, nc2 = 0, nsk = 0;
+    uint16_t nf0 = 0, nf1 = 0, nf2 = 0;
+    const uint32_t *skp = skip ? skip : codes;    // the skip word travels with the windows; without skip bits: any valid word, ignored
+    if (n_groups > 0) {
+        const int64_t gl = g_first < n_groups ? g_first : g_last;
+        nc0 = codes[gl]; nc1 = codes[gl + 1]; nc2 = codes[gl + 2];
+        nf0 = inval[gl]; nf1 = inval[gl + 1]; nf2 = inval[gl + 2];
+        nsk = skp[gl >> 1];
+    }
+    const uint32_t dummy = (uint32_t)HP_BINS + (threadIdx.x & 63u);   // LDSMODE: this lane's private bin behind the table
+    for (int64_t g = g_first; g < n_groups; g += stride) {
+        Win w;
+        w.t0 = ((uint64_t)nc0 << 32) | nc1;
+        w.c2 = nc2;
+        w.m = ((uint64_t)nf0 << 32) | ((uint64_t)nf1 << 16) | nf2;
+        const uint32_t sk16 = skip ? ((nsk >> ((g & 1) ? 0 : 16)) & 0xFFFFu) : 0u;   // skip16_of(skip, g)
+        {
+            const int64_t gn = g + stride < n_groups ? g + stride : g_last;      // clamped: the last round re-reads a valid group
+            nc0 = codes[gn]; nc1 = codes[gn + 1]; nc2 = codes[gn + 2];
+            nf0 = inval[gn]; nf1 = inval[gn + 1]; nf2 = inval[gn + 2];
+            nsk = skp[gn >> 1];
+        }
         if ((w.m >> 32) == 0xFFFFull) continue;   // group entirely invalid (cheap skip of masked regions)
         if constexpr (LDSMODE && !WIDE) {
             // 32-bit fast path (k <= 16): window i = bits [63-2i, 64-2i-2k) of t0 -> one v_alignbit + one shift; the 16
@@ -174,20 +200,23 @@ __global__ __launch_bounds__(LDSMODE ? HP_TPB : BLK) void hist_packed_kernel(con
                 bad |= bad << step;
                 have += step;
             }
-            const uint32_t bad16 = (uint32_t)(bad >> 32) | skip16_of(skip, g);   // windows 0..15 in bits 15..0 (+ per-read duplicates)
+            const uint32_t bad16 = (uint32_t)(bad >> 32) | sk16;   // windows 0..15 in bits 15..0 (+ per-read duplicates)
             const uint32_t hi = (uint32_t)(w.t0 >> 32), lo = (uint32_t)w.t0;
             const uint32_t b0 = (uint32_t)bin0;
             const int sh = 32 - 2 * k;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const uint32_t top = (i == 0) ? hi : __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * i);
-                uint32_t a = (top >> sh) - b0;
-                a = ((bad16 >> (15 - i)) & 1u) ? 0xFFFFFFFFu : a;
-                if (a < (uint32_t)HP_BINS) atomicAdd(&lb[a], 1u);
+                // no branch, no exec mask per window (a pass was bound by instruction issue: ~10 instructions per window, two of
+                // them scalar): a window that is invalid (sign-extended flag bit ORed in) or belongs to another pass's bin range
+                // lands, by one unsigned min, in the lane's private bin behind the table
+                uint32_t a = ((top >> sh) - b0) | (uint32_t)__builtin_amdgcn_sbfe((int)bad16, 15 - i, 1);
+                a = a < dummy ? a : dummy;
+                atomicAdd(&lb[a], 1u);
             }
             continue;
         }
-        const uint32_t sk = skip16_of(skip, g);
+        const uint32_t sk = sk16;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             bool bad;
@@ -1071,9 +1100,9 @@ int kmap_counts_hist_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const
         const size_t n_bins = (size_t)1 << (2 * k);
         const size_t passes = (n_bins + HP_BINS - 1) / HP_BINS;
         if (passes <= 32 && n >= (1 << 16)) {   // k <= 10: 32 passes x 0.375 B/position still beat scattered device atomics
-            KMAP_TRY(kmap_allow_lds((const void *)hist_packed_kernel<false, true>, HP_BINS * 4));
+            KMAP_TRY(kmap_allow_lds((const void *)hist_packed_kernel<false, true>, (HP_BINS + 64) * 4));
             for (size_t p = 0; p < passes; ++p)
-                hist_packed_kernel<false, true><<<256, HP_TPB, HP_BINS * 4, st>>>(codes_dev, inval_dev, n, k,
+                hist_packed_kernel<false, true><<<256, HP_TPB, (HP_BINS + 64) * 4, st>>>(codes_dev, inval_dev, n, k,
                                                                                   (uint64_t)p * HP_BINS, c->bins, skip);
         } else {
             int64_t g = ((n + 15) / 16 + BLK - 1) / BLK;

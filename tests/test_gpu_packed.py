@@ -219,3 +219,30 @@ def test_two_level_partitioned_counts_vs_oracle(env, k):
         assert u[-1] == 0xFFFFFFFF and c[-1] > 1000        # the all-T 16-mer is present and counted
     dc.close()
     ds.close()
+
+
+@pytest.mark.parametrize("k", [6, 8, 9, 10])
+def test_lds_histogram_hot_bins(env, k):
+    """LDS-pass histogram under extreme skew: 12 M positions, 85 % of them poly-A (plus poly-T and random reads), so one bin takes
+    > 8 M of the counts and every wave's lanes hit the same LDS word; windows of other passes' bin ranges and invalid windows go
+    to the lanes' private bins behind the table.  Counts must equal the oracle's, with and without per-read dedupe."""
+    _ffi, DeviceCounts, DeviceSeq, O = env
+    rng = np.random.default_rng(500 + k)
+    seq, borders = synth(rng, 60_000, 190, 210, p_n=0.001)
+    for r in range(len(borders)):
+        st, en = borders[r]
+        if r % 20 < 17:
+            seq[st:en] = 0                                      # poly-A
+        elif r % 20 == 17:
+            seq[st:en] = 3                                      # poly-T
+    ds, dc = DeviceSeq(seq, borders), DeviceCounts()
+    for dedupe in (False, True):
+        ds.count(dc, k, dedupe=dedupe, merge_revcom=False)
+        u, c = dc.fetch()
+        ou, oc = O.count_kmers(seq, borders, k, rep_mode=not dedupe, revcom_mode=False)
+        np.testing.assert_array_equal(u, ou)
+        np.testing.assert_array_equal(c, oc)
+        if not dedupe:
+            assert c.max() > 8_000_000
+    dc.close()
+    ds.close()
