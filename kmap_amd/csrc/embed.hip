@@ -226,21 +226,22 @@ int launch_knn_rows(const uint8_t *D_dev, int64_t ldd, const int32_t *nb_dev, co
     return KMAP_OK;
 }
 
-// k-NN selection on uint8 rows: wave per row.  Pass 1 histograms the row's values (LDS, 256 bins per wave);
-// the threshold value t is where the cumulative count reaches n_nb; pass 2 walks the row in index order and
-// takes every entry < t plus the first (n_nb - count_lt) entries == t (ballot-ordered compaction).
+// k-NN selection on uint8 rows: wave per row.  The threshold value t is where the cumulative count of the row's values reaches
+// n_nb; the row's entries < t are taken, plus the first (n_nb - count_lt) entries == t in index order.
+// Generic rows (any byte values; the fallback): pass 1 histograms the row in LDS (256 bins per wave, atomics), pass 2 walks the
+// row 64 entries at a time with ballot-ordered compaction.  That was the only kernel in r01 / early r02 and took 6.4 ms at
+// N = 50 000: a Hamming row holds ~9 distinct values, so all 64 lanes hit the same few LDS words, and same-address LDS atomics
+// run at ~0.1 lane per clock (tools/probes/lds_atomic_rate.hip: 8-10 lanes per clock on distinct addresses).
+// Fast rows (16-byte aligned pitch, every value < 32 -- Hamming distances of k < 32 always are): lane-private counters
+// bins[value][lane] (plain ds_add on 64 different words, 33 x 64 counters per wave), 16 bytes per lane and load; pass 2 tests 16
+// bytes per lane with SWAR compares (bytes < t, bytes == t) and only the rare steps that hold a selected entry (20 of 50 000)
+// leave the wave-uniform fast path.
 constexpr int SEL_WAVES = 4;
-__global__ __launch_bounds__(KMAP_WAVE *SEL_WAVES) void knn_select_kernel(const uint8_t *__restrict__ D, int64_t ldd,
-                                                                           int64_t n, int n_nb, int64_t row0, int64_t nrows,
-                                                                           int32_t *__restrict__ nb) {
-    __shared__ uint32_t hist[SEL_WAVES][256];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t lr = (int64_t)blockIdx.x * SEL_WAVES + wave;
-    if (lr >= nrows) return;
-    uint32_t *h = hist[wave];
+constexpr int SEL_VALS = 33;                    // values 0..31 + one bin for "32 and above" (such a row takes the generic path)
+__device__ __forceinline__ void knn_select_row_generic(const uint8_t *__restrict__ row, int64_t n, int n_nb, uint32_t *h, int lane,
+                                                       int32_t *__restrict__ out) {
     for (int b = lane; b < 256; b += 64) h[b] = 0;
     __builtin_amdgcn_wave_barrier();
-    const uint8_t *row = D + (row0 + lr) * ldd;
     for (int64_t j = lane; j < n; j += 64) atomicAdd(&h[row[j]], 1u);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -254,7 +255,6 @@ __global__ __launch_bounds__(KMAP_WAVE *SEL_WAVES) void knn_select_kernel(const 
     }
     uint32_t quota_eq = (uint32_t)n_nb - below;   // entries == t still to take (n >= n_nb guaranteed by the host)
     uint32_t written = 0;
-    int32_t *out = nb + lr * n_nb;
     for (int64_t j0 = 0; j0 < n && written < (uint32_t)n_nb; j0 += 64) {
         const int64_t j = j0 + lane;
         const int v = (j < n) ? (int)row[j] : 256;
@@ -268,6 +268,137 @@ __global__ __launch_bounds__(KMAP_WAVE *SEL_WAVES) void knn_select_kernel(const 
         const uint32_t take_eq = (uint32_t)__popcll(m_eq) < quota_eq ? (uint32_t)__popcll(m_eq) : quota_eq;
         quota_eq -= take_eq;
         written += n_lt + take_eq;
+    }
+}
+// bit 7 of every byte of x that is < t / == t (bytes and t below 128; T = t in every byte)
+__device__ __forceinline__ uint32_t swar_lt(uint32_t x, uint32_t T) { return ~((x | 0x80808080u) - T) & 0x80808080u; }
+__device__ __forceinline__ uint32_t swar_eq(uint32_t x, uint32_t T) { return ~(((x ^ T) | 0x80808080u) - 0x01010101u) & 0x80808080u; }
+// bits 7, 15, 23, 31 of m -> bits 0..3
+__device__ __forceinline__ uint32_t swar_pack4(uint32_t m) { return (((m >> 7) * 0x00204081u) >> 21) & 0xFu; }
+
+__global__ __launch_bounds__(KMAP_WAVE *SEL_WAVES) void knn_select_kernel(const uint8_t *__restrict__ D, int64_t ldd,
+                                                                           int64_t n, int n_nb, int64_t row0, int64_t nrows,
+                                                                           int32_t *__restrict__ nb, int aligned) {
+    __shared__ uint32_t bins[SEL_WAVES][SEL_VALS * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t lr = (int64_t)blockIdx.x * SEL_WAVES + wave;
+    if (lr >= nrows) return;
+    uint32_t *h = bins[wave];
+    const uint8_t *row = D + (row0 + lr) * ldd;
+    int32_t *out = nb + lr * n_nb;
+    if (!aligned) {
+        knn_select_row_generic(row, n, n_nb, h, lane, out);
+        return;
+    }
+#pragma unroll
+    for (int v = 0; v < SEL_VALS; ++v) h[v * 64 + lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const uint4 *row4 = reinterpret_cast<const uint4 *>(row);
+    const int nsteps = (int)((n + 1023) >> 10);                             // 1024 bytes per wave and step
+    const int nfull = (int)(n >> 10);
+    const int lane_chunks = (int)(ldd >> 4);                                // 16-byte chunks inside the row's pitch
+    for (int s = 0; s < nsteps; ++s) {
+        const int chunk = s * 64 + lane;
+        uint4 w = make_uint4(~0u, ~0u, ~0u, ~0u);
+        if (chunk < lane_chunks) w = row4[chunk];
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+        if (s < nfull) {                                                    // wave-uniform: all 1024 entries exist
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                uint32_t v = (ws[b >> 2] >> (8 * (b & 3))) & 0xFFu;
+                v = v < 32u ? v : 32u;
+                atomicAdd(&h[v * 64 + lane], 1u);
+            }
+        } else {
+            const int64_t j0 = (int64_t)chunk * 16;
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                uint32_t v = (ws[b >> 2] >> (8 * (b & 3))) & 0xFFu;
+                v = v < 32u ? v : 32u;
+                if (j0 + b < n) atomicAdd(&h[v * 64 + lane], 1u);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    // lane v (< 33) adds the 64 private counters of value v; an inclusive scan over values 0..31 finds the threshold
+    uint32_t tot = 0;
+    if (lane < SEL_VALS) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(h + lane * 64);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint4 c = p[q];
+            tot += (c.x + c.y) + (c.z + c.w);
+        }
+    }
+    const uint32_t big = (uint32_t)__builtin_amdgcn_readlane((int)tot, 32);
+    uint32_t cum = lane < 32 ? tot : 0u;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        const uint32_t up = __shfl_up(cum, o);
+        if (lane >= o) cum += up;
+    }
+    const unsigned long long reach = __ballot(lane < 32 && cum >= (uint32_t)n_nb);
+    if (big != 0u || reach == 0ull) {                                       // a value >= 32 in the row: exact generic path
+        __builtin_amdgcn_wave_barrier();
+        knn_select_row_generic(row, n, n_nb, h, lane, out);
+        return;
+    }
+    const int t = __builtin_ctzll(reach);
+    const uint32_t below = t ? (uint32_t)__builtin_amdgcn_readlane((int)cum, t - 1) : 0u;
+    uint32_t quota_eq = (uint32_t)n_nb - below;                             // entries == t still to take
+    uint32_t need_lt = below;                                               // entries < t still to find
+    uint32_t written = 0;
+    const uint32_t T = (uint32_t)t * 0x01010101u;
+    for (int s = 0; s < nsteps && written < (uint32_t)n_nb; ++s) {
+        const int chunk = s * 64 + lane;
+        uint4 w = make_uint4(~0u, ~0u, ~0u, ~0u);                           // 0xFF bytes: neither < t nor == t (t < 32)
+        if (chunk < lane_chunks) w = row4[chunk];
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+        uint32_t lt[4], eq[4], any = 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            // 0xFF bytes (>= 128) would break the SWAR borrow argument only by reading as (x & 0x7F) = 0x7F >= t: still "not below"
+            lt[d] = need_lt ? swar_lt(ws[d], T) : 0u;
+            eq[d] = quota_eq ? swar_eq(ws[d], T) : 0u;
+            any |= lt[d] | eq[d];
+        }
+        unsigned long long cand = __ballot(any != 0u);
+        if (cand == 0ull) continue;                                         // wave-uniform: nothing selectable in these 1024 entries
+        uint32_t lt16 = 0, eq16 = 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            lt16 |= swar_pack4(lt[d]) << (4 * d);
+            eq16 |= swar_pack4(eq[d]) << (4 * d);
+        }
+        const int64_t j0 = (int64_t)chunk * 16;
+        if (s >= nfull) {                                                   // entries behind the row's end do not count
+            const int64_t left = n - j0;
+            const uint32_t ok = left >= 16 ? 0xFFFFu : left <= 0 ? 0u : (1u << (int)left) - 1u;
+            lt16 &= ok;
+            eq16 &= ok;
+        }
+        cand = __ballot((lt16 | eq16) != 0u);
+        while (cand && written < (uint32_t)n_nb) {                          // scalar: lanes in order, bytes in order = index order
+            const int L = __builtin_ctzll(cand);
+            cand &= cand - 1;
+            uint32_t ltL = (uint32_t)__builtin_amdgcn_readlane((int)lt16, L);
+            uint32_t eqL = (uint32_t)__builtin_amdgcn_readlane((int)eq16, L);
+            uint32_t both = ltL | eqL;
+            const int32_t base = (int32_t)(((int64_t)s * 64 + L) * 16);
+            while (both && written < (uint32_t)n_nb) {
+                const int b = __builtin_ctz(both);
+                both &= both - 1;
+                const bool is_lt = (ltL >> b) & 1u;
+                if (is_lt || quota_eq) {
+                    if (lane == 0) out[written] = base + b;
+                    ++written;
+                    if (is_lt) --need_lt;
+                    else --quota_eq;
+                }
+            }
+        }
     }
 }
 
@@ -1399,8 +1530,9 @@ int kmap_knn_select_u8_dev(const uint8_t *D_dev, int64_t ldd, int64_t n, int n_n
     KMAP_REQUIRE(n_nb > 0 && n_nb <= n, "knn_select: n_nb=%d must be in [1, n]", n_nb);
     if (nrows == 0) return KMAP_OK;
     KMAP_REQUIRE(D_dev && nb_out_dev, "knn_select: null pointer");
+    const int aligned = (ldd % 16 == 0) && ((uintptr_t)D_dev % 16 == 0);   // 16-byte row loads (always true for kmap_hamdist_pitch)
     knn_select_kernel<<<(unsigned)((nrows + SEL_WAVES - 1) / SEL_WAVES), KMAP_WAVE * SEL_WAVES, 0, as_stream(stream)>>>(
-        D_dev, ldd, n, n_nb, row0, nrows, nb_out_dev);
+        D_dev, ldd, n, n_nb, row0, nrows, nb_out_dev, aligned);
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;
 }

@@ -80,6 +80,19 @@ def test_device_knn_selection_vs_oracle_rule(V):
         got = np.sort(nb_d.to_numpy(np.int32, (nr, n_nb)), axis=1)
         want = np.sort(O.knn_select_stable(D, n_nb)[r0:r0 + nr], axis=1)
         np.testing.assert_array_equal(got, want)
+    # arbitrary byte matrices: values >= 32 (rows leave the lane-private-counter path for the generic histogram one), a pitch
+    # that is no multiple of 16 (byte loads), many ties at the threshold, and rows longer than several 1024-entry steps
+    for n, n_nb, hi, pad in ((700, 20, 256, 0), (5000, 20, 256, 0), (5000, 20, 40, 0), (3000, 33, 4, 5), (4100, 20, 31, 0)):
+        D = rng.integers(0, hi, size=(n, n), dtype=np.uint8)
+        D[np.arange(n), np.arange(n)] = 0
+        ldd = (pitch_for(n) if pad == 0 else n + pad)
+        Dp = rng.integers(0, 256, size=(n, ldd), dtype=np.uint8)       # padding columns hold garbage
+        Dp[:, :n] = D
+        D_d = _ffi.DeviceBuffer.from_numpy(Dp)
+        nb_d = V.knn_select_dev(D_d.ptr, ldd, n, n_nb)
+        _ffi.sync()
+        got = np.sort(nb_d.to_numpy(np.int32, (n, n_nb)), axis=1)
+        np.testing.assert_array_equal(got, np.sort(O.knn_select_stable(D, n_nb), axis=1))
 
 
 def test_lut_matches_golden_hd_prob(V, golden):
