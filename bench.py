@@ -284,14 +284,34 @@ def c4_leg(dist, torch, res_dir, rank, world, barrier):
            "hamming_pairs_per_s": float(n) * n * 12 / wall, "hamming_note": "12 launches (2 warm-up + 10) of every rank's rows / wall time incl. barriers"}
     its = (3, 23)
     loops = []
+    err = ""
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda") if dist is not None else None
     for it in its:
+        if dist is not None:             # a rank that failed in the previous run is seen by all before anyone starts the next
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                break
         tr = {}
-        if dist is not None:
-            from kmap_amd.distributed import kmap_from_kmers_distributed
-            kmap_from_kmers_distributed(kh, np.ones(n, np.int64), lab, conseqs, K, n_max_iter=it, random_seed=7, trace=tr, mode=V.EMBED_FAST)
-        else:
-            V.kmap_from_kmers(kh, np.ones(n, np.int64), lab, conseqs, K, n_max_iter=it, random_seed=7, trace=tr, mode=V.EMBED_FAST)
-        loops.append(tr["loop_s"])
+        try:
+            if dist is not None:
+                from kmap_amd.distributed import kmap_from_kmers_distributed
+                kmap_from_kmers_distributed(kh, np.ones(n, np.int64), lab, conseqs, K, n_max_iter=it, random_seed=7, trace=tr, mode=V.EMBED_FAST)
+            else:
+                V.kmap_from_kmers(kh, np.ones(n, np.int64), lab, conseqs, K, n_max_iter=it, random_seed=7, trace=tr, mode=V.EMBED_FAST)
+            loops.append(tr["loop_s"])
+        except Exception as e:   # noqa: BLE001 -- reported in the line; the headline above is already measured
+            err = f"{type(e).__name__}: {e}"[:300]
+            if flag is not None:
+                flag.fill_(1)
+            else:
+                break
+    if dist is not None:
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            err = err or "another rank failed"
+    if err or len(loops) < 2:
+        res["embed_error"] = err or "embedding leg did not run"
+        return res
     per_it = (loops[1] - loops[0]) / (its[1] - its[0])
     if dist is not None:
         t = torch.tensor([per_it], dtype=torch.float64, device="cuda")

@@ -452,7 +452,7 @@ def locate_pickled_array(path, min_bytes=1 << 20):
     ops = []
     with open(path, "rb") as fh:
         try:
-            for op, arg, _ in pickletools.genops(_OpReader(fh, min_bytes)):
+            for op, arg, _ in pickletools.genops(_OpReader(fh, max(int(min_bytes), 1024))):   # (shorter reads are opcodes and small arguments)
                 if op.name not in _SKIP_OPS:
                     ops.append((op.name, arg))
             return None                                           # no large payload at all
@@ -514,12 +514,17 @@ def locate_pickled_array(path, min_bytes=1 << 20):
     return offset, dt, shape
 
 
-def load_array_pickle(path, min_bytes=64 << 20):
+MAP_PICKLE_MIN_BYTES = 64 << 20    # pickled arrays from this size on are memory-mapped instead of unpickled (load_array_pickle)
+
+
+def load_array_pickle(path, min_bytes=None):
     """The ndarray a pickle file holds.  Large plain arrays (locate_pickled_array) come back as a READ-ONLY view of a private
     memory map of the file -- no 1.5-GB copy through `pickle.load` at C3 (0.27 s + 0.11 s to free it); the upload then DMAs
     straight from the page cache.  Everything else is unpickled normally."""
     import mmap
     import os
+    if min_bytes is None:
+        min_bytes = MAP_PICKLE_MIN_BYTES
     loc = None
     try:
         if os.path.getsize(path) >= min_bytes:

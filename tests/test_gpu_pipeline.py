@@ -482,6 +482,29 @@ def test_scan_motif_deferred_occurrence_path(run_dir, tmp_path, monkeypatch):
             assert (run_dir / rel).read_bytes() == (res / rel).read_bytes(), rel
 
 
+def test_scan_motif_from_memory_mapped_input(run_dir, tmp_path, monkeypatch):
+    """Large inputs are not unpickled: scan_motif maps input.bin.pkl and uploads from the mapping (read-only array).  With the
+    size threshold at 0 the C1 run takes that path too and must write the same files."""
+    from kmap_amd import kmer_count as KC
+    monkeypatch.setattr(KC, "MAP_PICKLE_MIN_BYTES", 0)
+    seen = []
+    orig = KC.load_array_pickle
+
+    def spy(path, min_bytes=None):
+        a = orig(path, min_bytes)
+        seen.append((Path(path).name, bool(a.flags.writeable)))
+        return a
+    from kmap_amd import motif_discovery as MD
+    monkeypatch.setattr(MD, "load_array_pickle", spy)
+    res = _run_c1(tmp_path)
+    assert ("input.bin.pkl", False) in seen                          # the read array came back as a read-only view of the mapping
+    names = sorted(p.relative_to(run_dir) for p in run_dir.rglob("*") if p.is_file() and p.name != "low_dim_data.tsv")
+    assert sorted(p.relative_to(res) for p in res.rglob("*") if p.is_file()) == names
+    for rel in names:
+        if rel.suffix in (".csv", ".txt"):
+            assert (run_dir / rel).read_bytes() == (res / rel).read_bytes(), rel
+
+
 def test_second_dataset_repetitive_mode_and_noise_kmers(golden, tmp_path):
     """preproc + scan_motif on a second dataset (tests/golden/scan2: planted motifs, repetitive_mode = true, a noise k-mer
     file masked before counting, k = 6..9) == the files and arrays the reference produced with the same np.random seed"""
