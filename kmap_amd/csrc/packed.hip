@@ -608,15 +608,24 @@ __global__ __launch_bounds__(BLK) void mask_flag_packed_kernel(const uint32_t *_
         const uint32_t bad16 = (uint32_t)(bad >> 32), km = (uint32_t)kmask;
         const uint32_t hi = (uint32_t)(w.t0 >> 32), lo = (uint32_t)w.t0;
         const int sh = 32 - 2 * k;
+        uint32_t h[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const uint32_t top = (i == 0) ? hi : __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * i);
-            const uint32_t h = ((bad16 >> (15 - i)) & 1u) ? km : (top >> sh);   // invalid window: all ones, compared as is
-            bool f = false;
-            for (int c = 0; c < t.n; ++c) f |= (popc2((h ^ (uint32_t)t.cons[c]) & km) <= t.radius[c]);
-            if (16 * g + i >= n) f = false;       // positions past the end do not exist
-            hits |= (uint32_t)f << (15 - i);
+            h[i] = ((top >> sh) | (uint32_t)__builtin_amdgcn_sbfe((int)bad16, 15 - i, 1)) & km;   // invalid window: all ones, compared as is
         }
+        // consensus outside (scalar operands, one loop test per consensus instead of per window and consensus), the 16 windows
+        // unrolled inside; the flags shift in from the right, so window i ends in bit 15 - i
+        for (int c = 0; c < t.n; ++c) {
+            const uint32_t cc = (uint32_t)t.cons[c];
+            const int r = t.radius[c];
+            uint32_t acc = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc = (acc << 1) | (uint32_t)(popc2(h[i] ^ cc) <= r);
+            hits |= acc;
+        }
+        const int64_t left = n - 16 * g;          // positions past the end do not exist
+        if (left < 16) hits &= ~((1u << (16 - (int)left)) - 1u);
         hit16[g] = (uint16_t)hits;
         return;
     }
@@ -782,19 +791,38 @@ __global__ __launch_bounds__(BLK) void scan_nibble_kernel(const uint32_t *__rest
     const uint64_t kmask = low_mask<uint64_t>(k);
     uint64_t out = 0;
     if (!WIDE) {   // k <= 16: the hash fits 32 bits
+        // 32-bit windows as in the histogram kernel: v_alignbit + shift, the 16 "window touches an invalid position" flags from
+        // one doubling pass, nibbles packed into two 32-bit halves, the minimum kept on the way (the first version shifted the
+        // 64-bit stream and the 48-bit flag word per window and re-read the 16 nibbles for the minimum: ~30 vector instructions
+        // per window on a kernel that is bound by instruction issue)
         const uint32_t km = (uint32_t)kmask, c32 = (uint32_t)cons, r32 = (uint32_t)rcc;
-        const uint64_t vm = (1ull << k) - 1ull;
+        uint64_t bad = w.m;
+        for (int have = 1; have < k;) {
+            const int step = (have <= k - have) ? have : k - have;
+            bad |= bad << step;
+            have += step;
+        }
+        const uint32_t bad16 = (uint32_t)(bad >> 32);                        // windows 0..15 in bits 15..0
+        const uint32_t hi = (uint32_t)(w.t0 >> 32), lo = (uint32_t)w.t0;
+        const int sh = 32 - 2 * k;
+        uint32_t half[2] = {0u, 0u};
+        int mn = 15;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            uint32_t h = (uint32_t)((w.t0 << (2 * i)) >> 32) >> (32 - 2 * k);
-            if ((w.m >> (48 - i - k)) & vm) h = km;
-            int d = popc2((h ^ c32) & km);
+            const uint32_t top = (i == 0) ? hi : __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * i);
+            const uint32_t h = ((top >> sh) | (uint32_t)__builtin_amdgcn_sbfe((int)bad16, 15 - i, 1)) & km;   // invalid: all ones
+            int d = popc2(h ^ c32);
             if (revcom) {
-                const int d2 = popc2((h ^ r32) & km);
+                const int d2 = popc2(h ^ r32);
                 d = d2 < d ? d2 : d;
             }
-            out |= (uint64_t)(d <= radius ? d : 15) << (4 * i);
+            d = d <= radius ? d : 15;
+            mn = d < mn ? d : mn;
+            half[i >> 3] |= (uint32_t)d << (4 * (i & 7));
         }
+        nib[g] = ((uint64_t)half[1] << 32) | half[0];
+        wmin[g] = (uint8_t)mn;
+        return;
     } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {

@@ -136,7 +136,7 @@ int kmap_scan_reserve(kmap_scan *s, int64_t n_seq) {
         s->hits = nullptr; s->mind = nullptr; s->offs = nullptr; s->cap_seq = 0;
         KMAP_CHECK_HIP(hipMalloc((void **)&s->hits, (size_t)n_seq * 4));
         KMAP_CHECK_HIP(hipMalloc((void **)&s->mind, (size_t)n_seq));
-        KMAP_CHECK_HIP(hipMalloc((void **)&s->offs, ((size_t)n_seq + 1) * 8));
+        KMAP_CHECK_HIP(hipMalloc((void **)&s->offs, ((size_t)n_seq + 1) * 8 + 128));   // + slack: doubles as scratch of kmap_scan_summary / _fetch_stream_u8 (64 B header + n_seq bytes)
         s->cap_seq = n_seq;
     }
     return KMAP_OK;

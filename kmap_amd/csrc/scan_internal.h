@@ -6,7 +6,7 @@ struct kmap_scan {
     int64_t n_seq = 0, total = 0, cap_seq = 0, cap_pos = 0;
     int32_t *hits = nullptr;
     int8_t *mind = nullptr;
-    uint64_t *offs = nullptr;
+    uint64_t *offs = nullptr;           // exclusive scan of hits (run); afterwards scratch: summary words, byte-narrowed hits
     int32_t *pos = nullptr;
 };
 int kmap_scan_reserve(kmap_scan *s, int64_t n_seq);
