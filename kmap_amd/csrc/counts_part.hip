@@ -106,11 +106,20 @@ __global__ __launch_bounds__(PH_TPB) void part_hist_kernel(const uint32_t *__res
                                                            uint32_t bins_per_bucket, int passes, uint32_t sub,
                                                            uint32_t *__restrict__ table) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lb[];
-    const uint32_t bucket = blockIdx.x / passes, p = blockIdx.x % passes;
+    // The range passes of one bucket read the same keys: they get block ids that the dispatcher sends to the SAME XCD, one after the
+    // other (block b runs on XCD b mod 8), so that the first one's misses fill the L2 the others read.  With plain (bucket, pass)
+    // = (b / passes, b mod passes) the eight passes of a k = 14 bucket sat on eight different XCDs: 46 GB through the fabric.
+    uint32_t bucket = blockIdx.x / passes, p = blockIdx.x % passes;
+    if (passes > 1 && (gridDim.x / passes) % 8 == 0) {
+        const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        bucket = (j / passes) * 8 + xcd;
+        p = j % passes;
+    }
     for (uint32_t j = threadIdx.x; j < sub; j += PH_TPB) lb[j] = 0;
     __syncthreads();
     const uint64_t lo = goff[bucket], hi = goff[bucket + 1];
     const uint32_t low = bins_per_bucket - 1u, r0 = p * sub;
+    const uint32_t dummy = sub + (threadIdx.x & 63u);                     // 64 private bins behind the range (never read)
     // 16-byte loads over the 4-key-aligned interior of [lo, hi), scalar head and tail
     const uint64_t lo4 = (lo + 3) & ~(uint64_t)3, hi4 = hi & ~(uint64_t)3;
     if (lo4 < hi4) {
@@ -120,13 +129,22 @@ __global__ __launch_bounds__(PH_TPB) void part_hist_kernel(const uint32_t *__res
         }
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys);
-        for (uint64_t q = (lo4 >> 2) + threadIdx.x; q < (hi4 >> 2); q += PH_TPB) {
-            const u32x4 kv = k4[q];
+        // two loads ahead of the keys being counted (one block per CU: 16 waves; a plain load -> count loop exposed one memory
+        // round trip per 16 keys and thread).  Clamped, unconditional loads so that the compiler keeps them in flight.
+        const uint64_t qend = hi4 >> 2, qlast = qend - 1;
+        uint64_t q = (lo4 >> 2) + threadIdx.x;
+        u32x4 k0 = k4[q < qend ? q : qlast], k1 = k4[q + PH_TPB < qend ? q + PH_TPB : qlast];
+        for (; q < qend; q += PH_TPB) {
+            const u32x4 kv = k0;
+            k0 = k1;
+            k1 = k4[q + 2 * PH_TPB < qend ? q + 2 * PH_TPB : qlast];
+            // no branch per key: a key of another range lands, by one unsigned min, in the lane's private bin behind the range's
+            // bins (range passes > 1: seven of eight keys at k = 14 -- the exec-mask juggling cost more than their atomics do)
             const uint32_t a0 = (kv.x & low) - r0, a1 = (kv.y & low) - r0, a2 = (kv.z & low) - r0, a3 = (kv.w & low) - r0;
-            if (a0 < sub) atomicAdd(&lb[a0], 1u);
-            if (a1 < sub) atomicAdd(&lb[a1], 1u);
-            if (a2 < sub) atomicAdd(&lb[a2], 1u);
-            if (a3 < sub) atomicAdd(&lb[a3], 1u);
+            atomicAdd(&lb[a0 < dummy ? a0 : dummy], 1u);
+            atomicAdd(&lb[a1 < dummy ? a1 : dummy], 1u);
+            atomicAdd(&lb[a2 < dummy ? a2 : dummy], 1u);
+            atomicAdd(&lb[a3 < dummy ? a3 : dummy], 1u);
         }
         for (uint64_t i = hi4 + threadIdx.x; i < hi; i += PH_TPB) {
             const uint32_t a = (keys[i] & low) - r0;
@@ -289,7 +307,7 @@ int kmap_counts_part_hist_u32(kmap_counts *c, const uint32_t *hash_dev, int64_t 
     const uint32_t bins_per_bucket = (uint32_t)(n_bins >> PB);
     const uint32_t sub = bins_per_bucket < (uint32_t)PH_BINS ? bins_per_bucket : (uint32_t)PH_BINS;
     const int passes = (int)(bins_per_bucket / sub);
-    KMAP_TRY(kmap_allow_lds((const void *)part_hist_kernel, PH_BINS * 4));
+    KMAP_TRY(kmap_allow_lds((const void *)part_hist_kernel, (PH_BINS + 64) * 4));
     static const int two_level = [] { const char *e = getenv("KMAP_COUNT_PART2"); return e ? atoi(e) : 1; }();   // A/B switch
     if (k >= 15 && two_level && passes <= P2_MAX) {
         // second level: S = passes sub-buckets of 32768 bins per bucket; keys re-sorted tile by tile inside their bucket
@@ -315,11 +333,11 @@ int kmap_counts_part_hist_u32(kmap_counts *c, const uint32_t *hash_dev, int64_t 
         KMAP_TRY(kmap_allow_lds((const void *)part2_scatter_kernel, PT_TILE * 4));
         part2_scatter_kernel<<<1024, PS_TPB, (size_t)PT_TILE * 4, st>>>(keys, goff, tile_off, shift2, S, cursor2, keys2);
         // one pass per sub-bucket: "bucket" = sub-bucket index, 32768 bins each
-        part_hist_kernel<<<(unsigned)m, PH_TPB, (size_t)PH_BINS * 4, st>>>(keys2, goff2, (uint32_t)PH_BINS, 1, (uint32_t)PH_BINS, c->bins);
+        part_hist_kernel<<<(unsigned)m, PH_TPB, (size_t)(PH_BINS + 64) * 4, st>>>(keys2, goff2, (uint32_t)PH_BINS, 1, (uint32_t)PH_BINS, c->bins);
         KMAP_CHECK_HIP(hipGetLastError());
         return KMAP_OK;
     }
-    part_hist_kernel<<<(unsigned)(NBK * passes), PH_TPB, (size_t)sub * 4, st>>>(keys, goff, bins_per_bucket, passes, sub, c->bins);
+    part_hist_kernel<<<(unsigned)(NBK * passes), PH_TPB, (size_t)(sub + 64) * 4, st>>>(keys, goff, bins_per_bucket, passes, sub, c->bins);
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;
 }
