@@ -391,8 +391,12 @@ __global__ __launch_bounds__(KMAP_WAVE *DS_WAVES) void dedupe_bitmap_packed_kern
     const uint64_t kones = (1ull << k) - 1ull;
     const int64_t n_waves = (int64_t)gridDim.x * DS_WAVES;
     constexpr int NB = 3;
-    int64_t r = (int64_t)blockIdx.x * DS_WAVES + wave;
-    if (r >= n_seq) return;
+    // a wave takes 64 CONSECUTIVE reads per batch -- reads (b n_waves + w) 64 .. + 63 in batch b -- so that the batch's border load
+    // is one coalesced KiB (lane-strided by n_waves reads it fetched a whole sector per 16 bytes: 1.0 GB of the kernel's 1.6 GB
+    // of HBM traffic at C3) and the window loads walk through one contiguous stretch of the packed array
+    const int64_t wave_global = (int64_t)blockIdx.x * DS_WAVES + wave;
+    auto read_of = [&](int64_t it) -> int64_t { return ((it >> 6) * n_waves + wave_global) * 64 + (it & 63); };
+    if (read_of(0) >= n_seq) return;
     {   // the bitmap is zeroed once; after a read every lane zeroes the words it touched (3 scattered stores instead of bw / 256
         // 16-byte stores per lane: the LDS pipe is the busiest unit of this kernel)
         uint4 *b4 = reinterpret_cast<uint4 *>(bm);
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(KMAP_WAVE *DS_WAVES) void dedupe_bitmap_packed_kern
         uint32_t pk;                    // lo | hi << 5 | gmax << 16 | nsteps << 24
     };
     auto batch = [&](int64_t b, Batch &B) {
-        const int64_t rr = r + (b * 64 + lane) * n_waves;
+        const int64_t rr = (b * n_waves + wave_global) * 64 + lane;
         int64_t st = 0, en = 0;
         if (rr < n_seq) {
             st = borders[2 * rr];
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(KMAP_WAVE *DS_WAVES) void dedupe_bitmap_packed_kern
     DbRaw W[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) db_load(G, c * 64 + lane, W[c]);
-    int64_t rn = r + n_waves;
+    int64_t rn = read_of(1);
     for (;;) {
         const bool has_next = rn < n_seq;                                 // wave-uniform
         DbRead Gn = G;
@@ -468,7 +472,7 @@ __global__ __launch_bounds__(KMAP_WAVE *DS_WAVES) void dedupe_bitmap_packed_kern
         // the loads just issued
 #pragma unroll
         for (int c = 0; c < NB; ++c) db_load(Gn, c * 64 + lane, Wn[c]);
-        const int64_t rnn = rn + n_waves;
+        const int64_t rnn = read_of(it + 2);
         if (G.nsteps) {
             int touched[NB];                                              // word index per prefetched step, -1 = none
 #pragma unroll

@@ -246,3 +246,31 @@ def test_lds_histogram_hot_bins(env, k):
             assert c.max() > 8_000_000
     dc.close()
     ds.close()
+
+
+@pytest.mark.parametrize("max_len", [512, 513])
+def test_dedupe_long_reads_both_paths(env, max_len):
+    """Per-read dedupe at the length limit of the LDS-bitmap kernel: reads up to 512 positions (9 steps of 64 windows, claim masks
+    in LDS, whole-bitmap clears) and, with one read of 513, the materialised-hash-array path for the whole input.  Tandem repeats
+    and poly-A stretches make most windows duplicates; exact (k <= 8) and hashed (k >= 9) bitmaps."""
+    _ffi, DeviceCounts, DeviceSeq, O = env
+    rng = np.random.default_rng(900 + max_len)
+    seq, borders = synth(rng, 3000, 300, 512, p_n=0.003)
+    st, en = borders[7]
+    seq[st:en] = np.resize(np.array([0, 1, 2, 3, 0, 0, 1], np.uint8), en - st)      # tandem repeat
+    st, en = borders[11]
+    seq[st:en] = 0
+    if max_len > 512:                                                               # one read beyond the limit
+        extra = rng.integers(0, 4, size=max_len).astype(np.uint8)
+        seq = np.concatenate([seq, extra, np.array([255], np.uint8)])
+        borders = np.concatenate([borders, np.array([[len(seq) - max_len - 1, len(seq) - 1]], np.int64)])
+    assert (borders[:, 1] - borders[:, 0]).max() == max_len or max_len == 512
+    ds, dc = DeviceSeq(seq, borders), DeviceCounts()
+    for k in (6, 8, 9, 13, 16):
+        ds.count(dc, k, dedupe=True, merge_revcom=False)
+        u, c = dc.fetch()
+        ou, oc = O.count_kmers(seq, borders, k, rep_mode=False, revcom_mode=False)
+        np.testing.assert_array_equal(u, ou)
+        np.testing.assert_array_equal(c, oc)
+    dc.close()
+    ds.close()
