@@ -25,4 +25,7 @@ int kmap_counts_reserve_bins(kmap_counts *c, int k);   // allocation only (the p
 // windows of the all-T 16-mer (hash 0xFFFFFFFF = the uint32 invalid marker) are counted aside and added with part_add_bin
 bool kmap_counts_part_applies(int k, int64_t n);
 int kmap_counts_part_hist_u32(kmap_counts *c, const uint32_t *hash_dev, int64_t n, int k, hipStream_t st);
+// the same with the keys hashed on the fly from the 2-bit packed reads (+ per-read dedupe skip bits); adds the all-T 16-mer itself
+int kmap_counts_part_hist_packed(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, const uint32_t *skip_dev,
+                                 int64_t n, int k, hipStream_t st);
 int kmap_counts_part_add_bin(kmap_counts *c, size_t bin, const unsigned long long *extra_dev, hipStream_t st);

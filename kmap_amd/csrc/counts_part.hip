@@ -16,6 +16,7 @@
 
 #include "common.h"
 #include "counts_internal.h"
+#include "packed_keys.h"
 #include "scan_util.h"
 
 namespace {
@@ -39,6 +40,33 @@ __global__ __launch_bounds__(PT_TPB) void part_count_kernel(const uint32_t *__re
         if (cnt[b]) atomicAdd(&gcount[b], cnt[b]);
 }
 
+// the same count with the keys taken from the packed reads (thread = one 16-position group); k = 16: the all-T 16-mer's valid
+// windows are counted here (all_ones), once
+__global__ __launch_bounds__(PT_TPB) void part_count_packed_kernel(const uint32_t *__restrict__ codes, const uint16_t *__restrict__ inval,
+                                                                   const uint32_t *__restrict__ skip, int64_t n, int k, int shift,
+                                                                   uint32_t *__restrict__ gcount, unsigned long long *__restrict__ all_ones) {
+    __shared__ uint32_t cnt[NBK + 64];
+    for (int b = threadIdx.x; b < NBK + 64; b += PT_TPB) cnt[b] = 0;
+    __syncthreads();
+    const int64_t n_groups = (n + 15) >> 4, stride = (int64_t)gridDim.x * PT_TPB;
+    const uint32_t dummy = (uint32_t)NBK + (threadIdx.x & 63u);           // invalid keys: the lane's private counter
+    uint32_t ones = 0;
+    for (int64_t g = (int64_t)blockIdx.x * PT_TPB + threadIdx.x; g < n_groups; g += stride) {
+        uint32_t keys[16], n1;
+        packed_group_keys(codes, inval, skip, n, k, g, keys, n1);
+        ones += n1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t b = keys[i] == INV32 ? dummy : keys[i] >> shift;
+            atomicAdd(&cnt[b], 1u);
+        }
+    }
+    if (all_ones && ones) atomicAdd(all_ones, (unsigned long long)ones);
+    __syncthreads();
+    for (int b = threadIdx.x; b < NBK; b += PT_TPB)
+        if (cnt[b]) atomicAdd(&gcount[b], cnt[b]);
+}
+
 __global__ void part_init_cursor_kernel(const uint64_t *__restrict__ goff, unsigned long long *__restrict__ cursor) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < NBK) cursor[b] = goff[b];
@@ -49,7 +77,9 @@ __global__ void part_init_cursor_kernel(const uint64_t *__restrict__ goff, unsig
 // L2: 27 ms for 1.5e9 hashes against 6 GB of output).  LDS: sorted tile 128 KiB + offsets 4 KiB + global bases 8 KiB.
 constexpr int PS_TPB = 1024, PS_PER = PT_TILE / PS_TPB;   // 32 hashes per thread
 static_assert(PS_TPB == NBK, "one thread per bucket in the scan / reservation steps");
-__global__ __launch_bounds__(PS_TPB) void part_scatter_kernel(const uint32_t *__restrict__ h, int64_t n, int shift,
+template <bool PACKED>   // PACKED: keys hashed on the fly from the packed reads (h = codes), thread = two 16-position groups of the tile
+__global__ __launch_bounds__(PS_TPB) void part_scatter_kernel(const uint32_t *__restrict__ h, const uint16_t *__restrict__ inval,
+                                                              const uint32_t *__restrict__ skip, int k, int64_t n, int shift,
                                                               unsigned long long *__restrict__ cursor, uint32_t *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sorted[];      // PT_TILE entries
     __shared__ uint32_t cnt[NBK];                                           // counts -> exclusive offsets -> running cursors
@@ -62,11 +92,22 @@ __global__ __launch_bounds__(PS_TPB) void part_scatter_kernel(const uint32_t *__
         cnt[threadIdx.x] = 0;                                               // NBK == PS_TPB
         __syncthreads();
         uint32_t v[PS_PER];
+        if (PACKED) {
+            static_assert(PS_PER == 32, "two groups of 16 keys per thread");
+            const int64_t g0 = (t0 >> 4) + 2 * (int64_t)threadIdx.x;       // PT_TILE is a multiple of 16
+            uint32_t n1;
+            packed_group_keys(h, inval, skip, n, k, g0, v, n1);            // groups behind the array: all keys invalid (n test inside;
+            packed_group_keys(h, inval, skip, n, k, g0 + 1, v + 16, n1);   //  the two padding groups keep the loads in bounds)
 #pragma unroll
-        for (int j = 0; j < PS_PER; ++j) {
-            const int64_t i = t0 + (int64_t)j * PS_TPB + threadIdx.x;
-            v[j] = (i < n) ? h[i] : INV32;
-            if (v[j] != INV32) atomicAdd(&cnt[v[j] >> shift], 1u);
+            for (int j = 0; j < PS_PER; ++j)
+                if (v[j] != INV32) atomicAdd(&cnt[v[j] >> shift], 1u);
+        } else {
+#pragma unroll
+            for (int j = 0; j < PS_PER; ++j) {
+                const int64_t i = t0 + (int64_t)j * PS_TPB + threadIdx.x;
+                v[j] = (i < n) ? h[i] : INV32;
+                if (v[j] != INV32) atomicAdd(&cnt[v[j] >> shift], 1u);
+            }
         }
         __syncthreads();
         // exclusive scan of the 1024 counts (one per thread): wave scan + wave sums
@@ -280,8 +321,11 @@ bool kmap_counts_part_applies(int k, int64_t n) {
     return on && k >= 11 && k <= 16 && n >= ((int64_t)1 << 20);
 }
 
-// bins of c <- histogram of the valid (!= 0xFFFFFFFF) hashes; the whole table is written (no prior memset needed)
-int kmap_counts_part_hist_u32(kmap_counts *c, const uint32_t *hash_dev, int64_t n, int k, hipStream_t st) {
+// bins of c <- histogram of the valid (!= 0xFFFFFFFF) keys; the whole table is written (no prior memset needed).  Keys: a hash
+// array (hash_dev), or -- hash_dev null -- hashed on the fly from the packed reads in the count and the scatter pass (no 4 B /
+// position array written and read twice: 18 GB of the ~36 GB a k = 14 count pass moved at C3)
+static int part_hist_any(kmap_counts *c, const uint32_t *hash_dev, const uint32_t *codes_dev, const uint16_t *inval_dev,
+                         const uint32_t *skip_dev, int64_t n, int k, hipStream_t st) {
     const size_t n_bins = (size_t)1 << (2 * k);
     KMAP_TRY(kmap_counts_reserve_bins(c, k));
     const int shift = 2 * k - PB;
@@ -289,21 +333,34 @@ int kmap_counts_part_hist_u32(kmap_counts *c, const uint32_t *hash_dev, int64_t 
     uint64_t *goff = nullptr;
     unsigned long long *cursor = nullptr;
     void *small = nullptr;
-    KMAP_TRY(kmap_scratch(&small, (size_t)NBK * 4 + ((size_t)NBK + 1) * 8 + (size_t)NBK * 8, st, KMAP_SLOT_A));
+    KMAP_TRY(kmap_scratch(&small, (size_t)NBK * 4 + ((size_t)NBK + 1) * 8 + (size_t)NBK * 8 + 16, st, KMAP_SLOT_A));
     goff = reinterpret_cast<uint64_t *>(small);                       // 8-byte aligned parts first
     cursor = reinterpret_cast<unsigned long long *>(goff + NBK + 1);
-    gcount = reinterpret_cast<uint32_t *>(cursor + NBK);
+    unsigned long long *all_ones = cursor + NBK;                      // k = 16, packed source: valid windows of the all-T 16-mer
+    gcount = reinterpret_cast<uint32_t *>(all_ones + 1);
     KMAP_TRY(kmap_scratch((void **)&keys, (size_t)n * 4, st, KMAP_SLOT_PART));
-    KMAP_CHECK_HIP(hipMemsetAsync(gcount, 0, (size_t)NBK * 4, st));
-    int64_t g = (n + PT_TPB - 1) / PT_TPB;
-    if (g > 2048) g = 2048;
-    part_count_kernel<<<(unsigned)g, PT_TPB, 0, st>>>(hash_dev, n, shift, gcount);
+    KMAP_CHECK_HIP(hipMemsetAsync(all_ones, 0, 8 + (size_t)NBK * 4, st));
+    const bool packed = hash_dev == nullptr;
+    if (packed) {
+        int64_t g = (((n + 15) >> 4) + PT_TPB - 1) / PT_TPB;
+        if (g > 2048) g = 2048;
+        part_count_packed_kernel<<<(unsigned)g, PT_TPB, 0, st>>>(codes_dev, inval_dev, skip_dev, n, k, shift, gcount, k == 16 ? all_ones : nullptr);
+    } else {
+        int64_t g = (n + PT_TPB - 1) / PT_TPB;
+        if (g > 2048) g = 2048;
+        part_count_kernel<<<(unsigned)g, PT_TPB, 0, st>>>(hash_dev, n, shift, gcount);
+    }
     KMAP_TRY(exclusive_scan_u32(gcount, NBK, goff, st));              // goff[NBK] = number of valid hashes
     part_init_cursor_kernel<<<NBK / 256, 256, 0, st>>>(goff, cursor);
     int64_t tiles = (n + PT_TILE - 1) / PT_TILE;
     if (tiles > 1024) tiles = 1024;
-    KMAP_TRY(kmap_allow_lds((const void *)part_scatter_kernel, PT_TILE * 4));
-    part_scatter_kernel<<<(unsigned)tiles, PS_TPB, (size_t)PT_TILE * 4, st>>>(hash_dev, n, shift, cursor, keys);
+    if (packed) {
+        KMAP_TRY(kmap_allow_lds((const void *)part_scatter_kernel<true>, PT_TILE * 4));
+        part_scatter_kernel<true><<<(unsigned)tiles, PS_TPB, (size_t)PT_TILE * 4, st>>>(codes_dev, inval_dev, skip_dev, k, n, shift, cursor, keys);
+    } else {
+        KMAP_TRY(kmap_allow_lds((const void *)part_scatter_kernel<false>, PT_TILE * 4));
+        part_scatter_kernel<false><<<(unsigned)tiles, PS_TPB, (size_t)PT_TILE * 4, st>>>(hash_dev, nullptr, nullptr, k, n, shift, cursor, keys);
+    }
     const uint32_t bins_per_bucket = (uint32_t)(n_bins >> PB);
     const uint32_t sub = bins_per_bucket < (uint32_t)PH_BINS ? bins_per_bucket : (uint32_t)PH_BINS;
     const int passes = (int)(bins_per_bucket / sub);
@@ -334,12 +391,22 @@ int kmap_counts_part_hist_u32(kmap_counts *c, const uint32_t *hash_dev, int64_t 
         part2_scatter_kernel<<<1024, PS_TPB, (size_t)PT_TILE * 4, st>>>(keys, goff, tile_off, shift2, S, cursor2, keys2);
         // one pass per sub-bucket: "bucket" = sub-bucket index, 32768 bins each
         part_hist_kernel<<<(unsigned)m, PH_TPB, (size_t)(PH_BINS + 64) * 4, st>>>(keys2, goff2, (uint32_t)PH_BINS, 1, (uint32_t)PH_BINS, c->bins);
+        if (packed && k == 16) part_add_bin_kernel<<<1, 1, 0, st>>>(c->bins, (size_t)0xFFFFFFFFu, all_ones);
         KMAP_CHECK_HIP(hipGetLastError());
         return KMAP_OK;
     }
     part_hist_kernel<<<(unsigned)(NBK * passes), PH_TPB, (size_t)(sub + 64) * 4, st>>>(keys, goff, bins_per_bucket, passes, sub, c->bins);
+    if (packed && k == 16) part_add_bin_kernel<<<1, 1, 0, st>>>(c->bins, (size_t)0xFFFFFFFFu, all_ones);
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;
+}
+
+int kmap_counts_part_hist_u32(kmap_counts *c, const uint32_t *hash_dev, int64_t n, int k, hipStream_t st) {
+    return part_hist_any(c, hash_dev, nullptr, nullptr, nullptr, n, k, st);
+}
+int kmap_counts_part_hist_packed(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, const uint32_t *skip_dev,
+                                 int64_t n, int k, hipStream_t st) {
+    return part_hist_any(c, nullptr, codes_dev, inval_dev, skip_dev, n, k, st);
 }
 
 int kmap_counts_part_add_bin(kmap_counts *c, size_t bin, const unsigned long long *extra_dev, hipStream_t st) {

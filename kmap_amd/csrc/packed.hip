@@ -1106,7 +1106,10 @@ int kmap_counts_hist_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const
         return kmap_counts_hist_hashes(c, hash, n, k, st);
     }
     if (kmap_counts_part_applies(k, n)) {
-        // 11 <= k <= 16: materialise the hashes once (4 B/position, 16-mers too) and take the bucket-partitioned histogram
+        // 11 <= k <= 16: bucket-partitioned histogram, keys hashed from the packed reads inside its count and scatter passes
+        // (KMAP_COUNT_PART_FUSED=0: materialise the 4 B/position hash array first, the r01 / early r02 arrangement)
+        static const bool fused = [] { const char *e = getenv("KMAP_COUNT_PART_FUSED"); return !(e && e[0] == '0'); }();
+        if (fused) return kmap_counts_part_hist_packed(c, codes_dev, inval_dev, skip, n, k, st);
         void *hash = nullptr;
         KMAP_TRY(kmap_scratch(&hash, (size_t)n * 4 + 16, st, KMAP_SLOT_HASH));
         unsigned long long *all_ones = nullptr;
