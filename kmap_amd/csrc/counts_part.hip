@@ -201,6 +201,72 @@ __global__ __launch_bounds__(PH_TPB) void part_hist_kernel(const uint32_t *__res
     uint32_t *dst = table + (size_t)bucket * bins_per_bucket + r0;
     for (uint32_t j = threadIdx.x; j < sub; j += PH_TPB) dst[j] = lb[j];
 }
+// The same with two 16-bit counters per LDS word: 65 536 bins per block, half the range passes over a bucket's keys (k = 13: one
+// instead of two, k = 14: four instead of eight).  A counter never carries into its neighbour: the thread whose add takes it from
+// 0x7FFF to 0x8000 (returning ds_add: same LDS rate as the plain one on this part) takes those 32 768 counts out again and notes
+// the bin in a global list (at most one entry per 32 768 keys); part_spill_kernel adds them to the finished table.  Until the
+// ds_sub lands at most 1024 threads x 4 keys more can arrive (< 0x10000).
+constexpr uint32_t PH_HALF_BINS = 2 * PH_BINS, PH_HALF_LIMIT = 0x8000u;
+__global__ __launch_bounds__(PH_TPB) void part_hist_half_kernel(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ goff,
+                                                                uint32_t bins_per_bucket, int passes, uint32_t *__restrict__ table,
+                                                                unsigned long long *__restrict__ spill_n, uint32_t *__restrict__ spill) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lb[];
+    uint32_t bucket = blockIdx.x / passes, p = blockIdx.x % passes;
+    if (passes > 1 && (gridDim.x / passes) % 8 == 0) {                    // range passes of a bucket on one XCD (see part_hist_kernel)
+        const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        bucket = (j / passes) * 8 + xcd;
+        p = j % passes;
+    }
+    for (uint32_t j = threadIdx.x; j < PH_BINS; j += PH_TPB) lb[j] = 0;
+    __syncthreads();
+    const uint64_t lo = goff[bucket], hi = goff[bucket + 1];
+    const uint32_t low = bins_per_bucket - 1u, r0 = p * PH_HALF_BINS;
+    const uint32_t bin_base = bucket * bins_per_bucket + r0;             // < 4^14: fits 32 bits
+    const uint32_t dummy = PH_HALF_BINS + 2u * (threadIdx.x & 63u);       // the lane's private counter behind the range
+    auto count = [&](uint32_t key) {
+        const uint32_t a = (key & low) - r0;
+        const uint32_t b = a < dummy ? a : dummy;
+        const int hs = (int)(b & 1u) * 16;
+        const uint32_t old = atomicAdd(&lb[b >> 1], 1u << hs);
+        if ((((old >> hs) & 0xFFFFu) == PH_HALF_LIMIT - 1u) && a < PH_HALF_BINS) {   // this add made it 0x8000: spill
+            atomicSub(&lb[b >> 1], PH_HALF_LIMIT << hs);
+            spill[atomicAdd(spill_n, 1ull)] = bin_base + a;
+        }
+    };
+    const uint64_t lo4 = (lo + 3) & ~(uint64_t)3, hi4 = hi & ~(uint64_t)3;
+    if (lo4 < hi4) {
+        for (uint64_t i = lo + threadIdx.x; i < lo4; i += PH_TPB) count(keys[i]);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys);
+        const uint64_t qend = hi4 >> 2, qlast = qend - 1;
+        uint64_t q = (lo4 >> 2) + threadIdx.x;
+        u32x4 k0 = k4[q < qend ? q : qlast], k1 = k4[q + PH_TPB < qend ? q + PH_TPB : qlast];
+        for (; q < qend; q += PH_TPB) {
+            const u32x4 kv = k0;
+            k0 = k1;
+            k1 = k4[q + 2 * PH_TPB < qend ? q + 2 * PH_TPB : qlast];
+            count(kv.x);
+            count(kv.y);
+            count(kv.z);
+            count(kv.w);
+        }
+        for (uint64_t i = hi4 + threadIdx.x; i < hi; i += PH_TPB) count(keys[i]);
+    } else {
+        for (uint64_t i = lo + threadIdx.x; i < hi; i += PH_TPB) count(keys[i]);
+    }
+    __syncthreads();
+    uint2 *dst = reinterpret_cast<uint2 *>(table + (size_t)bucket * bins_per_bucket + r0);
+    for (uint32_t j = threadIdx.x; j < PH_BINS; j += PH_TPB) {
+        const uint32_t w = lb[j];
+        dst[j] = make_uint2(w & 0xFFFFu, w >> 16);
+    }
+}
+__global__ void part_spill_kernel(uint32_t *__restrict__ table, const unsigned long long *__restrict__ spill_n,
+                                  const uint32_t *__restrict__ spill) {
+    const unsigned long long m = *spill_n;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (unsigned long long)gridDim.x * blockDim.x)
+        atomicAdd(&table[spill[i]], PH_HALF_LIMIT);
+}
 // ---- second level: tiles of <= 32768 keys inside one first-level bucket ---------------------------------------------------
 constexpr int P2_MAX = 128;        // sub-buckets per bucket (k = 16); 32 at k = 15
 __global__ void part2_ntiles_kernel(const uint64_t *__restrict__ goff, uint32_t *__restrict__ ntile) {
@@ -395,7 +461,21 @@ static int part_hist_any(kmap_counts *c, const uint32_t *hash_dev, const uint32_
         KMAP_CHECK_HIP(hipGetLastError());
         return KMAP_OK;
     }
-    part_hist_kernel<<<(unsigned)(NBK * passes), PH_TPB, (size_t)(sub + 64) * 4, st>>>(keys, goff, bins_per_bucket, passes, sub, c->bins);
+    static const bool half = [] { const char *e = getenv("KMAP_COUNT_PART_HALF"); return !(e && e[0] == '0'); }();   // A/B switch
+    if (half && passes > 1 && bins_per_bucket % PH_HALF_BINS == 0) {     // k = 13, 14: 16-bit counters, half the range passes
+        void *sp = nullptr;
+        const size_t cap = (size_t)(n / (int64_t)PH_HALF_LIMIT) + 16;
+        KMAP_TRY(kmap_scratch(&sp, 16 + cap * 4, st, KMAP_SLOT_B));
+        unsigned long long *spill_n = reinterpret_cast<unsigned long long *>(sp);
+        uint32_t *spill = reinterpret_cast<uint32_t *>(spill_n + 2);
+        KMAP_CHECK_HIP(hipMemsetAsync(spill_n, 0, 16, st));
+        const int hp = (int)(bins_per_bucket / PH_HALF_BINS);
+        KMAP_TRY(kmap_allow_lds((const void *)part_hist_half_kernel, (PH_BINS + 64) * 4));
+        part_hist_half_kernel<<<(unsigned)(NBK * hp), PH_TPB, (size_t)(PH_BINS + 64) * 4, st>>>(keys, goff, bins_per_bucket, hp, c->bins, spill_n, spill);
+        part_spill_kernel<<<64, 256, 0, st>>>(c->bins, spill_n, spill);
+    } else {
+        part_hist_kernel<<<(unsigned)(NBK * passes), PH_TPB, (size_t)(sub + 64) * 4, st>>>(keys, goff, bins_per_bucket, passes, sub, c->bins);
+    }
     if (packed && k == 16) part_add_bin_kernel<<<1, 1, 0, st>>>(c->bins, (size_t)0xFFFFFFFFu, all_ones);
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;

@@ -221,11 +221,13 @@ def test_two_level_partitioned_counts_vs_oracle(env, k):
     ds.close()
 
 
-@pytest.mark.parametrize("k", [6, 8, 9, 10])
+@pytest.mark.parametrize("k", [6, 8, 9, 10, 12, 13, 14])
 def test_lds_histogram_hot_bins(env, k):
     """LDS-pass histogram under extreme skew: 12 M positions, 85 % of them poly-A (plus poly-T and random reads), so one bin takes
     > 8 M of the counts and every wave's lanes hit the same LDS word; windows of other passes' bin ranges and invalid windows go
-    to the lanes' private bins behind the table.  Counts must equal the oracle's, with and without per-read dedupe."""
+    to the lanes' private bins behind the table.  k = 13 / 14 take the partitioned histogram with two 16-bit counters per LDS
+    word: the poly-A bin spills its 32 768-count chunks to the global list ~300 times.  Counts must equal the oracle's, with and
+    without per-read dedupe."""
     _ffi, DeviceCounts, DeviceSeq, O = env
     rng = np.random.default_rng(500 + k)
     seq, borders = synth(rng, 60_000, 190, 210, p_n=0.001)
