@@ -384,7 +384,8 @@ __global__ void part_add_bin_kernel(uint32_t *__restrict__ table, size_t bin, co
 
 bool kmap_counts_part_applies(int k, int64_t n) {
     static const int on = [] { const char *e = getenv("KMAP_COUNT_PART"); return e ? atoi(e) : 1; }();
-    return on && k >= 11 && k <= 16 && n >= ((int64_t)1 << 20);
+    static const int min_k = [] { const char *e = getenv("KMAP_COUNT_PART_MINK"); return e ? atoi(e) : 10; }();   // k = 10: 32 LDS passes (13.7 ms at C3) against ~6 ms here; k = 9: 8 passes (3.7 ms) win
+    return on && k >= min_k && k >= 8 && k <= 16 && n >= ((int64_t)1 << 20);
 }
 
 // bins of c <- histogram of the valid (!= 0xFFFFFFFF) keys; the whole table is written (no prior memset needed).  Keys: a hash
