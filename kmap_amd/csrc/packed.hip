@@ -395,8 +395,8 @@ __global__ __launch_bounds__(KMAP_WAVE *DS_WAVES) void dedupe_bitmap_packed_kern
     // is one coalesced KiB (lane-strided by n_waves reads it fetched a whole sector per 16 bytes: 1.0 GB of the kernel's 1.6 GB
     // of HBM traffic at C3) and the window loads walk through one contiguous stretch of the packed array
     const int64_t wave_global = (int64_t)blockIdx.x * DS_WAVES + wave;
-    auto read_of = [&](int64_t it) -> int64_t { return ((it >> 6) * n_waves + wave_global) * 64 + (it & 63); };
-    if (read_of(0) >= n_seq) return;
+    if (wave_global * 64 >= n_seq) return;
+    const int64_t batch_step = n_waves * 64;                              // first read of the wave's next batch - of this one
     {   // the bitmap is zeroed once; after a read every lane zeroes the words it touched (3 scattered stores instead of bw / 256
         // 16-byte stores per lane: the LDS pipe is the busiest unit of this kernel)
         uint4 *b4 = reinterpret_cast<uint4 *>(bm);
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(KMAP_WAVE *DS_WAVES) void dedupe_bitmap_packed_kern
     DbRaw W[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) db_load(G, c * 64 + lane, W[c]);
-    int64_t rn = read_of(1);
+    int64_t rn = wave_global * 64 + 1;                                        // read of iteration it + 1 (adds only: no 64-bit multiply per read)
     for (;;) {
         const bool has_next = rn < n_seq;                                 // wave-uniform
         DbRead Gn = G;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(KMAP_WAVE *DS_WAVES) void dedupe_bitmap_packed_kern
         // the loads just issued
 #pragma unroll
         for (int c = 0; c < NB; ++c) db_load(Gn, c * 64 + lane, Wn[c]);
-        const int64_t rnn = read_of(it + 2);
+        const int64_t rnn = ((it + 2) & 63) ? rn + 1 : rn - 63 + batch_step;   // rn is the last read of its batch when it + 2 opens one
         if (G.nsteps) {
             int touched[NB];                                              // word index per prefetched step, -1 = none
 #pragma unroll
