@@ -108,9 +108,19 @@ __global__ __launch_bounds__(256) void scan_summary_kernel(const int32_t *__rest
         const unsigned long long m2 = __shfl_down(mx, o);
         mx = m2 > mx ? m2 : mx;
     }
-    if ((threadIdx.x & 63) == 0) {
-        if (cnt) atomicAdd(&stat[0], cnt);
-        if (mx) atomicMax(&stat[1], mx);
+    __shared__ unsigned long long wc[4], wm[4];                          // one pair of global atomics per block: thousands of
+    if ((threadIdx.x & 63) == 0) {                                        // same-address 64-bit atomics cost 200 us, not 20
+        wc[threadIdx.x >> 6] = cnt;
+        wm[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long c = (wc[0] + wc[1]) + (wc[2] + wc[3]);
+        unsigned long long m = wm[0] > wm[1] ? wm[0] : wm[1];
+        m = wm[2] > m ? wm[2] : m;
+        m = wm[3] > m ? wm[3] : m;
+        if (c) atomicAdd(&stat[0], c);
+        if (m) atomicMax(&stat[1], m);
     }
 }
 
@@ -226,7 +236,7 @@ int kmap_scan_summary(kmap_scan *s, int64_t *reads_with_hits, int32_t *max_hits,
     hipStream_t st = as_stream(stream);
     unsigned long long *stat = reinterpret_cast<unsigned long long *>(s->offs);   // offs is dead once the positions are written
     KMAP_CHECK_HIP(hipMemsetAsync(stat, 0, 16, st));
-    scan_summary_kernel<<<(unsigned)std::min<int64_t>((s->n_seq + 2047) / 2048, 2048), 256, 0, st>>>(s->hits, s->n_seq, stat);
+    scan_summary_kernel<<<(unsigned)std::min<int64_t>((s->n_seq + 2047) / 2048, 512), 256, 0, st>>>(s->hits, s->n_seq, stat);
     KMAP_CHECK_HIP(hipGetLastError());
     unsigned long long host[2] = {0, 0};
     KMAP_CHECK_HIP(hipMemcpyAsync(host, stat, 16, hipMemcpyDeviceToHost, st));
