@@ -20,10 +20,9 @@ def main():
     path = os.path.join(d, "input.bin.pkl")
     with open(path, "wb") as fh:
         pickle.dump(arr, fh, protocol=4)
-    head = open(path, "rb").read(256)
-    off = head.index(b"\x89") + 1        # NEWFALSE (fortran flag) precedes the BINBYTES op of the data
-    print("op", head[off:off + 1], "offset", off)
-    off += 5 if head[off:off + 1] == b"B" else 9
+    from kmap_amd.kmer_count import locate_pickled_array
+    off, dt, shape = locate_pickled_array(path, 1 << 20)
+    print("payload offset", off, dt, shape)
     dev = _ffi.DeviceBuffer(n)
     _ffi.sync()
     for rep in range(3):
