@@ -80,9 +80,8 @@ __device__ __forceinline__ uint64_t rc_bits(uint64_t x, int k) { return revcom_h
 
 // keep/emit decision for bin x (see merge_revcom, kmer_count.py:643-685): returns true if an
 // entry is emitted; key/cnt are the emitted values.
-__device__ __forceinline__ bool bin_entry(const uint32_t *__restrict__ bins, uint64_t x, int k, int merge, uint64_t &key,
+__device__ __forceinline__ bool bin_entry(const uint32_t *__restrict__ bins, uint64_t x, uint32_t c, int k, int merge, uint64_t &key,
                                           uint32_t &cnt) {
-    const uint32_t c = bins[x];
     if (c == 0) return false;
     key = x;
     cnt = c;
@@ -164,21 +163,51 @@ __global__ __launch_bounds__(BLK) void rc_merge_tiles_kernel(uint32_t *__restric
     }
 }
 
-__global__ __launch_bounds__(BLK) void compact_count_kernel(const uint32_t *__restrict__ bins, uint64_t n_bins, int k,
-                                                            int merge, uint32_t *__restrict__ block_counts) {
-    __shared__ uint32_t wsum[BLK / 64];
-    const uint64_t x0 = ((uint64_t)blockIdx.x * BLK + threadIdx.x) * CT_PER_THREAD;
-    uint32_t m = 0;
+// the CT_PER_THREAD consecutive bins of a thread: 16-byte loads (element loads through the `x < n_bins` guards were eight
+// 4-byte loads per thread at a 32-byte lane stride: every line fetched by eight instructions -- 2 TB/s on a pure streaming read)
+__device__ __forceinline__ void load_bins(const uint32_t *__restrict__ bins, uint64_t x0, uint64_t n_bins, uint32_t (&c)[CT_PER_THREAD]) {
+    static_assert(CT_PER_THREAD == 8, "two 16-byte loads");
+    if (x0 + CT_PER_THREAD <= n_bins) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 a = *reinterpret_cast<const u32x4 *>(bins + x0), b = *reinterpret_cast<const u32x4 *>(bins + x0 + 4);
+        c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
+        c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+    } else {
 #pragma unroll
-    for (int j = 0; j < CT_PER_THREAD; ++j) {
-        uint64_t key;
-        uint32_t cnt;
-        if (x0 + j < n_bins) m += bin_entry(bins, x0 + j, k, merge, key, cnt);
+        for (int j = 0; j < CT_PER_THREAD; ++j) c[j] = (x0 + j < n_bins) ? bins[x0 + j] : 0u;
     }
-    for (int o = 32; o > 0; o >>= 1) m += __shfl_down(m, o);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = m;
+}
+// A block walks CT_TPB consecutive tiles (the per-tile counts / offsets keep their meaning): with one 8-KiB tile per block the
+// 16-GiB table of k = 16 is 2 M blocks and the pass ran at the dispatch rate (2 TB/s), not at the memory's.
+constexpr int CT_TPB = 8;
+__global__ __launch_bounds__(BLK) void compact_count_kernel(const uint32_t *__restrict__ bins, uint64_t n_bins, int k,
+                                                            int merge, uint32_t *__restrict__ block_counts, unsigned n_tiles) {
+    __shared__ uint32_t wsum[CT_TPB][BLK / 64];
+    uint32_t m[CT_TPB];
+#pragma unroll
+    for (int t = 0; t < CT_TPB; ++t) {
+        const uint64_t tile = (uint64_t)blockIdx.x * CT_TPB + t;
+        const uint64_t x0 = (tile * BLK + threadIdx.x) * CT_PER_THREAD;
+        m[t] = 0;
+        uint32_t c8[CT_PER_THREAD];
+        load_bins(bins, x0, n_bins, c8);
+#pragma unroll
+        for (int j = 0; j < CT_PER_THREAD; ++j) {
+            uint64_t key;
+            uint32_t cnt;
+            m[t] += bin_entry(bins, x0 + j, c8[j], k, merge, key, cnt);      // bins past the end were loaded as 0
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < CT_TPB; ++t) {
+        for (int o = 32; o > 0; o >>= 1) m[t] += __shfl_down(m[t], o);
+        if ((threadIdx.x & 63) == 0) wsum[t][threadIdx.x >> 6] = m[t];
+    }
     __syncthreads();
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x < CT_TPB) {
+        const unsigned tile = blockIdx.x * CT_TPB + threadIdx.x;
+        if (tile < n_tiles) block_counts[tile] = wsum[threadIdx.x][0] + wsum[threadIdx.x][1] + wsum[threadIdx.x][2] + wsum[threadIdx.x][3];
+    }
 }
 
 template <typename H>
@@ -186,13 +215,18 @@ __global__ __launch_bounds__(BLK) void compact_write_kernel(const uint32_t *__re
                                                             int merge, const uint64_t *__restrict__ block_off,
                                                             H *__restrict__ uniq, uint32_t *__restrict__ cnt_out) {
     __shared__ uint32_t wsum[BLK / 64];
-    const uint64_t x0 = ((uint64_t)blockIdx.x * BLK + threadIdx.x) * CT_PER_THREAD;
+  for (int t = 0; t < CT_TPB; ++t) {                                      // the block's tiles, one after the other
+    const uint64_t tile = (uint64_t)blockIdx.x * CT_TPB + t;
+    if (tile * CT_TILE >= n_bins) break;                                  // block-uniform
+    const uint64_t x0 = (tile * BLK + threadIdx.x) * CT_PER_THREAD;
     uint64_t keys[CT_PER_THREAD];
     uint32_t cnts[CT_PER_THREAD];
     uint32_t flags = 0, m = 0;
+    uint32_t c8[CT_PER_THREAD];
+    load_bins(bins, x0, n_bins, c8);
 #pragma unroll
     for (int j = 0; j < CT_PER_THREAD; ++j) {
-        if (x0 + j < n_bins && bin_entry(bins, x0 + j, k, merge, keys[j], cnts[j])) {
+        if (bin_entry(bins, x0 + j, c8[j], k, merge, keys[j], cnts[j])) {
             flags |= 1u << j;
             ++m;
         }
@@ -208,7 +242,7 @@ __global__ __launch_bounds__(BLK) void compact_write_kernel(const uint32_t *__re
     __syncthreads();
     uint32_t woff = 0;
     for (int w = 0; w < wave; ++w) woff += wsum[w];
-    uint64_t pos = block_off[blockIdx.x] + woff + (inc - m);
+    uint64_t pos = block_off[tile] + woff + (inc - m);
 #pragma unroll
     for (int j = 0; j < CT_PER_THREAD; ++j) {
         if (flags & (1u << j)) {
@@ -217,6 +251,8 @@ __global__ __launch_bounds__(BLK) void compact_write_kernel(const uint32_t *__re
             ++pos;
         }
     }
+    __syncthreads();                                                      // wsum is re-used by the next tile
+  }
 }
 
 __global__ __launch_bounds__(BLK) void sum_counts_kernel(const uint32_t *__restrict__ cnt, int64_t n, int as_signed,
@@ -376,7 +412,8 @@ int kmap_counts_finish_hist(kmap_counts *c, int k, int merge, int64_t *n_uniq, h
         rc_merge_tiles_kernel<<<(unsigned)((size_t)1 << (2 * (k - 6))), BLK, 0, st>>>(c->bins, k);
         merge = 2;
     }
-    compact_count_kernel<<<nb, BLK, 0, st>>>(c->bins, n_bins, k, merge, bc);
+    const unsigned nblk = (nb + CT_TPB - 1) / CT_TPB;
+    compact_count_kernel<<<nblk, BLK, 0, st>>>(c->bins, n_bins, k, merge, bc, nb);
     KMAP_TRY(exclusive_scan_u32(bc, nb, boff, st));
     uint64_t total = 0;
     KMAP_CHECK_HIP(hipMemcpyAsync(&total, boff + nb, 8, hipMemcpyDeviceToHost, st));
@@ -393,8 +430,8 @@ int kmap_counts_finish_hist(kmap_counts *c, int k, int merge, int64_t *n_uniq, h
         c->cap = cap;
     }
     if (total) {
-        if (k < 16) compact_write_kernel<uint32_t><<<nb, BLK, 0, st>>>(c->bins, n_bins, k, merge, boff, (uint32_t *)c->uniq, c->cnt);
-        else compact_write_kernel<uint64_t><<<nb, BLK, 0, st>>>(c->bins, n_bins, k, merge, boff, (uint64_t *)c->uniq, c->cnt);
+        if (k < 16) compact_write_kernel<uint32_t><<<nblk, BLK, 0, st>>>(c->bins, n_bins, k, merge, boff, (uint32_t *)c->uniq, c->cnt);
+        else compact_write_kernel<uint64_t><<<nblk, BLK, 0, st>>>(c->bins, n_bins, k, merge, boff, (uint64_t *)c->uniq, c->cnt);
     }
     KMAP_CHECK_HIP(hipGetLastError());
     c->k = k;
