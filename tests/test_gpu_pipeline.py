@@ -469,6 +469,21 @@ def test_occurrence_file_lazy_lists_and_background_writer(tmp_path):
         pending.host()
 
 
+def test_background_writer_failure_surfaces_at_join(tmp_path):
+    """a CSV writer that cannot open its file fails on its own thread; join() re-raises that on the caller's thread (scan_motif
+    joins every writer before it reports success)"""
+    from kmap_amd.kmer_count import encode_fasta, init_motif_def_dict, _pkg_file
+    from kmap_amd.motif_discovery import DeviceSeq, gen_motif_occurence_file
+    mdd = init_motif_def_dict(_pkg_file("default_motif_def_table.csv"))
+    arr, borders = encode_fasta(str(GOLD / "occ20" / "occ20.fa"))
+    ds = DeviceSeq(arr, borders)
+    writers = []
+    gen_motif_occurence_file(["ACGTACGT"], mdd, None, tmp_path / "no_such_dir" / "o.csv", True, dev_seq=ds, writers=writers)
+    with pytest.raises(ValueError, match="cannot open"):
+        writers[0].join()
+    ds.close()
+
+
 def test_scan_motif_deferred_occurrence_path(run_dir, tmp_path, monkeypatch):
     """scan_motif starts a k's occurrence CSV right after that k's find_motif unless a read needs the > 20-hit draw; then the
     file waits for its turn in ascending k (np.random order).  Forcing every k down the deferred path must give the same files."""
