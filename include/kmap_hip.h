@@ -54,6 +54,10 @@ int kmap_memcpy_d2d(void *dev_dst, const void *dev_src, size_t bytes, void *stre
 /* pitched device->host copy: `rows` rows of `width` bytes, device pitch `dpitch`, dense host */
 int kmap_memcpy2d_d2h(void *host_dst, size_t hpitch, const void *dev_src, size_t dpitch, size_t width, size_t rows,
                       void *stream);
+/* The library caches its transient device buffers (hash arrays, the 4^k-bin histogram table -- 16 GiB at k = 16 --, partition
+ * keys) per device between calls.  kmap_scratch_release frees those of at least `min_bytes` on the current device (synchronises
+ * it first); counts handles that were between kmap_counts_hist_packed_dev and kmap_counts_finish then fail with KMAP_E_STATE. */
+int kmap_scratch_release(size_t min_bytes);
 int kmap_stream_sync(void *stream);
 int kmap_stream_create(void **stream);
 int kmap_stream_destroy(void *stream);
@@ -157,6 +161,8 @@ int kmap_counts_run_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const 
  * (`kmap_counts_bins` returns the device pointer), then every rank compacts identically (`kmap_counts_finish`). */
 int kmap_counts_hist_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n,
                                 const int64_t *borders_dev, int64_t n_seq, int k, int dedupe_per_read, void *stream);
+/* All handles of a device share ONE table: kmap_counts_bins / kmap_counts_finish return KMAP_E_STATE if another handle has
+ * counted (or kmap_scratch_release ran) since this handle's kmap_counts_hist_packed_dev. */
 int kmap_counts_bins(kmap_counts *c, void **bins_dev, int64_t *n_bins);
 int kmap_counts_finish(kmap_counts *c, int k, int merge_revcom, int64_t *n_uniq, void *stream);
 int kmap_mask_hamball_packed_dev(const uint32_t *codes_dev, uint16_t *inval_dev, int64_t n, int k, const uint64_t *cons,
@@ -182,6 +188,9 @@ int kmap_scan_fetch(kmap_scan *s, int32_t *hits_per_read, int8_t *min_dist, int3
  * CSV while the launching thread goes on (the handle keeps the lists until its next run) */
 int kmap_scan_summary(kmap_scan *s, int64_t *reads_with_hits, int32_t *max_hits, void *stream);
 int kmap_scan_fetch_stream(kmap_scan *s, int32_t *hits_per_read, int32_t *positions, void *stream);
+/* device addresses of the last run's lists (hits int32[n_seq], positions int32[total]; valid until the handle's next run), for
+ * callers that gather the shards of a read-sharded scan with a device collective ("scan hits: gather in read order") */
+int kmap_scan_result_dev(kmap_scan *s, void **hits_dev, void **pos_dev, int64_t *n_seq, int64_t *total);
 /* hit counts as bytes (narrowed on the device; for lists whose summary max_hits <= 255, larger counts saturate) */
 int kmap_scan_fetch_stream_u8(kmap_scan *s, uint8_t *hits_u8, int32_t *positions, void *stream);
 
@@ -324,6 +333,16 @@ int kmap_embed_set_jitter(kmap_embed *e, const double *normals, int n_normals);
  * `kmap_embed_apply`.  NULL pointers select the session's own buffers. */
 int kmap_embed_forces(kmap_embed *e, float *grad_dev_2xn, double *loss_dev, void *stream);
 int kmap_embed_apply(kmap_embed *e, const float *grad_dev_2xn, const double *loss_dev, void *stream);
+/* one-message form of the pair above (the multi-GPU loop: ONE collective per iteration, no memset, no float64 collective):
+ * msg_dev = float[kmap_embed_msg_floats(n)] = [gradient 2 x N | the rank's loss partial as an exact integer: f64 -> 48.48 fixed
+ * point -> six 16-bit limbs stored as floats | flag | pad].  `kmap_embed_forces_msg` writes the rank's entries and its limbs,
+ * the caller SUM-all-reduces the whole buffer as float32 (limb sums of up to 256 ranks are exact in any order, so every rank
+ * decodes the same loss whatever algorithm the collective uses), `kmap_embed_apply_msg` decodes and applies it -- and, for
+ * row-sharded sessions, zeroes every entry it has read, so the next message again starts from x + 0 + ... + 0.  The buffer must
+ * be zero before the first call. */
+int64_t kmap_embed_msg_floats(int64_t n);
+int kmap_embed_forces_msg(kmap_embed *e, float *msg_dev, void *stream);
+int kmap_embed_apply_msg(kmap_embed *e, float *msg_dev, void *stream);
 /* single-GPU convenience: n_iter iterations of forces+apply on `stream` */
 int kmap_embed_step(kmap_embed *e, int n_iter, void *stream);
 /* loop state: iterations done, stopped flag, last loss, best loss, jitter normals consumed */

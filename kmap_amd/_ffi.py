@@ -31,6 +31,7 @@ _SIGS = {
     "kmap_memcpy_d2h": (i32, [vp, vp, sz, vp]),
     "kmap_memcpy_d2d": (i32, [vp, vp, sz, vp]),
     "kmap_memcpy2d_d2h": (i32, [vp, sz, vp, sz, sz, sz, vp]),
+    "kmap_scratch_release": (i32, [C.c_size_t]),
     "kmap_stream_sync": (i32, [vp]),
     "kmap_stream_create": (i32, [P(vp)]),
     "kmap_stream_destroy": (i32, [vp]),
@@ -95,6 +96,7 @@ _SIGS = {
     "kmap_scan_fetch": (i32, [vp, vp, vp, vp]),
     "kmap_scan_fetch_stream": (i32, [vp, vp, vp, vp]),
     "kmap_scan_fetch_stream_u8": (i32, [vp, vp, vp, vp]),
+    "kmap_scan_result_dev": (i32, [vp, P(vp), P(vp), P(i64), P(i64)]),
     "kmap_scan_summary": (i32, [vp, P(i64), P(i32), vp]),
     "kmap_write_occurrence_csv": (i32, [C.c_char_p, C.c_char_p, i64, i32, vp, vp, vp, P(i64)]),
     "kmap_write_occurrence_csv_u8": (i32, [C.c_char_p, C.c_char_p, i64, i32, vp, vp, vp, P(i64)]),
@@ -120,6 +122,9 @@ _SIGS = {
     "kmap_embed_set_jitter": (i32, [vp, vp, i32]),
     "kmap_embed_forces": (i32, [vp, vp, vp, vp]),
     "kmap_embed_apply": (i32, [vp, vp, vp, vp]),
+    "kmap_embed_msg_floats": (i64, [i64]),
+    "kmap_embed_forces_msg": (i32, [vp, vp, vp]),
+    "kmap_embed_apply_msg": (i32, [vp, vp, vp]),
     "kmap_embed_step": (i32, [vp, i32, vp]),
     "kmap_embed_state": (i32, [vp, P(i64), P(i32), P(f32), P(f32), P(i32), vp]),
     "kmap_embed_get_coords": (i32, [vp, vp, vp]),

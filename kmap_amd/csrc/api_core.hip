@@ -50,6 +50,29 @@ int kmap_scratch(void **ptr, size_t bytes, hipStream_t stream, int slot) {
     return KMAP_OK;
 }
 
+// frees the cached buffers of at least `min_bytes` on the current device (all streams, all slots); the device is synchronised
+// first, so no work using them is in flight
+static int scratch_release(size_t min_bytes) {
+    int dev = 0;
+    KMAP_CHECK_HIP(hipGetDevice(&dev));
+    KMAP_CHECK_HIP(hipDeviceSynchronize());
+    bool bins = false;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        for (auto it = g_scratch.begin(); it != g_scratch.end();) {
+            if (std::get<0>(it->first) == dev && it->second.bytes >= min_bytes) {
+                if (it->second.p) (void)hipFree(it->second.p);
+                bins = bins || std::get<2>(it->first) == KMAP_SLOT_BINS;
+                it = g_scratch.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
+    if (bins) kmap_counts_bins_invalidate(dev);
+    return KMAP_OK;
+}
+
 int kmap_allow_lds(const void *kernel, int bytes) {
     static std::mutex mu;
     static std::map<std::pair<const void *, int>, int> done;     // (kernel, device) -> bytes granted
@@ -67,6 +90,7 @@ int kmap_allow_lds(const void *kernel, int bytes) {
 extern "C" {
 
 int kmap_version(void) { return 1000 * 0 + 1; }
+int kmap_scratch_release(size_t min_bytes) { return scratch_release(min_bytes); }
 const char *kmap_last_error(void) { return g_err; }
 
 int kmap_device_count(int *n) {

@@ -43,6 +43,8 @@ static inline hipStream_t as_stream(void *s) { return (hipStream_t)s; }
 // same kernels on hipMalloc memory are correct.  Work that uses a slot is ordered by its stream.
 enum { KMAP_SLOT_A = 0, KMAP_SLOT_B = 1, KMAP_SLOT_C = 2, KMAP_SLOT_D = 3, KMAP_SLOT_HASH = 4, KMAP_SLOT_PART = 5, KMAP_SLOT_BINS = 6 };
 int kmap_scratch(void **ptr, size_t bytes, hipStream_t stream, int slot);
+// counts.hip: the shared histogram table of `dev` changed hands or was freed -- every handle's cached pointer is stale
+void kmap_counts_bins_invalidate(int dev);
 // raises a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) once per (kernel, device); thread-safe
 int kmap_allow_lds(const void *kernel, int bytes);
 

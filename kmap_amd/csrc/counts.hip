@@ -365,6 +365,9 @@ static uint64_t host_revcom(uint64_t h, int k, int narrow) {
 
 }  // namespace
 
+#include <map>
+#include <mutex>
+
 #include "counts_internal.h"
 
 namespace {
@@ -372,6 +375,12 @@ namespace {
 // The 4^k-bin histogram is transient (one count call, or hist -> all-reduce -> finish in the sharded flow), so all handles of a
 // device share ONE table from the scratch arena instead of owning one each: a fresh handle per k and per find_motif round paid
 // ~1 s of hipMalloc / hipFree for the 16-GiB table at k = 16.  (Counting is single-threaded per device, like the arena.)
+// Ownership: every (re)fill takes a new generation number of the device's table and stamps the handle with it.  The split API
+// hist -> kmap_counts_bins -> (caller's all-reduce) -> kmap_counts_finish checks the stamp, so a count through another handle in
+// between (which overwrites the table, or regrows the arena and frees it) is an error instead of a silently wrong compaction.
+std::mutex g_bins_mu;
+std::map<int, uint64_t> g_bins_gen;     // device -> generation of the table's current contents
+
 int ensure_bins(kmap_counts *c, size_t n_bins) {
     void *p = nullptr;
     const int rc = kmap_scratch(&p, n_bins * 4, (hipStream_t) nullptr, KMAP_SLOT_BINS);
@@ -379,12 +388,33 @@ int ensure_bins(kmap_counts *c, size_t n_bins) {
         kmap_set_error("counts: cannot allocate %zu-bin histogram (%.1f GiB)", n_bins, n_bins * 4.0 / (1 << 30));
         return rc;
     }
+    int dev = 0;
+    KMAP_CHECK_HIP(hipGetDevice(&dev));
     c->bins = (uint32_t *)p;
     c->bins_cap = n_bins;
+    c->bins_dev = dev;
+    std::lock_guard<std::mutex> lock(g_bins_mu);
+    c->bins_gen = ++g_bins_gen[dev];
     return KMAP_OK;
 }
 
 }  // namespace
+
+void kmap_counts_bins_invalidate(int dev) {
+    std::lock_guard<std::mutex> lock(g_bins_mu);
+    ++g_bins_gen[dev];
+}
+
+int kmap_counts_bins_check(const kmap_counts *c, const char *who) {
+    std::lock_guard<std::mutex> lock(g_bins_mu);
+    auto it = g_bins_gen.find(c->bins_dev);
+    if (!c->bins || it == g_bins_gen.end() || it->second != c->bins_gen) {
+        kmap_set_error("%s: the device's shared histogram table no longer holds this handle's counts (another handle counted, or "
+                       "the scratch arena was released, since kmap_counts_hist_packed_dev)", who);
+        return KMAP_E_STATE;
+    }
+    return KMAP_OK;
+}
 
 int kmap_counts_reserve_bins(kmap_counts *c, int k) {
     KMAP_REQUIRE(k > 0 && k <= 16, "counts: direct histogram needs k <= 16 (k=%d)", k);

@@ -11,7 +11,13 @@ struct kmap_counts {
     size_t cap = 0;          // entries allocated
     uint32_t *bins = nullptr;
     size_t bins_cap = 0;     // bins allocated
+    // the 4^k-bin table is ONE per device (scratch arena), shared by all handles: (bins_dev, bins_gen) say which fill of it this
+    // handle made; kmap_counts_bins / kmap_counts_finish refuse to touch a table another handle has written since
+    int bins_dev = -1;
+    uint64_t bins_gen = 0;
 };
+// does the shared table still hold THIS handle's last histogram? (KMAP_E_STATE + message otherwise)
+int kmap_counts_bins_check(const kmap_counts *c, const char *who);
 
 
 // k >= 17: sort + run-length encode + revcom merge (counts_sort.hip)

@@ -1260,6 +1260,50 @@ __global__ __launch_bounds__(RL_TPB) void reduce_loss_kernel(const double *__res
     if (threadIdx.x == 0) loss_out[0] = sh[0];
 }
 
+// ---- multi-GPU one-message protocol ---------------------------------------------------------------
+// A rank's contribution to an iteration is ONE float buffer: [0, 2N) its gradient entries (own rows, or partial sums for all
+// points in the cyclic layout) and MSG_EXTRA floats behind them that carry its loss partial as an exact integer: the f64 value
+// in 48.48 fixed point, cut into six 16-bit limbs, each stored as a float.  A float32 SUM all-reduce adds limbs of up to 256
+// ranks without rounding (6 x < 2^24), in any order, so every rank decodes the same total whatever algorithm the collective
+// library picks -- one collective per iteration instead of a float32 and a float64 one, and the stop / snapshot decisions
+// (which come from the loss alone) cannot diverge between ranks.  Limb 6 flags a non-finite or out-of-range partial (-> NaN).
+constexpr int MSG_EXTRA = 8;   // six limbs, flag, pad
+__device__ __forceinline__ void loss_to_limbs(double v, float *__restrict__ tail) {
+    const bool bad = !(v >= 0.0) || !(v < 140737488355328.0);            // NaN, negative or >= 2^47
+    unsigned long long hi = 0, lo = 0;
+    if (!bad) {
+        hi = (unsigned long long)v;                                       // floor (v >= 0)
+        lo = (unsigned long long)((v - (double)hi) * 281474976710656.0);  // exact difference, truncated at 2^-48
+    }
+    for (int i = 0; i < 3; ++i) tail[i] = (float)((lo >> (16 * i)) & 0xFFFFull);
+    for (int i = 0; i < 3; ++i) tail[3 + i] = (float)((hi >> (16 * i)) & 0xFFFFull);
+    tail[6] = bad ? 1.0f : 0.0f;
+    tail[7] = 0.0f;
+}
+__device__ __forceinline__ double loss_from_limbs(const float *__restrict__ tail) {
+    if (tail[6] != 0.0f) return (double)NAN;
+    unsigned long long lo = 0, hi = 0;                                    // summed limbs carry past 16 bits: integer Horner
+    for (int i = 2; i >= 0; --i) lo = (lo << 16) + (unsigned long long)tail[i];
+    for (int i = 2; i >= 0; --i) hi = (hi << 16) + (unsigned long long)tail[3 + i];
+    hi += lo >> 48;
+    lo &= 0xFFFFFFFFFFFFull;
+    return (double)hi + (double)lo * (1.0 / 281474976710656.0);
+}
+// reduce_loss_kernel with the total written as limbs behind the gradient (n_part = 0: a rank without rows sends zero)
+__global__ __launch_bounds__(RL_TPB) void reduce_loss_limbs_kernel(const double *__restrict__ part, int n_part,
+                                                                   float *__restrict__ tail) {
+    __shared__ double sh[RL_TPB];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n_part; i += RL_TPB) s += part[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = RL_TPB / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_to_limbs(sh[0], tail);
+}
+
 // =================================================================================================
 // loop state + apply
 // =================================================================================================
@@ -1376,6 +1420,34 @@ __global__ __launch_bounds__(BLK) void apply_kernel(LoopState *__restrict__ stat
         float gsp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int c = 0; c < 2; ++c)
             for (int p = 0; p < 2 && p < n; ++p) gsp[2 * c + p] = G[(int64_t)c * n + p];
+        step_leader(states, cur, d, Y, gsp, snaps, n, lr, normals, n_normals_dev, loss_log, loss_log_cap);
+    }
+}
+
+// apply for the one-message protocol: the summed message M = [gradient 2N | loss limbs].  CLEAR (row-sharded sessions, whose
+// force kernel fills only the rank's own rows): every entry is zeroed once it has been read, so the next iteration's message
+// starts from x + 0 + ... + 0 without a memset launch (the cyclic layout overwrites all 2N entries itself).
+template <bool CLEAR>
+__global__ __launch_bounds__(BLK) void apply_msg_kernel(LoopState *__restrict__ states, int cur, float *__restrict__ Y,
+                                                        float *__restrict__ M, float *__restrict__ snaps, int64_t n, float lr,
+                                                        const double *__restrict__ normals, const int *__restrict__ n_normals_dev,
+                                                        float *__restrict__ loss_log, int64_t loss_log_cap) {
+    const double total = loss_from_limbs(M + 2 * n);
+    const StepDecision d = step_decide(&states[cur], total);
+    const int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    const bool special = (idx == 0 || idx == 1 || idx == n || idx == n + 1);   // owned by the leader (jitter)
+    if (idx < 2 * n && !special) {
+        const float g = M[idx];
+        if (CLEAR) M[idx] = 0.0f;
+        if (!d.halted) step_element(d, idx, g, Y, snaps, n, lr);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float gsp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int c = 0; c < 2; ++c)
+            for (int p = 0; p < 2 && p < n; ++p) {
+                gsp[2 * c + p] = M[(int64_t)c * n + p];
+                if (CLEAR) M[(int64_t)c * n + p] = 0.0f;
+            }
         step_leader(states, cur, d, Y, gsp, snaps, n, lr, normals, n_normals_dev, loss_log, loss_log_cap);
     }
 }
@@ -1800,6 +1872,36 @@ int kmap_embed_apply(kmap_embed *e, const float *grad_dev_2xn, const double *los
     const unsigned grid = (unsigned)((2 * e->n + BLK - 1) / BLK);
     apply_kernel<false><<<grid, BLK, 0, st>>>(e->states, e->cur, e->Y, G, L, 0, e->snaps, e->n, e->lr, e->normals, e->n_normals_dev,
                                               e->loss_log, e->loss_log_cap);
+    KMAP_CHECK_HIP(hipGetLastError());
+    e->cur ^= 1;
+    return KMAP_OK;
+}
+
+int64_t kmap_embed_msg_floats(int64_t n) { return n > 0 ? 2 * n + MSG_EXTRA : 0; }
+
+int kmap_embed_forces_msg(kmap_embed *e, float *msg_dev, void *stream) {
+    KMAP_REQUIRE(e && e->have_prob && e->have_coords, "embed_forces_msg: probabilities/coordinates not set");
+    KMAP_REQUIRE(msg_dev, "embed_forces_msg: null message buffer");
+    hipStream_t st = as_stream(stream);
+    const int nblk = n_force_blocks(e);
+    if (nblk > 0) KMAP_TRY(launch_forces(e, msg_dev, true, st));
+    reduce_loss_limbs_kernel<<<1, RL_TPB, 0, st>>>(e->loss_part, nblk, msg_dev + 2 * e->n);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+
+int kmap_embed_apply_msg(kmap_embed *e, float *msg_dev, void *stream) {
+    KMAP_REQUIRE(e && e->have_coords, "embed_apply_msg: coordinates not set");
+    KMAP_REQUIRE(msg_dev, "embed_apply_msg: null message buffer");
+    hipStream_t st = as_stream(stream);
+    const unsigned grid = (unsigned)((2 * e->n + BLK - 1) / BLK);
+    const bool clear = !e->sym && !(e->row0 == 0 && e->nrows == e->n);      // the force kernel leaves other ranks' rows alone
+    if (clear)
+        apply_msg_kernel<true><<<grid, BLK, 0, st>>>(e->states, e->cur, e->Y, msg_dev, e->snaps, e->n, e->lr, e->normals, e->n_normals_dev,
+                                                     e->loss_log, e->loss_log_cap);
+    else
+        apply_msg_kernel<false><<<grid, BLK, 0, st>>>(e->states, e->cur, e->Y, msg_dev, e->snaps, e->n, e->lr, e->normals, e->n_normals_dev,
+                                                      e->loss_log, e->loss_log_cap);
     KMAP_CHECK_HIP(hipGetLastError());
     e->cur ^= 1;
     return KMAP_OK;

@@ -1169,6 +1169,7 @@ int kmap_counts_hist_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const
 
 int kmap_counts_bins(kmap_counts *c, void **bins_dev, int64_t *n_bins) {
     KMAP_REQUIRE(c && bins_dev && n_bins, "counts_bins: null");
+    KMAP_TRY(kmap_counts_bins_check(c, "counts_bins"));
     *bins_dev = c->bins;
     *n_bins = (int64_t)c->bins_cap;
     return KMAP_OK;
@@ -1176,6 +1177,7 @@ int kmap_counts_bins(kmap_counts *c, void **bins_dev, int64_t *n_bins) {
 
 int kmap_counts_finish(kmap_counts *c, int k, int merge_revcom, int64_t *n_uniq, void *stream) {
     KMAP_REQUIRE(c && c->bins && k > 0 && k <= 16 && c->bins_cap >= ((size_t)1 << (2 * k)), "counts_finish: no histogram for k=%d", k);
+    KMAP_TRY(kmap_counts_bins_check(c, "counts_finish"));
     return kmap_counts_finish_hist(c, k, merge_revcom, n_uniq, as_stream(stream));
 }
 

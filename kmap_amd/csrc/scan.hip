@@ -227,6 +227,17 @@ int kmap_scan_fetch_stream(kmap_scan *s, int32_t *hits_per_read, int32_t *positi
     return KMAP_OK;
 }
 
+// device addresses of the last run's lists (valid until the handle's next run): a multi-GPU caller gathers them with a
+// device collective instead of fetching, exchanging and re-uploading them
+int kmap_scan_result_dev(kmap_scan *s, void **hits_dev, void **pos_dev, int64_t *n_seq, int64_t *total) {
+    KMAP_REQUIRE(s && hits_dev && pos_dev, "scan_result_dev: null");
+    *hits_dev = s->n_seq ? (void *)s->hits : nullptr;
+    *pos_dev = s->total ? (void *)s->pos : nullptr;
+    if (n_seq) *n_seq = s->n_seq;
+    if (total) *total = s->total;
+    return KMAP_OK;
+}
+
 // what gen_motif_occurence_file's caller needs of a hit list without fetching it: reads with >= 1 hit, largest hit count
 int kmap_scan_summary(kmap_scan *s, int64_t *reads_with_hits, int32_t *max_hits, void *stream) {
     KMAP_REQUIRE(s && reads_with_hits && max_hits, "scan_summary: null");

@@ -7,7 +7,8 @@ Sharding: every rank holds all N hashes (<= 1.6 MB) and owns row 
   * neighbour sums: from the k-mers' base-count profiles (csrc/knn_profile.hip), which need the neighbour table but no D
     rows, for exactly the rows the rank's embedding session owns.  (k > 16 or > 4 short consensuses: the matrix-based
     fallback needs arbitrary rows of D, so D is then computed in full on every rank.)
-  * embedding loop: per iteration the 2 x N gradient and one float64 loss partial are all-reduced.  Two layouts:
+  * embedding loop: ONE float32 all-reduce per iteration of [gradient 2 x N | the loss partial as integer limbs]
+    (DistEmbedLoop).  Two layouts:
       - SEQ, and FAST below N = 16384: one contiguous row block per rank, every rank evaluates all columns of its rows and
         fills only its rows of the gradient (sum = concatenation, exact);
       - FAST from N = 16384: the symmetric kernel -- each unordered pair once -- with the 256-row blocks dealt out cyclically
@@ -103,40 +104,110 @@ def broadcast_seed(dist, random_seed, group=None):
     return int(t.item())
 
 
+MSG_EXTRA = 8          # floats behind the 2 x N gradient in an iteration's message (csrc/embed.hip MSG_EXTRA)
+_TWO48 = float(1 << 48)
+
+
+def loss_to_limbs(v):
+    """Host mirror of the device encoding (embed.hip loss_to_limbs): a rank's float64 loss partial as an exact integer -- 48.48
+    fixed point cut into six 16-bit limbs stored as float32, limb 6 = "not representable" flag, limb 7 = padding.  A float32 SUM
+    all-reduce adds the limbs of up to 256 ranks without rounding, in any order."""
+    out = np.zeros(MSG_EXTRA, np.float32)
+    v = float(v)
+    if not (v >= 0.0) or not (v < float(1 << 47)):
+        out[6] = 1.0
+        return out
+    hi = int(v)
+    lo = int((v - hi) * _TWO48)
+    for i in range(3):
+        out[i] = (lo >> (16 * i)) & 0xFFFF
+        out[3 + i] = (hi >> (16 * i)) & 0xFFFF
+    return out
+
+
+def loss_from_limbs(tail):
+    """the summed limbs back to float64 (embed.hip loss_from_limbs); NaN if any rank raised the flag"""
+    if float(tail[6]) != 0.0:
+        return float("nan")
+    lo = sum(int(tail[i]) << (16 * i) for i in range(3))
+    hi = sum(int(tail[3 + i]) << (16 * i) for i in range(3))
+    hi += lo >> 48
+    lo &= (1 << 48) - 1
+    return float(hi) + float(lo) / _TWO48
+
+
+def assert_default_stream():
+    """The library launches on the null stream; ProcessGroupNCCL orders a collective against torch's CURRENT stream.  The two
+    are the same only while the caller has not switched streams (torch.cuda.stream(...)): otherwise the collective could run
+    before the kernels that fill its operand -- silently.  Cheap host-side check, no device work."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.current_stream() != torch.cuda.default_stream():
+        raise RuntimeError("kmap_amd.distributed: call with torch's default stream current (the HIP library launches on the null "
+                           "stream; collectives on another stream would not be ordered after its kernels)")
+
+
 class DistEmbedLoop:
-    """Drives a (row-sharded) embedding session: forces -> all-reduce(grad, loss) -> apply.
+    """Drives a (row-sharded) embedding session with ONE collective per iteration:
+        forces_msg -> all_reduce(SUM, float32 message) -> apply_msg.
+    The message (kmap_hip.h, kmap_embed_forces_msg) is [gradient 2 x N | loss limbs]: a rank writes only its own entries, the
+    apply kernel of a row-sharded session zeroes what it has read, so the sum is a concatenation (x + 0 + ... + 0, exact) without
+    a memset launch; the loss travels as integer limbs whose float32 sums are exact in any order, so every rank decodes the
+    same total and takes the same stop / snapshot decisions.  `session` needs forces_msg(ptr) / apply_msg(ptr); msg_t is a
+    zero-initialised float32 torch tensor of 2 N + MSG_EXTRA elements on the session's device.
+    always_collective: issue the all-reduce even on a one-rank group (bench.py measures the loop's overhead that way)."""
 
-    `session` needs forces(grad_ptr, loss_ptr), apply(grad_ptr, loss_ptr); grad_t / loss_t are torch tensors
-    (2 x N float32, 1 x float64) on the session's device.  forces() writes only the rows this rank owns, and
-    the in-place all-reduce leaves the other ranks' rows in the buffer, so the buffer is zeroed before every
-    forces(): the SUM all-reduce is then a concatenation (x + 0 + ... + 0, exact)."""
-
-    def __init__(self, session, grad_t, loss_t, dist=None, group=None):
-        self.s, self.g, self.l, self.dist, self.group = session, grad_t, loss_t, dist, group
-        self.gp, self.lp = grad_t.data_ptr(), loss_t.data_ptr()
+    def __init__(self, session, msg_t, dist=None, group=None, always_collective=False):
+        self.s, self.m, self.dist, self.group = session, msg_t, dist, group
+        self.mp = msg_t.data_ptr()
         self.n_collectives = 0
+        self.coll = dist is not None and (always_collective or dist.get_world_size(group) > 1)
+        if self.coll and msg_t.is_cuda:
+            assert_default_stream()
 
     def step(self, n_iter):
-        d = self.dist
-        sharded = d is not None and d.get_world_size(self.group) > 1
+        d, s, m, mp, g = self.dist, self.s, self.m, self.mp, self.group
+        if not self.coll:
+            for _ in range(n_iter):
+                s.forces_msg(mp)
+                s.apply_msg(mp)
+            return
         for _ in range(n_iter):
-            if sharded:
-                self.g.zero_()
-            self.s.forces(self.gp, self.lp)
-            if sharded:
-                # rank-ordered ring sum; identical bits on every rank.  x + 0 + ... + 0 is exact for the gradient.
-                d.all_reduce(self.g, op=d.ReduceOp.SUM, group=self.group)
-                d.all_reduce(self.l, op=d.ReduceOp.SUM, group=self.group)
-                self.n_collectives += 2
-            self.s.apply(self.gp, self.lp)
+            s.forces_msg(mp)
+            d.all_reduce(m, op=d.ReduceOp.SUM, group=g)      # stream-ordered between the two kernels: no host sync
+            s.apply_msg(mp)
+        self.n_collectives += n_iter
+
+    def profile(self, n_iter):
+        """n_iter iterations with device events around the three phases -> mean ms per iteration of each (events on torch's
+        current stream = the library's stream).  The event records perturb the loop a little: use step() for the headline time."""
+        import torch
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_iter)]
+        d = self.dist
+        for e in ev:
+            e[0].record()
+            self.s.forces_msg(self.mp)
+            e[1].record()
+            if self.coll:
+                d.all_reduce(self.m, op=d.ReduceOp.SUM, group=self.group)
+            e[2].record()
+            self.s.apply_msg(self.mp)
+            e[3].record()
+        if self.coll:
+            self.n_collectives += n_iter
+        torch.cuda.synchronize()
+        ph = [sum(e[i].elapsed_time(e[i + 1]) for e in ev) / n_iter for i in range(3)]
+        total = ev[0][0].elapsed_time(ev[-1][3]) / n_iter
+        return {"forces_ms": ph[0], "collective_ms": ph[1], "apply_ms": ph[2], "iteration_ms": total}
 
 
 def kmap_from_kmers_distributed(samp_kh, samp_cnts, samp_label, conseq_list, kmer_len, n_neighbour=20, n_max_iter=2500,
                                 learning_rate=0.01, n_best_result=10, random_seed=None, mode=None, trace=None,
-                                neighbor_inds_mat=None):
+                                neighbor_inds_mat=None, always_collective=False, profile_iters=0):
     """Multi-GPU version of visualization.kmap_from_kmers.  Call from every rank after
     torch.distributed.init_process_group("nccl") and torch.cuda.set_device(local_rank).
-    neighbor_inds_mat: optional full (N, n_neighbour) table to use instead of the selection (tests inject it)."""
+    neighbor_inds_mat: optional full (N, n_neighbour) table to use instead of the selection (tests inject it).
+    always_collective / profile_iters: bench.py's instruments (all-reduce even on a one-rank group; that many leading
+    iterations with events around forces / collective / apply, reported in trace["phases"])."""
     import torch
     import torch.distributed as dist
     from . import _ffi
@@ -206,13 +277,22 @@ def kmap_from_kmers_distributed(samp_kh, samp_cnts, samp_label, conseq_list, kme
     try:
         sess.set_prob_lut(sums_d, lds, lut)
         sess.set_coords(ld_data, placeholders)
-        grad_t = torch.zeros((2, n), dtype=torch.float32, device="cuda")
-        loss_t = torch.zeros(1, dtype=torch.float64, device="cuda")
-        loop = DistEmbedLoop(sess, grad_t, loss_t, dist)
-        vz._run_loop(sess, n_max_iter, step_fn=loop.step, trace=trace)
+        msg_t = torch.zeros(2 * n + MSG_EXTRA, dtype=torch.float32, device="cuda")
+        loop = DistEmbedLoop(sess, msg_t, dist, always_collective=always_collective)
+        prof = {}
+
+        def step_fn(seg):              # the first profile_iters iterations run with events around their three phases
+            k = 0 if prof else min(profile_iters, seg)
+            if k:
+                prof.update(loop.profile(k))
+            loop.step(seg - k)
+        vz._run_loop(sess, n_max_iter, step_fn=step_fn if profile_iters else loop.step, trace=trace)
         if trace is not None:
             trace["hbm"] = hbm
             trace["seed"] = random_seed
+            trace["collectives"] = loop.n_collectives
+            if profile_iters:
+                trace["phases"] = prof
         return sess.best(), lab
     finally:
         sess.close()
@@ -224,13 +304,69 @@ def read_partition(borders, world, rank):
     return row_partition(len(borders), world, rank)
 
 
+def _gathered_hits_cls():
+    from .motif_discovery import ScanHits
+
+    class GatheredHits(ScanHits):
+        """The hit list of ALL reads of a read-sharded scan, gathered by device collectives (RCCL) and still resident in HBM:
+        `parts_hits[r, :reads_of[r]]` / `parts_pos[r, :totals[r]]` are rank r's shard.  Same interface as ScanHits: the summary
+        numbers are known at once, the arrays reach the host on first use (in practice: rank 0's CSV writer thread)."""
+
+        def __init__(self, parts_hits, parts_pos, reads_of, totals, n_reads_hit, max_hits, device):
+            import threading
+            self._ph, self._pp, self._reads_of, self._totals, self._dev = parts_hits, parts_pos, reads_of, totals, device
+            self.n_seq, self.total, self.n_reads_hit, self.max_hits = int(sum(reads_of)), int(sum(totals)), int(n_reads_hit), int(max_hits)
+            self._host, self._owner, self._handle = None, None, None
+            self._lock = threading.Lock()
+
+        def _cat(self, narrow):
+            import torch
+            with torch.cuda.device(self._dev):          # torch's current device is per thread (CSV writer threads)
+                st = torch.cuda.Stream()                 # own stream: neither waits for nor blocks the launching thread
+                st.wait_stream(torch.cuda.default_stream())
+                with torch.cuda.stream(st):
+                    hits = torch.cat([self._ph[r, :m] for r, m in enumerate(self._reads_of)])
+                    if narrow:
+                        hits = hits.clamp(max=255).to(torch.uint8)
+                    pos = torch.cat([self._pp[r, :m] for r, m in enumerate(self._totals)]) if self.total else torch.zeros(0, dtype=torch.int32)
+                    out = hits.cpu().numpy(), pos.cpu().numpy()
+                st.synchronize()
+            self._ph = self._pp = None
+            return out
+
+        def host(self):
+            with self._lock:
+                if self._host is None:
+                    if self._ph is None:
+                        raise RuntimeError("GatheredHits: the list was already handed to a CSV writer (host_u8)")
+                    self._host = list(self._cat(False))
+                return self._host
+
+        @property
+        def unfetched(self):
+            return self._host is None and self._ph is not None
+
+        def host_u8(self):
+            with self._lock:
+                assert self._host is None and self._ph is not None and self.max_hits <= 255
+                return self._cat(True)
+
+        def __del__(self):
+            pass
+
+    return GatheredHits
+
+
 def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None):
     """A DeviceSeq holding only this rank's reads whose count()/scan() results are global:
     count = local histogram -> all-reduce(SUM) of the 4^k uint32 bins -> identical compaction on every rank
     (k <= 16; per-read dedupe, masking and scanning are local to a read, hence to a rank).  Because every rank then
     sees the same counts, find_motif(dev_seq=...) makes the same decisions everywhere without further exchange.
     scan() returns the hits of ALL reads (all-gathered in read order); `out_n_seq` / `out_read_len` describe the reads those
-    results cover (all of them), `n_seq` / `read_len` stay the local shard the kernels run on."""
+    results cover (all of them), `n_seq` / `read_len` stay the local shard the kernels run on.
+    On RCCL the hit lists never pass through the host on their way to the collective: the shards are gathered as device
+    tensors (scan_lazy -> GatheredHits) and only the rank that writes the occurrence file fetches them.
+    The arrays may be views of memory-mapped pickles (kmer_count.load_array_pickle): a rank touches its own slice only."""
     import ctypes as C
     import torch
     from . import _ffi
@@ -238,7 +374,11 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None):
     from .motif_discovery import DeviceSeq
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    borders = np.ascontiguousarray(boarder_mat, dtype=np.int64).reshape(-1, 2)
+    on_dev = _coll_device(dist, group) == "cuda"
+    if on_dev:
+        assert_default_stream()
+    borders = boarder_mat if isinstance(boarder_mat, np.ndarray) and boarder_mat.dtype == np.int64 and boarder_mat.ndim == 2 \
+        else np.ascontiguousarray(boarder_mat, dtype=np.int64).reshape(-1, 2)
     r0, nr = read_partition(borders, world, rank)
     if nr:
         lo, hi = int(borders[r0, 0]), int(borders[r0 + nr - 1, 1]) + 1          # include the last read's separator
@@ -248,14 +388,29 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None):
     local_seq = np.ascontiguousarray(seq_np_arr[lo:hi])
     local_borders = borders[r0:r0 + nr] - lo
     reads_of = [read_partition(borders, world, r)[1] for r in range(world)]
+    GatheredHits = _gathered_hits_cls() if on_dev else None
 
     class DistDeviceSeq(DeviceSeq):
         first_read, n_local_reads, n_all_reads = r0, nr, len(borders)
-        scan_lazy = None        # hit lists are all-gathered through the host: no device-resident variant
+        _all_read_len = None
+
+        @property
+        def out_read_len(self):
+            """lengths of ALL reads (the reads scan() results cover), computed on first use: only the rank that writes the
+            occurrence file ever asks (160 MB of borders at C3)"""
+            if self._all_read_len is None:
+                self._all_read_len = (borders[:, 1] - borders[:, 0]).astype(np.int64)
+            return self._all_read_len
+
+        @out_read_len.setter
+        def out_read_len(self, value):      # DeviceSeq.__init__ assigns the local shard's lengths: not what scan() covers here
+            pass
 
         def count(self, dc, k, dedupe, merge_revcom, use_work=True):
             if k > 16:
                 raise ValueError("sharded counting all-reduces the 4^k histogram and needs k <= 16")
+            if on_dev:
+                assert_default_stream()
             inval = self.inval_work if use_work else self.inval_orig
             check(_ffi.lib().kmap_counts_hist_packed_dev(dc._h, self.codes.ptr, inval.ptr, self.n, self.borders.ptr,
                                                          self.n_seq, k, int(dedupe), None))
@@ -268,12 +423,47 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None):
             dc.k, dc.n_uniq = k, nu.value
             return dc.n_uniq
 
+        def _scan_gathered(self, k, consensus_kh, radius, revcom):
+            """local scan -> device gather of the shards -> GatheredHits (RCCL only)"""
+            assert_default_stream()
+            lib = _ffi.lib()
+            if self._scan is None:
+                h = _ffi.vp()
+                check(lib.kmap_scan_create(C.byref(h)))
+                self._scan = h.value
+            tot, nhit, mx = _ffi.i64(0), _ffi.i64(0), _ffi.i32(0)
+            check(lib.kmap_scan_run_packed_dev(self._scan, self.codes.ptr, self.inval_orig.ptr, self.n, self.borders.ptr, self.n_seq, k,
+                                               int(consensus_kh), int(radius), int(revcom), C.byref(tot), None))
+            check(lib.kmap_scan_summary(self._scan, C.byref(nhit), C.byref(mx), None))
+            hp, pp = _ffi.vp(), _ffi.vp()
+            check(lib.kmap_scan_result_dev(self._scan, C.byref(hp), C.byref(pp), None, None))
+            meta = torch.tensor([tot.value, nhit.value, mx.value], dtype=torch.int64, device="cuda")
+            metas = torch.empty((world, 3), dtype=torch.int64, device="cuda")
+            dist.all_gather_into_tensor(metas, meta, group=group)
+            metas = metas.cpu().numpy()                                  # 24 bytes per rank: the only host hop
+            totals = [int(t) for t in metas[:, 0]]
+            cap_r, cap_p = max(max(reads_of), 1), max(max(totals), 1)
+            mine_h = torch.zeros(cap_r, dtype=torch.int32, device="cuda")
+            if self.n_seq:
+                mine_h[:self.n_seq].copy_(torch.as_tensor(_DevArray(hp.value, self.n_seq, "<i4"), device="cuda"))
+            mine_p = torch.zeros(cap_p, dtype=torch.int32, device="cuda")
+            if tot.value:
+                mine_p[:tot.value].copy_(torch.as_tensor(_DevArray(pp.value, tot.value, "<i4"), device="cuda"))
+            parts_h = torch.empty((world, cap_r), dtype=torch.int32, device="cuda")
+            parts_p = torch.empty((world, cap_p), dtype=torch.int32, device="cuda")
+            dist.all_gather_into_tensor(parts_h, mine_h, group=group)
+            dist.all_gather_into_tensor(parts_p, mine_p, group=group)
+            return GatheredHits(parts_h, parts_p, reads_of, totals, int(metas[:, 1].sum()), int(metas[:, 2].max()), torch.cuda.current_device())
+
         def scan(self, k, consensus_kh, radius, revcom):
+            if on_dev:
+                return tuple(self._scan_gathered(k, consensus_kh, radius, revcom).host())
             hits, pos = DeviceSeq.scan(self, k, consensus_kh, radius, revcom)
             all_hits = all_gather_concat(dist, hits, reads_of, group)                   # read order = rank order
             return all_hits, all_gather_concat(dist, pos, None, group)
 
+    # gloo rehearsals: hit lists are exchanged as host tensors, no device-resident variant
+    DistDeviceSeq.scan_lazy = DistDeviceSeq._scan_gathered if on_dev else None
     ds = DistDeviceSeq(local_seq, local_borders)
     ds.out_n_seq = len(borders)
-    ds.out_read_len = (borders[:, 1] - borders[:, 0]).astype(np.int64)
     return ds

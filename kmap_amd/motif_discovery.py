@@ -84,6 +84,9 @@ class DeviceSeq:
         raw.free()                      # the uint8 array does not stay on the device
         self.reset()
         self._scan = None
+        dev = _ffi.i32(0)
+        check(_ffi.lib().kmap_get_device(C.byref(dev)))
+        self.device = dev.value         # HIP's current device is per thread: worker threads that fetch hit lists select it
         import threading
         self._lazy_lock, self._lazy_free, self._lazy_all = threading.Lock(), [], []     # scan handles of scan_lazy()
 
@@ -182,6 +185,7 @@ class ScanHits:
                 if self._owner._lazy_all is None:
                     raise RuntimeError("ScanHits: the DeviceSeq was closed before the hit list was fetched")
                 hits, pos = np.empty(self.n_seq, np.int32), np.empty(self.total, np.int32)
+                check(_ffi.lib().kmap_set_device(self._owner.device))  # this may be a CSV writer thread (fresh threads start on device 0)
                 st = _ffi.vp()
                 check(_ffi.lib().kmap_stream_create(C.byref(st)))      # own stream: neither waits for nor blocks the launching thread
                 try:
@@ -205,6 +209,7 @@ class ScanHits:
             if self._owner._lazy_all is None:
                 raise RuntimeError("ScanHits: the DeviceSeq was closed before the hit list was fetched")
             hits, pos = np.empty(self.n_seq, np.uint8), np.empty(self.total, np.int32)
+            check(_ffi.lib().kmap_set_device(self._owner.device))
             st = _ffi.vp()
             check(_ffi.lib().kmap_stream_create(C.byref(st)))
             try:
@@ -307,10 +312,14 @@ class TableSaver:
             n, dts = self.dc.n_uniq, (get_hash_dtype(self.k), get_cnt_dtype(self.k))
             lay = _PickleLayout()
             pickle.Pickler(lay, protocol=5).dump([self.k, np.empty(n, dts[0]), np.empty(n, dts[1])])   # layout only: pages never touched
+            # written under a temporary name and renamed when complete: a killed / failed run must not leave a truncated
+            # k{k}.pkl behind that the next run's "already exists" branches would load
+            tmp = str(self.path) + ".tmp"
             if [b for _, b in lay.big] != [n * np.dtype(d).itemsize for d in dts]:
                 u, c = self.dc.fetch()                             # small table (payloads inside a frame): plain dump
-                with open(self.path, "wb") as fh:
+                with open(tmp, "wb") as fh:
                     pickle.dump([self.k, u, c], fh, protocol=5)
+                os.replace(tmp, self.path)
                 return
             st = _ffi.vp()
             check(lib.kmap_stream_create(C.byref(st)))
@@ -323,7 +332,7 @@ class TableSaver:
                 return buf[:count]
             try:
                 pieces = sorted([(pos, None, b) for pos, b in lay.small] + [(pos, i, None) for i, (pos, _) in enumerate(lay.big)])
-                with open(self.path, "wb") as fh:
+                with open(tmp, "wb") as fh:
                     for pos, which, small in pieces:
                         assert fh.tell() == pos
                         if which is None:
@@ -338,17 +347,25 @@ class TableSaver:
                                 nxt = pool.submit(fetch, which, first + step, min(step, n - first - step), bufs[(i + 1) & 1])
                             fh.write(memoryview(cur))
                     assert fh.tell() == lay.pos
+                os.replace(tmp, self.path)
             finally:
                 pool.shutdown()
                 lib.kmap_stream_destroy(st.value)
             STAGE_TIMES[f"bg_save_k{self.k}"] = time.perf_counter() - t0    # background: overlaps the main thread's stages
         except BaseException as e:   # noqa: BLE001 -- re-raised by join()
             self.err = e
+            try:
+                os.unlink(str(self.path) + ".tmp")
+            except OSError:
+                pass
 
     def join(self):
         self._t.join()
         if self.err is not None:
             raise self.err
+
+    def finished_ok(self):
+        return not self._t.is_alive() and self.err is None
 
     def close(self):
         self._t.join()
@@ -418,8 +435,15 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
                 dc = take()
             else:
                 uniq_kh_arr, uniq_kh_cnt_arr = dc.fetch()
-                with open(kmer_cnt_pkl_file, "wb") as fh:
-                    pickle.dump([kmer_len, uniq_kh_arr, uniq_kh_cnt_arr], fh, protocol=4)
+                tmp = str(kmer_cnt_pkl_file) + ".tmp"
+                try:
+                    with open(tmp, "wb") as fh:
+                        pickle.dump([kmer_len, uniq_kh_arr, uniq_kh_cnt_arr], fh, protocol=4)
+                    os.replace(tmp, kmer_cnt_pkl_file)      # never a truncated k{k}.pkl under the cached name
+                except BaseException:
+                    if os.path.exists(tmp):
+                        os.unlink(tmp)
+                    raise
         elif not big:
             uniq_kh_arr, uniq_kh_cnt_arr = dc.fetch()
 
@@ -939,6 +963,9 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
                 lines.append(row)
         for h in counts_pool:
             h.close()
+        # counting is over: give back the multi-GiB transient tables the library caches between count calls (the shared 4^k-bin
+        # histogram: 16 GiB after a k = 16 count, partition keys, hash arrays); small buffers stay for the scans below
+        check(_ffi.lib().kmap_scratch_release(1 << 30))
         print(f"kmer counting finished for k={min_k}...{max_k}. Candidate consensus sequences generated.")
         if lead:
             write_lines(lines, candidate_conseq_file)
@@ -952,6 +979,12 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
         final_conseq_list = merge_consensus_seqs(candidate_conseq_list)
         if lead:
             write_lines(final_conseq_list, final_conseq_file)
+
+    # the count tables kept resident for their background k{k}.pkl writers: only the longest final's k is read again (labelled
+    # sampling); the others leave HBM as soon as their writer has finished (a failed writer is kept: join() below re-raises)
+    keep_k = max((len(c) for c in final_conseq_list), default=None)
+    for k_done in [k for k, sv in savers.items() if isinstance(sv, TableSaver) and k != keep_k and sv.finished_ok()]:
+        savers.pop(k_done).close()
 
     final_conseq_info_file = res / FileNameDict["final_conseq_info_file"]
     if not lead:

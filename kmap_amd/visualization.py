@@ -257,6 +257,13 @@ class EmbedSession:
     def apply(self, grad_ptr=None, loss_ptr=None, stream=None):
         check(_ffi.lib().kmap_embed_apply(self._h, grad_ptr, loss_ptr, stream))
 
+    def forces_msg(self, msg_ptr, stream=None):
+        """this rank's contribution to the iteration in ONE float buffer (gradient entries + loss limbs, kmap_hip.h)"""
+        check(_ffi.lib().kmap_embed_forces_msg(self._h, msg_ptr, stream))
+
+    def apply_msg(self, msg_ptr, stream=None):
+        check(_ffi.lib().kmap_embed_apply_msg(self._h, msg_ptr, stream))
+
     def state(self, stream=None):
         it, st, ll, bl, ju = _ffi.i64(0), _ffi.i32(0), _ffi.f32(0), _ffi.f32(0), _ffi.i32(0)
         check(_ffi.lib().kmap_embed_state(self._h, C.byref(it), C.byref(st), C.byref(ll), C.byref(bl), C.byref(ju), stream))

@@ -1,5 +1,5 @@
 """World-size-2 `gloo` test (CPU) of the multi-GPU protocol of the embedding loop: row partition ->
-local forces -> all-reduce(grad, loss) -> identical apply on every rank.  The HIP session is replaced by a
+local forces -> ONE all-reduce of the message [gradient | loss limbs] -> identical apply on every rank.  The HIP session is replaced by a
 test double that computes with the CPU oracle (tests may use the oracle; the product never does)."""
 import os
 import socket
@@ -14,33 +14,39 @@ sys.path.insert(0, str(ROOT))
 
 
 class OracleSession:
-    """EmbedSession stand-in: same forces/apply contract, rows [row0,row0+nrows) only."""
+    """EmbedSession stand-in: same forces_msg/apply_msg contract (kmap_hip.h), rows [row0,row0+nrows) only."""
 
-    def __init__(self, p, ld, row0, nrows, lr, grad_np, loss_np):
+    def __init__(self, p, ld, row0, nrows, lr, msg_np):
         from oracle import oracle as O
         self.O, self.p, self.ld, self.row0, self.nrows, self.lr = O, p, ld.copy(), row0, nrows, lr
-        self.g, self.l = grad_np, loss_np
+        self.n = p.shape[0]
+        self.msg = msg_np
         self.losses, self.prev = [], np.inf
 
-    def forces(self, gp, lp):
-        O = self.O
+    def forces_msg(self, mp):
+        from kmap_amd.distributed import loss_to_limbs
+        O, n = self.O, self.n
         q = O.cal_ld_prob_mat(self.ld)
         g = O.gradient_loss(self.p, q, self.ld) / 4.0                      # kernel output before the x4
         r = slice(self.row0, self.row0 + self.nrows)
-        self.g[:, r] = g[:, r]
+        self.msg[:2 * n].reshape(2, n)[:, r] = g[:, r]                      # own rows only; the rest must still be zero
         eps, one = np.float32(1e-10), np.float32(1)
         with np.errstate(divide="ignore", invalid="ignore"):
             full = -self.p * np.log(q) - (one - self.p) * np.log(one - q)
             ce = np.where(self.p < eps, -np.log(one - q), np.where(self.p > one - eps, -np.log(q), full))
-        self.l[0] = np.triu(ce, 1)[r].astype(np.float64).sum()
+        self.msg[2 * n:] = loss_to_limbs(np.triu(ce, 1)[r].astype(np.float64).sum())
 
-    def apply(self, gp, lp):
-        cur = np.float32(2.0 * self.l[0])
+    def apply_msg(self, mp):
+        from kmap_amd.distributed import loss_from_limbs
+        n = self.n
+        g = self.msg[:2 * n].reshape(2, n).copy()
+        cur = np.float32(2.0 * loss_from_limbs(self.msg[2 * n:]))
+        self.msg[:2 * n] = 0                                               # apply_msg_kernel<CLEAR>: read, then zero
         self.losses.append(cur)
         if abs(self.prev - cur) < 1e-7 * abs(cur):
             return
         self.prev = cur
-        self.ld += (-(4.0 * self.g) * self.lr)
+        self.ld += (-(4.0 * g) * self.lr)
         self.ld = self.O.add_jitter(self.ld, eps=0.1)
 
 
@@ -48,7 +54,7 @@ def _worker(rank, world, port, n_iter, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
     import torch.distributed as dist
-    from kmap_amd.distributed import DistEmbedLoop, row_partition
+    from kmap_amd.distributed import MSG_EXTRA, DistEmbedLoop, row_partition
     from oracle import oracle as O
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -61,12 +67,11 @@ def _worker(rank, world, port, n_iter, out_dir):
         for _ in range(10):
             np.random.randn(2, n)
         row0, nrows = row_partition(n, world, rank)
-        grad_t = torch.zeros((2, n), dtype=torch.float32)
-        loss_t = torch.zeros(1, dtype=torch.float64)
-        sess = OracleSession(p, ld, row0, nrows, 0.01, grad_t.numpy(), loss_t.numpy())
-        loop = DistEmbedLoop(sess, grad_t, loss_t, dist if world > 1 else None)
+        msg_t = torch.zeros(2 * n + MSG_EXTRA, dtype=torch.float32)
+        sess = OracleSession(p, ld, row0, nrows, 0.01, msg_t.numpy())
+        loop = DistEmbedLoop(sess, msg_t, dist if world > 1 else None)
         loop.step(n_iter)
-        assert loop.n_collectives == (2 * n_iter if world > 1 else 0)
+        assert loop.n_collectives == (n_iter if world > 1 else 0)          # ONE collective per iteration
         np.savez(Path(out_dir) / f"rank{rank}_of{world}.npz", ld=sess.ld, losses=np.array(sess.losses, np.float32),
                  rows=np.array([row0, nrows]))
     finally:
@@ -102,40 +107,44 @@ class CyclicOracleSession:
     """Stand-in for EmbedSession(cyclic=(world, rank)): the rank evaluates each unordered pair (i < j) whose row i lies in
     one of its cyclic 256-row blocks and writes partial gradients for BOTH points; the all-reduce then is a true sum."""
 
-    def __init__(self, p, ld, blocks, lr, grad_np, loss_np):
+    def __init__(self, p, ld, blocks, lr, msg_np):
         from oracle import oracle as O
         self.O, self.p, self.ld, self.lr = O, p, ld.copy(), lr
-        self.g, self.l = grad_np, loss_np
-        n = p.shape[0]
+        self.msg = msg_np
+        n = self.n = p.shape[0]
         own = np.zeros(n, bool)
         for r0, nr in blocks:
             own[r0:r0 + nr] = True
         self.mask = own[:, None] & (np.arange(n)[None, :] > np.arange(n)[:, None])
         self.losses, self.prev = [], np.inf
 
-    def forces(self, gp, lp):
-        O, p = self.O, self.p
+    def forces_msg(self, mp):
+        from kmap_amd.distributed import loss_to_limbs
+        O, p, n = self.O, self.p, self.n
         q = O.cal_ld_prob_mat(self.ld).astype(np.float64)
         t = np.where(self.mask, (q / (1 - q)) * (p - q), 0.0)
+        g = self.msg[:2 * n].reshape(2, n)
         for c in (0, 1):
             d = self.ld[c][:, None].astype(np.float64) - self.ld[c][None, :]
             f = t * d
-            self.g[c] = (f.sum(axis=1) - f.sum(axis=0)).astype(np.float32)   # row side minus column side
+            g[c] = (f.sum(axis=1) - f.sum(axis=0)).astype(np.float32)   # row side minus column side: ALL entries overwritten
         ce = -(p * np.log(q) + (1 - p) * np.log(1 - q))
-        self.l[0] = np.where(self.mask, ce, 0.0).sum()
+        self.msg[2 * n:] = loss_to_limbs(np.where(self.mask, ce, 0.0).sum())
 
-    def apply(self, gp, lp):
-        cur = np.float32(2.0 * self.l[0])
+    def apply_msg(self, mp):
+        from kmap_amd.distributed import loss_from_limbs
+        n = self.n
+        cur = np.float32(2.0 * loss_from_limbs(self.msg[2 * n:]))
         self.losses.append(cur)
         self.prev = cur
-        self.ld += (-(4.0 * self.g) * self.lr)
+        self.ld += (-(4.0 * self.msg[:2 * n].reshape(2, n)) * self.lr)     # apply_msg_kernel<no CLEAR>: nothing zeroed
 
 
 def _cyclic_worker(rank, world, port, n_iter, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
     import torch.distributed as dist
-    from kmap_amd.distributed import DistEmbedLoop
+    from kmap_amd.distributed import MSG_EXTRA, DistEmbedLoop
     from kmap_amd.visualization import cyclic_blocks
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -146,10 +155,9 @@ def _cyclic_worker(rank, world, port, n_iter, out_dir):
         p = (p + p.T).astype(np.float32)
         ld = (rng.standard_normal((2, n)) * 3).astype(np.float32)
         blocks = cyclic_blocks(n, world, rank)
-        grad_t = torch.zeros((2, n), dtype=torch.float32)
-        loss_t = torch.zeros(1, dtype=torch.float64)
-        sess = CyclicOracleSession(p, ld, blocks, 0.0005, grad_t.numpy(), loss_t.numpy())   # small steps: no chaotic amplification
-        loop = DistEmbedLoop(sess, grad_t, loss_t, dist if world > 1 else None)
+        msg_t = torch.zeros(2 * n + MSG_EXTRA, dtype=torch.float32)
+        sess = CyclicOracleSession(p, ld, blocks, 0.0005, msg_t.numpy())   # small steps: no chaotic amplification
+        loop = DistEmbedLoop(sess, msg_t, dist if world > 1 else None)
         loop.step(n_iter)
         np.savez(Path(out_dir) / f"cyc{rank}_of{world}.npz", ld=sess.ld, losses=np.array(sess.losses, np.float32),
                  blocks=np.array(blocks).reshape(-1, 2))
@@ -220,3 +228,27 @@ def test_all_gather_concat_and_seed_broadcast(tmp_path):
         assert r["u16"].dtype == np.uint16
         assert int(r["seed_none"]) == int(rs[0]["seed_none"]) and 0 <= int(r["seed_none"]) < 2 ** 32
         assert int(r["seed_given"]) == 41
+
+
+def test_loss_limbs_are_exact_and_order_free():
+    """the loss partial travels as integer limbs inside the float32 message: float32 sums of the limbs of many ranks are exact in
+    any order, so every rank decodes the same total; non-finite / negative / huge partials raise the flag -> NaN"""
+    from kmap_amd.distributed import MSG_EXTRA, loss_from_limbs, loss_to_limbs
+    rng = np.random.default_rng(0)
+    for scale in (1e-6, 1.0, 1e5, 1e11):
+        parts = rng.random(64) * scale
+        limbs = np.stack([loss_to_limbs(v) for v in parts])
+        assert limbs.shape == (64, MSG_EXTRA) and limbs.dtype == np.float32
+        fwd = limbs.sum(axis=0, dtype=np.float32)
+        acc = np.zeros(MSG_EXTRA, np.float32)
+        for row in limbs[rng.permutation(64)]:
+            acc = (acc + row).astype(np.float32)            # a different summation order, float32 all the way
+        np.testing.assert_array_equal(fwd, acc)
+        got, want = loss_from_limbs(fwd), float(np.sum(parts))
+        assert abs(got - want) <= 64 * 2.0 ** -48 + 4e-16 * want        # truncation at 2^-48 per rank + the f64 reference sum's own rounding
+    one = 123456.789012345678
+    assert loss_from_limbs(loss_to_limbs(one)) == one                   # >= 16: the f64 mantissa fits the 48 fractional bits
+    assert loss_from_limbs(loss_to_limbs(0.0)) == 0.0
+    for bad in (float("nan"), float("inf"), -1.0, 2.0 ** 47):
+        t = loss_to_limbs(bad) + loss_to_limbs(3.0)
+        assert np.isnan(loss_from_limbs(t))

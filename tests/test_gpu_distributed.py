@@ -342,12 +342,30 @@ def _nccl_worker(rank, world, port, out_dir):
         best, _ = kmap_from_kmers_distributed(kh, cnts, lab, conseqs, K, n_max_iter=ITERS, random_seed=SEED, mode=1, trace=tr)
         out = {"best": best, "losses": tr["losses"], "seed": broadcast_seed(dist, None),
                "cat": all_gather_concat(dist, np.arange(7, dtype=np.uint16).reshape(-1, 1))}
+        assert tr["collectives"] == 0                      # a one-rank group needs no collective ...
+        tr2 = {}
+        best2, _ = kmap_from_kmers_distributed(kh, cnts, lab, conseqs, K, n_max_iter=ITERS, random_seed=SEED, mode=1, trace=tr2,
+                                               always_collective=True, profile_iters=4)
+        assert tr2["collectives"] == ITERS                 # ... bench.py's overhead leg issues exactly ONE per iteration anyway
+        out["best2"], out["phases"] = best2, tr2["phases"]
         seq, borders = synth.synth_reads(20_003, 75, 4)
         ds = make_dist_device_seq(seq, borders, dist)
         dc = DeviceCounts()
         ds.count(dc, 9, dedupe=True, merge_revcom=True)
         out["counts"] = dc.fetch()
         out["scan"] = ds.scan(8, kmer2hash("ATCGATAG"), 2, True)
+        # the device-gathered hit list (GatheredHits) through the background CSV writer, fetched on the writer's thread
+        from kmap_amd.kmer_count import _pkg_file, init_motif_def_dict
+        from kmap_amd.motif_discovery import ScanHits, gen_motif_occurence_file
+        lazy = ds.scan_lazy(8, kmer2hash("ATCGATAG"), 2, True)
+        assert isinstance(lazy, ScanHits) and lazy.unfetched and lazy.n_seq == 20_003
+        out["lazy_summary"] = (lazy.n_reads_hit, lazy.total, lazy.max_hits)
+        writers = []
+        np.random.seed(3)
+        gen_motif_occurence_file(["AATCGATAGC", "CCTACGTA"], init_motif_def_dict(_pkg_file("default_motif_def_table.csv")), None,
+                                 Path(out_dir) / "occ_nccl.csv", True, dev_seq=ds, writers=writers)
+        for w in writers:
+            w.join()
         dc.close()
         ds.close()
         with open(Path(out_dir) / "nccl.pkl", "wb") as fh:
@@ -384,5 +402,14 @@ def test_rccl_backend_single_rank(tmp_path):
     hits, pos = ds.scan(8, kmer2hash("ATCGATAG"), 2, True)
     np.testing.assert_array_equal(got["scan"][0], hits)
     np.testing.assert_array_equal(got["scan"][1], pos)
+    assert got["lazy_summary"] == (int(np.count_nonzero(hits)), len(pos), int(hits.max()))
+    np.testing.assert_array_equal(got["best2"], best)
+    assert set(got["phases"]) == {"forces_ms", "collective_ms", "apply_ms", "iteration_ms"} and got["phases"]["collective_ms"] > 0
+    from kmap_amd.kmer_count import _pkg_file, init_motif_def_dict
+    from kmap_amd.motif_discovery import gen_motif_occurence_file
+    np.random.seed(3)
+    gen_motif_occurence_file(["AATCGATAGC", "CCTACGTA"], init_motif_def_dict(_pkg_file("default_motif_def_table.csv")), None,
+                             tmp_path / "occ_single.csv", True, dev_seq=ds)
+    assert (tmp_path / "occ_nccl.csv").read_text() == (tmp_path / "occ_single.csv").read_text()
     dc.close()
     ds.close()

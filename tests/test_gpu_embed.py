@@ -398,3 +398,59 @@ def test_graph_replay_switch_gives_the_same_run(V, golden):
             for key in ("best", "losses", "last"):
                 np.testing.assert_array_equal(outs[0][key], outs[1][key])
             assert len(outs[0]["losses"]) == 41
+
+
+@pytest.mark.parametrize("mode,row0,nrows", [(1, 0, 701), (1, 200, 301), (0, 350, 351)])
+def test_message_protocol_equals_two_buffer_protocol(V, mode, row0, nrows):
+    """The one-message form of forces / apply (multi-GPU loop: ONE float32 all-reduce per iteration): the gradient entries are
+    the two-buffer protocol's, the loss limbs decode (host mirror of the device code) to the float64 partial, a row-sharded
+    session's apply zeroes the message, and message-driven iterations reproduce kmap_embed_step bit for bit."""
+    from kmap_amd import _ffi
+    from kmap_amd.distributed import MSG_EXTRA, loss_from_limbs
+    rng = np.random.default_rng(11)
+    n = 701
+    P = rng.random((n, n), dtype=np.float32)
+    P = np.triu(P, 1)
+    P = (P + P.T).astype(np.float32)
+    ld = (rng.standard_normal((2, n)) * 3).astype(np.float32)
+    assert int(_ffi.lib().kmap_embed_msg_floats(n)) == 2 * n + MSG_EXTRA
+    p_d = _ffi.DeviceBuffer.from_numpy(P[row0:row0 + nrows])
+    sess = V.EmbedSession(n, 10, 0.01, mode, row0=row0, nrows=nrows)
+    try:
+        sess.set_prob_f32(p_d, n)
+        sess.set_coords(ld)
+        g_d, l_d, m_d = _ffi.DeviceBuffer(2 * n * 4), _ffi.DeviceBuffer(8), _ffi.DeviceBuffer((2 * n + MSG_EXTRA) * 4)
+        g_d.zero()
+        m_d.zero()
+        sess.forces(g_d.ptr, l_d.ptr)
+        sess.forces_msg(m_d.ptr)
+        _ffi.sync()
+        g, loss = g_d.to_numpy(np.float32, (2, n)), l_d.to_numpy(np.float64, (1,))[0]
+        msg = m_d.to_numpy(np.float32, (2 * n + MSG_EXTRA,))
+        np.testing.assert_array_equal(msg[:2 * n].reshape(2, n).view(np.uint32), g.view(np.uint32))
+        assert np.all(msg[2 * n:2 * n + 6] == np.floor(msg[2 * n:2 * n + 6])) and msg[2 * n:2 * n + 6].max() < 65536 and msg[2 * n + 6] == 0
+        got = loss_from_limbs(msg[2 * n:])
+        assert abs(got - loss) <= 2.0 ** -48 + 1e-15 * abs(loss)
+        if nrows == n:
+            # full-row session driven through the message for 5 iterations == the resident loop
+            ref = V.EmbedSession(n, 10, 0.01, mode)
+            ref.set_prob_f32(_ffi.DeviceView(p_d.ptr, p_d.nbytes), n)
+            ref.set_coords(ld)
+            jit = np.random.default_rng(1).normal(0, 0.01, 64)
+            for s in (sess, ref):
+                s.set_jitter(jit)
+            ref.step(5)
+            for _ in range(5):
+                sess.forces_msg(m_d.ptr)
+                sess.apply_msg(m_d.ptr)
+            np.testing.assert_array_equal(sess.coords().view(np.uint32), ref.coords().view(np.uint32))
+            np.testing.assert_allclose(sess.losses(), ref.losses(), rtol=1e-7)
+            ref._keep = []
+            ref.close()
+        else:
+            sess.apply_msg(m_d.ptr)
+            _ffi.sync()
+            after = m_d.to_numpy(np.float32, (2 * n + MSG_EXTRA,))
+            assert not after[:2 * n].any()                                 # read, then zeroed: the next sum is x + 0 + ... + 0
+    finally:
+        sess.close()
