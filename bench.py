@@ -12,15 +12,22 @@ rows of the 7-mer's label take the kernel's prefix-compare branch -- not an idea
 
 Multi-GPU (--gpus G, launched by torch.distributed.run, one rank per GPU): the matrix is sharded by row blocks, every rank
 holds all N hashes, no data-path collective.  `value` is the weak-scaling Hamming stage: N_total = 50 000 * sqrt(G)
-(rounded to 16) so that every GPU keeps 2.5e9 pairs per step.  The same line carries `c4`: BASELINE config C4, N = 200 000 FIXED
-(strong scaling): Hamming rows + the row-sharded embedding iteration with its all-reduces.
+(rounded to 16) so that every GPU keeps 2.5e9 pairs per step.  The same line carries the STRONG-scaling legs: `embed_dist` (the
+C3 embedding, N = 50 000 fixed, sharded loop with its ONE all-reduce per iteration: ms per iteration and, from device events,
+forces / collective / apply ms) and `c4` (BASELINE config C4, N = 200 000 fixed: Hamming rows + the sharded embedding iteration).
+At G = 1 `embed_dist` runs the sharded loop on a one-rank RCCL group next to the resident loop: `overhead_ms_per_iter` is what
+the multi-GPU plumbing (message kernels, collective launch, Python) costs before any link is involved.
 
 Extra objects on the JSON line:
   roofline      HIP-event kernel time of the headline kernel (mean / min / median per launch) vs the 8 TB/s HBM peak, algorithmic
-                bytes = rows*N + 5N; `stages`: the same for every other stage of the C3 path with SURVEY 8(d)'s algorithmic bytes
-  cpu_baseline  the CPU oracle (OpenMP) on a bounded sample of the same workload: Hamming rows, and `e2e` = find_motif +
-                smoothing + embedding iterations extrapolated to the C3 job (a reported baseline, not the target)
-  e2e           C3 scan_motif + visualize_kmers wall time: k = 6..9 in both embedding modes, and the reference's default k = 6..16
+                bytes = rows*N + 5N; `frac_of_achievable` = the same against a plain device fill of the same bytes measured in
+                this run on this box; `stages`: the same for every other stage of the C3 path with SURVEY 8(d)'s bytes
+  cpu_baseline  the compiled OpenMP port (oracle/kmap_cpu_baseline.c + the oracle's Hamming rows) timed on this box's host
+                cores, all cores AND one core, CPU model stated: Hamming rows, find_motif k = 6..9 on >= 1 M reads, >= 10 embedding
+                iterations at N = 50 000 (a reported baseline, not the target)
+  e2e           scan_motif + visualize_kmers wall time: C3 k = 6..9 in both embedding modes, C3 with the reference's default
+                k = 6..16, and C2 (100 k reads, N = 5 k, 2500 iterations, the reference's default size)
+  c5            BASELINE config C5 at full size: k = 14, radius 5 Hamming-ball scan over 50 M x 300 bp reads generated in HBM
 """
 import argparse
 import json
@@ -166,105 +173,156 @@ def stage_rooflines(reads, kh, lab, conseq_lens):
     return out
 
 
-# ---- CPU baselines (oracle = the CPU restatement; the checker, timed here as the reported baseline) ------------------------
-def cpu_baseline(kh, lab, conseq_lens, target_s=10.0):
-    """Oracle (CPU restatement, OpenMP) timed on a bounded row sample of the same N."""
-    from oracle import oracle as O
-    L = O.lib()
+# ---- CPU baseline (the compiled port, timed on this box's host cores; the checker's code, measured -- never shipped) ---------
+def cpu_baseline(kh, lab, conseq_lens, quick=False):
+    """SURVEY 8(d) / BASELINE.md "CPU baseline": the compiled OpenMP port on the GPU box's host cores, with ALL the cores this
+    process may use (affinity mask capped by the cgroup CPU quota) and with ONE core; CPU model stated.  Bounded samples:
+      * Hamming rows of the same N (oracle ko_hamdist_rows) -- the headline metric on the CPU;
+      * find_motif for k = 6..9 on 1 M synthetic reads (a tenth of C3; 100 k reads on one core), every stage linear in the reads;
+      * >= 10 embedding iterations at N = 50 000 (one pass over a row sample on one core; an iteration is linear in the rows)."""
+    from kmap_amd import synth, visualization as V
+    from kmap_amd.kmer_count import gen_motif_def_dict, read_default_config_file
+    from oracle import baseline as B, oracle as O
+    L, BL = O.lib(), B.lib()
+    info = B.host_cpu_info()
+    T = info["usable"]
     n = len(kh)
     kh64 = np.ascontiguousarray(kh, np.uint64)
     cl = np.ascontiguousarray(conseq_lens, np.int32)
-    cores = os.cpu_count() or 1
-    rows = min(n, 2048)
-    out = np.empty((rows, n), np.uint8)
-    L.ko_hamdist_rows(kh64, lab, n, K, cl, len(cl), 0, rows, out)          # warm-up (thread pool, page faults)
-    done, t0 = 0, time.perf_counter()
-    while True:                                                            # row blocks round-robin over the matrix
-        r0 = done % max(n - rows + 1, 1)
-        L.ko_hamdist_rows(kh64, lab, n, K, cl, len(cl), r0, rows, out)
-        done += rows
-        dt = time.perf_counter() - t0
-        if dt >= target_s:
-            break
-    return {"value": done * n / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{done} of {n} rows x {n} cols (oracle ko_hamdist_rows, OpenMP, {dt:.1f} s)"}
 
+    def ham(threads, target_s):
+        BL.kb_set_threads(threads)                       # the oracle's OpenMP loops run with this many threads from here on
+        rows = min(n, 64 * threads)
+        out = np.empty((rows, n), np.uint8)
+        L.ko_hamdist_rows(kh64, lab, n, K, cl, len(cl), 0, rows, out)          # warm-up (thread pool, page faults)
+        done, t0 = 0, time.perf_counter()
+        while True:                                                            # row blocks round-robin over the matrix
+            L.ko_hamdist_rows(kh64, lab, n, K, cl, len(cl), done % max(n - rows + 1, 1), rows, out)
+            done += rows
+            dt = time.perf_counter() - t0
+            if dt >= target_s:
+                return done * n / dt, done, dt
 
-def cpu_e2e_baseline(kh, lab, conseq_lens, n_reads_sample=30_000, n_embed=3000, embed_iters=3):
-    """The CPU oracle on a bounded sample of the C3 job, extrapolated (and labelled so): find_motif for k = 6..9 on
-    n_reads_sample synthetic reads (x 10 M / n_reads_sample: every stage is linear in the reads), smoothing + embedding
-    iterations at n_embed sampled k-mers (x (50 000 / n_embed)^2 per iteration, x 2500 iterations)."""
-    from kmap_amd import synth
-    from kmap_amd.kmer_count import gen_motif_def_dict, read_default_config_file
-    from oracle import oracle as O
-    O.lib()
-    cores = os.cpu_count() or 1
-    seq, borders = synth.synth_reads(n_reads_sample, 150, 2)
+    v_all, rows_all, dt_all = ham(T, 1.0 if quick else 4.0)
+    v_one, rows_one, dt_one = ham(1, 1.0 if quick else 3.0)
+    res = {"value": v_all, "unit": "pairs/s", "cores": T, "kind": "port", "cpu": info,
+           "one_core": {"value": v_one, "unit": "pairs/s", "cores": 1},
+           "sample": (f"Hamming rows of the timed N={n} sample: {rows_all} rows x {n} columns on {T} threads ({dt_all:.1f} s), {rows_one} rows on "
+                      f"1 thread ({dt_one:.1f} s); oracle ko_hamdist_rows, OpenMP; {info['model']}, {info['logical_cpus']} logical CPUs on the host, "
+                      f"{info['affinity_cpus']} in this process's affinity mask, cgroup quota {info['cgroup_cpu_quota']}")}
+    # ---- the e2e components
+    n_reads_all, n_reads_one = (100_000, 20_000) if quick else (1_000_000, 100_000)
+    seq, borders = synth.synth_reads(n_reads_all, 150, 2)
     mdd = gen_motif_def_dict(read_default_config_file())
+
+    def fm(nr, threads):
+        sub, bsub = seq[:nr * 151].copy(), borders[:nr]
+        t0 = time.perf_counter()
+        found = {}
+        for k in range(6, 10):
+            found[k] = len(B.find_motif(sub.copy() if k < 9 else sub, bsub, k, mdd[k], threads=threads))
+        return time.perf_counter() - t0, found
+    fm_all, found_all = fm(n_reads_all, T)
+    fm_one, _ = fm(n_reads_one, 1)
+    del seq, borders
+    lut = V.hd_prob_lut(K, 20, 400 * K)
+    kh32 = np.ascontiguousarray(kh, np.uint32)
+    y = np.random.default_rng(7).standard_normal((2, n)).astype(np.float32)
     t0 = time.perf_counter()
-    for k in range(6, 10):
-        O.find_motif(seq.copy(), borders, k, mdd[k])
-    fm = time.perf_counter() - t0
-    idx = np.linspace(0, len(kh) - 1, n_embed).astype(np.int64)
+    g, loss0 = B.embed_forces_kmers(kh32, lut, 400, y, threads=T)
+    t_first = time.perf_counter() - t0
+    iters = 2 if quick else (10 if t_first * 10 <= 45.0 else max(3, int(45.0 / t_first)))
     t0 = time.perf_counter()
-    D = O.hamdist_matrix_u8(kh[idx].astype(np.uint64), lab[idx], K, conseq_lens)
-    nb = O.knn_select_stable(D, 20)
-    S = O.knn_smooth(D.astype(np.int64), 20, nb=nb)
-    smooth = time.perf_counter() - t0
-    T = O.sigmoid(S, 16.0, change_point=K / 2, scale_factor=0.2 * K - 0.2)
+    for _ in range(iters):
+        g, loss = B.embed_forces_kmers(kh32, lut, 400, y, threads=T)
+        BL.kb_embed_update(y, g, n, 0.01)
+    it_all = (time.perf_counter() - t0) / iters
+    rows1 = int(min(n, max(64, n * (2.0 if quick else 6.0) / max(it_all * T, 1e-9))))
     t0 = time.perf_counter()
-    O.umap(T, n_max_iter=embed_iters, random_seed=7)
-    it = (time.perf_counter() - t0) / embed_iters
-    scale_reads, scale_n2 = 10_000_000 / n_reads_sample, (N_BASE / n_embed) ** 2
-    ext = {"scan_motif_s": fm * scale_reads, "smoothing_s": smooth * scale_n2, "embedding_s": it * scale_n2 * 2500}
-    return {"kind": "port", "cores": cores, "extrapolated": True,
-            "measured": {"find_motif_k6_9_s": fm, "n_reads": n_reads_sample, "hamming_select_smooth_s": smooth, "embed_s_per_iter": it,
-                         "n_kmers": n_embed, "embed_iters": embed_iters},
-            "extrapolated_to_c3": {**ext, "e2e_s": sum(ext.values())},
-            "sample": (f"oracle find_motif k=6..9 on {n_reads_sample} x 150 bp reads (x{scale_reads:.0f}, linear in reads; the occurrence "
-                       f"scans and file writing of scan_motif are NOT included), Hamming + neighbour selection + smoothing and "
-                       f"{embed_iters} embedding iterations at N={n_embed} (x{scale_n2:.0f} for N=50000, x2500 iterations)")}
+    B.embed_forces_kmers(kh32, lut, 400, y, 0, rows1, threads=1)
+    it_one = (time.perf_counter() - t0) * n / rows1
+    c3_reads, c3_iters = 10_000_000, 2500
+    res["e2e"] = {
+        "kind": "port", "cores": T,
+        "measured": {"find_motif_k6_9_s": {"all_cores": fm_all, "reads": n_reads_all, "one_core": fm_one, "reads_one_core": n_reads_one,
+                                          "motifs_found_per_k": found_all},
+                     "embed_s_per_iteration": {"all_cores": it_all, "iterations": iters, "n_kmers": n, "one_core": it_one,
+                                               "one_core_rows": rows1, "loss_first_iteration_x2": 2.0 * loss0}},
+        "extrapolated_to_c3": {"find_motif_k6_9_s": {"all_cores": fm_all * c3_reads / n_reads_all, "one_core": fm_one * c3_reads / n_reads_one},
+                               "embedding_2500_iterations_s": {"all_cores": it_all * c3_iters, "one_core": it_one * c3_iters},
+                               "note": "linear extrapolation (reads x, iterations x); the occurrence scans, neighbour smoothing and file "
+                                       "writing of the two verbs are NOT included -- a lower bound of the CPU job"},
+        "sample": (f"oracle/kmap_cpu_baseline.c (gcc -O2 -fopenmp): find_motif k=6..9 on {n_reads_all} x 150 bp synthetic reads with {T} threads and on "
+                   f"{n_reads_one} reads with 1 thread; {iters} embedding iterations at N={n} with {T} threads (fused single pass, the "
+                   f"reference's f32 summation order, p looked up from the k-mers on the fly instead of a 10 GB matrix -- cheaper than the "
+                   f"reference's data flow), one pass over {rows1} of {n} rows with 1 thread")}
+    return res
 
 
 # ---- multi-GPU legs ----------------------------------------------------------------------------------------------------
-def embed_dist_leg(dist, torch, kh, lab, conseqs, n, iters=100):
-    """Sharded embedding of the same N sampled k-mers on all ranks (kmap_amd.distributed): wall time of the iteration loop
-    alone (device-synchronised on both sides, max over ranks), after a short run that absorbs one-time costs.  Errors are
-    reported, not raised: a rank that failed sets a flag that every rank sees before anyone enters the next phase."""
+def _all_ok(dist, torch, flag):
+    """has any rank failed so far (a rank that failed sets its flag; every rank sees it before anyone enters the next phase)"""
+    if dist is None:
+        return int(flag.item()) == 0
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    return int(flag.item()) == 0
+
+
+def embed_dist_leg(dist, torch, world, kh, lab, conseqs, iters=200):
+    """STRONG scaling of the C3 embedding: the N = 50 000 hand-over sample FIXED, sharded over all ranks (kmap_amd.distributed):
+    ms per iteration of the loop (device-synchronised on both sides, max over ranks) and, from a separate short run with device
+    events around the phases, forces / collective / apply ms.  On one rank the all-reduce is issued anyway (one-rank RCCL
+    group) and the resident single-GPU loop is timed next to it: their difference is the plumbing's own cost.
+    Errors are reported in the line, not raised: the headline above is already measured."""
+    from kmap_amd import visualization as V
     from kmap_amd.distributed import kmap_from_kmers_distributed
-    err, loop_s, hbm = "", 0.0, {}
+    n = len(kh)
+    ones = np.ones(n, np.int64)
+    err, loop_s, hbm, phases = "", 0.0, {}, None
     flag = torch.zeros(1, dtype=torch.int32, device="cuda")
-    for it in (3, iters):
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag.item()):
+    for it, prof in ((24, 20), (iters, 0)):
+        if not _all_ok(dist, torch, flag):
             break
         dist.barrier()
         tr = {}
         try:
-            kmap_from_kmers_distributed(kh, np.ones(n, np.int64), lab, conseqs, K, n_max_iter=it, random_seed=7, trace=tr)
+            kmap_from_kmers_distributed(kh, ones, lab, conseqs, K, n_max_iter=it, random_seed=7, trace=tr, mode=V.EMBED_FAST,
+                                        always_collective=True, profile_iters=prof)
             loop_s, hbm = tr["loop_s"], tr["hbm"]
+            phases = tr.get("phases", phases)
         except Exception as e:   # noqa: BLE001
             err = f"{type(e).__name__}: {e}"[:300]
             flag.fill_(1)
-    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-    if int(flag.item()):
+    if not _all_ok(dist, torch, flag):
         return {"error": err or "another rank failed"}
     t = torch.tensor([loop_s], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    cyc = os.environ.get("KMAP_DIST_CYCLIC", "1") != "0" and n >= 16384
-    return {"n_kmers": n, "mode": "FAST, each unordered pair once, cyclic 256-row blocks per rank" if cyc else "FAST, contiguous row blocks",
-            "iterations": iters, "loop_s": float(t.item()), "ms_per_iteration": float(t.item()) / iters * 1e3,
-            "collectives_per_iteration": 2, "d_rows_per_rank": hbm.get("d_rows"), "d_bytes_per_rank": hbm.get("d_bytes")}
+    cyc = os.environ.get("KMAP_DIST_CYCLIC", "1") != "0" and n >= 16384 and world > 1
+    res = {"n_kmers": n, "scaling": "strong", "layout": "each unordered pair once, cyclic 256-row blocks per rank" if cyc else "contiguous row blocks",
+           "mode": "FAST", "iterations": iters, "loop_s": float(t.item()), "ms_per_iteration": float(t.item()) / iters * 1e3,
+           "collectives_per_iteration": 1, "message_bytes": (2 * n + 8) * 4, "phases_ms_rank0": phases,
+           "phases_note": "device events around forces (force kernel + partial sums + loss limbs), the all-reduce, apply; 20 iterations of a separate run",
+           "d_rows_per_rank": hbm.get("d_rows"), "d_bytes_per_rank": hbm.get("d_bytes")}
+    if world == 1:
+        tr = {}
+        V.kmap_from_kmers(kh, ones, lab, conseqs, K, n_max_iter=24, random_seed=7, mode=V.EMBED_FAST)
+        V.kmap_from_kmers(kh, ones, lab, conseqs, K, n_max_iter=iters, random_seed=7, trace=tr, mode=V.EMBED_FAST)
+        res["resident_ms_per_iteration"] = tr["loop_s"] / iters * 1e3
+        res["overhead_ms_per_iter"] = res["ms_per_iteration"] - res["resident_ms_per_iteration"]
+        res["overhead_note"] = ("sharded loop on a one-rank RCCL group (forces_msg -> all_reduce -> apply_msg, issued from Python) minus the "
+                                "resident loop (kmap_embed_step) on the same GPU, same N, same iteration count")
+    return res
 
 
 def c4_leg(dist, torch, res_dir, rank, world, barrier):
     """BASELINE config C4: N = 200 000 sampled k-mers FIXED as the GPU count grows (strong scaling).  Hamming rows of this rank
-    (HIP events, no collective) and the embedding iteration (row-sharded FAST loop with its two all-reduces for world > 1)."""
+    (HIP events, no collective) and the embedding iteration (sharded FAST loop with its one all-reduce for world > 1; phases
+    from device events)."""
     from kmap_amd import _ffi, visualization as V
     from kmap_amd.distributed import row_partition
     from kmap_amd.hamdist import hamdist_matrix_dev, pitch_for
     kh, lab, lens, conseqs = pipeline_sample(res_dir, N_C4) if rank == 0 else (None, None, None, None)
-    if dist is not None:
+    if world > 1:
         box = [kh, lab, lens, conseqs]
         dist.broadcast_object_list(box, 0)      # set-up only (1.6 MB once), outside every timed region
         kh, lab, lens, conseqs = box
@@ -282,44 +340,99 @@ def c4_leg(dist, torch, res_dir, rank, world, barrier):
         b.free()
     res = {"n_kmers": n, "scaling": "strong", "rows_per_gpu": nrows, "hamming_ms_median_rank0": statistics.median(ms), "hamming_ms_min_rank0": min(ms),
            "hamming_pairs_per_s": float(n) * n * 12 / wall, "hamming_note": "12 launches (2 warm-up + 10) of every rank's rows / wall time incl. barriers"}
-    its = (3, 23)
-    loops = []
-    err = ""
-    flag = torch.zeros(1, dtype=torch.int32, device="cuda") if dist is not None else None
+    its = (5, 25)
+    loops, err, phases = [], "", None
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
     for it in its:
-        if dist is not None:             # a rank that failed in the previous run is seen by all before anyone starts the next
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            if int(flag.item()):
-                break
+        if not _all_ok(dist if world > 1 else None, torch, flag):      # a rank that failed in the previous run is seen by all before the next
+            break
         tr = {}
         try:
-            if dist is not None:
+            if world > 1:
                 from kmap_amd.distributed import kmap_from_kmers_distributed
-                kmap_from_kmers_distributed(kh, np.ones(n, np.int64), lab, conseqs, K, n_max_iter=it, random_seed=7, trace=tr, mode=V.EMBED_FAST)
+                kmap_from_kmers_distributed(kh, np.ones(n, np.int64), lab, conseqs, K, n_max_iter=it, random_seed=7, trace=tr, mode=V.EMBED_FAST,
+                                            profile_iters=4 if it == its[0] else 0)
+                phases = tr.get("phases", phases)
             else:
                 V.kmap_from_kmers(kh, np.ones(n, np.int64), lab, conseqs, K, n_max_iter=it, random_seed=7, trace=tr, mode=V.EMBED_FAST)
             loops.append(tr["loop_s"])
         except Exception as e:   # noqa: BLE001 -- reported in the line; the headline above is already measured
             err = f"{type(e).__name__}: {e}"[:300]
-            if flag is not None:
-                flag.fill_(1)
-            else:
-                break
-    if dist is not None:
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag.item()):
-            err = err or "another rank failed"
+            flag.fill_(1)
+    if not _all_ok(dist if world > 1 else None, torch, flag):
+        err = err or "another rank failed"
     if err or len(loops) < 2:
         res["embed_error"] = err or "embedding leg did not run"
         return res
     per_it = (loops[1] - loops[0]) / (its[1] - its[0])
-    if dist is not None:
+    if world > 1:
         t = torch.tensor([per_it], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         per_it = float(t.item())
+        res["embed_phases_ms_rank0"] = phases
     res["embed_ms_per_iteration"] = per_it * 1e3
-    res["embed_note"] = f"FAST, from the difference of a {its[1]}- and a {its[0]}-iteration run (max over ranks)"
+    res["embed_note"] = (f"FAST, from the difference of a {its[1]}- and a {its[0]}-iteration run (max over ranks)" +
+                         ("; one all-reduce of (2 N + 8) floats per iteration" if world > 1 else "; resident single-GPU loop"))
     return res
+
+
+def c5_leg(reps=5):
+    """BASELINE config C5 at FULL size: k = 14, max_ham_dist = 5 Hamming-ball (occurrence) scan over 50 M x 300 bp reads =
+    1.505e10 positions, generated in HBM (csrc/synth.hip; numpy needs minutes for the 15 GB array), packed to 0.375 B/position.
+    Device time of one consensus (HIP events; incl. the scan's one host sync for the hit total) against SURVEY 8(d)'s
+    1 B/position, and a spot check of the timed result against the oracle on reads fetched back from the generated array."""
+    import ctypes as C
+    from kmap_amd import _ffi, synth
+    from kmap_amd.kmer_count import kmer2hash
+    from oracle import oracle as O
+    n_reads, L, k, radius = 50_000_000, 300, 14, 5
+    motif = "AGGACCTACGTACA"
+    t0 = time.perf_counter()
+    ds, raw = synth.synth_reads_dev(n_reads, L, 3, motifs=(motif, "AATCGATAGC"), keep_raw=True)
+    _ffi.sync()
+    t_gen = time.perf_counter() - t0
+    lib = _ffi.lib()
+    h = _ffi.vp()
+    _ffi.check(lib.kmap_scan_create(C.byref(h)))
+    tot = _ffi.i64(0)
+    cons = int(kmer2hash(motif))
+
+    def scan():
+        _ffi.check(lib.kmap_scan_run_packed_dev(h.value, ds.codes.ptr, ds.inval_orig.ptr, ds.n, ds.borders.ptr, ds.n_seq, k, cons, radius, 1,
+                                                C.byref(tot), None))
+    ms = timed_launches(scan, reps, warmup=1)
+    hits = np.empty(n_reads, np.int32)
+    pos = np.empty(tot.value, np.int32)
+    _ffi.check(lib.kmap_scan_fetch(h.value, _ffi.ptr(hits), None, _ffi.ptr(pos)))
+    offs = np.concatenate([[0], np.cumsum(hits, dtype=np.int64)])
+    buf, md = np.empty(L, np.int32), C.c_int(0)
+    picks = np.unique(np.concatenate([[0, n_reads - 1], np.random.default_rng(5).integers(0, n_reads, 198)]))
+    for r in picks:
+        read = raw(int(r) * (L + 1), int(r) * (L + 1) + L)
+        m = O.lib().ko_scan_read(read, L, k, cons, radius, 1, buf, md)
+        assert m == hits[r] and np.array_equal(pos[offs[r]:offs[r + 1]], buf[:m]), f"C5 scan differs from the oracle on read {r}"
+    lib.kmap_scan_destroy(h.value)
+    raw.free()
+    ds.close()
+    d = roof(float(ds.n), ms, "C5: Hamming-ball scan, k = 14, radius 5, one consensus, 50 M x 300 bp reads, one GPU")
+    d.update({"reads": n_reads, "read_len": L, "positions": ds.n, "k": k, "radius": radius, "positions_per_s": ds.n / (d["ms_median"] * 1e-3),
+              "reads_with_hit": int(np.count_nonzero(hits)), "total_hits": int(tot.value), "generate_and_pack_s": t_gen,
+              "spot_check": f"{len(picks)} reads == oracle ko_scan_read on the generated bytes",
+              "data": "synthetic, generated in HBM by kmap_synth_reads_dev (seed 3; 40 % of the reads carry the 14-mer, 5 % substitutions)"})
+    return d
+
+
+def fill_rate(nbytes, reps=7):
+    """what a plain device fill of the same number of bytes reaches on THIS box in THIS run (hipMemsetAsync on the library's
+    stream, HIP events): the store-side ceiling the headline kernel can be held against, separating box-to-box spread from
+    kernel quality"""
+    from kmap_amd import _ffi
+    buf = _ffi.DeviceBuffer(nbytes)
+    ms = timed_launches(lambda: buf.zero(), reps, warmup=2)
+    buf.free()
+    med = statistics.median(ms)
+    return {"GBps_median": nbytes / (med * 1e-3) / 1e9, "GBps_best": nbytes / (min(ms) * 1e-3) / 1e9, "ms_median": med, "bytes": nbytes,
+            "what": "hipMemsetAsync of the same byte count, HIP events, same stream, same run"}
 
 
 def main():
@@ -328,8 +441,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-embed-dist", action="store_true", help="skip the multi-GPU embedding leg (world > 1)")
+    ap.add_argument("--no-embed-dist", action="store_true", help="skip the sharded-embedding leg")
     ap.add_argument("--no-c4", action="store_true", help="skip the N = 200 000 strong-scaling leg")
+    ap.add_argument("--no-c5", action="store_true", help="skip the full-size C5 scan leg (N=1 only)")
+    ap.add_argument("--quick", action="store_true", help="smaller CPU-baseline samples (rehearsals)")
     ap.add_argument("--no-stages", action="store_true", help="skip the per-stage roofline timings")
     ap.add_argument("--e2e", default="full", choices=["none", "k9", "full"],
                     help="end-to-end timings on C3 (rank 0, N=1 only): k9 = k 6..9 in both embedding modes; full = also the default k 6..16")
@@ -377,12 +492,14 @@ def main():
         os.environ.pop("KMAP_DIST_DISABLE")
         res_dir = first["res_dir"]
         kh, lab, lens, conseqs = pipeline_sample(res_dir, n)
+        s50 = (kh, lab, lens, conseqs) if n == N_BASE else pipeline_sample(res_dir, N_BASE)
+        c3s = (s50[0], s50[1], s50[3])              # the C3 hand-over itself, N = 50 000 (the strong-scaling embedding leg)
     else:
-        kh = lab = lens = conseqs = None
+        kh = lab = lens = conseqs = c3s = None
     if dist is not None:
-        box = [kh, lab, lens, conseqs]
+        box = [kh, lab, lens, conseqs, c3s]
         dist.broadcast_object_list(box, 0)          # set-up only, outside the timed region
-        kh, lab, lens, conseqs = box
+        kh, lab, lens, conseqs, c3s = box
     n = len(kh)
     rows_per = (n + world - 1) // world
     row0 = rank * rows_per
@@ -423,9 +540,32 @@ def main():
             assert np.array_equal(got, want[0]), f"timed kernel output differs from the oracle in row {r}"
     out_d.free()
 
+    fill = fill_rate(max(nrows, 1) * ld) if rank == 0 else None
+
     embed_dist = None
-    if dist is not None and not args.no_embed_dist:
-        embed_dist = embed_dist_leg(dist, torch, kh, lab, conseqs, n)
+    if not args.no_embed_dist:
+        own_group = False
+        try:
+            if dist is None:        # one GPU: the sharded loop runs on a one-rank RCCL group, so its overhead is a number in the line
+                import socket
+                import torch.distributed as dist1
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    port = sk.getsockname()[1]
+                dist1.init_process_group("nccl" if backend == "nccl" else backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                         **({"device_id": torch.device("cuda", dev)} if backend == "nccl" else {}))
+                own_group = True
+                embed_dist = embed_dist_leg(dist1, torch, 1, *c3s)
+            else:
+                embed_dist = embed_dist_leg(dist, torch, world, *c3s)
+        except Exception as e:   # noqa: BLE001 -- reported, the headline is already measured
+            embed_dist = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            if own_group:
+                try:
+                    dist1.destroy_process_group()
+                except Exception:   # noqa: BLE001
+                    pass
     c4 = None
     if not args.no_c4:
         if dist is not None:
@@ -449,6 +589,7 @@ def main():
                        "sample": "sample_kmers.pkl of scan_motif on 10M x 150 bp synthetic reads (k=6..9), expanded by counts"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "achievable": fill, "frac_of_achievable": achieved / fill["GBps_median"],
                          "kernel": "hamdist_tile_kernel<1 code word> (+ build_gid / build_codes pre-passes, inside the timed region)",
                          "kernel_ms": kern_ms, "kernel_ms_min": min(per_launch), "kernel_ms_median": statistics.median(per_launch),
                          "kernel_ms_max": max(per_launch), "algorithmic_bytes": algo_bytes},
@@ -486,14 +627,22 @@ def main():
                                f"reference's default k range (default_config.toml:7-8); default = package default embedding mode (FAST "
                                f"wavefront sums above N = 16384: per-step pinned, no digit-level reference exists at this N), seq = the "
                                f"reference's summation order (the parity-grade number)")
+            reads = None          # 1.5 GB of host memory back before the next legs
+            c2 = run_e2e("C2", "default")
+            e2e["c2"] = {"default": pack(c2), "workload": (f"C2: {c2['n_reads']} x {c2['read_len']} bp synthetic reads, N={c2['n_total']} sampled k-mers, "
+                                                           f"{c2['iters']} iterations (the reference's default size, default_config.toml:24-32), k = 6..9, "
+                                                           f"package default embedding mode = SEQ (the reference's summation order) at this N, 1 GPU, clean res_dir")}
             line["e2e"] = e2e
+        reads = None
+        if world == 1 and not args.no_c5:
+            try:
+                line["c5"] = c5_leg()
+            except AssertionError:
+                raise
+            except Exception as e:   # noqa: BLE001 -- e.g. a box without the memory for it: reported, the rest of the line stands
+                line["c5"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(kh, lab, lens)
-            line["cpu_baseline"]["e2e"] = cpu_e2e_baseline(kh, lab, lens)
-            if "e2e" in line:
-                cpu_s = line["cpu_baseline"]["e2e"]["extrapolated_to_c3"]["e2e_s"]
-                line["cpu_baseline"]["e2e"]["gpu_e2e_s"] = {"default": line["e2e"]["k6_9"]["default"]["e2e_s"], "seq": line["e2e"]["k6_9"]["seq"]["e2e_s"]}
-                line["cpu_baseline"]["e2e"]["ratio_cpu_over_gpu"] = {m: cpu_s / v for m, v in line["cpu_baseline"]["e2e"]["gpu_e2e_s"].items()}
+            line["cpu_baseline"] = cpu_baseline(kh, lab, lens, quick=args.quick)
         print(json.dumps(line), flush=True)
     if res_dir:
         import shutil

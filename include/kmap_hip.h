@@ -249,6 +249,16 @@ int kmap_fasta_open(const char *path, kmap_fasta **f, int64_t *n_bytes, int64_t 
 int kmap_fasta_read(kmap_fasta *f, uint8_t *seq_out, int64_t *borders_out);
 int kmap_fasta_close(kmap_fasta *f);
 
+/* ---- synthetic workload generator (benchmarks / tests; no reference operator corresponds to it): seeded reads in the array
+ * contract above, generated in HBM -- BASELINE config C5 is 15 GB, minutes of numpy on the host.  Fixed-length reads, uniform
+ * bases; the first fractions[0] * n_reads reads carry motif 0, the next fractions[1] * n_reads motif 1, ... at a uniform
+ * position with per-base substitution rate mutation_rate (the style of the reference's tests/kmap_tests.py:75-114).
+ * seq_dev: uint8[n_reads * (read_len + 1)], 16-byte aligned; borders_dev (optional): int64[n_reads][2]; motif_codes: the
+ * motifs' base codes 0..3 concatenated (host), motif_len / fractions: host arrays of n_motifs <= 4 entries. */
+int kmap_synth_reads_dev(uint8_t *seq_dev, int64_t *borders_dev, int64_t n_reads, int read_len, uint64_t seed,
+                         const uint8_t *motif_codes, const int32_t *motif_len, const double *fractions, int n_motifs,
+                         double mutation_rate, void *stream);
+
 /* ---- all-pairs Hamming matrix: cal_samp_kmer_hamdist_mat motif_discovery.py:759-808
  * (one launch instead of n_uniq launches + Python block expansion).  kh: N hashes (already
  * expanded by counts), label: N int32; pairs sharing label l with clen[l] < k are compared on the

@@ -103,6 +103,7 @@ _SIGS = {
     "kmap_fasta_open": (i32, [C.c_char_p, P(vp), P(i64), P(i64)]),
     "kmap_fasta_read": (i32, [vp, vp, vp]),
     "kmap_fasta_close": (i32, [vp]),
+    "kmap_synth_reads_dev": (i32, [vp, vp, i64, i32, C.c_uint64, vp, vp, vp, i32, C.c_double, vp]),
     "kmap_hamdist_matrix_u32_dev": (i32, [vp, vp, i64, i32, vp, i32, i64, i64, vp, i64, vp]),
     "kmap_hamdist_matrix_u64_dev": (i32, [vp, vp, i64, i32, vp, i32, i64, i64, vp, i64, vp]),
     "kmap_hamdist_matrix_u8": (i32, [vp, vp, i64, i32, vp, i32, vp]),

@@ -65,20 +65,25 @@ class DeviceSeq:
     """The encoded reads resident in HBM as 2-bit codes + invalid bitmask (packed.hip), plus the (n_seq, 2) borders.
     `inval_orig` is the pristine mask, `inval_work` the one find_motif masks; the codes are shared."""
 
-    def __init__(self, seq_np_arr, boarder_mat):
-        seq = np.ascontiguousarray(seq_np_arr, dtype=np.uint8)
-        self.n = len(seq)
-        self.borders_host = np.ascontiguousarray(boarder_mat, dtype=np.int64).reshape(-1, 2)
-        self.n_seq = len(self.borders_host)
-        self.borders = _ffi.DeviceBuffer.from_numpy(self.borders_host)
-        self.read_len = (self.borders_host[:, 1] - self.borders_host[:, 0]).astype(np.int64)
+    def __init__(self, seq_np_arr, boarder_mat, _device_arrays=None):
+        if _device_arrays is not None:           # from_device(): the uint8 array and the borders already lie in HBM
+            raw, self.n, self.borders, self.n_seq, fixed_len = _device_arrays
+            self.borders_host = None
+            self.read_len = np.full(self.n_seq, fixed_len, np.int64) if fixed_len is not None else None
+        else:
+            seq = np.ascontiguousarray(seq_np_arr, dtype=np.uint8)
+            self.n = len(seq)
+            self.borders_host = np.ascontiguousarray(boarder_mat, dtype=np.int64).reshape(-1, 2)
+            self.n_seq = len(self.borders_host)
+            self.borders = _ffi.DeviceBuffer.from_numpy(self.borders_host)
+            self.read_len = (self.borders_host[:, 1] - self.borders_host[:, 0]).astype(np.int64)
+            raw = _ffi.DeviceBuffer.from_numpy(seq) if self.n else _ffi.DeviceBuffer(16)
         # the reads scan() results cover: these reads here; ALL reads for a read-sharded DistDeviceSeq (distributed.py)
         self.out_n_seq, self.out_read_len = self.n_seq, self.read_len
         self.groups = int(_ffi.lib().kmap_packed_groups(self.n))
         self.codes = _ffi.DeviceBuffer(self.groups * 4)
         self.inval_orig = _ffi.DeviceBuffer(self.groups * 2)
         self.inval_work = _ffi.DeviceBuffer(self.groups * 2)
-        raw = _ffi.DeviceBuffer.from_numpy(seq) if self.n else _ffi.DeviceBuffer(16)
         check(_ffi.lib().kmap_pack_reads_dev(raw.ptr, self.n, self.codes.ptr, self.inval_orig.ptr, None))
         _ffi.sync()
         raw.free()                      # the uint8 array does not stay on the device
@@ -89,6 +94,13 @@ class DeviceSeq:
         self.device = dev.value         # HIP's current device is per thread: worker threads that fetch hit lists select it
         import threading
         self._lazy_lock, self._lazy_free, self._lazy_all = threading.Lock(), [], []     # scan handles of scan_lazy()
+
+    @classmethod
+    def from_device(cls, raw_u8, n, borders_dev, n_seq, fixed_read_len=None):
+        """the reads already in HBM (raw_u8: DeviceBuffer with the uint8 array contract, consumed -- freed once packed;
+        borders_dev: DeviceBuffer int64[n_seq][2]), e.g. from synth.synth_reads_dev; fixed_read_len: every read's length, if
+        the caller knows it (the occurrence CSV needs the lengths on the host)"""
+        return cls(None, None, _device_arrays=(raw_u8, int(n), borders_dev, int(n_seq), fixed_read_len))
 
     def reset(self):
         """restore the unmasked reads (reference motif_discovery.py:263): n/8 bytes"""

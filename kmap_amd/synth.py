@@ -41,6 +41,39 @@ def synth_reads(n_reads, read_len, seed, motifs=(MOTIF_A, MOTIF_B), fractions=(0
     return seq, borders
 
 
+def synth_reads_dev(n_reads, read_len, seed, motifs=(MOTIF_A, MOTIF_B), fractions=(0.4, 0.4), mutation_rate=0.05, keep_raw=False):
+    """The same kind of reads generated in HBM (csrc/synth.hip: counter-based, NOT the numpy stream of synth_reads) for the
+    configurations that are too large to build on the host inside a benchmark (C5: 50 M x 300 bp = 15 GB).
+    Returns a DeviceSeq (packed reads + borders resident); keep_raw=True returns (DeviceSeq, raw) where raw() fetches
+    the uint8 bytes [lo, hi) of the array as generated (for spot checks against the oracle) until raw.free() is called --
+    the 1 B / position array otherwise leaves HBM as soon as it is packed."""
+    import ctypes as C
+    from . import _ffi
+    from .motif_discovery import DeviceSeq
+    n = n_reads * (read_len + 1)
+    raw = _ffi.DeviceBuffer(max(n, 16))
+    borders = _ffi.DeviceBuffer(max(n_reads, 1) * 16)
+    codes = np.array([_CODE[c] for m in motifs for c in m], np.uint8)
+    lens = np.array([len(m) for m in motifs], np.int32)
+    fr = np.array(fractions, np.float64)
+    _ffi.check(_ffi.lib().kmap_synth_reads_dev(raw.ptr, borders.ptr, n_reads, read_len, C.c_uint64(seed), _ffi.ptr(codes) if len(codes) else None,
+                                               _ffi.ptr(lens) if len(lens) else None, _ffi.ptr(fr) if len(fr) else None, len(motifs),
+                                               float(mutation_rate), None))
+    if not keep_raw:
+        return DeviceSeq.from_device(raw, n, borders, n_reads, read_len)
+    copy = _ffi.DeviceBuffer(max(n, 16))
+    _ffi.check(_ffi.lib().kmap_memcpy_d2d(copy.ptr, raw.ptr, n, None))
+    ds = DeviceSeq.from_device(raw, n, borders, n_reads, read_len)
+
+    class _Raw:
+        def __call__(self, lo, hi):
+            return copy.to_numpy(np.uint8, (hi - lo,), offset=lo)
+
+        def free(self):
+            copy.free()
+    return ds, _Raw()
+
+
 def write_res_dir(res_dir, seq, borders, overrides=None, fasta_name="synthetic.fa"):
     """Create a res_dir as `kmap preproc` would leave it (config.toml, motif_def_table.csv, the two pickles)."""
     from ._toml import dump_toml

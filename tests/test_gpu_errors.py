@@ -62,3 +62,40 @@ def test_empty_inputs_are_fine():
     assert len(u) == 0 and len(c) == 0
     out = K.mask_input(np.zeros(0, np.uint8), 4, np.array([1]), np.array([0]))
     assert len(out) == 0
+
+
+def test_shared_histogram_table_has_one_owner():
+    """All counts handles of a device share ONE 4^k-bin table.  The split API hist -> bins -> (all-reduce) -> finish must not
+    compact a table another handle has overwritten in between, nor one the arena has freed: KMAP_E_STATE, not wrong counts."""
+    from kmap_amd import _ffi, synth
+    from kmap_amd.kmer_count import DeviceCounts
+    from kmap_amd.motif_discovery import DeviceSeq
+    L = _ffi.lib()
+    seq, borders = synth.synth_reads(3000, 60, 5)
+    ds = DeviceSeq(seq, borders)
+    a, b = DeviceCounts(), DeviceCounts()
+    hist = lambda h, k: L.kmap_counts_hist_packed_dev(h._h, ds.codes.ptr, ds.inval_orig.ptr, ds.n, ds.borders.ptr, ds.n_seq, k, 0, None)
+    p, nb, nu = _ffi.vp(), _ffi.i64(0), _ffi.i64(0)
+    assert hist(a, 7) == 0
+    assert L.kmap_counts_bins(a._h, C.byref(p), C.byref(nb)) == 0 and nb.value == 4 ** 7
+    assert L.kmap_counts_finish(a._h, 7, 1, C.byref(nu), None) == 0
+    a.k, a.n_uniq = 7, nu.value
+    ref_u, ref_c = a.fetch()
+    # interleaved: A fills the table, B counts, A must not finish
+    assert hist(a, 7) == 0
+    ds.count(b, 6, dedupe=False, merge_revcom=True)
+    assert L.kmap_counts_bins(a._h, C.byref(p), C.byref(nb)) == -5 and b"shared histogram" in L.kmap_last_error()
+    assert L.kmap_counts_finish(a._h, 7, 1, C.byref(nu), None) == -5
+    # the arena released between hist and finish: the same refusal instead of a read of freed memory
+    assert hist(a, 7) == 0
+    assert L.kmap_scratch_release(0) == 0
+    assert L.kmap_counts_finish(a._h, 7, 1, C.byref(nu), None) == -5
+    # and the handle is fine again after a fresh histogram
+    assert hist(a, 7) == 0 and L.kmap_counts_finish(a._h, 7, 1, C.byref(nu), None) == 0
+    a.k, a.n_uniq = 7, nu.value
+    u, c = a.fetch()
+    np.testing.assert_array_equal(u, ref_u)
+    np.testing.assert_array_equal(c, ref_c)
+    for h in (a, b):
+        h.close()
+    ds.close()

@@ -244,3 +244,73 @@ def test_c3_embedding_force_evaluation_full_size():
     (gs, ls), (gf, lf) = outs["seq"], outs["fast"]
     assert abs(lf - ls) <= 2e-6 * abs(ls)
     np.testing.assert_allclose(gf, gs, rtol=0, atol=2e-5 * np.abs(gs).max())
+
+
+def test_c2_whole_run():
+    """BASELINE config C2 -- the reference's DEFAULT size (default_config.toml:24-32): 100 k x 150 bp reads, k = 6..9, N = 5000
+    sampled k-mers, 2500 iterations -- as one run of both verbs on a clean res_dir, in the package's default (SEQ) embedding
+    mode: the planted motifs come out as the finals, low_dim_data.tsv has the contract's shape, the loss falls; the
+    hand-over's first 10 iterations equal the oracle's restatement of the reference loop at this size (1e-5 abs)."""
+    import pickle
+    import shutil
+    from pathlib import Path
+    from kmap_amd import _ffi, synth, visualization as V
+    from kmap_amd.e2e import run_e2e
+    from kmap_amd.hamdist import hamdist_matrix_dev, pitch_for
+    from oracle import oracle as O
+    r = run_e2e("C2", "default", keep=True)
+    res = Path(r["res_dir"])
+    try:
+        finals = r["final_conseq"]
+        planted = [synth.MOTIF_A, synth.MOTIF_B]
+        both = planted + [O.reverse_complement(m) for m in planted]
+        assert len(finals) == 2 and all(any(f in m for m in both) for f in finals), finals
+        assert {next(i for i, m in enumerate(both) if f in m) % 2 for f in finals} == {0, 1}      # one final per planted motif
+        rows = (res / "low_dim_data.tsv").read_text().splitlines()
+        assert rows[0] == "x\ty\tlabel" and len(rows) == 5001
+        tab = np.array([ln.split("\t") for ln in rows[1:]], dtype=np.float64)
+        assert tab.shape == (5000, 3) and np.isfinite(tab).all() and set(np.unique(tab[:, 2])) <= {0.0, 1.0, 2.0}
+        with open(res / "sample_kmers.pkl", "rb") as fh:
+            samp_kh, samp_cnts, samp_label, conseqs = pickle.load(fh)
+        assert int(np.sum(samp_cnts)) == 5000 and list(conseqs) == finals
+        with open(res / "sample_kmer_hamdist_mat.pkl", "rb") as fh:
+            klen, D, labels = pickle.load(fh)
+        assert klen == max(len(f) for f in finals) and D.shape == (5000, 5000) and D.dtype == np.int64     # dense contract at this N
+        np.testing.assert_array_equal(labels, tab[:, 2].astype(np.int64))
+        # the embedding the verb wrote == a traced re-run from the hand-over (same seed); the loss trace falls and stays finite
+        nb = np.argpartition(D, 20, axis=1)[:, :20]
+        tr = {}
+        best = V.kmap(D, klen, n_max_iter=2500, random_seed=7, debug=False, neighbor_inds_mat=nb, trace=tr)
+        np.testing.assert_allclose(np.round(best.astype(np.float64), 3).T, tab[:, :2], atol=1.1e-3)
+        losses = tr["losses"]
+        assert len(losses) == 2500 and np.isfinite(losses).all() and losses.min() < 0.5 * losses[0]
+        run_best = np.minimum.accumulate(losses)
+        assert run_best[-1] <= run_best[len(run_best) // 2] <= run_best[10] < losses[0]
+        # first 10 iterations at the full C2 size against the oracle loop (IEEE f32, j-ascending sums), from the same probabilities
+        n = 5000
+        ldd = pitch_for(n)
+        Dp = np.zeros((n, ldd), np.uint8)
+        Dp[:, :n] = D
+        D_d = _ffi.DeviceBuffer.from_numpy(Dp)
+        sums_d, lds = V.knn_sums_dev(D_d.ptr, ldd, nb, n, 20)
+        sums = sums_d.to_numpy(np.uint16, (n, lds))[:, :n]
+        D_d.free()
+        sums_d.free()
+        p = V.hd_prob_lut(klen, 20, 400 * klen)[sums]
+        np.fill_diagonal(p, 0.0)
+        tr10 = {}
+        V.kmap(D, klen, n_max_iter=10, random_seed=7, debug=False, neighbor_inds_mat=nb, mode=V.EMBED_SEQ, trace=tr10)
+        np.random.seed(7)
+        ld = np.random.randn(2, n).astype("float32")
+        for _ in range(10):
+            np.random.randn(2, n)
+        want_losses = []
+        for _ in range(10):
+            q = O.cal_ld_prob_mat(ld)
+            want_losses.append(O.cross_entropy(p, q))
+            ld += (-O.gradient_loss(p, q, ld) * 0.01)
+            ld = O.add_jitter(ld, eps=0.1)
+        np.testing.assert_allclose(tr10["losses"], np.array(want_losses, np.float32), rtol=3e-6)
+        np.testing.assert_allclose(tr10["last_coords"], ld, rtol=0, atol=1e-5)
+    finally:
+        shutil.rmtree(res, ignore_errors=True)

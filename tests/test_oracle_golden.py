@@ -328,3 +328,72 @@ def test_occurrence_subsample_golden():
     want = open(f"{GOLD}/occ20/occ20.motif_occurence.csv").read().splitlines()
     assert lines == want
     assert sum(cell.count(",") == 19 for ln in want[1:] for cell in ln.split(";")[1:-1]) >= 10
+
+
+# ---- the timed CPU baseline (oracle/kmap_cpu_baseline.c) computes what the oracle computes ----------------------------------
+def test_cpu_baseline_equals_oracle():
+    """bench.py's cpu_baseline leg times oracle/kmap_cpu_baseline.c (per-thread histograms, hashed per-read sets, fused embedding
+    pass); a baseline that computed something else would be meaningless, so every function is pinned against the oracle."""
+    from oracle import baseline as B, oracle as O
+    from kmap_amd import synth
+    from kmap_amd.kmer_count import gen_motif_def_dict, read_default_config_file
+    seq, borders = synth.synth_reads(3000, 75, 11)
+    seq[1000:1030] = 255                                       # a masked stretch inside a read
+    seq[5020:5060] = 3                                         # poly-T inside read 66 ([5016, 5091)): duplicates within one read
+    for k in (6, 8, 11):
+        for dedupe in (True, False):
+            for merge in (True, False):
+                h = O.comp_kmer_hash(seq, k)
+                if dedupe:
+                    h = O.remove_duplicate_hash_per_seq(h, borders)
+                u, c = O.count_uniq_hash(h, k)
+                if merge:
+                    u, c = O.merge_revcom(u, c, k)
+                bu, bc = B.count(seq, borders, k, dedupe, merge, threads=3)
+                assert dict(zip(u.tolist(), c.tolist())) == dict(zip(bu.tolist(), bc.tolist())), (k, dedupe, merge)
+    # masking incl. the poly-T / separator quirk (golden G5) and a radius-1 ball
+    m = O.dna2arr("ACGTACGTAC")
+    arr = np.concatenate([m, O.dna2arr("GGGGGGGGGG")]).astype(np.uint8)
+    want = O.mask_input(arr.copy(), 4, np.array([O.kmer2hash("TTTT")], np.uint64), np.array([0]))
+    got = B.mask(arr.copy(), 4, [O.kmer2hash("TTTT")], [0], threads=2)
+    np.testing.assert_array_equal(got, want)
+    cons = [int(O.kmer2hash("AATCGATA")), int(O.revcom_hash(O.kmer2hash("AATCGATA"), 8))]
+    np.testing.assert_array_equal(B.mask(seq.copy(), 8, cons, [1, 1], threads=3),
+                                  O.mask_input(seq.copy(), 8, np.array(cons, np.uint64), np.array([1, 1])))
+    # find_motif: same consensus sequences and proportions as the oracle's restatement of the reference loop
+    mdd = gen_motif_def_dict(read_default_config_file())
+    seq2, borders2 = synth.synth_reads(6000, 60, 5)
+    for k in (7, 8, 9):
+        res_o, _, _ = O.find_motif(seq2.copy(), borders2, k, mdd[k])
+        res_b = B.find_motif(seq2.copy(), borders2, k, mdd[k], threads=3)
+        assert [int(h) for h in res_o] == list(res_b), k
+        for h, (prop, _, _) in res_o.items():
+            assert abs(res_b[int(h)] - prop) <= 1e-12
+        assert len(res_b) >= 1
+    # one fused embedding pass: the gradient bit for bit (same f32 order), the loss to f32 round-off
+    rng = np.random.default_rng(2)
+    n = 257
+    kh = rng.integers(0, 4 ** 8, size=n).astype(np.uint32)
+    lut = np.exp(-np.arange(9, dtype=np.float32) / np.float32(3.0)).astype(np.float32)
+    P = np.empty((n, n), np.float32)
+    B.lib().kb_fill_prob(kh, n, lut, 1, P, 2)
+    D = O.hamdist_matrix_u8(kh.astype(np.uint64), np.zeros(n, np.int32), 8, [8])
+    np.testing.assert_array_equal(P, lut[D])
+    np.fill_diagonal(P, 0.0)
+    y = (rng.standard_normal((2, n)) * 2).astype(np.float32)
+    q = O.cal_ld_prob_mat(y)
+    g, loss = B.embed_forces(P, y, threads=3)
+    np.testing.assert_array_equal((np.float32(4.0) * g).view(np.uint32), O.gradient_loss(P, q, y).view(np.uint32))
+    ref = float(O.cross_entropy(P, q))
+    assert abs(2.0 * loss - ref) <= 3e-6 * abs(ref)
+    P_off = P.copy()                                            # the on-the-fly form bench.py times: p from the k-mers, no matrix
+    g3, l3 = B.embed_forces_kmers(kh, lut, 1, y, threads=3)
+    B.lib().kb_fill_prob(kh, n, lut, 1, P_off, 2)              # (its diagonal is lut[0]; the pass skips j == i either way)
+    g4, l4 = B.embed_forces(P_off, y, threads=3)
+    np.testing.assert_array_equal(g3, g4)
+    assert l3 == l4
+    g2, l2 = B.embed_forces(P, y, 100, 180, threads=2)          # a row range (the 1-core sample of bench.py)
+    np.testing.assert_array_equal(g2[:, 100:180], g[:, 100:180])
+    assert not g2[:, :100].any() and not g2[:, 180:].any() and 0 < l2 < loss
+    info = B.host_cpu_info()
+    assert info["usable"] >= 1 and info["logical_cpus"] >= info["usable"] and isinstance(info["model"], str)
