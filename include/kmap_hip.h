@@ -363,6 +363,13 @@ int kmap_embed_get_best(kmap_embed *e, float *coords_2xn, void *stream);        
 int kmap_embed_get_losses(kmap_embed *e, float *losses, int64_t max_n, int64_t *n_out, void *stream);
 void *kmap_embed_coords_dev(kmap_embed *e);                                      /* device ptr (2 x N f32) */
 
+/* ---- device self-tests (test support): exhaustive bit comparison of the SEQ force kernel's two shortened f32 divisions
+ * (csrc/seq_div.h) with IEEE division over EVERY float bit pattern in [lo_bits, hi_bits].  which = 0: clip(1 / s1, 1e-3, 0.999)
+ * with rcp_steps Newton steps; which = 1: q / (1 - q) with rcp_steps steps on the reciprocal and quo_steps residual corrections.
+ * *n_bad = number of operands whose result differs, *first_bad_bits = the smallest such bit pattern. */
+int kmap_selftest_seq_div(int which, int rcp_steps, int quo_steps, uint32_t lo_bits, uint32_t hi_bits, uint64_t *n_bad,
+                          uint32_t *first_bad_bits);
+
 #ifdef __cplusplus
 }
 #endif

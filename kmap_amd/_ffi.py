@@ -132,6 +132,7 @@ _SIGS = {
     "kmap_embed_get_best": (i32, [vp, vp, vp]),
     "kmap_embed_get_losses": (i32, [vp, vp, i64, P(i64), vp]),
     "kmap_embed_coords_dev": (vp, [vp]),
+    "kmap_selftest_seq_div": (i32, [i32, i32, i32, C.c_uint32, C.c_uint32, P(C.c_uint64), P(C.c_uint32)]),
 }
 
 

@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "seq_div.h"
 
 namespace {
 
@@ -434,20 +435,6 @@ __device__ __forceinline__ float q_of(float dx, float dy) {
     q = fminf(q, 0.999f);                            // np.minimum(prob, 1 - 1e-3)   visualization.py:254
     q = fmaxf(q, 0.001f);                            // np.maximum(prob, 1e-3)       visualization.py:255
     return q;
-}
-// a / b exactly as hipcc's IEEE f32 division computes it (v_div_scale, v_rcp, 2 + 3 fma refinements, v_div_fmas, v_div_fixup)
-// for operands on which v_div_scale does not rescale and v_div_fixup passes the quotient through: finite, normal, quotient and
-// 1/b normal.  Both divisions of the SEQ path are of that kind (1/(1+d2) with d2 < 1e30; q/(1-q) with both in [1e-3, 0.999]),
-// which saves the three wrapper instructions per division.
-__device__ __forceinline__ float div_normal(float a, float b) {
-    float r = __builtin_amdgcn_rcpf(b);
-    const float e = __builtin_fmaf(-b, r, 1.0f);
-    r = __builtin_fmaf(e, r, r);
-    float q = a * r;
-    float m = __builtin_fmaf(-b, q, a);
-    q = __builtin_fmaf(m, r, q);
-    m = __builtin_fmaf(-b, q, a);
-    return __builtin_fmaf(m, r, q);
 }
 __device__ __forceinline__ float t_of(float p, float q) {
     return (q / (1.0f - q)) * (p - q);               // visualization.py:132-134
@@ -1116,27 +1103,85 @@ __device__ __forceinline__ void seq_load(SeqBatch &b, const ProbSrc &src, const 
 }
 
 constexpr int SQ_WAVES = 4;                     // waves per block (the LUT is staged once per block)
-template <bool LUTSRC>
-__global__ __launch_bounds__(KMAP_WAVE *SQ_WAVES) void forces_seq_kernel(ProbSrc src, const float *__restrict__ Y, int64_t n,
-                                                               int64_t row0, int64_t nrows, float *__restrict__ G,
-                                                               double *__restrict__ loss_part) {
-    extern __shared__ __attribute__((aligned(16))) float lut_s[];
-    if (LUTSRC) {
-        for (int t = threadIdx.x; t < src.lut_len && t < F_LUT_LDS; t += blockDim.x) lut_s[t] = src.lut[t];
-        __syncthreads();
+
+// The 8 terms of one lane's batch: t * dx, t * dy of columns jl32 .. jl32 + 7 against point (xi, yi) = row i32, and the batch's
+// cross-entropy contribution in log2 units.  SLOW: generic IEEE divisions (some squared distance beyond 1e30); LOSS: the batch has
+// columns right of the wave's rows; MASK: per-term predicates (the batch reaches past column n - 1 or contains the diagonal of
+// one of the wave's rows).  The two divisions are the exhaustively verified short sequences of seq_div.h.
+template <bool LUTSRC, bool SLOW, bool LOSS, bool MASK>
+__device__ __forceinline__ void seq_terms(const SeqBatch &cur, const float *__restrict__ lut_s, float xi, float yi, int i32, int n32,
+                                          int jl32, float (&tx)[SQ_CPL], float (&ty)[SQ_CPL], float &ce2) {
+    float prod = 1.0f, esum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < SQ_CPL; ++c) {                               // 8 independent terms
+        const int j = jl32 + c;
+        const float p = LUTSRC ? lut_s[(cur.w[c >> 1] >> (16 * (c & 1))) & 0xFFFFu] : cur.pf[c];
+        const float dx = xi - cur.x[c], dy = yi - cur.y[c];
+        const float d2 = dx * dx + dy * dy;                          // (dx*dx) + (dy*dy), no FMA (taichi_core.py:254)
+        float q = SLOW ? 1.0f / (1.0f + d2) : seq_rcp<KMAP_SEQ_RCP_STEPS>(1.0f + d2);        // :255
+        q = __builtin_amdgcn_fmed3f(q, 0.001f, 0.999f);              // np.minimum(.., 1 - 1e-3), np.maximum(.., 1e-3)
+        const float omq = 1.0f - q;
+        const float u = SLOW ? q / omq : seq_quo<KMAP_SEQ_QUO_RSTEPS, KMAP_SEQ_QUO_STEPS>(q, omq);   // visualization.py:132-134
+        const float t = u * (p - q);
+        const bool use = !MASK || ((j < n32) && (j != i32));
+        tx[c] = use ? t * dx : 0.0f;                                 // products rounded on their own (-ffp-contract=off)
+        ty[c] = use ? t * dy : 0.0f;
+        if (LOSS) {
+            // -(p ln q + (1-p) ln(1-q)) = -ln2 (log2(1-q) + p log2(q/(1-q))): one log per pair + one log of the product
+            // of the eight (1-q); the reference's eps branches change a term by < 1e-9 relative (p < 1e-10) or not at
+            // all (p = 1), and the loss is not part of the bit-pinned path
+            const bool live = !MASK || ((j < n32) && (j > i32));     // a plain batch with loss lies right of all the wave's rows
+            esum += live ? p * __builtin_amdgcn_logf(u) : 0.0f;
+            prod *= live ? omq : 1.0f;
+        }
     }
-    __shared__ double wl[SQ_WAVES];
+    if (LOSS) ce2 = __builtin_amdgcn_logf(prod) + esum;
+}
+// wave-uniform dispatch over the variants.  rows_in_wave consecutive rows from wave_row_min; batch = columns [j0, j0 + batch_cols)
+template <bool LUTSRC>
+__device__ __forceinline__ void seq_terms_dispatch(const SeqBatch &cur, const float *__restrict__ lut_s, float xi, float yi, int i32,
+                                                   int64_t n, int64_t j0, int batch_cols, int64_t wave_row_min, int rows_in_wave,
+                                                   int jl32, float (&tx)[SQ_CPL], float (&ty)[SQ_CPL], float &ce2) {
+    // (a) no column of the batch lies right of any of the wave's rows -> no loss terms (each unordered pair is charged to its
+    // j > i side); (b) some squared distance is too large for the short divisions -> generic division
+    const bool want_loss = (j0 + batch_cols - 1) > wave_row_min;
+    float d2max = 0.0f;
+#pragma unroll
+    for (int c = 0; c < SQ_CPL; ++c) {
+        const float dx = xi - cur.x[c], dy = yi - cur.y[c];
+        d2max = fmaxf(d2max, dx * dx + dy * dy);
+    }
+    const bool slow = __any(!(d2max < 1e30f));
+    // (c) the batch neither reaches past column n-1 nor contains the diagonal of any of the wave's rows -> no per-term masks
+    const bool plain = (j0 + batch_cols <= n) && (j0 + batch_cols - 1 < wave_row_min || j0 > wave_row_min + rows_in_wave - 1);
+    const int n32 = (int)n;
+    ce2 = 0.0f;
+    if (slow) {   // rare (coordinates beyond 1e15): one generic instantiation
+        seq_terms<LUTSRC, true, true, true>(cur, lut_s, xi, yi, i32, n32, jl32, tx, ty, ce2);
+    } else if (plain) {
+        if (want_loss) seq_terms<LUTSRC, false, true, false>(cur, lut_s, xi, yi, i32, n32, jl32, tx, ty, ce2);
+        else seq_terms<LUTSRC, false, false, false>(cur, lut_s, xi, yi, i32, n32, jl32, tx, ty, ce2);
+    } else {
+        seq_terms<LUTSRC, false, true, true>(cur, lut_s, xi, yi, i32, n32, jl32, tx, ty, ce2);
+    }
+}
+
+// quad form, block `bid` of the rows [0, nrows) (lut_s: the block's LUT copy in LDS, already filled; wl: SQ_WAVES doubles of LDS)
+template <bool LUTSRC>
+__device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *__restrict__ Y, int64_t n, int64_t row0, int64_t nrows,
+                                              float *__restrict__ G, double *__restrict__ loss_part, int64_t bid,
+                                              const float *__restrict__ lut_s, double *wl) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane & (SQ_SUB - 1);
-    const int64_t lr = ((int64_t)blockIdx.x * SQ_WAVES + wave) * SQ_ROWS + (lane / SQ_SUB);
+    const int64_t lr = (bid * SQ_WAVES + wave) * SQ_ROWS + (lane / SQ_SUB);
     const bool valid = lr < nrows;
     const int64_t lrc = valid ? lr : nrows - 1;
     const int64_t i = row0 + lrc;
     const float *X = Y, *Yy = Y + n;
     const float xi = X[i], yi = Yy[i];
     const bool vec = ((n & 3) == 0) && (!LUTSRC || (src.ld % 8 == 0));
-    const int n32 = (int)n, i32 = (int)i;        // n < 2^31 (checked by the host)
-    const int64_t wave_row_min = row0 + ((int64_t)blockIdx.x * SQ_WAVES + wave) * SQ_ROWS;   // smallest global row of the wave
+    const int i32 = (int)i;                      // n < 2^31 (checked by the host)
+    const int64_t wave_row_min = row0 + (bid * SQ_WAVES + wave) * SQ_ROWS;   // smallest global row of the wave
     float gx = 0.0f, gy = 0.0f, ce_acc = 0.0f;
     double loss = 0.0;
     SeqBatch cur, nxt;
@@ -1145,56 +1190,8 @@ __global__ __launch_bounds__(KMAP_WAVE *SQ_WAVES) void forces_seq_kernel(ProbSrc
         const int64_t jl = j0 + (int64_t)sub * SQ_CPL;                       // this lane's first column of the batch
         if (j0 + SQ_BATCH < n) seq_load<LUTSRC>(nxt, src, X, Yy, lrc, jl + SQ_BATCH, n, vec);   // prefetch
         float tx[SQ_CPL], ty[SQ_CPL];
-        float ce2 = 0.0f;                                                    // loss terms in log2 units (order-free)
-        const int jl32 = (int)jl;
-        // wave-uniform choices: (a) no column of the batch lies right of any of the wave's 16 rows -> no loss terms (each
-        // unordered pair is charged to its j > i side); (b) some squared distance is too large for div_normal -> generic division
-        const bool want_loss = (j0 + SQ_BATCH - 1) > wave_row_min;
-        float d2max = 0.0f;
-#pragma unroll
-        for (int c = 0; c < SQ_CPL; ++c) {
-            const float dx = xi - cur.x[c], dy = yi - cur.y[c];
-            d2max = fmaxf(d2max, dx * dx + dy * dy);
-        }
-        const bool slow = __any(!(d2max < 1e30f));
-        // (c) the batch neither reaches past column n-1 nor contains the diagonal of any of the wave's rows -> no per-term masks
-        const bool plain = (j0 + SQ_BATCH <= n) && (j0 + SQ_BATCH - 1 < wave_row_min || j0 > wave_row_min + SQ_ROWS - 1);
-        auto terms = [&](auto slow_tag, auto loss_tag, auto mask_tag) {
-            constexpr bool SLOW = decltype(slow_tag)::value, LOSS = decltype(loss_tag)::value, MASK = decltype(mask_tag)::value;
-            float prod = 1.0f, esum = 0.0f;
-#pragma unroll
-            for (int c = 0; c < SQ_CPL; ++c) {                               // 8 independent terms
-                const int j = jl32 + c;
-                const float p = LUTSRC ? lut_s[(cur.w[c >> 1] >> (16 * (c & 1))) & 0xFFFFu] : cur.pf[c];
-                const float dx = xi - cur.x[c], dy = yi - cur.y[c];
-                const float d2 = dx * dx + dy * dy;                          // (dx*dx) + (dy*dy), no FMA (taichi_core.py:254)
-                float q = SLOW ? 1.0f / (1.0f + d2) : div_normal(1.0f, 1.0f + d2);          // :255
-                q = __builtin_amdgcn_fmed3f(q, 0.001f, 0.999f);              // np.minimum(.., 1 - 1e-3), np.maximum(.., 1e-3)
-                const float omq = 1.0f - q;
-                const float u = SLOW ? q / omq : div_normal(q, omq);         // visualization.py:132-134
-                const float t = u * (p - q);
-                const bool use = !MASK || ((j < n32) && (j != i32));
-                tx[c] = use ? t * dx : 0.0f;                                 // products rounded on their own (-ffp-contract=off)
-                ty[c] = use ? t * dy : 0.0f;
-                if (LOSS) {
-                    // -(p ln q + (1-p) ln(1-q)) = -ln2 (log2(1-q) + p log2(q/(1-q))): one log per pair + one log of the product
-                    // of the eight (1-q); the reference's eps branches change a term by < 1e-9 relative (p < 1e-10) or not at
-                    // all (p = 1), and the loss is not part of the bit-pinned path
-                    const bool live = !MASK || ((j < n32) && (j > i32));   // a plain batch with loss lies right of all 16 rows
-                    esum += live ? p * __builtin_amdgcn_logf(u) : 0.0f;
-                    prod *= live ? omq : 1.0f;
-                }
-            }
-            if (LOSS) ce2 = __builtin_amdgcn_logf(prod) + esum;
-        };
-        if (slow) {   // rare (coordinates beyond 1e15): one generic instantiation
-            terms(std::true_type{}, std::true_type{}, std::true_type{});
-        } else if (plain) {
-            if (want_loss) terms(std::false_type{}, std::true_type{}, std::false_type{});
-            else terms(std::false_type{}, std::false_type{}, std::false_type{});
-        } else {
-            terms(std::false_type{}, std::true_type{}, std::true_type{});
-        }
+        float ce2;                                                           // loss terms in log2 units (order-free)
+        seq_terms_dispatch<LUTSRC>(cur, lut_s, xi, yi, i32, n, j0, SQ_BATCH, wave_row_min, SQ_ROWS, (int)jl, tx, ty, ce2);
         ce_acc += ce2;
         // ordered accumulation over the batch's 32 columns: column j0 + 8*s2 + c lives in sub-lane s2, slot c
         asm volatile("s_nop 1");
@@ -1224,8 +1221,117 @@ __global__ __launch_bounds__(KMAP_WAVE *SQ_WAVES) void forces_seq_kernel(ProbSrc
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int w = 0; w < SQ_WAVES; ++w) t += wl[w];
-        loss_part[blockIdx.x] = t;
+        loss_part[bid] = t;
     }
+}
+
+// SEQ forces, WIDE form: a row is owned by GW lanes (GW = 8 .. 64; 64 / GW rows per wave).  Same terms, same order of the row
+// sum; what differs is how the terms reach the accumulator: every lane writes its 8 (t dx, t dy) pairs to a per-wave LDS strip,
+// and the row's first lane then adds the strip's 8 GW pairs in column order (one packed f32 add per pair).
+// Per column and wave that costs 288 / (8 GW) + 1 VALU instructions instead of the quad form's 11 -- but GW / 4 times the lanes
+// per row, i.e. more total work: it is for the rows that do NOT fill the machine.  With 16 rows per quad wave and 3 waves per SIMD
+// (145 VGPRs), 49 152 rows fill an MI355X exactly; the 848 remaining rows of N = 50 000 were a fourth round of 14 blocks that ran
+// alone for a full millisecond (N = 49 152: 3.00 ms, N = 49 216: 3.98 ms).  As 848 one-row waves they take ~0.16 ms.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// wide form, block `bid` of the local rows [lrow0, nrows); xch_all: SQ_WAVES x 64 x 8 (t dx, t dy) pairs of LDS
+template <bool LUTSRC, int GW>
+__device__ __forceinline__ void seq_wide_body(const ProbSrc &src, const float *__restrict__ Y, int64_t n, int64_t row0, int64_t lrow0,
+                                              int64_t nrows, float *__restrict__ G, double *__restrict__ loss_part, int64_t bid,
+                                              const float *__restrict__ lut_s, double *wl, f32x2 *xch_all) {
+    constexpr int RW = KMAP_WAVE / GW;                       // rows per wave
+    constexpr int BC = GW * SQ_CPL;                          // columns per batch
+    f32x2 *xch = xch_all + (size_t)(threadIdx.x >> 6) * (KMAP_WAVE * SQ_CPL);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & (GW - 1), grp = lane / GW;
+    const int64_t wave_lr = lrow0 + (bid * SQ_WAVES + wave) * RW;    // first local row of the wave
+    const int64_t lr = wave_lr + grp;
+    const bool valid = lr < nrows;
+    const int64_t lrc = valid ? lr : nrows - 1;
+    const int64_t i = row0 + lrc;
+    const float *X = Y, *Yy = Y + n;
+    const float xi = X[i], yi = Yy[i];
+    const bool vec = ((n & 3) == 0) && (!LUTSRC || (src.ld % 8 == 0));
+    const int i32 = (int)i;
+    const int64_t wave_row_min = row0 + wave_lr;
+    f32x2 acc = {0.0f, 0.0f};
+    float ce_acc = 0.0f;
+    double loss = 0.0;
+    SeqBatch cur, nxt;
+    seq_load<LUTSRC>(cur, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n, vec);
+    f32x2 *mine = xch + (size_t)lane * SQ_CPL;                         // = strip of row grp, columns sub * 8 .. + 7
+    const f32x4 *strip = reinterpret_cast<const f32x4 *>(xch + (size_t)grp * BC);
+    int batch = 0;
+    for (int64_t j0 = 0; j0 < n; j0 += BC, ++batch) {
+        const int64_t jl = j0 + (int64_t)sub * SQ_CPL;
+        if (j0 + BC < n) seq_load<LUTSRC>(nxt, src, X, Yy, lrc, jl + BC, n, vec);          // prefetch
+        float tx[SQ_CPL], ty[SQ_CPL];
+        float ce2;
+        seq_terms_dispatch<LUTSRC>(cur, lut_s, xi, yi, i32, n, j0, BC, wave_row_min, RW, (int)jl, tx, ty, ce2);
+        ce_acc += ce2;
+#pragma unroll
+        for (int c = 0; c < SQ_CPL; c += 2) {
+            const f32x4 v = {tx[c], ty[c], tx[c + 1], ty[c + 1]};
+            *reinterpret_cast<f32x4 *>(mine + c) = v;
+        }
+        // same wave writes and reads: LDS operations of a wave execute in order; the compiler must not move the reads up
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (sub == 0) {   // ONE lane per row carries the sum: 64 lanes reading the same 16 bytes made the strip reads LDS-bandwidth bound
+#pragma unroll 16
+            for (int m = 0; m < BC / 2; ++m) {                               // ordered: columns j0 + 2m, j0 + 2m + 1
+                const f32x4 v = strip[m];
+                acc += f32x2{v.x, v.y};
+                acc += f32x2{v.z, v.w};
+            }
+        }
+        asm volatile("" ::: "memory");                                       // the next batch's writes stay behind these reads
+        if ((batch & 7) == 7) {
+            loss += (double)ce_acc;
+            ce_acc = 0.0f;
+        }
+        cur = nxt;
+    }
+    loss += (double)ce_acc;
+    loss *= -0.6931471805599453;
+    if (valid && sub == 0) {
+        G[i] = acc.x;
+        G[n + i] = acc.y;
+    }
+    if (!valid) loss = 0.0;
+    for (int o = 32; o > 0; o >>= 1) loss += __shfl_down(loss, o);
+    if (lane == 0) wl[wave] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < SQ_WAVES; ++w) t += wl[w];
+        loss_part[bid] = t;
+    }
+}
+
+// One launch for both forms: blocks [0, nb_tail) take the left-over rows in the wide form (GW lanes per row; GW = 0: none), the
+// blocks behind them the whole rounds in the quad form.  Launched together the wide waves share their SIMDs with three quad
+// waves each, which hides the latency of their N-step dependent add chain (alone on the machine -- as a second launch -- the
+// 848 one-row waves of N = 50 000 took 0.5 - 0.6 ms; as a fourth wave per SIMD they cost their ~8 % of issue slots).  Wide
+// blocks come first in the grid so that they are placed before the CUs fill up.
+template <bool LUTSRC, int GW>
+__global__ __launch_bounds__(KMAP_WAVE *SQ_WAVES) void forces_seq_kernel(ProbSrc src, const float *__restrict__ Y, int64_t n,
+                                                               int64_t row0, int64_t main_rows, int64_t nrows, int nb_tail,
+                                                               int nb_main, float *__restrict__ G, double *__restrict__ loss_part) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr size_t XCH_FLOATS = GW ? (size_t)SQ_WAVES * KMAP_WAVE * SQ_CPL * 2 : 0;   // exchange strips first, the LUT behind them
+    float *lut_s = smem + XCH_FLOATS;
+    if (LUTSRC) {
+        for (int t = threadIdx.x; t < src.lut_len && t < F_LUT_LDS; t += blockDim.x) lut_s[t] = src.lut[t];
+        __syncthreads();
+    }
+    __shared__ double wl[SQ_WAVES];
+    if constexpr (GW != 0) {
+        if ((int)blockIdx.x < nb_tail) {   // block-uniform
+            seq_wide_body<LUTSRC, GW>(src, Y, n, row0, main_rows, nrows, G, loss_part + nb_main, (int64_t)blockIdx.x, lut_s, wl,
+                                      reinterpret_cast<f32x2 *>(smem));
+            return;
+        }
+    }
+    seq_quad_body<LUTSRC>(src, Y, n, row0, main_rows, G, loss_part, (int64_t)blockIdx.x - nb_tail, lut_s, wl);
 }
 
 // deterministic reduction of the per-block loss partials inside the fused apply kernel (every block computes the same total):
@@ -1514,6 +1620,10 @@ struct kmap_embed {
     LoopState *states = nullptr;
     int cur = 0;
     bool have_prob = false, have_coords = false;
+    // SEQ: rows [0, seq_main_rows) of the local range go to the quad kernel (16 rows per wave), the rest -- the rows that would
+    // form a last, nearly empty round of blocks -- to the wide kernel with seq_tail_g lanes per row (0: no tail)
+    int64_t seq_main_rows = 0;
+    int seq_tail_g = 0;
     // symmetric FAST path (all rows local): partial buffers
     float *rowpart = nullptr, *colpart = nullptr;
     int64_t symI = 0, symJ = 0;
@@ -1538,9 +1648,44 @@ void drop_graph(kmap_embed *e) {   // kernel arguments changed: the captured ite
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     e->gexec = nullptr;
 }
+int seq_main_blocks(const kmap_embed *e) { return (int)((e->seq_main_rows + SQ_ROWS * SQ_WAVES - 1) / (SQ_ROWS * SQ_WAVES)); }
+int seq_tail_blocks(const kmap_embed *e) {
+    if (!e->seq_tail_g) return 0;
+    const int64_t rows_per_block = (int64_t)SQ_WAVES * (KMAP_WAVE / e->seq_tail_g);
+    return (int)((e->nrows - e->seq_main_rows + rows_per_block - 1) / rows_per_block);
+}
+// How the SEQ rows are split between the quad kernel and the wide kernel.  The kernels are VALU-issue bound and every wave of a
+// SIMD shares its issue slots, so the cost of a set of waves is (waves on the fullest SIMD) x (instructions per wave); per
+// column a quad wave issues ~11 instructions, a wide wave with g lanes per row ~(36 / g + 1.2).  Whole rounds of quad waves (one
+// wave on every SIMD) are the cheapest way to do rows; what is left over is given to whichever form finishes it soonest.
+void seq_split(kmap_embed *e) {
+    e->seq_main_rows = e->nrows;
+    e->seq_tail_g = 0;
+    static const int off = [] { const char *v = getenv("KMAP_SEQ_TAIL"); return v && v[0] == '0'; }();   // A/B switch
+    if (off || e->nrows <= 0) return;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const int64_t simds = 4 * (int64_t)cus;
+    const int64_t round_rows = simds * SQ_ROWS;                       // rows of one wave on every SIMD
+    const int64_t main_rows = (e->nrows / round_rows) * round_rows;
+    const int64_t rem = e->nrows - main_rows;
+    if (rem == 0) return;
+    auto rounds = [&](int64_t waves) { return (double)((waves + simds - 1) / simds); };
+    double best = rounds((rem + SQ_ROWS - 1) / SQ_ROWS) * 11.0;      // the remainder as quad waves
+    int best_g = 0;
+    for (int g : {8, 16, 32, 64}) {
+        const int64_t waves = (rem + (KMAP_WAVE / g) - 1) / (KMAP_WAVE / g);
+        const double cost = rounds(waves) * (36.0 / g + 1.2);
+        if (cost < best) { best = cost; best_g = g; }
+    }
+    if (best_g) {
+        e->seq_main_rows = main_rows;
+        e->seq_tail_g = best_g;
+    }
+}
 int n_force_blocks(const kmap_embed *e) {
     if (e->sym) return (int)(e->n_lblocks * (((e->symJ + SY_WAVES - 1) / SY_WAVES) * SY_WAVES));
-    if (e->mode == KMAP_EMBED_SEQ) return (int)((e->nrows + SQ_ROWS * SQ_WAVES - 1) / (SQ_ROWS * SQ_WAVES));
+    if (e->mode == KMAP_EMBED_SEQ) return seq_main_blocks(e) + seq_tail_blocks(e);
     return (int)((e->nrows + F_RPW * F_WAVES - 1) / (F_RPW * F_WAVES));
 }
 }  // namespace
@@ -1665,6 +1810,7 @@ static int embed_create_impl(kmap_embed **out, int64_t n, int64_t row0, int64_t 
         e->rank = rank;
         e->n_lblocks = kmap_embed_cyclic_blocks(n, world, rank);
     }
+    if (mode == KMAP_EMBED_SEQ) seq_split(e);
     e->n_part = n_force_blocks(e) > 0 ? n_force_blocks(e) : 1;
     hipError_t err = hipSuccess;
     auto A = [&](void **p, size_t b) { if (err == hipSuccess) err = hipMalloc(p, b ? b : 16); };
@@ -1787,8 +1933,23 @@ int launch_forces(kmap_embed *e, float *G, bool reduce_sym, hipStream_t st) {
         if (reduce_sym)
             sym_reduce_kernel<<<(unsigned)((2 * e->n * 8 + BLK - 1) / BLK), BLK, 0, st>>>(e->rowpart, e->colpart, e->n, e->n_lblocks, e->symJ, e->world, e->rank, G);
     } else if (e->mode == KMAP_EMBED_SEQ) {
-        if (lut) forces_seq_kernel<true><<<nblk, KMAP_WAVE * SQ_WAVES, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
-        else forces_seq_kernel<false><<<nblk, KMAP_WAVE * SQ_WAVES, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
+        const int nb_main = seq_main_blocks(e), nb_tail = seq_tail_blocks(e);
+        const size_t lds_w = (nb_tail ? (size_t)SQ_WAVES * KMAP_WAVE * SQ_CPL * 8 : 0) + lds;
+#define KMAP_SEQ(LUT, GW)                                                                                                          \
+        do {                                                                                                                       \
+            KMAP_TRY(kmap_allow_lds((const void *)forces_seq_kernel<LUT, GW>, (int)lds_w));                                        \
+            forces_seq_kernel<LUT, GW><<<nb_tail + nb_main, KMAP_WAVE * SQ_WAVES, lds_w, st>>>(e->src, e->Y, e->n, e->row0, e->seq_main_rows, \
+                                                                                              e->nrows, nb_tail, nb_main, G, e->loss_part); \
+        } while (0)
+#define KMAP_SEQ_G(LUT)                                                                                       \
+        do {                                                                                                  \
+            const int g = nb_tail ? e->seq_tail_g : 0;                                                        \
+            if (g == 0) KMAP_SEQ(LUT, 0); else if (g == 8) KMAP_SEQ(LUT, 8); else if (g == 16) KMAP_SEQ(LUT, 16); \
+            else if (g == 32) KMAP_SEQ(LUT, 32); else KMAP_SEQ(LUT, 64);                                        \
+        } while (0)
+        if (lut) KMAP_SEQ_G(true); else KMAP_SEQ_G(false);
+#undef KMAP_SEQ_G
+#undef KMAP_SEQ
     } else {
         if (lut) forces_fast_kernel<true><<<nblk, KMAP_WAVE * F_WAVES, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);
         else forces_fast_kernel<false><<<nblk, KMAP_WAVE * F_WAVES, lds, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, G, e->loss_part);

@@ -454,3 +454,65 @@ def test_message_protocol_equals_two_buffer_protocol(V, mode, row0, nrows):
             assert not after[:2 * n].any()                                 # read, then zeroed: the next sum is x + 0 + ... + 0
     finally:
         sess.close()
+
+
+def test_seq_divisions_exhaustive():
+    """The SEQ force kernel replaces the two IEEE f32 divisions of the reference's gradient (1 / (1 + d2), q / (1 - q)) by
+    v_rcp_f32 + one Newton step / + one residual correction (csrc/seq_div.h: 7 instructions instead of 16).  That is only
+    admissible if it changes no bit: checked here against the compiler's IEEE division for EVERY float operand the kernel can
+    meet -- all 8.3e8 values of 1 + d2 in [1, 2^100) (as far as the clipped q is concerned) and all 8.2e7 values of the clipped
+    q in [1e-3, 0.999] (1 - q is a function of q).  The shorter sequences DO differ: the test has teeth."""
+    import ctypes as C
+    import struct
+    from kmap_amd import _ffi
+    bits = lambda x: struct.unpack("<I", struct.pack("<f", x))[0]
+    L = _ffi.lib()
+    nb, fb = C.c_uint64(0), C.c_uint32(0)
+    # the configuration compiled into the kernel (seq_div.h: KMAP_SEQ_RCP_STEPS = 1, KMAP_SEQ_QUO_RSTEPS = 0, KMAP_SEQ_QUO_STEPS = 1)
+    _ffi.check(L.kmap_selftest_seq_div(0, 1, 0, bits(1.0), bits(2.0 ** 100), C.byref(nb), C.byref(fb)))
+    assert nb.value == 0, f"1/(1+d2): {nb.value} operands differ from IEEE division, first bits {fb.value:#x}"
+    _ffi.check(L.kmap_selftest_seq_div(1, 0, 1, bits(0.001), bits(0.999), C.byref(nb), C.byref(fb)))
+    assert nb.value == 0, f"q/(1-q): {nb.value} operands differ from IEEE division, first bits {fb.value:#x}"
+    # one step less is NOT exact
+    _ffi.check(L.kmap_selftest_seq_div(0, 0, 0, bits(1.0), bits(2.0 ** 100), C.byref(nb), C.byref(fb)))
+    assert nb.value > 1_000_000
+    _ffi.check(L.kmap_selftest_seq_div(1, 0, 0, bits(0.001), bits(0.999), C.byref(nb), C.byref(fb)))
+    assert nb.value > 1_000_000
+    assert L.kmap_selftest_seq_div(2, 0, 0, 0, 1, C.byref(nb), None) == -1
+
+
+@pytest.mark.parametrize("n,row0,nrows", [(16384 + 1029, 0, None), (16384 + 1029, 300, 16384 + 77), (5000, 0, None), (1000, 100, 650)])
+def test_seq_wide_tail_kernel_is_bit_identical(V, n, row0, nrows, tmp_path):
+    """Rows that do not fill a round of quad waves go to the wide SEQ kernel (8 .. 64 lanes per row, terms exchanged through
+    LDS, same j-ascending f32 sum): the gradient must equal the all-quad kernel's (KMAP_SEQ_TAIL=0) bit for bit, whatever the
+    split -- a full round + 1029 left-over rows (one-row waves), a row-sharded session, N = 5000 (all rows wide), a small N."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    from kmap_amd import _ffi
+    nrows = n - row0 if nrows is None else nrows
+    rng = np.random.default_rng(n + row0)
+    lds = (n + 127) & ~127
+    sums = rng.integers(0, 3201, size=(nrows, lds), dtype=np.uint16)
+    lut = V.hd_prob_lut(8, 20, 3200)
+    ld = (rng.standard_normal((2, n)) * 5).astype(np.float32)
+    np.savez(tmp_path / "in.npz", sums=sums, ld=ld, lut=lut, meta=np.array([n, row0, nrows, lds]))
+    # one force evaluation per process: the A/B switch KMAP_SEQ_TAIL is read once per process
+    code = ("import numpy as np, sys; sys.path.insert(0, sys.argv[1]); from kmap_amd import _ffi, visualization as V; d = np.load(sys.argv[2]);"
+            "n, row0, nrows, lds = [int(v) for v in d['meta']]; sd = _ffi.DeviceBuffer.from_numpy(d['sums']);"
+            "s = V.EmbedSession(n, 10, 0.01, V.EMBED_SEQ, row0=row0, nrows=nrows);"
+            "_ffi.check(_ffi.lib().kmap_embed_set_prob_lut(s._h, sd.ptr, lds, _ffi.ptr(d['lut']), len(d['lut']))); s.set_coords(d['ld']);"
+            "g = _ffi.DeviceBuffer(2 * n * 4); l = _ffi.DeviceBuffer(8); g.zero(); s.forces(g.ptr, l.ptr); _ffi.sync();"
+            "np.savez(sys.argv[3], g=g.to_numpy(np.float32, (2, n)), l=l.to_numpy(np.float64, (1,)))")
+    root = str(Path(__file__).resolve().parent.parent)
+    outs = {}
+    for tag, env in (("split", {}), ("quad", {"KMAP_SEQ_TAIL": "0"})):
+        r = subprocess.run([sys.executable, "-c", code, root, str(tmp_path / "in.npz"), str(tmp_path / f"{tag}.npz")],
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(tmp_path / f"{tag}.npz")
+    np.testing.assert_array_equal(outs["split"]["g"].view(np.uint32), outs["quad"]["g"].view(np.uint32))
+    assert outs["split"]["g"][:, row0:row0 + nrows].any() and not outs["split"]["g"][:, :row0].any()
+    ls, lq = float(outs["split"]["l"][0]), float(outs["quad"]["l"][0])
+    assert abs(ls - lq) <= 1e-8 * abs(lq)        # the loss is not bit-pinned: f32 partial sums over batches of different width

@@ -271,7 +271,7 @@ def test_c2_whole_run():
         rows = (res / "low_dim_data.tsv").read_text().splitlines()
         assert rows[0] == "x\ty\tlabel" and len(rows) == 5001
         tab = np.array([ln.split("\t") for ln in rows[1:]], dtype=np.float64)
-        assert tab.shape == (5000, 3) and np.isfinite(tab).all() and set(np.unique(tab[:, 2])) <= {0.0, 1.0, 2.0}
+        assert tab.shape == (5000, 3) and np.isfinite(tab).all() and set(np.unique(tab[:, 2])) <= set(map(float, range(len(finals) + 1)))     # one label per final + the noise label
         with open(res / "sample_kmers.pkl", "rb") as fh:
             samp_kh, samp_cnts, samp_label, conseqs = pickle.load(fh)
         assert int(np.sum(samp_cnts)) == 5000 and list(conseqs) == finals
