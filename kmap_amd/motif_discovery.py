@@ -842,6 +842,19 @@ def _scan_motif(res_dir: str, debug=False):
             dist.destroy_process_group()
 
 
+def _write_co_occurrence_files(out_dir, occ, conseqs):
+    """the four co-occurrence data files of scan_motif (reference motif_discovery.py:400-425 writes the same tables): pair counts,
+    counts normalised by the two motifs' own read counts (Dice: 2 n_ab / (n_a + n_b)), median hit distance per pair, and the raw
+    distances"""
+    counts, median_dist, dist_lists = get_motif_co_occurence_mat(occ, len(conseqs))
+    own = np.diag(counts)
+    tables = {"co_occur_mat_file": counts + 0.0, "co_occur_mat_norm_file": 2 * counts / (own[None, :] + own[:, None]),
+              "co_occur_dist_mat_file": median_dist}
+    for key, table in tables.items():
+        write_co_occurence_mat(out_dir / FileNameDict[key], table, conseqs)
+    write_co_occurence_dist_arr(out_dir / FileNameDict["co_occur_dist_data_file"], dist_lists, conseqs)
+
+
 def _flat(savers):
     """background jobs of a scan_motif run: k -> TableSaver, "occurrence" -> [CSV writers]"""
     for v in savers.values():
@@ -879,9 +892,11 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
     rep_mode = config_dict["general"]["repetitive_mode"]
 
     with _stage("load_inputs"):
-        seq_np_arr = load_array_pickle(proc_fasta_file_path)      # large inputs: a read-only view of the mapped file
+        # large inputs: a read-only view of the mapped file; a rank of a sharded run touches only its own slice of it
+        # (distributed.make_dist_device_seq), so no rank unpickles or pre-faults the whole input
+        seq_np_arr = load_array_pickle(proc_fasta_file_path, populate=dist is None)
         boarder_pkl_file = res / FileNameDict["processed_fasta_seqboarder_file"]
-        boarder_mat = load_array_pickle(boarder_pkl_file)
+        boarder_mat = load_array_pickle(boarder_pkl_file, populate=dist is None)
     n_all_seq = len(boarder_mat)
 
     def resident(arr):
@@ -1059,14 +1074,7 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
             print(f"{co_occur_mat_file}, re-use it!")
         else:
             with _stage("co_occurrence"):
-                co_occur_mat, loc_dist_mat, loc_dist_dict = get_motif_co_occurence_mat(occ, len(final_conseq_list))
-                co_sum_mat = np.diag(co_occur_mat) + np.diag(co_occur_mat).reshape((-1, 1))
-                co_occur_norm_mat = 2 * co_occur_mat / co_sum_mat
-                write_co_occurence_mat(co_occur_mat_file, co_occur_mat + 0.0, final_conseq_list)
-                write_co_occurence_mat(co_occur_dir / FileNameDict["co_occur_mat_norm_file"], co_occur_norm_mat, final_conseq_list)
-                write_co_occurence_mat(co_occur_dir / FileNameDict["co_occur_dist_mat_file"], loc_dist_mat, final_conseq_list)
-                write_co_occurence_dist_arr(co_occur_dir / FileNameDict["co_occur_dist_data_file"], loc_dist_dict,
-                                            final_conseq_list)
+                _write_co_occurrence_files(co_occur_dir, occ, final_conseq_list)
         print("motif co-occurence matrix generated.")
 
     sample_kmer_pkl_file = res / FileNameDict["sample_kmer_pkl_file"]

@@ -45,7 +45,7 @@ def synth_reads_dev(n_reads, read_len, seed, motifs=(MOTIF_A, MOTIF_B), fraction
     """The same kind of reads generated in HBM (csrc/synth.hip: counter-based, NOT the numpy stream of synth_reads) for the
     configurations that are too large to build on the host inside a benchmark (C5: 50 M x 300 bp = 15 GB).
     Returns a DeviceSeq (packed reads + borders resident); keep_raw=True returns (DeviceSeq, raw) where raw() fetches
-    the uint8 bytes [lo, hi) of the array as generated (for spot checks against the oracle) until raw.free() is called --
+    the uint8 bytes [lo, hi) of the array as generated (for spot checks by tests and bench.py) until raw.free() is called --
     the 1 B / position array otherwise leaves HBM as soon as it is packed."""
     import ctypes as C
     from . import _ffi
