@@ -152,7 +152,7 @@ def stage_rooflines(reads, kh, lab, conseq_lens):
 
     def scan(k, kh_, r):
         _ffi.check(lib.kmap_scan_run_packed_dev(h.value, ds.codes.ptr, ds.inval_orig.ptr, ds.n, ds.borders.ptr, ds.n_seq, k, kh_, r, 1,
-                                                C.byref(tot), None))
+                                                C.byref(tot), ds.planes.ptr, None))
     out["scan_k8_r2"] = roof(npos, timed_launches(lambda: scan(8, cons, 2), 6),
                              "occurrence scan of one consensus over all reads, device part (incl. its one host sync for the hit total)")
     out["scan_k14_r5"] = roof(npos, timed_launches(lambda: scan(14, int(kmer2hash("AGGACCTACGTACA")), 5), 4),
@@ -422,7 +422,7 @@ def c5_leg(reps=5):
 
     def scan():
         _ffi.check(lib.kmap_scan_run_packed_dev(h.value, ds.codes.ptr, ds.inval_orig.ptr, ds.n, ds.borders.ptr, ds.n_seq, k, cons, radius, 1,
-                                                C.byref(tot), None))
+                                                C.byref(tot), ds.planes.ptr, None))
     ms = timed_launches(scan, reps, warmup=1)
     hits = np.empty(n_reads, np.int32)
     pos = np.empty(tot.value, np.int32)

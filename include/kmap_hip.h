@@ -165,8 +165,13 @@ int kmap_counts_hist_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const
  * counted (or kmap_scratch_release ran) since this handle's kmap_counts_hist_packed_dev. */
 int kmap_counts_bins(kmap_counts *c, void **bins_dev, int64_t *n_bins);
 int kmap_counts_finish(kmap_counts *c, int k, int merge_revcom, int64_t *n_uniq, void *stream);
+/* planes_dev (optional, from kmap_pack_planes_dev): with it and k <= 16 the Hamming-ball test of all windows runs bit-sliced
+ * over positions (csrc/bitslice.hip) instead of window by window; NULL keeps the per-window kernels.  Results are identical. */
 int kmap_mask_hamball_packed_dev(const uint32_t *codes_dev, uint16_t *inval_dev, int64_t n, int k, const uint64_t *cons,
-                                 const int32_t *radius, int n_cons, void *stream);        /* cons/radius: host */
+                                 const int32_t *radius, int n_cons, const uint32_t *planes_dev, void *stream);  /* cons/radius: host */
+/* bit planes of the packed reads, built once per upload: planes[g] = (H16 << 16) | L16, the high / low bits of the 16 base
+ * codes of group g, first position most significant; planes_dev: uint32[kmap_packed_groups(n)] */
+int kmap_pack_planes_dev(const uint32_t *codes_dev, int64_t n, uint32_t *planes_dev, void *stream);
 
 /* ---- motif occurrence scan: get_motif_occurence motif_discovery.py:1422-1477.
  * For every read and one consensus: positions p in the reference's slice [0 : len-k+1] whose
@@ -180,7 +185,7 @@ int kmap_scan_run_dev(kmap_scan *s, const uint8_t *seq_dev, int64_t n, const int
                       int k, uint64_t cons, int radius, int revcom, int64_t *total_hits, void *stream);
 int kmap_scan_run_packed_dev(kmap_scan *s, const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n,
                              const int64_t *borders_dev, int64_t n_seq, int k, uint64_t cons, int radius, int revcom,
-                             int64_t *total_hits, void *stream);
+                             int64_t *total_hits, const uint32_t *planes_dev /* optional, see above */, void *stream);
 int kmap_scan_fetch(kmap_scan *s, int32_t *hits_per_read, int8_t *min_dist, int32_t *positions);
 /* the last run's results without (or before) a fetch: the two numbers scan_motif's candidate table needs of a hit list --
  * reads with a hit (get_motif_seq_num, motif_discovery.py:1345-1393) and the largest per-read hit count (> 20 triggers the

@@ -88,8 +88,9 @@ _SIGS = {
     "kmap_counts_hist_packed_dev": (i32, [vp, vp, vp, i64, vp, i64, i32, i32, vp]),
     "kmap_counts_bins": (i32, [vp, P(vp), P(i64)]),
     "kmap_counts_finish": (i32, [vp, i32, i32, P(i64), vp]),
-    "kmap_mask_hamball_packed_dev": (i32, [vp, vp, i64, i32, vp, vp, i32, vp]),
-    "kmap_scan_run_packed_dev": (i32, [vp, vp, vp, i64, vp, i64, i32, u64, i32, i32, P(i64), vp]),
+    "kmap_mask_hamball_packed_dev": (i32, [vp, vp, i64, i32, vp, vp, i32, vp, vp]),
+    "kmap_pack_planes_dev": (i32, [vp, i64, vp, vp]),
+    "kmap_scan_run_packed_dev": (i32, [vp, vp, vp, i64, vp, i64, i32, u64, i32, i32, P(i64), vp, vp]),
     "kmap_scan_create": (i32, [P(vp)]),
     "kmap_scan_destroy": (i32, [vp]),
     "kmap_scan_run_dev": (i32, [vp, vp, i64, vp, i64, i32, u64, i32, i32, P(i64), vp]),

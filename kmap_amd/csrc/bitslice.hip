@@ -1,0 +1,414 @@
+// bitslice.hip -- "is this window within Hamming distance r of the consensus" for EVERY window of the packed reads, bit-sliced
+// over positions: 32 windows per thread at once instead of one funnel-shifted window at a time.
+//
+// Used by the occurrence scan (get_motif_occurence, motif_discovery.py:1422-1477 -- BASELINE config C5) and by masking
+// (mask_input, kmer_count.py:580-610), k <= 16.  Both need, per window, only the predicate d <= r (the scan then evaluates the
+// few hit windows exactly to find each read's minimum).  The per-window formulation (scan_nibble_kernel /
+// mask_flag_packed_kernel in packed.hip: alignbit, shift, xor, 2-bit popcount, compare per window and strand: ~21 vector
+// instructions per window, VALU-issue bound at 0.85 ms per consensus on the C3 reads) is replaced by:
+//
+//   * bit planes of the reads, built once per upload: planes[g] = (H16 << 16) | L16 for the 16 positions of group g, H / L =
+//     the high / low bit of every base code, first position most significant (same order as the invalid mask);
+//   * a thread takes 32 positions: H, L (and the following 32 for the window tails).  For consensus base j the mismatch plane
+//     over the 32 windows is M_j = ((H << j) ^ CH_j) | ((L << j) ^ CL_j) with CH_j / CL_j = 0 or ~0 (scalar): 2 funnel shifts
+//     shared by both strands + 3 logic ops per strand;
+//   * the K mismatch planes are added bit-sliced by a balanced adder tree (compile-time K: ~3.3 ops per plane) into a 4..5-bit
+//     counter per window, and "count > r" is the carry out of adding the constant 2^B - 1 - r (2 ops per counter bit);
+//   * hit = (le_fwd | le_rc) for valid windows; a window that touches an invalid position has the reference's all-ones hash
+//     ("compared like any value"), i.e. the same distance d_inv for all of them: hit = (d_inv <= r), a scalar.
+// ~5.2 vector instructions per window at k = 8 with both strands, ~8.5 at k = 14, and the intermediate shrinks from 0.56 B
+// (nibble + minimum) to 0.125 B (one bit) per position.
+#include "common.h"
+#include "scan_internal.h"
+#include "scan_util.h"
+
+namespace {
+
+constexpr int BS_TPB = 256;
+
+// ---- planes -------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t squeeze_even_bits(uint32_t x) {   // bits 30, 28, ..., 0 -> bits 15..0, order kept
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    x = (x | (x >> 8)) & 0x0000FFFFu;
+    return x;
+}
+__global__ __launch_bounds__(BS_TPB) void planes_kernel(const uint32_t *__restrict__ codes, int64_t n_groups, uint32_t *__restrict__ planes) {
+    const int64_t g = (int64_t)blockIdx.x * BS_TPB + threadIdx.x;
+    if (g >= n_groups) return;
+    const uint32_t w = codes[g];
+    planes[g] = (squeeze_even_bits(w >> 1) << 16) | squeeze_even_bits(w);
+}
+
+// ---- bit-sliced counters --------------------------------------------------------------------------------------------
+template <int B>
+struct Num {
+    uint32_t b[B];     // b[i] = bit i of the count of each of the 32 windows
+};
+constexpr int bits_for(int n) {   // bits that hold 0..n
+    int b = 0;
+    while ((1 << b) <= n) ++b;
+    return b;
+}
+// x + y, result truncated to BR bits (the caller knows the sum fits).  Missing high bits are literal zeros: the optimiser folds
+// the adder cells they feed, and the carry out of the last cell is never computed.
+template <int BA, int BB, int BR>
+__device__ __forceinline__ Num<BR> add_num(const Num<BA> &x, const Num<BB> &y) {
+    Num<BR> r;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        const uint32_t xi = (i < BA) ? x.b[i < BA ? i : 0] : 0u, yi = (i < BB) ? y.b[i < BB ? i : 0] : 0u;
+        const uint32_t t = xi ^ yi;
+        r.b[i] = t ^ carry;
+        carry = (xi & yi) | (carry & t);
+    }
+    return r;
+}
+template <int LO, int HI, int K>
+__device__ __forceinline__ Num<bits_for(HI - LO)> tree_sum(const uint32_t (&m)[K]) {
+    constexpr int N = HI - LO;
+    if constexpr (N == 1) {
+        Num<1> r;
+        r.b[0] = m[LO];
+        return r;
+    } else {
+        constexpr int MID = LO + N / 2;
+        const auto x = tree_sum<LO, MID, K>(m);
+        const auto y = tree_sum<MID, HI, K>(m);
+        return add_num<bits_for(MID - LO), bits_for(HI - MID), bits_for(N)>(x, y);
+    }
+}
+// windows whose count exceeds r: the carry out of count + (2^B - 1 - r), r clamped to 2^B - 1.  kmask[b] = 0 / ~0 for bit b of
+// that constant (scalars): carry' = majority(count_b, carry, kmask_b)
+template <int B>
+__device__ __forceinline__ uint32_t greater_than(const Num<B> &c, int r) {
+    const int rr = r > (1 << B) - 1 ? (1 << B) - 1 : r;
+    const uint32_t konst = (uint32_t)((1 << B) - 1 - rr);
+    uint32_t carry = 0;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const uint32_t kb = 0u - ((konst >> b) & 1u);
+        carry = (c.b[b] & carry) | (kb & (c.b[b] | carry));
+    }
+    return carry;
+}
+
+// ---- hit bits of 32 windows per thread ------------------------------------------------------------------------------
+struct HitCons {
+    uint32_t fwd, rc;      // consensus codes (2 bits per base, first base most significant), rc used when two != 0
+    int32_t radius;
+    uint32_t two;          // also test the reverse-complement strand
+    uint32_t inv_hit;      // ~0 when an invalid window (all-ones hash) lies within radius of this entry, else 0
+};
+struct HitTab {
+    HitCons c[16];
+    int n;
+};
+
+template <int K>
+__device__ __forceinline__ uint32_t strand_gt(const uint32_t (&hs)[K], const uint32_t (&ls)[K], uint32_t code, int radius) {
+    uint32_t m[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const uint32_t base = (code >> (2 * (K - 1 - j))) & 3u;          // scalar
+        const uint32_t ch = 0u - (base >> 1), cl = 0u - (base & 1u);
+        m[j] = (hs[j] ^ ch) | (ls[j] ^ cl);
+    }
+    const auto cnt = tree_sum<0, K, K>(m);
+    return greater_than<bits_for(K)>(cnt, radius);
+}
+
+// hit16[g]: bit (15 - i) set when the window at position 16 g + i is within radius of any table entry (invalid windows: the
+// entry's inv_hit).  Thread = groups 2t, 2t + 1.  planes / inval are read up to group 2t + 3 (guarded against n_alloc_groups).
+template <int K>
+__global__ __launch_bounds__(BS_TPB) void hits_planes_kernel(const uint32_t *__restrict__ planes, const uint16_t *__restrict__ inval,
+                                                            int64_t n, int64_t n_alloc_groups, HitTab tab,
+                                                            uint16_t *__restrict__ hit16) {
+    const int64_t t = (int64_t)blockIdx.x * BS_TPB + threadIdx.x;
+    const int64_t g0 = 2 * t;
+    if (16 * g0 >= n) return;
+    uint32_t pl[4], iv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const bool in = g0 + q < n_alloc_groups;
+        pl[q] = in ? planes[g0 + q] : 0u;
+        iv[q] = in ? (uint32_t)inval[g0 + q] : 0xFFFFu;
+    }
+    const uint32_t H = (pl[0] & 0xFFFF0000u) | (pl[1] >> 16), L = (pl[0] << 16) | (pl[1] & 0xFFFFu);
+    const uint32_t H2 = (pl[2] & 0xFFFF0000u) | (pl[3] >> 16), L2 = (pl[2] << 16) | (pl[3] & 0xFFFFu);
+    // windows that touch an invalid position: OR of the invalid flags of positions p .. p + K - 1 (doubling on the 64-bit stream)
+    uint64_t acc = ((uint64_t)((iv[0] << 16) | iv[1]) << 32) | ((iv[2] << 16) | iv[3]);
+#pragma unroll
+    for (int have = 1; have < K;) {
+        const int step = (have <= K - have) ? have : K - have;
+        acc |= acc << step;
+        have += step;
+    }
+    const uint32_t bad = (uint32_t)(acc >> 32);
+    uint32_t hs[K], ls[K];
+    hs[0] = H;
+    ls[0] = L;
+#pragma unroll
+    for (int j = 1; j < K; ++j) {
+        hs[j] = __builtin_amdgcn_alignbit(H, H2, 32 - j);                 // bit (31 - i): base at position P + i + j
+        ls[j] = __builtin_amdgcn_alignbit(L, L2, 32 - j);
+    }
+    uint32_t hit = 0;
+    for (int c = 0; c < tab.n; ++c) {
+        const HitCons e = tab.c[c];
+        uint32_t gt = strand_gt<K>(hs, ls, e.fwd, e.radius);
+        if (e.two) gt &= strand_gt<K>(hs, ls, e.rc, e.radius);           // within radius on either strand <=> not (both exceed)
+        hit |= (~gt & ~bad) | (bad & e.inv_hit);
+    }
+    const int64_t left = n - 16 * g0;                                     // positions past the end do not exist
+    if (left < 32) hit &= ~((1u << (32 - (int)left)) - 1u);
+    *reinterpret_cast<uint32_t *>(hit16 + g0) = (hit << 16) | (hit >> 16);   // little-endian halves: hit16[g0] = windows 0..15
+}
+
+// ---- per-read passes of the scan on the hit bits ---------------------------------------------------------------------
+constexpr int HR_TPB = 256;
+constexpr int HR_LONG = 1024;
+__device__ __forceinline__ int64_t hr_slice_stop(int64_t L, int k) {     // python slice [0 : L - k + 1] (motif_discovery.py:1443)
+    int64_t stop = L - k + 1;
+    if (stop < 0) {
+        stop += L;
+        if (stop < 0) stop = 0;
+    }
+    return stop > L ? L : stop;
+}
+// exact min(fwd, rc) distance of the window at absolute position p (an invalid window compares as the all-ones hash)
+__device__ __forceinline__ int hr_dist(const uint32_t *__restrict__ codes, const uint16_t *__restrict__ inval, int64_t p, int k,
+                                       uint32_t km, uint32_t cons, uint32_t rcc, int revcom) {
+    const int64_t g = p >> 4;
+    const int i = (int)(p & 15);
+    const uint32_t hi = codes[g], lo = codes[g + 1];
+    const uint64_t m = ((uint64_t)inval[g] << 32) | ((uint64_t)inval[g + 1] << 16) | inval[g + 2];
+    const bool bad = ((m >> (48 - i - k)) & ((1ull << k) - 1ull)) != 0;
+    const uint32_t top = i ? __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * i) : hi;
+    const uint32_t h = bad ? km : ((top >> (32 - 2 * k)) & km);
+    int d = popc2(h ^ cons);
+    if (revcom) {
+        const int d2 = popc2(h ^ rcc);
+        d = d2 < d ? d2 : d;
+    }
+    return d;
+}
+// hit word wi restricted to absolute positions [a, b)
+__device__ __forceinline__ uint32_t hr_word(const uint16_t *__restrict__ hit16, int64_t wi, int64_t a, int64_t b) {
+    uint32_t x = hit16[wi];
+    const int64_t p0 = wi << 4;
+    if (a > p0) x &= 0xFFFFu >> (int)(a - p0);
+    if (b < p0 + 16) x &= (0xFFFFu << (int)(p0 + 16 - b)) & 0xFFFFu;
+    return x;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(HR_TPB) void scan_hits_reads_kernel(const uint16_t *__restrict__ hit16, const uint32_t *__restrict__ codes,
+                                                                 const uint16_t *__restrict__ inval, int64_t n,
+                                                                 const int64_t *__restrict__ borders, int64_t n_seq, int k,
+                                                                 uint32_t cons, uint32_t rcc, int revcom, int d_inv, int radius,
+                                                                 int32_t *__restrict__ hits, int8_t *__restrict__ min_dist,
+                                                                 const uint64_t *__restrict__ offs, int32_t *__restrict__ pos_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t km = low_mask<uint32_t>(k);
+    int64_t st = 0, stop = 0;
+    bool quirk = false;
+    if (s < n_seq) {
+        st = borders[2 * s];
+        int64_t en = borders[2 * s + 1];
+        if (st < 0) st = 0;
+        if (en > n) en = n;
+        const int64_t L = en > st ? en - st : 0;
+        quirk = (L - k + 1 < 0);                 // negative slice stop: every window runs off the read (all-ones hash)
+        stop = hr_slice_stop(L, k);
+    }
+    int best = 127, count = 0;
+    uint64_t base = 0;
+    if (WRITE && s < n_seq) {
+        count = hits[s];
+        best = min_dist[s];
+        base = offs[s];
+        if (count == 0) stop = 0;                // nothing to write for this read
+    }
+    if (quirk) {
+        if (!WRITE) {
+            best = d_inv <= radius ? d_inv : 127;
+            count = d_inv <= radius ? (int)stop : 0;
+        } else {
+            for (int64_t p = 0; p < stop; ++p) pos_out[base + p] = (int32_t)p;
+        }
+        stop = 0;
+    }
+    const bool is_long = stop > HR_LONG;
+    if (stop > 0 && !is_long) {
+        const int64_t a = st, b = st + stop;
+        const int64_t w0 = a >> 4, w1 = (b - 1) >> 4;
+        for (int64_t wi = w0; wi <= w1; ++wi) {
+            uint32_t x = hr_word(hit16, wi, a, b);
+            while (x) {                          // ascending positions: most significant bit first
+                const int tb = 31 - __builtin_clz(x);
+                x &= ~(1u << tb);
+                const int64_t p = (wi << 4) + (15 - tb);
+                const int d = hr_dist(codes, inval, p, k, km, cons, rcc, revcom);
+                if (!WRITE) {
+                    if (d < best) { best = d; count = 1; }
+                    else if (d == best) ++count;
+                } else if (d == best) {
+                    pos_out[base++] = (int32_t)(p - st);
+                }
+            }
+        }
+    }
+    // long reads: the whole wave works on one read at a time, 64 words per step
+    unsigned long long todo = __ballot(is_long);
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int64_t a = __shfl(st, src), b = a + __shfl(stop, src);
+        const int64_t w0 = a >> 4, w1 = (b - 1) >> 4;
+        if (!WRITE) {
+            int m = 127, c = 0;
+            for (int64_t wi = w0 + lane; wi <= w1; wi += 64) {
+                uint32_t x = hr_word(hit16, wi, a, b);
+                while (x) {
+                    const int tb = 31 - __builtin_clz(x);
+                    x &= ~(1u << tb);
+                    const int d = hr_dist(codes, inval, (wi << 4) + (15 - tb), k, km, cons, rcc, revcom);
+                    if (d < m) { m = d; c = 1; }
+                    else if (d == m) ++c;
+                }
+            }
+            int gm = m;
+            for (int o = 32; o > 0; o >>= 1) {
+                const int v = __shfl_xor(gm, o);
+                gm = v < gm ? v : gm;
+            }
+            c = (m == gm) ? c : 0;
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+            if (lane == src) {
+                best = gm;
+                count = c;
+            }
+        } else {
+            const int bst = __shfl(best, src);
+            uint64_t wbase = __shfl(base, src);
+            for (int64_t c0 = w0; c0 <= w1; c0 += 64) {
+                const int64_t wi = c0 + lane;
+                uint32_t x = (wi <= w1) ? hr_word(hit16, wi, a, b) : 0u, keep = 0;
+                while (x) {                      // positions of the word at the read's minimum
+                    const int tb = 31 - __builtin_clz(x);
+                    x &= ~(1u << tb);
+                    if (hr_dist(codes, inval, (wi << 4) + (15 - tb), k, km, cons, rcc, revcom) == bst) keep |= 1u << tb;
+                }
+                const int c = __builtin_popcount(keep);
+                int inc = c;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(inc, o);
+                    if (lane >= o) inc += v;
+                }
+                uint64_t at = wbase + (uint64_t)(inc - c);
+                while (keep) {
+                    const int tb = 31 - __builtin_clz(keep);
+                    keep &= ~(1u << tb);
+                    pos_out[at++] = (int32_t)((wi << 4) + (15 - tb) - a);
+                }
+                wbase += (uint64_t)__shfl(inc, 63);
+            }
+        }
+    }
+    if (!WRITE && s < n_seq) {
+        hits[s] = count;
+        min_dist[s] = (int8_t)(best <= radius ? best : -1);
+    }
+}
+
+unsigned grid_of(int64_t n, int64_t per) {
+    const int64_t g = (n + per - 1) / per;
+    return (unsigned)(g < 1 ? 1 : g);
+}
+
+int pc2_host(uint32_t x) { return __builtin_popcount((x | (x >> 1)) & 0x55555555u); }
+uint32_t rc_host(uint32_t c, int k) {
+    const uint32_t m = low_mask<uint32_t>(k);
+    uint32_t com = m - c, r = com & 3u;
+    for (int i = 0; i < k - 1; ++i) { r <<= 2; com >>= 2; r += com & 3u; }
+    return r;
+}
+
+template <int K>
+void launch_hits(const uint32_t *planes, const uint16_t *inval, int64_t n, int64_t n_alloc, const HitTab &tab, uint16_t *hit16,
+                 hipStream_t st) {
+    hits_planes_kernel<K><<<grid_of((n + 31) / 32, BS_TPB), BS_TPB, 0, st>>>(planes, inval, n, n_alloc, tab, hit16);
+}
+
+}  // namespace
+
+// hit bits of all windows for up to 16 table entries (k <= 16); hit16: uint16[(n + 15) / 16 rounded up to even]
+int kmap_bitslice_hits(const uint32_t *planes, const uint16_t *inval, int64_t n, int k, const uint64_t *cons, const int32_t *radius,
+                       int n_cons, int revcom_pairs, uint16_t *hit16, hipStream_t st) {
+    KMAP_REQUIRE(k >= 1 && k <= 16 && n_cons >= 1 && n_cons <= 16, "bitslice_hits: k / table size out of range");
+    HitTab tab;
+    memset(&tab, 0, sizeof tab);
+    tab.n = n_cons;
+    const uint32_t km = low_mask<uint32_t>(k);
+    for (int c = 0; c < n_cons; ++c) {
+        HitCons &e = tab.c[c];
+        e.fwd = (uint32_t)cons[c] & km;
+        e.rc = rc_host(e.fwd, k);
+        e.two = revcom_pairs ? 1u : 0u;
+        e.radius = radius[c];
+        int d_inv = pc2_host((km ^ e.fwd) & km);
+        if (e.two) {
+            const int d2 = pc2_host((km ^ e.rc) & km);
+            d_inv = d2 < d_inv ? d2 : d_inv;
+        }
+        e.inv_hit = d_inv <= e.radius ? ~0u : 0u;
+    }
+    const int64_t n_alloc = kmap_packed_groups(n);
+    switch (k) {
+#define KMAP_BS_CASE(KK) case KK: launch_hits<KK>(planes, inval, n, n_alloc, tab, hit16, st); break;
+        KMAP_BS_CASE(1) KMAP_BS_CASE(2) KMAP_BS_CASE(3) KMAP_BS_CASE(4) KMAP_BS_CASE(5) KMAP_BS_CASE(6) KMAP_BS_CASE(7) KMAP_BS_CASE(8)
+        KMAP_BS_CASE(9) KMAP_BS_CASE(10) KMAP_BS_CASE(11) KMAP_BS_CASE(12) KMAP_BS_CASE(13) KMAP_BS_CASE(14) KMAP_BS_CASE(15) KMAP_BS_CASE(16)
+#undef KMAP_BS_CASE
+    }
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+
+// the scan's per-read passes on the hit bits (counts + minimum, then -- after the caller's scan of the counts -- the positions)
+int kmap_bitslice_scan_reads(bool write, const uint16_t *hit16, const uint32_t *codes, const uint16_t *inval, int64_t n,
+                             const int64_t *borders, int64_t n_seq, int k, uint64_t cons, int revcom, int radius, kmap_scan *s,
+                             hipStream_t st) {
+    const uint32_t km = low_mask<uint32_t>(k), c = (uint32_t)cons & km, rcc = rc_host(c, k);
+    int d_inv = pc2_host((km ^ c) & km);
+    if (revcom) {
+        const int d2 = pc2_host((km ^ rcc) & km);
+        d_inv = d2 < d_inv ? d2 : d_inv;
+    }
+    const unsigned grid = grid_of(n_seq, HR_TPB);
+    if (!write)
+        scan_hits_reads_kernel<false><<<grid, HR_TPB, 0, st>>>(hit16, codes, inval, n, borders, n_seq, k, c, rcc, revcom, d_inv, radius,
+                                                               s->hits, s->mind, nullptr, nullptr);
+    else
+        scan_hits_reads_kernel<true><<<grid, HR_TPB, 0, st>>>(hit16, codes, inval, n, borders, n_seq, k, c, rcc, revcom, d_inv, radius,
+                                                              s->hits, s->mind, s->offs, s->pos);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+
+extern "C" {
+
+int kmap_pack_planes_dev(const uint32_t *codes_dev, int64_t n, uint32_t *planes_dev, void *stream) {
+    KMAP_REQUIRE(n >= 0, "pack_planes: negative size");
+    const int64_t ng = kmap_packed_groups(n);
+    KMAP_REQUIRE(codes_dev && planes_dev, "pack_planes: null pointer");
+    planes_kernel<<<grid_of(ng, BS_TPB), BS_TPB, 0, as_stream(stream)>>>(codes_dev, ng, planes_dev);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+
+}  // extern "C"

@@ -1202,14 +1202,35 @@ int kmap_counts_run_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const 
     return kmap_counts_finish_hist(c, k, merge_revcom, n_uniq, st);
 }
 
+// does the bit-sliced formulation (bitslice.hip) serve this call?  KMAP_BITSLICE=0 keeps the per-window kernels (A/B runs)
+static bool bitslice_on(const uint32_t *planes_dev, int k) {
+    static const bool on = !(getenv("KMAP_BITSLICE") && getenv("KMAP_BITSLICE")[0] == '0');
+    return on && planes_dev && k <= 16;
+}
+
 int kmap_mask_hamball_packed_dev(const uint32_t *codes_dev, uint16_t *inval_dev, int64_t n, int k, const uint64_t *cons,
-                                 const int32_t *radius, int n_cons, void *stream) {
+                                 const int32_t *radius, int n_cons, const uint32_t *planes_dev, void *stream) {
     KMAP_REQUIRE(k > 0 && k < 32, "mask_hamball_packed: k=%d out of range", k);
     KMAP_REQUIRE(n_cons >= 0 && (n_cons == 0 || (cons && radius)), "mask_hamball_packed: null consensus list");
     if (n <= 0 || n_cons == 0) return KMAP_OK;
     KMAP_REQUIRE(codes_dev && inval_dev, "mask_hamball_packed: null pointer");
     hipStream_t st = as_stream(stream);
     const int64_t ng = (n + 15) >> 4;
+    if (bitslice_on(planes_dev, k)) {
+        // 16 consensuses per flag pass, all passes on the mask as it is on entry, then the coverage passes
+        const int nb = (n_cons + 15) / 16;
+        uint16_t *hitb = nullptr;
+        const int64_t ngq = (ng + 9) & ~(int64_t)7;                // even (the kernel stores group pairs) and 16-byte aligned batches
+        KMAP_TRY(kmap_scratch((void **)&hitb, (size_t)ngq * 2 * nb, st, KMAP_SLOT_A));
+        for (int b = 0; b < nb; ++b) {
+            const int m = (n_cons - 16 * b < 16) ? n_cons - 16 * b : 16;
+            KMAP_TRY(kmap_bitslice_hits(planes_dev, inval_dev, n, k, cons + 16 * b, radius + 16 * b, m, 0, hitb + (size_t)b * ngq, st));
+        }
+        for (int b = 0; b < nb; ++b)
+            mask_cover_packed_kernel<<<grid_for((ng + 3) / 4, BLK), BLK, 0, st>>>(hitb + (size_t)b * ngq, n, k, inval_dev);
+        KMAP_CHECK_HIP(hipGetLastError());
+        return KMAP_OK;
+    }
     const int batches = (n_cons + 31) / 32;
     uint16_t *hit = nullptr;
     const int64_t ngp = (ng + 7) & ~(int64_t)7;                   // per-batch stride: every batch's hit array 16-byte aligned
@@ -1234,7 +1255,7 @@ int kmap_mask_hamball_packed_dev(const uint32_t *codes_dev, uint16_t *inval_dev,
 
 int kmap_scan_run_packed_dev(kmap_scan *s, const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n,
                              const int64_t *borders_dev, int64_t n_seq, int k, uint64_t cons, int radius, int revcom,
-                             int64_t *total_hits, void *stream) {
+                             int64_t *total_hits, const uint32_t *planes_dev, void *stream) {
     KMAP_REQUIRE(s, "scan_run_packed: null handle");
     KMAP_REQUIRE(k > 0 && k < 32, "scan_run_packed: k=%d out of range", k);
     KMAP_REQUIRE(n >= 0 && n_seq >= 0 && radius >= 0, "scan_run_packed: negative size");
@@ -1249,6 +1270,23 @@ int kmap_scan_run_packed_dev(kmap_scan *s, const uint32_t *codes_dev, const uint
     const uint64_t c = cons & m;
     uint64_t com = m - c, rcc = com & 3u;
     for (int i = 0; i < k - 1; ++i) { rcc <<= 2; com >>= 2; rcc += com & 3u; }
+    if (bitslice_on(planes_dev, k)) {
+        // hit bit per window (bit-sliced, 0.125 B per position written), then the per-read passes evaluate the few hits exactly
+        const int64_t ng = (n + 15) >> 4;
+        uint16_t *hit16 = nullptr;
+        KMAP_TRY(kmap_scratch((void **)&hit16, (size_t)((ng + 9) & ~(int64_t)7) * 2, st, KMAP_SLOT_HASH));
+        if (n > 0) KMAP_TRY(kmap_bitslice_hits(planes_dev, inval_dev, n, k, &c, &radius, 1, revcom, hit16, st));
+        KMAP_TRY(kmap_bitslice_scan_reads(false, hit16, codes_dev, inval_dev, n, borders_dev, n_seq, k, c, revcom, radius, s, st));
+        KMAP_TRY(exclusive_scan_u32(reinterpret_cast<const uint32_t *>(s->hits), n_seq, s->offs, st));
+        uint64_t total = 0;
+        KMAP_CHECK_HIP(hipMemcpyAsync(&total, s->offs + n_seq, 8, hipMemcpyDeviceToHost, st));
+        KMAP_CHECK_HIP(hipStreamSynchronize(st));
+        KMAP_TRY(kmap_scan_reserve_pos(s, total));
+        if (total) KMAP_TRY(kmap_bitslice_scan_reads(true, hit16, codes_dev, inval_dev, n, borders_dev, n_seq, k, c, revcom, radius, s, st));
+        s->total = (int64_t)total;
+        if (total_hits) *total_hits = (int64_t)total;
+        return KMAP_OK;
+    }
     static const bool flat_ok = !(getenv("KMAP_SCAN_FLAT") && getenv("KMAP_SCAN_FLAT")[0] == '0');
     const bool flat = flat_ok && radius <= 14;
     const unsigned grid = (unsigned)((n_seq + SC_WAVES - 1) / SC_WAVES);

@@ -433,7 +433,7 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None):
                 self._scan = h.value
             tot, nhit, mx = _ffi.i64(0), _ffi.i64(0), _ffi.i32(0)
             check(lib.kmap_scan_run_packed_dev(self._scan, self.codes.ptr, self.inval_orig.ptr, self.n, self.borders.ptr, self.n_seq, k,
-                                               int(consensus_kh), int(radius), int(revcom), C.byref(tot), None))
+                                               int(consensus_kh), int(radius), int(revcom), C.byref(tot), self.planes.ptr, None))
             check(lib.kmap_scan_summary(self._scan, C.byref(nhit), C.byref(mx), None))
             hp, pp = _ffi.vp(), _ffi.vp()
             check(lib.kmap_scan_result_dev(self._scan, C.byref(hp), C.byref(pp), None, None))

@@ -85,6 +85,9 @@ class DeviceSeq:
         self.inval_orig = _ffi.DeviceBuffer(self.groups * 2)
         self.inval_work = _ffi.DeviceBuffer(self.groups * 2)
         check(_ffi.lib().kmap_pack_reads_dev(raw.ptr, self.n, self.codes.ptr, self.inval_orig.ptr, None))
+        # bit planes of the codes (0.25 B / position more): the scans and the masking test all windows bit-sliced on them
+        self.planes = _ffi.DeviceBuffer(self.groups * 4)
+        check(_ffi.lib().kmap_pack_planes_dev(self.codes.ptr, self.n, self.planes.ptr, None))
         _ffi.sync()
         raw.free()                      # the uint8 array does not stay on the device
         self.reset()
@@ -118,7 +121,7 @@ class DeviceSeq:
         cons = np.ascontiguousarray(consensus_kh_arr, dtype=np.uint64)
         rad = np.ascontiguousarray(max_ham_dist_arr, dtype=np.int32)
         check(_ffi.lib().kmap_mask_hamball_packed_dev(self.codes.ptr, self.inval_work.ptr, self.n, k, ptr(cons), ptr(rad),
-                                                      len(cons), None))
+                                                      len(cons), self.planes.ptr, None))
 
     def download(self):
         """the working reads as the reference's uint8 array (masked positions = 255)"""
@@ -137,7 +140,8 @@ class DeviceSeq:
             self._scan = h.value
         tot = _ffi.i64(0)
         check(_ffi.lib().kmap_scan_run_packed_dev(self._scan, self.codes.ptr, self.inval_orig.ptr, self.n, self.borders.ptr,
-                                                  self.n_seq, k, int(consensus_kh), int(radius), int(revcom), C.byref(tot), None))
+                                                  self.n_seq, k, int(consensus_kh), int(radius), int(revcom), C.byref(tot),
+                                                  self.planes.ptr, None))
         hits = np.empty(self.n_seq, np.int32)
         pos = np.empty(tot.value, np.int32)
         check(_ffi.lib().kmap_scan_fetch(self._scan, ptr(hits), None, ptr(pos)))   # per-read minimum distances stay on the device
@@ -157,7 +161,8 @@ class DeviceSeq:
             self._lazy_all.append(h)
         tot, nhit, mx = _ffi.i64(0), _ffi.i64(0), _ffi.i32(0)
         check(_ffi.lib().kmap_scan_run_packed_dev(h, self.codes.ptr, self.inval_orig.ptr, self.n, self.borders.ptr,
-                                                  self.n_seq, k, int(consensus_kh), int(radius), int(revcom), C.byref(tot), None))
+                                                  self.n_seq, k, int(consensus_kh), int(radius), int(revcom), C.byref(tot),
+                                                  self.planes.ptr, None))
         check(_ffi.lib().kmap_scan_summary(h, C.byref(nhit), C.byref(mx), None))    # returns once the lists are complete
         return ScanHits(self, h, self.n_seq, tot.value, nhit.value, mx.value)
 
@@ -174,7 +179,7 @@ class DeviceSeq:
             handles, self._lazy_all, self._lazy_free = self._lazy_all or [], None, []
         for h in handles:                 # a ScanHits not fetched by now reports that its sequence is closed
             _ffi.lib().kmap_scan_destroy(h)
-        for b in (self.codes, self.inval_orig, self.inval_work, self.borders):
+        for b in (self.codes, self.planes, self.inval_orig, self.inval_work, self.borders):
             b.free()
 
 

@@ -74,7 +74,9 @@ def test_packed_mask_vs_oracle_incl_quirks(env):
     _ffi, _, DeviceSeq, O = env
     rng = np.random.default_rng(11)
     seq, borders = synth(rng, 1500, 25, 150)
-    for k, r in ((4, 0), (6, 1), (8, 2), (16, 6), (17, 7), (31, 12)):
+    # k <= 16: the bit-sliced window test (bitslice.hip, one template instance per k); above: the per-window kernels
+    for k, r in ((1, 0), (2, 0), (3, 1), (4, 0), (5, 1), (6, 1), (7, 2), (8, 2), (9, 2), (10, 3), (11, 3), (12, 4), (13, 4), (14, 5), (15, 5),
+                 (16, 6), (17, 7), (31, 12)):
         cons = rng.integers(0, 4 ** k, size=3, dtype=np.uint64)
         cons[0] = int(O.kmer2hash("T" * k))            # poly-T matches invalid (all-ones) hashes: masks across separators
         rad = np.array([r, r, 0])
@@ -109,10 +111,12 @@ def test_packed_mask_many_consensuses(env):
     ds.close()
 
 
-@pytest.mark.parametrize("k,r", [(6, 1), (8, 2), (14, 5), (16, 14), (17, 3), (20, 8), (31, 10), (31, 15)])
+@pytest.mark.parametrize("k,r", [(3, 0), (5, 1), (6, 1), (7, 7), (8, 2), (9, 3), (10, 0), (11, 4), (12, 3), (13, 5), (14, 5), (15, 6), (16, 14),
+                                 (16, 20), (17, 3), (20, 8), (31, 10), (31, 15)])
 def test_packed_scan_vs_oracle(env, k, r):
-    """flat nibble path (radius <= 14; reads above 1024 positions are scanned by a whole wave) and the wave-per-read
-    kernel (radius 15), incl. the negative-slice quirk for reads shorter than k-1 and borders off the separators"""
+    """k <= 16: bit-sliced hit bits + exact evaluation of the hits per read (reads above 1024 positions by a whole wave); above:
+    the flat nibble path (radius <= 14) and the wave-per-read kernel (radius 15); incl. the negative-slice quirk for reads
+    shorter than k-1, radii up to and beyond k, and borders off the separators"""
     _ffi, _, DeviceSeq, O = env
     rng = np.random.default_rng(k)
     lens = [0, 1, k - 2, k - 1, k, k + 1, 63, 64, 65, 256, 257, 300, 700, 1023 + k, 1024 + k, 1025 + k, 3000, 5003] \

@@ -505,8 +505,8 @@ def test_scan_motif_from_memory_mapped_input(run_dir, tmp_path, monkeypatch):
     seen = []
     orig = KC.load_array_pickle
 
-    def spy(path, min_bytes=None):
-        a = orig(path, min_bytes)
+    def spy(path, min_bytes=None, populate=True):
+        a = orig(path, min_bytes, populate)
         seen.append((Path(path).name, bool(a.flags.writeable)))
         return a
     from kmap_amd import motif_discovery as MD

@@ -44,7 +44,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.reps):   # device part only: nibble pass + per-read passes + scan of the counts (results stay in HBM)
         _ffi.check(_ffi.lib().kmap_scan_run_packed_dev(ds._scan, ds.codes.ptr, ds.inval_orig.ptr, ds.n, ds.borders.ptr, ds.n_seq,
-                                                       args.k, int(kmer2hash(motif)), args.radius, 1, C.byref(tot), None))
+                                                       args.k, int(kmer2hash(motif)), args.radius, 1, C.byref(tot), ds.planes.ptr, None))
     _ffi.sync()
     dt = (time.perf_counter() - t0) / args.reps
     out["scan"].update({"s_per_pass_device": dt, "positions_per_s_device": n / dt})

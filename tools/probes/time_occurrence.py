@@ -23,7 +23,7 @@ for rep in range(3):
     ds.scan(8, kmer2hash(cons[0]), 1, True) if rep == 0 else None
     t[0] = time.perf_counter()
     _ffi.check(_ffi.lib().kmap_scan_run_packed_dev(ds._scan, ds.codes.ptr, ds.inval_orig.ptr, ds.n, ds.borders.ptr, ds.n_seq, 8,
-                                                   int(kmer2hash(cons[0])), 1, 1, C.byref(tot), None))
+                                                   int(kmer2hash(cons[0])), 1, 1, C.byref(tot), ds.planes.ptr, None))
     _ffi.sync(); t.append(time.perf_counter())
     hits, pos = ds.scan(8, kmer2hash(cons[0]), 1, True); t.append(time.perf_counter())
     per = md.scan_motif_occurence(ds, cons, mdd, True); t.append(time.perf_counter())
