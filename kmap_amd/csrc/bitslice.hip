@@ -123,7 +123,9 @@ __device__ __forceinline__ uint32_t strand_gt(const uint32_t (&hs)[K], const uin
 
 // hit16[g]: bit (15 - i) set when the window at position 16 g + i is within radius of any table entry (invalid windows: the
 // entry's inv_hit).  Thread = groups 2t, 2t + 1.  planes / inval are read up to group 2t + 3 (guarded against n_alloc_groups).
-template <int K>
+// WORDS: store the 32 hit bits as ONE word, window i in bit 31 - i (hit32[t], the scan's per-read passes); otherwise as the
+// two uint16 of the mask's coverage pass.
+template <int K, bool WORDS>
 __global__ __launch_bounds__(BS_TPB) void hits_planes_kernel(const uint32_t *__restrict__ planes, const uint16_t *__restrict__ inval,
                                                             int64_t n, int64_t n_alloc_groups, HitTab tab,
                                                             uint16_t *__restrict__ hit16) {
@@ -165,7 +167,8 @@ __global__ __launch_bounds__(BS_TPB) void hits_planes_kernel(const uint32_t *__r
     }
     const int64_t left = n - 16 * g0;                                     // positions past the end do not exist
     if (left < 32) hit &= ~((1u << (32 - (int)left)) - 1u);
-    *reinterpret_cast<uint32_t *>(hit16 + g0) = (hit << 16) | (hit >> 16);   // little-endian halves: hit16[g0] = windows 0..15
+    if (WORDS) reinterpret_cast<uint32_t *>(hit16)[t] = hit;
+    else *reinterpret_cast<uint32_t *>(hit16 + g0) = (hit << 16) | (hit >> 16);   // little-endian halves: hit16[g0] = windows 0..15
 }
 
 // ---- per-read passes of the scan on the hit bits ---------------------------------------------------------------------
@@ -179,16 +182,21 @@ __device__ __forceinline__ int64_t hr_slice_stop(int64_t L, int k) {     // pyth
     }
     return stop > L ? L : stop;
 }
-// exact min(fwd, rc) distance of the window at absolute position p (an invalid window compares as the all-ones hash)
+// exact min(fwd, rc) distance of the window at absolute position p.  CHECK_INVALID: a hit may be a window that touches an
+// invalid position (only when the all-ones hash itself lies within the radius, d_inv <= r) -- it then has distance d_inv;
+// otherwise every hit window is valid and the invalid mask need not be read.
+template <bool CHECK_INVALID>
 __device__ __forceinline__ int hr_dist(const uint32_t *__restrict__ codes, const uint16_t *__restrict__ inval, int64_t p, int k,
                                        uint32_t km, uint32_t cons, uint32_t rcc, int revcom) {
     const int64_t g = p >> 4;
     const int i = (int)(p & 15);
     const uint32_t hi = codes[g], lo = codes[g + 1];
-    const uint64_t m = ((uint64_t)inval[g] << 32) | ((uint64_t)inval[g + 1] << 16) | inval[g + 2];
-    const bool bad = ((m >> (48 - i - k)) & ((1ull << k) - 1ull)) != 0;
     const uint32_t top = i ? __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * i) : hi;
-    const uint32_t h = bad ? km : ((top >> (32 - 2 * k)) & km);
+    uint32_t h = (top >> (32 - 2 * k)) & km;
+    if (CHECK_INVALID) {
+        const uint64_t m = ((uint64_t)inval[g] << 32) | ((uint64_t)inval[g + 1] << 16) | inval[g + 2];
+        if (((m >> (48 - i - k)) & ((1ull << k) - 1ull)) != 0) h = km;
+    }
     int d = popc2(h ^ cons);
     if (revcom) {
         const int d2 = popc2(h ^ rcc);
@@ -196,17 +204,22 @@ __device__ __forceinline__ int hr_dist(const uint32_t *__restrict__ codes, const
     }
     return d;
 }
-// hit word wi restricted to absolute positions [a, b)
-__device__ __forceinline__ uint32_t hr_word(const uint16_t *__restrict__ hit16, int64_t wi, int64_t a, int64_t b) {
-    uint32_t x = hit16[wi];
-    const int64_t p0 = wi << 4;
-    if (a > p0) x &= 0xFFFFu >> (int)(a - p0);
-    if (b < p0 + 16) x &= (0xFFFFu << (int)(p0 + 16 - b)) & 0xFFFFu;
-    return x;
+// hit word wi (positions 32 wi .. 32 wi + 31, position i in bit 31 - i) restricted to absolute positions [a, b)
+__device__ __forceinline__ uint32_t hr_mask(int64_t wi, int64_t a, int64_t b) {
+    uint32_t m = ~0u;
+    const int64_t p0 = wi << 5;
+    if (a > p0) m &= ~0u >> (int)(a - p0);
+    if (b < p0 + 32) m &= ~0u << (int)(p0 + 32 - b);
+    return m;
 }
 
-template <bool WRITE>
-__global__ __launch_bounds__(HR_TPB) void scan_hits_reads_kernel(const uint16_t *__restrict__ hit16, const uint32_t *__restrict__ codes,
+// Pass 1 (WRITE = false): per read, the exact distance of every hit window -> minimum and the number of hits at the minimum.
+// A read whose hits lie at more than one distance is flagged (bit 6 of its min_dist byte): only for those does pass 2 (WRITE =
+// true, after the scan of the counts) evaluate distances again; for all others it lists the set bits of the read's range.
+// (Clearing the losing bits in place instead would break reads whose borders overlap -- the API allows them.)
+constexpr int HR_MIXED = 0x40;
+template <bool WRITE, bool CHECK_INVALID>
+__global__ __launch_bounds__(HR_TPB) void scan_hits_reads_kernel(const uint32_t *__restrict__ hit32, const uint32_t *__restrict__ codes,
                                                                  const uint16_t *__restrict__ inval, int64_t n,
                                                                  const int64_t *__restrict__ borders, int64_t n_seq, int k,
                                                                  uint32_t cons, uint32_t rcc, int revcom, int d_inv, int radius,
@@ -228,11 +241,17 @@ __global__ __launch_bounds__(HR_TPB) void scan_hits_reads_kernel(const uint16_t 
     }
     int best = 127, count = 0;
     uint64_t base = 0;
+    bool mixed = false;                          // hits at more than one distance
     if (WRITE && s < n_seq) {
         count = hits[s];
-        best = min_dist[s];
         base = offs[s];
         if (count == 0) stop = 0;                // nothing to write for this read
+        else {
+            const int md = min_dist[s];
+            mixed = (md & HR_MIXED) != 0;
+            best = md & (HR_MIXED - 1);
+            if (mixed) min_dist[s] = (int8_t)best;
+        }
     }
     if (quirk) {
         if (!WRITE) {
@@ -246,18 +265,27 @@ __global__ __launch_bounds__(HR_TPB) void scan_hits_reads_kernel(const uint16_t 
     const bool is_long = stop > HR_LONG;
     if (stop > 0 && !is_long) {
         const int64_t a = st, b = st + stop;
-        const int64_t w0 = a >> 4, w1 = (b - 1) >> 4;
-        for (int64_t wi = w0; wi <= w1; ++wi) {
-            uint32_t x = hr_word(hit16, wi, a, b);
-            while (x) {                          // ascending positions: most significant bit first
-                const int tb = 31 - __builtin_clz(x);
-                x &= ~(1u << tb);
-                const int64_t p = (wi << 4) + (15 - tb);
-                const int d = hr_dist(codes, inval, p, k, km, cons, rcc, revcom);
-                if (!WRITE) {
-                    if (d < best) { best = d; count = 1; }
+        const int64_t w0 = a >> 5, w1 = (b - 1) >> 5;
+        if (!WRITE) {
+            for (int64_t wi = w0; wi <= w1; ++wi) {
+                uint32_t x = hit32[wi] & hr_mask(wi, a, b);
+                while (x) {
+                    const int tb = 31 - __builtin_clz(x);
+                    x &= ~(1u << tb);
+                    const int d = hr_dist<CHECK_INVALID>(codes, inval, (wi << 5) + (31 - tb), k, km, cons, rcc, revcom);
+                    if (d < best) { mixed = mixed || count > 0; best = d; count = 1; }
                     else if (d == best) ++count;
-                } else if (d == best) {
+                    else mixed = true;
+                }
+            }
+        } else {
+            for (int64_t wi = w0; wi <= w1; ++wi) {
+                uint32_t x = hit32[wi] & hr_mask(wi, a, b);
+                while (x) {                      // ascending positions: most significant bit first
+                    const int tb = 31 - __builtin_clz(x);
+                    x &= ~(1u << tb);
+                    const int64_t p = (wi << 5) + (31 - tb);
+                    if (mixed && hr_dist<CHECK_INVALID>(codes, inval, p, k, km, cons, rcc, revcom) != best) continue;
                     pos_out[base++] = (int32_t)(p - st);
                 }
             }
@@ -269,15 +297,15 @@ __global__ __launch_bounds__(HR_TPB) void scan_hits_reads_kernel(const uint16_t 
         const int src = __builtin_ctzll(todo);
         todo &= todo - 1;
         const int64_t a = __shfl(st, src), b = a + __shfl(stop, src);
-        const int64_t w0 = a >> 4, w1 = (b - 1) >> 4;
+        const int64_t w0 = a >> 5, w1 = (b - 1) >> 5;
         if (!WRITE) {
             int m = 127, c = 0;
             for (int64_t wi = w0 + lane; wi <= w1; wi += 64) {
-                uint32_t x = hr_word(hit16, wi, a, b);
+                uint32_t x = hit32[wi] & hr_mask(wi, a, b);
                 while (x) {
                     const int tb = 31 - __builtin_clz(x);
                     x &= ~(1u << tb);
-                    const int d = hr_dist(codes, inval, (wi << 4) + (15 - tb), k, km, cons, rcc, revcom);
+                    const int d = hr_dist<CHECK_INVALID>(codes, inval, (wi << 5) + (31 - tb), k, km, cons, rcc, revcom);
                     if (d < m) { m = d; c = 1; }
                     else if (d == m) ++c;
                 }
@@ -289,20 +317,29 @@ __global__ __launch_bounds__(HR_TPB) void scan_hits_reads_kernel(const uint16_t 
             }
             c = (m == gm) ? c : 0;
             for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+            // any hit of the read above its minimum?
+            int total_c = 0;
+            for (int64_t wi = w0 + lane; wi <= w1; wi += 64) total_c += __builtin_popcount(hit32[wi] & hr_mask(wi, a, b));
+            for (int o = 32; o > 0; o >>= 1) total_c += __shfl_xor(total_c, o);
             if (lane == src) {
                 best = gm;
                 count = c;
+                mixed = total_c != c;
             }
         } else {
-            const int bst = __shfl(best, src);
             uint64_t wbase = __shfl(base, src);
+            const bool mx = __shfl((int)mixed, src) != 0;
+            const int bst = __shfl(best, src);
             for (int64_t c0 = w0; c0 <= w1; c0 += 64) {
                 const int64_t wi = c0 + lane;
-                uint32_t x = (wi <= w1) ? hr_word(hit16, wi, a, b) : 0u, keep = 0;
-                while (x) {                      // positions of the word at the read's minimum
-                    const int tb = 31 - __builtin_clz(x);
-                    x &= ~(1u << tb);
-                    if (hr_dist(codes, inval, (wi << 4) + (15 - tb), k, km, cons, rcc, revcom) == bst) keep |= 1u << tb;
+                uint32_t keep = (wi <= w1) ? (hit32[wi] & hr_mask(wi, a, b)) : 0u;
+                if (mx) {                        // drop the hits above the read's minimum
+                    uint32_t x = keep;
+                    while (x) {
+                        const int tb = 31 - __builtin_clz(x);
+                        x &= ~(1u << tb);
+                        if (hr_dist<CHECK_INVALID>(codes, inval, (wi << 5) + (31 - tb), k, km, cons, rcc, revcom) != bst) keep &= ~(1u << tb);
+                    }
                 }
                 const int c = __builtin_popcount(keep);
                 int inc = c;
@@ -314,7 +351,7 @@ __global__ __launch_bounds__(HR_TPB) void scan_hits_reads_kernel(const uint16_t 
                 while (keep) {
                     const int tb = 31 - __builtin_clz(keep);
                     keep &= ~(1u << tb);
-                    pos_out[at++] = (int32_t)((wi << 4) + (15 - tb) - a);
+                    pos_out[at++] = (int32_t)((wi << 5) + (31 - tb) - a);
                 }
                 wbase += (uint64_t)__shfl(inc, 63);
             }
@@ -322,7 +359,7 @@ __global__ __launch_bounds__(HR_TPB) void scan_hits_reads_kernel(const uint16_t 
     }
     if (!WRITE && s < n_seq) {
         hits[s] = count;
-        min_dist[s] = (int8_t)(best <= radius ? best : -1);
+        min_dist[s] = (int8_t)(best <= radius ? (best | (mixed ? HR_MIXED : 0)) : -1);
     }
 }
 
@@ -340,16 +377,18 @@ uint32_t rc_host(uint32_t c, int k) {
 }
 
 template <int K>
-void launch_hits(const uint32_t *planes, const uint16_t *inval, int64_t n, int64_t n_alloc, const HitTab &tab, uint16_t *hit16,
+void launch_hits(const uint32_t *planes, const uint16_t *inval, int64_t n, int64_t n_alloc, const HitTab &tab, uint16_t *hit16, bool words,
                  hipStream_t st) {
-    hits_planes_kernel<K><<<grid_of((n + 31) / 32, BS_TPB), BS_TPB, 0, st>>>(planes, inval, n, n_alloc, tab, hit16);
+    if (words) hits_planes_kernel<K, true><<<grid_of((n + 31) / 32, BS_TPB), BS_TPB, 0, st>>>(planes, inval, n, n_alloc, tab, hit16);
+    else hits_planes_kernel<K, false><<<grid_of((n + 31) / 32, BS_TPB), BS_TPB, 0, st>>>(planes, inval, n, n_alloc, tab, hit16);
 }
 
 }  // namespace
 
-// hit bits of all windows for up to 16 table entries (k <= 16); hit16: uint16[(n + 15) / 16 rounded up to even]
+// hit bits of all windows for up to 16 table entries (k <= 16); hit16: uint16[(n + 15) / 16 rounded up to even] in group order,
+// or (words) uint32[(n + 31) / 32] with window i of word t in bit 31 - i
 int kmap_bitslice_hits(const uint32_t *planes, const uint16_t *inval, int64_t n, int k, const uint64_t *cons, const int32_t *radius,
-                       int n_cons, int revcom_pairs, uint16_t *hit16, hipStream_t st) {
+                       int n_cons, int revcom_pairs, uint16_t *hit16, bool words, hipStream_t st) {
     KMAP_REQUIRE(k >= 1 && k <= 16 && n_cons >= 1 && n_cons <= 16, "bitslice_hits: k / table size out of range");
     HitTab tab;
     memset(&tab, 0, sizeof tab);
@@ -370,7 +409,7 @@ int kmap_bitslice_hits(const uint32_t *planes, const uint16_t *inval, int64_t n,
     }
     const int64_t n_alloc = kmap_packed_groups(n);
     switch (k) {
-#define KMAP_BS_CASE(KK) case KK: launch_hits<KK>(planes, inval, n, n_alloc, tab, hit16, st); break;
+#define KMAP_BS_CASE(KK) case KK: launch_hits<KK>(planes, inval, n, n_alloc, tab, hit16, words, st); break;
         KMAP_BS_CASE(1) KMAP_BS_CASE(2) KMAP_BS_CASE(3) KMAP_BS_CASE(4) KMAP_BS_CASE(5) KMAP_BS_CASE(6) KMAP_BS_CASE(7) KMAP_BS_CASE(8)
         KMAP_BS_CASE(9) KMAP_BS_CASE(10) KMAP_BS_CASE(11) KMAP_BS_CASE(12) KMAP_BS_CASE(13) KMAP_BS_CASE(14) KMAP_BS_CASE(15) KMAP_BS_CASE(16)
 #undef KMAP_BS_CASE
@@ -380,7 +419,7 @@ int kmap_bitslice_hits(const uint32_t *planes, const uint16_t *inval, int64_t n,
 }
 
 // the scan's per-read passes on the hit bits (counts + minimum, then -- after the caller's scan of the counts -- the positions)
-int kmap_bitslice_scan_reads(bool write, const uint16_t *hit16, const uint32_t *codes, const uint16_t *inval, int64_t n,
+int kmap_bitslice_scan_reads(bool write, const uint32_t *hit32, const uint32_t *codes, const uint16_t *inval, int64_t n,
                              const int64_t *borders, int64_t n_seq, int k, uint64_t cons, int revcom, int radius, kmap_scan *s,
                              hipStream_t st) {
     const uint32_t km = low_mask<uint32_t>(k), c = (uint32_t)cons & km, rcc = rc_host(c, k);
@@ -390,12 +429,13 @@ int kmap_bitslice_scan_reads(bool write, const uint16_t *hit16, const uint32_t *
         d_inv = d2 < d_inv ? d2 : d_inv;
     }
     const unsigned grid = grid_of(n_seq, HR_TPB);
-    if (!write)
-        scan_hits_reads_kernel<false><<<grid, HR_TPB, 0, st>>>(hit16, codes, inval, n, borders, n_seq, k, c, rcc, revcom, d_inv, radius,
-                                                               s->hits, s->mind, nullptr, nullptr);
-    else
-        scan_hits_reads_kernel<true><<<grid, HR_TPB, 0, st>>>(hit16, codes, inval, n, borders, n_seq, k, c, rcc, revcom, d_inv, radius,
-                                                              s->hits, s->mind, s->offs, s->pos);
+    const bool chk = d_inv <= radius;            // only then can a hit be a window that touches an invalid position
+#define KMAP_HR(W, C)                                                                                                              \
+    scan_hits_reads_kernel<W, C><<<grid, HR_TPB, 0, st>>>(hit32, codes, inval, n, borders, n_seq, k, c, rcc, revcom, d_inv, radius, \
+                                                          s->hits, s->mind, (const uint64_t *)(W ? s->offs : nullptr), W ? s->pos : nullptr)
+    if (!write) { if (chk) KMAP_HR(false, true); else KMAP_HR(false, false); }
+    else { if (chk) KMAP_HR(true, true); else KMAP_HR(true, false); }
+#undef KMAP_HR
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;
 }

@@ -1224,7 +1224,7 @@ int kmap_mask_hamball_packed_dev(const uint32_t *codes_dev, uint16_t *inval_dev,
         KMAP_TRY(kmap_scratch((void **)&hitb, (size_t)ngq * 2 * nb, st, KMAP_SLOT_A));
         for (int b = 0; b < nb; ++b) {
             const int m = (n_cons - 16 * b < 16) ? n_cons - 16 * b : 16;
-            KMAP_TRY(kmap_bitslice_hits(planes_dev, inval_dev, n, k, cons + 16 * b, radius + 16 * b, m, 0, hitb + (size_t)b * ngq, st));
+            KMAP_TRY(kmap_bitslice_hits(planes_dev, inval_dev, n, k, cons + 16 * b, radius + 16 * b, m, 0, hitb + (size_t)b * ngq, false, st));
         }
         for (int b = 0; b < nb; ++b)
             mask_cover_packed_kernel<<<grid_for((ng + 3) / 4, BLK), BLK, 0, st>>>(hitb + (size_t)b * ngq, n, k, inval_dev);
@@ -1275,14 +1275,15 @@ int kmap_scan_run_packed_dev(kmap_scan *s, const uint32_t *codes_dev, const uint
         const int64_t ng = (n + 15) >> 4;
         uint16_t *hit16 = nullptr;
         KMAP_TRY(kmap_scratch((void **)&hit16, (size_t)((ng + 9) & ~(int64_t)7) * 2, st, KMAP_SLOT_HASH));
-        if (n > 0) KMAP_TRY(kmap_bitslice_hits(planes_dev, inval_dev, n, k, &c, &radius, 1, revcom, hit16, st));
-        KMAP_TRY(kmap_bitslice_scan_reads(false, hit16, codes_dev, inval_dev, n, borders_dev, n_seq, k, c, revcom, radius, s, st));
+        if (n > 0) KMAP_TRY(kmap_bitslice_hits(planes_dev, inval_dev, n, k, &c, &radius, 1, revcom, hit16, true, st));
+        uint32_t *hit32 = reinterpret_cast<uint32_t *>(hit16);
+        KMAP_TRY(kmap_bitslice_scan_reads(false, hit32, codes_dev, inval_dev, n, borders_dev, n_seq, k, c, revcom, radius, s, st));
         KMAP_TRY(exclusive_scan_u32(reinterpret_cast<const uint32_t *>(s->hits), n_seq, s->offs, st));
         uint64_t total = 0;
         KMAP_CHECK_HIP(hipMemcpyAsync(&total, s->offs + n_seq, 8, hipMemcpyDeviceToHost, st));
         KMAP_CHECK_HIP(hipStreamSynchronize(st));
         KMAP_TRY(kmap_scan_reserve_pos(s, total));
-        if (total) KMAP_TRY(kmap_bitslice_scan_reads(true, hit16, codes_dev, inval_dev, n, borders_dev, n_seq, k, c, revcom, radius, s, st));
+        if (total) KMAP_TRY(kmap_bitslice_scan_reads(true, hit32, codes_dev, inval_dev, n, borders_dev, n_seq, k, c, revcom, radius, s, st));
         s->total = (int64_t)total;
         if (total_hits) *total_hits = (int64_t)total;
         return KMAP_OK;

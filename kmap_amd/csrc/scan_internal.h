@@ -12,9 +12,10 @@ struct kmap_scan {
 int kmap_scan_reserve(kmap_scan *s, int64_t n_seq);
 int kmap_scan_reserve_pos(kmap_scan *s, uint64_t total);
 
-// bitslice.hip: hit bits of every window (k <= 16) from the bit planes of the reads, and the scan's per-read passes on them
+// bitslice.hip: hit bits of every window (k <= 16) from the bit planes of the reads (words: one uint32 per 32 windows for the
+// scan; else uint16 per group for the mask's coverage pass), and the scan's per-read passes on them
 int kmap_bitslice_hits(const uint32_t *planes, const uint16_t *inval, int64_t n, int k, const uint64_t *cons, const int32_t *radius,
-                       int n_cons, int revcom_pairs, uint16_t *hit16, hipStream_t st);
-int kmap_bitslice_scan_reads(bool write, const uint16_t *hit16, const uint32_t *codes, const uint16_t *inval, int64_t n,
+                       int n_cons, int revcom_pairs, uint16_t *hit16, bool words, hipStream_t st);
+int kmap_bitslice_scan_reads(bool write, const uint32_t *hit32, const uint32_t *codes, const uint16_t *inval, int64_t n,
                              const int64_t *borders, int64_t n_seq, int k, uint64_t cons, int revcom, int radius, kmap_scan *s,
                              hipStream_t st);
