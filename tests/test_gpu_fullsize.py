@@ -316,3 +316,66 @@ def test_c2_whole_run():
         np.testing.assert_allclose(tr10["last_coords"], ld, rtol=0, atol=1e-5)
     finally:
         shutil.rmtree(res, ignore_errors=True)
+
+
+def test_c4_embedding_force_evaluation_full_size():
+    """BASELINE config C4's embedding stage at N = 200 000 (80 GB of neighbour sums on one GPU): one force evaluation of the
+    symmetric FAST kernel (4x the tiles of C3; 782 row blocks) against the SEQ kernel (the reference's summation order) -- loss
+    to 2e-6, gradient to 2e-5 of its scale -- and the same evaluation sharded cyclically over 3 ranks (each rank's session run
+    here in turn, their messages summed as the all-reduce sums them): the sharded gradient and loss equal the one-GPU FAST
+    result to summation round-off, no block is lost or counted twice."""
+    from kmap_amd import _ffi, visualization as V
+    from kmap_amd.distributed import MSG_EXTRA, loss_from_limbs
+    from kmap_amd.hamdist import hamdist_matrix_dev, pitch_for
+    n = 200_000
+    kh, lab, lens = _pipeline_like_sample(n, 8)
+    ldd = pitch_for(n)
+    kh_d, lab_d, D_d = _ffi.DeviceBuffer.from_numpy(kh), _ffi.DeviceBuffer.from_numpy(lab), _ffi.DeviceBuffer(n * ldd)
+    hamdist_matrix_dev(kh_d.ptr, lab_d.ptr, n, K, lens, D_d.ptr, ldd)
+    nb_d = V.knn_select_dev(D_d.ptr, ldd, n, 20)
+    D_d.free()
+    sums_d, lds = V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, K, lens, nb_d, 20)
+    lut = V.hd_prob_lut(K, 20, 400 * K)
+    coords = np.random.default_rng(9).standard_normal((2, n)).astype(np.float32)
+    outs = {}
+    for tag, mode in (("seq", V.EMBED_SEQ), ("fast", V.EMBED_FAST)):
+        sess = V.EmbedSession(n, 10, 0.01, mode)
+        _ffi.check(_ffi.lib().kmap_embed_set_prob_lut(sess._h, sums_d.ptr, lds, _ffi.ptr(lut), len(lut)))
+        sess.set_coords(coords)
+        g_d, l_d = _ffi.DeviceBuffer(2 * n * 4), _ffi.DeviceBuffer(8)
+        g_d.zero()
+        sess.forces(g_d.ptr, l_d.ptr)
+        _ffi.sync()
+        outs[tag] = (g_d.to_numpy(np.float32, (2, n)), float(l_d.to_numpy(np.float64, (1,))[0]))
+        sess.close()
+        g_d.free()
+    (gs, ls), (gf, lf) = outs["seq"], outs["fast"]
+    assert abs(lf - ls) <= 2e-6 * abs(ls)
+    np.testing.assert_allclose(gf, gs, rtol=0, atol=2e-5 * np.abs(gs).max())
+    # three cyclic shards: rank r owns the 256-row blocks r, r + 3, ...; its probability rows are passed block after block
+    world, msum = 3, np.zeros(2 * n + MSG_EXTRA, np.float32)
+    n_blocks = 0
+    for rank in range(world):
+        blocks = V.cyclic_blocks(n, world, rank)
+        n_blocks += len(blocks)
+        blk_bytes = V.CYCLIC_BLOCK_ROWS * lds * 2
+        part_d = _ffi.DeviceBuffer(len(blocks) * blk_bytes)
+        for b, (r0, nr) in enumerate(blocks):
+            _ffi.check(_ffi.lib().kmap_memcpy_d2d(part_d.ptr + b * blk_bytes, sums_d.ptr + r0 * lds * 2, nr * lds * 2, None))
+        sess = V.EmbedSession(n, 10, 0.01, V.EMBED_FAST, cyclic=(world, rank))
+        _ffi.check(_ffi.lib().kmap_embed_set_prob_lut(sess._h, part_d.ptr, lds, _ffi.ptr(lut), len(lut)))
+        sess.set_coords(coords)
+        m_d = _ffi.DeviceBuffer((2 * n + MSG_EXTRA) * 4)
+        m_d.zero()
+        sess.forces_msg(m_d.ptr)
+        _ffi.sync()
+        msum = msum + m_d.to_numpy(np.float32, (2 * n + MSG_EXTRA,))        # float32 sum, as the all-reduce computes it
+        sess.close()
+        for buf in (m_d, part_d):
+            buf.free()
+    assert n_blocks == (n + 255) // 256
+    l3 = loss_from_limbs(msum[2 * n:])
+    assert abs(l3 - lf) <= 1e-9 * abs(lf)                                       # the same pairs, f64 partials in another grouping
+    np.testing.assert_allclose(msum[:2 * n].reshape(2, n), gf, rtol=0, atol=3e-6 * np.abs(gf).max())
+    for b in (sums_d, nb_d, kh_d, lab_d):
+        b.free()
