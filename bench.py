@@ -166,14 +166,11 @@ def stage_rooflines(reads, kh, lab, conseq_lens):
     kh_d, lab_d = _ffi.DeviceBuffer.from_numpy(kh), _ffi.DeviceBuffer.from_numpy(lab)
     D_d = _ffi.DeviceBuffer(n * ldd)
     hamdist_matrix_dev(kh_d.ptr, lab_d.ptr, n, K, conseq_lens, D_d.ptr, ldd)
-    nb_holder = []
+    nb_d = _ffi.DeviceBuffer(n * 20 * 4)            # allocated once: hipMalloc / hipFree inside the timed loop made this stage noisy
 
     def select():
-        for b in nb_holder:
-            b.free()
-        nb_holder[:] = [V.knn_select_dev(D_d.ptr, ldd, n, 20)]
-    out["knn_select"] = roof(float(n) * n, timed_launches(select, 4), "20 nearest rows per row of D (device tie rule), one read of D")
-    nb_d = nb_holder[0]
+        _ffi.check(lib.kmap_knn_select_u8_dev(D_d.ptr, ldd, n, 20, 0, n, nb_d.ptr, None))
+    out["knn_select"] = roof(float(n) * n, timed_launches(select, 6), "20 nearest rows per row of D (device tie rule), one read of D")
     lds = (n + 127) & ~127
     sums_d = _ffi.DeviceBuffer(n * lds * 2)
     out["knn_sums"] = roof(3.0 * n * n, timed_launches(lambda: V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, K, conseq_lens, nb_d, 20, out=sums_d.ptr), 4),

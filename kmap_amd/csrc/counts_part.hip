@@ -202,14 +202,18 @@ __global__ __launch_bounds__(PH_TPB) void part_hist_kernel(const uint32_t *__res
     for (uint32_t j = threadIdx.x; j < sub; j += PH_TPB) dst[j] = lb[j];
 }
 // The same with two 16-bit counters per LDS word: 65 536 bins per block, half the range passes over a bucket's keys (k = 13: one
-// instead of two, k = 14: four instead of eight).  A counter never carries into its neighbour: the thread whose add takes it from
-// 0x7FFF to 0x8000 (returning ds_add: same LDS rate as the plain one on this part) takes those 32 768 counts out again and notes
-// the bin in a global list (at most one entry per 32 768 keys); part_spill_kernel adds them to the finished table.  Until the
-// ds_sub lands at most 1024 threads x 4 keys more can arrive (< 0x10000).
-constexpr uint32_t PH_HALF_BINS = 2 * PH_BINS, PH_HALF_LIMIT = 0x8000u;
+// instead of two, k = 14: four instead of eight).  A counter must never carry into its neighbour: the thread whose returning
+// ds_add (same LDS rate as the plain one on this part) SETS bit 14 of the counter (0x3FFF -> 0x4000, or, if an earlier
+// withdrawal is still in flight, 0xBFFF -> 0xC000) takes 0x4000 counts out again and notes the bin in a global list;
+// part_spill_kernel adds them to the finished table.  Margin: a carry needs 0xC000 = 49 152 further adds to ONE bin between a
+// thread's ds_add and its ds_sub (a block has 1024 threads with four keys in flight each); the r02 version spilled at 0x8000
+// with a 32 768 margin and an equality test that a delayed withdrawal could step over.  Between two spills of a bin lie at
+// least 0x4000 adds to it, so the list holds at most n / 16 384 entries (the write is bounds-checked all the same).
+constexpr uint32_t PH_HALF_BINS = 2 * PH_BINS, PH_HALF_LIMIT = 0x4000u;
 __global__ __launch_bounds__(PH_TPB) void part_hist_half_kernel(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ goff,
                                                                 uint32_t bins_per_bucket, int passes, uint32_t *__restrict__ table,
-                                                                unsigned long long *__restrict__ spill_n, uint32_t *__restrict__ spill) {
+                                                                unsigned long long *__restrict__ spill_n, uint32_t *__restrict__ spill,
+                                                                unsigned long long spill_cap) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lb[];
     uint32_t bucket = blockIdx.x / passes, p = blockIdx.x % passes;
     if (passes > 1 && (gridDim.x / passes) % 8 == 0) {                    // range passes of a bucket on one XCD (see part_hist_kernel)
@@ -228,9 +232,11 @@ __global__ __launch_bounds__(PH_TPB) void part_hist_half_kernel(const uint32_t *
         const uint32_t b = a < dummy ? a : dummy;
         const int hs = (int)(b & 1u) * 16;
         const uint32_t old = atomicAdd(&lb[b >> 1], 1u << hs);
-        if ((((old >> hs) & 0xFFFFu) == PH_HALF_LIMIT - 1u) && a < PH_HALF_BINS) {   // this add made it 0x8000: spill
+        const uint32_t o16 = (old >> hs) & 0xFFFFu;
+        if ((~o16 & (o16 + 1u) & PH_HALF_LIMIT) && a < PH_HALF_BINS) {   // this add set bit 14: take 0x4000 out, note the bin
             atomicSub(&lb[b >> 1], PH_HALF_LIMIT << hs);
-            spill[atomicAdd(spill_n, 1ull)] = bin_base + a;
+            const unsigned long long at = atomicAdd(spill_n, 1ull);
+            if (at < spill_cap) spill[at] = bin_base + a;
         }
     };
     const uint64_t lo4 = (lo + 3) & ~(uint64_t)3, hi4 = hi & ~(uint64_t)3;
@@ -262,8 +268,9 @@ __global__ __launch_bounds__(PH_TPB) void part_hist_half_kernel(const uint32_t *
     }
 }
 __global__ void part_spill_kernel(uint32_t *__restrict__ table, const unsigned long long *__restrict__ spill_n,
-                                  const uint32_t *__restrict__ spill) {
-    const unsigned long long m = *spill_n;
+                                  const uint32_t *__restrict__ spill, unsigned long long spill_cap) {
+    unsigned long long m = *spill_n;
+    if (m > spill_cap) m = spill_cap;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (unsigned long long)gridDim.x * blockDim.x)
         atomicAdd(&table[spill[i]], PH_HALF_LIMIT);
 }
@@ -472,8 +479,8 @@ static int part_hist_any(kmap_counts *c, const uint32_t *hash_dev, const uint32_
         KMAP_CHECK_HIP(hipMemsetAsync(spill_n, 0, 16, st));
         const int hp = (int)(bins_per_bucket / PH_HALF_BINS);
         KMAP_TRY(kmap_allow_lds((const void *)part_hist_half_kernel, (PH_BINS + 64) * 4));
-        part_hist_half_kernel<<<(unsigned)(NBK * hp), PH_TPB, (size_t)(PH_BINS + 64) * 4, st>>>(keys, goff, bins_per_bucket, hp, c->bins, spill_n, spill);
-        part_spill_kernel<<<64, 256, 0, st>>>(c->bins, spill_n, spill);
+        part_hist_half_kernel<<<(unsigned)(NBK * hp), PH_TPB, (size_t)(PH_BINS + 64) * 4, st>>>(keys, goff, bins_per_bucket, hp, c->bins, spill_n, spill, (unsigned long long)cap);
+        part_spill_kernel<<<64, 256, 0, st>>>(c->bins, spill_n, spill, (unsigned long long)cap);
     } else {
         part_hist_kernel<<<(unsigned)(NBK * passes), PH_TPB, (size_t)(sub + 64) * 4, st>>>(keys, goff, bins_per_bucket, passes, sub, c->bins);
     }
