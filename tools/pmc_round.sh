@@ -6,7 +6,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/pmc_${1:-r02}
+OUT=$R/gpurun_out/pmc_${1:-r03}
 rm -rf $OUT && mkdir -p $OUT
 declare -A SETS
 SETS[sq_a]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"

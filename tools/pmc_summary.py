@@ -3,6 +3,12 @@
     python tools/pmc_summary.py gpurun_out/pmc_r02 profiles/r02_pmc.json
 Per kernel: launches, mean of every counter per launch, and derived ratios
   valu_busy      = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES   (share of resident wave-cycles spent issuing VALU; both count quad-cycles)
+  valu_issue_util= SQ_ACTIVE_INST_VALU * 4 / (n_simd * SQ_BUSY_CYCLES / 32)   (share of the chip's SIMD issue slots that issued VALU:
+                   the SQ counters tick in quad-cycles and are summed over 32 shader engines; n_simd = 1024 on MI355X) -- the
+                   "VALU utilisation" of DESIGN.md; a different quantity from valu_busy (3 waves per SIMD at 90 % utilisation have
+                   valu_busy 0.3)
+  resident_waves = SQ_WAVE_CYCLES * 4 / (SQ_BUSY_CYCLES / 32)   (average waves on the chip while it is busy; 4096 slots)
+  valu_per_wave  = SQ_INSTS_VALU / SQ_WAVES               (VALU instructions per wave; x 64 / pairs-per-wave = lane instructions per pair)
   wait_any       = SQ_WAIT_ANY / SQ_WAVE_CYCLES           (waves parked on s_waitcnt / barriers)
   issue_stall    = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
   lds_conflict   = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
@@ -60,6 +66,13 @@ def main():
                                 ("active_any", "SQ_ACTIVE_INST_ANY")):
                     if c in d:
                         d[name] = d[c] / wc
+            if d.get("SQ_BUSY_CYCLES") and "SQ_ACTIVE_INST_VALU" in d:
+                busy = d["SQ_BUSY_CYCLES"] / 32.0
+                d["valu_issue_util"] = d["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * busy)
+                if wc:
+                    d["resident_waves"] = wc * 4.0 / busy
+            if d.get("SQ_WAVES") and "SQ_INSTS_VALU" in d:
+                d["valu_per_wave"] = d["SQ_INSTS_VALU"] / d["SQ_WAVES"]
             if d.get("SQ_LDS_IDX_ACTIVE"):
                 d["lds_conflict"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]
             if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
@@ -69,11 +82,13 @@ def main():
         out_path.write_text(json.dumps(result, indent=1))
     for wl, kern in result["workloads"].items():
         print(f"== {wl}")
-        print(f"{'kernel':60s} {'n':>5s} {'valu':>6s} {'wait':>6s} {'stall':>6s} {'ldsconf':>7s} {'hbm MB':>10s} {'VALU inst':>12s} {'LDS inst':>12s}")
+        print(f"{'kernel':60s} {'n':>5s} {'valu_busy':>9s} {'issue_util':>10s} {'res.waves':>9s} {'wait':>6s} {'stall':>6s} {'ldsconf':>7s} {'hbm MB':>10s} "
+              f"{'VALU inst':>12s} {'VALU/wave':>10s} {'LDS inst':>12s}")
+        nan = float("nan")
         for k, d in kern.items():
-            print(f"{k[:60]:60s} {d.get('launches', 0):5d} {d.get('valu_busy', float('nan')):6.2f} {d.get('wait_any', float('nan')):6.2f} "
-                  f"{d.get('issue_stall', float('nan')):6.2f} {d.get('lds_conflict', float('nan')):7.3f} {d.get('hbm_bytes', float('nan')) / 1e6:10.1f} "
-                  f"{d.get('SQ_INSTS_VALU', float('nan')):12.3g} {d.get('SQ_INSTS_LDS', float('nan')):12.3g}")
+            print(f"{k[:60]:60s} {d.get('launches', 0):5d} {d.get('valu_busy', nan):9.2f} {d.get('valu_issue_util', nan):10.2f} {d.get('resident_waves', nan):9.0f} "
+                  f"{d.get('wait_any', nan):6.2f} {d.get('issue_stall', nan):6.2f} {d.get('lds_conflict', nan):7.3f} {d.get('hbm_bytes', nan) / 1e6:10.1f} "
+                  f"{d.get('SQ_INSTS_VALU', nan):12.3g} {d.get('valu_per_wave', nan):10.0f} {d.get('SQ_INSTS_LDS', nan):12.3g}")
 
 
 if __name__ == "__main__":
