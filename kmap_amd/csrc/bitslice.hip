@@ -213,155 +213,195 @@ __device__ __forceinline__ uint32_t hr_mask(int64_t wi, int64_t a, int64_t b) {
     return m;
 }
 
-// Pass 1 (WRITE = false): per read, the exact distance of every hit window -> minimum and the number of hits at the minimum.
-// A read whose hits lie at more than one distance is flagged (bit 6 of its min_dist byte): only for those does pass 2 (WRITE =
-// true, after the scan of the counts) evaluate distances again; for all others it lists the set bits of the read's range.
-// (Clearing the losing bits in place instead would break reads whose borders overlap -- the API allows them.)
-constexpr int HR_MIXED = 0x40;
-template <bool WRITE, bool CHECK_INVALID>
-__global__ __launch_bounds__(HR_TPB) void scan_hits_reads_kernel(const uint32_t *__restrict__ hit32, const uint32_t *__restrict__ codes,
-                                                                 const uint16_t *__restrict__ inval, int64_t n,
-                                                                 const int64_t *__restrict__ borders, int64_t n_seq, int k,
-                                                                 uint32_t cons, uint32_t rcc, int revcom, int d_inv, int radius,
-                                                                 int32_t *__restrict__ hits, int8_t *__restrict__ min_dist,
-                                                                 const uint64_t *__restrict__ offs, int32_t *__restrict__ pos_out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t km = low_mask<uint32_t>(k);
+// The per-read work in two phases.  COUNT: the exact distance of every hit window of the read -> minimum, number of hits at
+// the minimum, and whether the hits lie at more than one distance ("mixed").  WRITE: the positions at the minimum, ascending,
+// to pos_out[base ...] -- for a read that is not mixed simply the set bits of its range; only mixed reads evaluate distances
+// again.  (Clearing the losing bits in place instead would break reads whose borders overlap -- the API allows them.)
+// Reads longer than HR_LONG positions are walked by their whole wave, 64 hit words per step, in both phases.
+constexpr int HR_MIXED = 0x40;           // flag bit in the min_dist byte between the two kernels of the two-pass form
+struct HrCtx {
+    const uint32_t *__restrict__ hit32;
+    const uint32_t *__restrict__ codes;
+    const uint16_t *__restrict__ inval;
+    int64_t n;
+    int k, revcom, d_inv, radius;
+    uint32_t km, cons, rcc;
+};
+struct HrRead {
     int64_t st = 0, stop = 0;
-    bool quirk = false;
-    if (s < n_seq) {
-        st = borders[2 * s];
-        int64_t en = borders[2 * s + 1];
-        if (st < 0) st = 0;
-        if (en > n) en = n;
-        const int64_t L = en > st ? en - st : 0;
-        quirk = (L - k + 1 < 0);                 // negative slice stop: every window runs off the read (all-ones hash)
-        stop = hr_slice_stop(L, k);
-    }
+    bool quirk = false;                  // negative slice stop: every window runs off the read (all-ones hash)
     int best = 127, count = 0;
-    uint64_t base = 0;
-    bool mixed = false;                          // hits at more than one distance
-    if (WRITE && s < n_seq) {
-        count = hits[s];
-        base = offs[s];
-        if (count == 0) stop = 0;                // nothing to write for this read
-        else {
-            const int md = min_dist[s];
-            mixed = (md & HR_MIXED) != 0;
-            best = md & (HR_MIXED - 1);
-            if (mixed) min_dist[s] = (int8_t)best;
-        }
+    bool mixed = false;
+};
+__device__ __forceinline__ void hr_setup(const HrCtx &c, const int64_t *__restrict__ borders, int64_t s, int64_t n_seq, HrRead &r) {
+    if (s < n_seq) {
+        r.st = borders[2 * s];
+        int64_t en = borders[2 * s + 1];
+        if (r.st < 0) r.st = 0;
+        if (en > c.n) en = c.n;
+        const int64_t L = en > r.st ? en - r.st : 0;
+        r.quirk = (L - c.k + 1 < 0);
+        r.stop = hr_slice_stop(L, c.k);
     }
-    if (quirk) {
-        if (!WRITE) {
-            best = d_inv <= radius ? d_inv : 127;
-            count = d_inv <= radius ? (int)stop : 0;
-        } else {
-            for (int64_t p = 0; p < stop; ++p) pos_out[base + p] = (int32_t)p;
-        }
+}
+template <bool CHECK_INVALID>
+__device__ __forceinline__ void hr_count(const HrCtx &c, HrRead &r) {
+    const int lane = threadIdx.x & 63;
+    int64_t stop = r.stop;
+    if (r.quirk) {
+        r.best = c.d_inv <= c.radius ? c.d_inv : 127;
+        r.count = c.d_inv <= c.radius ? (int)stop : 0;
         stop = 0;
     }
     const bool is_long = stop > HR_LONG;
     if (stop > 0 && !is_long) {
-        const int64_t a = st, b = st + stop;
+        const int64_t a = r.st, b = r.st + stop;
         const int64_t w0 = a >> 5, w1 = (b - 1) >> 5;
-        if (!WRITE) {
-            for (int64_t wi = w0; wi <= w1; ++wi) {
-                uint32_t x = hit32[wi] & hr_mask(wi, a, b);
-                while (x) {
-                    const int tb = 31 - __builtin_clz(x);
-                    x &= ~(1u << tb);
-                    const int d = hr_dist<CHECK_INVALID>(codes, inval, (wi << 5) + (31 - tb), k, km, cons, rcc, revcom);
-                    if (d < best) { mixed = mixed || count > 0; best = d; count = 1; }
-                    else if (d == best) ++count;
-                    else mixed = true;
-                }
-            }
-        } else {
-            for (int64_t wi = w0; wi <= w1; ++wi) {
-                uint32_t x = hit32[wi] & hr_mask(wi, a, b);
-                while (x) {                      // ascending positions: most significant bit first
-                    const int tb = 31 - __builtin_clz(x);
-                    x &= ~(1u << tb);
-                    const int64_t p = (wi << 5) + (31 - tb);
-                    if (mixed && hr_dist<CHECK_INVALID>(codes, inval, p, k, km, cons, rcc, revcom) != best) continue;
-                    pos_out[base++] = (int32_t)(p - st);
-                }
+        for (int64_t wi = w0; wi <= w1; ++wi) {
+            uint32_t x = c.hit32[wi] & hr_mask(wi, a, b);
+            while (x) {
+                const int tb = 31 - __builtin_clz(x);
+                x &= ~(1u << tb);
+                const int d = hr_dist<CHECK_INVALID>(c.codes, c.inval, (wi << 5) + (31 - tb), c.k, c.km, c.cons, c.rcc, c.revcom);
+                if (d < r.best) { r.mixed = r.mixed || r.count > 0; r.best = d; r.count = 1; }
+                else if (d == r.best) ++r.count;
+                else r.mixed = true;
             }
         }
     }
-    // long reads: the whole wave works on one read at a time, 64 words per step
     unsigned long long todo = __ballot(is_long);
     while (todo) {
         const int src = __builtin_ctzll(todo);
         todo &= todo - 1;
-        const int64_t a = __shfl(st, src), b = a + __shfl(stop, src);
+        const int64_t a = __shfl(r.st, src), b = a + __shfl(stop, src);
         const int64_t w0 = a >> 5, w1 = (b - 1) >> 5;
-        if (!WRITE) {
-            int m = 127, c = 0;
-            for (int64_t wi = w0 + lane; wi <= w1; wi += 64) {
-                uint32_t x = hit32[wi] & hr_mask(wi, a, b);
-                while (x) {
-                    const int tb = 31 - __builtin_clz(x);
-                    x &= ~(1u << tb);
-                    const int d = hr_dist<CHECK_INVALID>(codes, inval, (wi << 5) + (31 - tb), k, km, cons, rcc, revcom);
-                    if (d < m) { m = d; c = 1; }
-                    else if (d == m) ++c;
-                }
+        int m = 127, cc = 0, total_c = 0;
+        for (int64_t wi = w0 + lane; wi <= w1; wi += 64) {
+            uint32_t x = c.hit32[wi] & hr_mask(wi, a, b);
+            total_c += __builtin_popcount(x);
+            while (x) {
+                const int tb = 31 - __builtin_clz(x);
+                x &= ~(1u << tb);
+                const int d = hr_dist<CHECK_INVALID>(c.codes, c.inval, (wi << 5) + (31 - tb), c.k, c.km, c.cons, c.rcc, c.revcom);
+                if (d < m) { m = d; cc = 1; }
+                else if (d == m) ++cc;
             }
-            int gm = m;
-            for (int o = 32; o > 0; o >>= 1) {
-                const int v = __shfl_xor(gm, o);
-                gm = v < gm ? v : gm;
-            }
-            c = (m == gm) ? c : 0;
-            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-            // any hit of the read above its minimum?
-            int total_c = 0;
-            for (int64_t wi = w0 + lane; wi <= w1; wi += 64) total_c += __builtin_popcount(hit32[wi] & hr_mask(wi, a, b));
-            for (int o = 32; o > 0; o >>= 1) total_c += __shfl_xor(total_c, o);
-            if (lane == src) {
-                best = gm;
-                count = c;
-                mixed = total_c != c;
-            }
-        } else {
-            uint64_t wbase = __shfl(base, src);
-            const bool mx = __shfl((int)mixed, src) != 0;
-            const int bst = __shfl(best, src);
-            for (int64_t c0 = w0; c0 <= w1; c0 += 64) {
-                const int64_t wi = c0 + lane;
-                uint32_t keep = (wi <= w1) ? (hit32[wi] & hr_mask(wi, a, b)) : 0u;
-                if (mx) {                        // drop the hits above the read's minimum
-                    uint32_t x = keep;
-                    while (x) {
-                        const int tb = 31 - __builtin_clz(x);
-                        x &= ~(1u << tb);
-                        if (hr_dist<CHECK_INVALID>(codes, inval, (wi << 5) + (31 - tb), k, km, cons, rcc, revcom) != bst) keep &= ~(1u << tb);
-                    }
-                }
-                const int c = __builtin_popcount(keep);
-                int inc = c;
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int v = __shfl_up(inc, o);
-                    if (lane >= o) inc += v;
-                }
-                uint64_t at = wbase + (uint64_t)(inc - c);
-                while (keep) {
-                    const int tb = 31 - __builtin_clz(keep);
-                    keep &= ~(1u << tb);
-                    pos_out[at++] = (int32_t)((wi << 5) + (31 - tb) - a);
-                }
-                wbase += (uint64_t)__shfl(inc, 63);
+        }
+        int gm = m;
+        for (int o = 32; o > 0; o >>= 1) {
+            const int v = __shfl_xor(gm, o);
+            gm = v < gm ? v : gm;
+        }
+        cc = (m == gm) ? cc : 0;
+        for (int o = 32; o > 0; o >>= 1) {
+            cc += __shfl_xor(cc, o);
+            total_c += __shfl_xor(total_c, o);
+        }
+        if (lane == src) {
+            r.best = gm;
+            r.count = cc;
+            r.mixed = total_c != cc;             // some hit of the read lies above its minimum
+        }
+    }
+}
+// cap: capacity of pos_out (writes beyond it are dropped; the caller re-runs with a larger buffer)
+template <bool CHECK_INVALID>
+__device__ __forceinline__ void hr_write(const HrCtx &c, const HrRead &r, uint64_t base, int32_t *__restrict__ pos_out, uint64_t cap) {
+    const int lane = threadIdx.x & 63;
+    int64_t stop = r.count ? r.stop : 0;                                   // nothing to write for a read without hits
+    if (r.quirk) {
+        for (int64_t p = 0; p < stop; ++p)
+            if (base + p < cap) pos_out[base + p] = (int32_t)p;
+        stop = 0;
+    }
+    const bool is_long = stop > HR_LONG;
+    if (stop > 0 && !is_long) {
+        const int64_t a = r.st, b = r.st + stop;
+        const int64_t w0 = a >> 5, w1 = (b - 1) >> 5;
+        for (int64_t wi = w0; wi <= w1; ++wi) {
+            uint32_t x = c.hit32[wi] & hr_mask(wi, a, b);
+            while (x) {                          // ascending positions: most significant bit first
+                const int tb = 31 - __builtin_clz(x);
+                x &= ~(1u << tb);
+                const int64_t p = (wi << 5) + (31 - tb);
+                if (r.mixed && hr_dist<CHECK_INVALID>(c.codes, c.inval, p, c.k, c.km, c.cons, c.rcc, c.revcom) != r.best) continue;
+                if (base < cap) pos_out[base] = (int32_t)(p - r.st);
+                ++base;
             }
         }
     }
-    if (!WRITE && s < n_seq) {
-        hits[s] = count;
-        min_dist[s] = (int8_t)(best <= radius ? (best | (mixed ? HR_MIXED : 0)) : -1);
+    unsigned long long todo = __ballot(is_long);
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int64_t a = __shfl(r.st, src), b = a + __shfl(stop, src);
+        const int64_t w0 = a >> 5, w1 = (b - 1) >> 5;
+        uint64_t wbase = __shfl(base, src);
+        const bool mx = __shfl((int)r.mixed, src) != 0;
+        const int bst = __shfl(r.best, src);
+        for (int64_t c0 = w0; c0 <= w1; c0 += 64) {
+            const int64_t wi = c0 + lane;
+            uint32_t keep = (wi <= w1) ? (c.hit32[wi] & hr_mask(wi, a, b)) : 0u;
+            if (mx) {                            // drop the hits above the read's minimum
+                uint32_t x = keep;
+                while (x) {
+                    const int tb = 31 - __builtin_clz(x);
+                    x &= ~(1u << tb);
+                    if (hr_dist<CHECK_INVALID>(c.codes, c.inval, (wi << 5) + (31 - tb), c.k, c.km, c.cons, c.rcc, c.revcom) != bst) keep &= ~(1u << tb);
+                }
+            }
+            const int cnt = __builtin_popcount(keep);
+            int inc = cnt;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(inc, o);
+                if (lane >= o) inc += v;
+            }
+            uint64_t at = wbase + (uint64_t)(inc - cnt);
+            while (keep) {
+                const int tb = 31 - __builtin_clz(keep);
+                keep &= ~(1u << tb);
+                if (at < cap) pos_out[at] = (int32_t)((wi << 5) + (31 - tb) - a);
+                ++at;
+            }
+            wbase += (uint64_t)__shfl(inc, 63);
+        }
     }
 }
+
+// two-pass form: count kernel -> exclusive scan of the counts (caller) -> write kernel
+template <bool WRITE, bool CHECK_INVALID>
+__global__ __launch_bounds__(HR_TPB) void scan_hits_reads_kernel(HrCtx c, const int64_t *__restrict__ borders, int64_t n_seq,
+                                                                 int32_t *__restrict__ hits, int8_t *__restrict__ min_dist,
+                                                                 const uint64_t *__restrict__ offs, int32_t *__restrict__ pos_out) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    HrRead r;
+    hr_setup(c, borders, s, n_seq, r);
+    if (!WRITE) {
+        hr_count<CHECK_INVALID>(c, r);
+        if (s < n_seq) {
+            hits[s] = r.count;
+            min_dist[s] = (int8_t)(r.best <= c.radius ? (r.best | (r.mixed ? HR_MIXED : 0)) : -1);
+        }
+    } else {
+        uint64_t base = 0;
+        if (s < n_seq) {
+            r.count = hits[s];
+            base = offs[s];
+            if (r.count) {
+                const int md = min_dist[s];
+                r.mixed = (md & HR_MIXED) != 0;
+                r.best = md & (HR_MIXED - 1);
+                if (r.mixed) min_dist[s] = (int8_t)r.best;
+            }
+        }
+        hr_write<CHECK_INVALID>(c, r, base, pos_out, ~0ull);
+    }
+}
+
+// (A fused form -- counts -> block scan -> decoupled look-back over the blocks' published aggregates -> positions in ONE kernel --
+// was built and measured in r03: 5.1 ms at C3 against 0.32 + 0.09 + 0.28 ms for the three launches.  On a part with eight L2s
+// every agent-scope release / acquire of the status words is an L2 write-back / invalidate; 39 000 blocks of 256 reads pay
+// for it 39 000 times.  Larger blocks amortise it only linearly.  Dropped.)
 
 unsigned grid_of(int64_t n, int64_t per) {
     const int64_t g = (n + per - 1) / per;
@@ -419,20 +459,30 @@ int kmap_bitslice_hits(const uint32_t *planes, const uint16_t *inval, int64_t n,
 }
 
 // the scan's per-read passes on the hit bits (counts + minimum, then -- after the caller's scan of the counts -- the positions)
+static HrCtx make_ctx(const uint32_t *hit32, const uint32_t *codes, const uint16_t *inval, int64_t n, int k, uint64_t cons, int revcom,
+                      int radius) {
+    HrCtx c;
+    c.hit32 = hit32; c.codes = codes; c.inval = inval; c.n = n; c.k = k; c.revcom = revcom; c.radius = radius;
+    c.km = low_mask<uint32_t>(k);
+    c.cons = (uint32_t)cons & c.km;
+    c.rcc = rc_host(c.cons, k);
+    c.d_inv = pc2_host((c.km ^ c.cons) & c.km);
+    if (revcom) {
+        const int d2 = pc2_host((c.km ^ c.rcc) & c.km);
+        c.d_inv = d2 < c.d_inv ? d2 : c.d_inv;
+    }
+    return c;
+}
+
 int kmap_bitslice_scan_reads(bool write, const uint32_t *hit32, const uint32_t *codes, const uint16_t *inval, int64_t n,
                              const int64_t *borders, int64_t n_seq, int k, uint64_t cons, int revcom, int radius, kmap_scan *s,
                              hipStream_t st) {
-    const uint32_t km = low_mask<uint32_t>(k), c = (uint32_t)cons & km, rcc = rc_host(c, k);
-    int d_inv = pc2_host((km ^ c) & km);
-    if (revcom) {
-        const int d2 = pc2_host((km ^ rcc) & km);
-        d_inv = d2 < d_inv ? d2 : d_inv;
-    }
+    const HrCtx c = make_ctx(hit32, codes, inval, n, k, cons, revcom, radius);
     const unsigned grid = grid_of(n_seq, HR_TPB);
-    const bool chk = d_inv <= radius;            // only then can a hit be a window that touches an invalid position
-#define KMAP_HR(W, C)                                                                                                              \
-    scan_hits_reads_kernel<W, C><<<grid, HR_TPB, 0, st>>>(hit32, codes, inval, n, borders, n_seq, k, c, rcc, revcom, d_inv, radius, \
-                                                          s->hits, s->mind, (const uint64_t *)(W ? s->offs : nullptr), W ? s->pos : nullptr)
+    const bool chk = c.d_inv <= radius;            // only then can a hit be a window that touches an invalid position
+#define KMAP_HR(W, C)                                                                                                      \
+    scan_hits_reads_kernel<W, C><<<grid, HR_TPB, 0, st>>>(c, borders, n_seq, s->hits, s->mind, (const uint64_t *)(W ? s->offs : nullptr), \
+                                                          W ? s->pos : nullptr)
     if (!write) { if (chk) KMAP_HR(false, true); else KMAP_HR(false, false); }
     else { if (chk) KMAP_HR(true, true); else KMAP_HR(true, false); }
 #undef KMAP_HR
