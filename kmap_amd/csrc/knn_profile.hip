@@ -13,7 +13,8 @@
 
 namespace {
 constexpr int KP_NG = 4;          // short-consensus labels handled here (more: the matrix-based kernel)
-constexpr int KP_CPL = 4;         // columns per lane (one 8-byte store of uint16 sums)
+// columns per lane: 8 at k <= 8 (one 16-byte non-temporal store of uint16 sums per row; 64 registers of column profiles), 4 at
+// k <= 16 (8-byte store; the 16-dword profiles of 8 columns would take 128 registers)
 constexpr int KP_ROWS = 8;        // rows per wave
 constexpr int KP_WAVES = 4;
 
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void knn_profile_kernel(const H *__restrict__ 
     }
 }
 
-template <int KD>
+template <int KD, int KP_CPL>
 __global__ __launch_bounds__(KMAP_WAVE *KP_WAVES) void knn_sums_profile_kernel(const uint32_t *__restrict__ V,
                                                                               const uint32_t *__restrict__ Vg,
                                                                               const uint8_t *__restrict__ cg, int64_t n, int k,
@@ -112,9 +113,16 @@ __global__ __launch_bounds__(KMAP_WAVE *KP_WAVES) void knn_sums_profile_kernel(c
         for (int c = 0; c < KP_CPL; ++c)
             if (j0 + c == i) s[c] = 0;                         // diagonal forced to 0 (visualization.py:103,107)
         uint16_t *dst = T + lr * ldt + j0;
-        if (full && ((ldt & 3) == 0)) {
-            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<u32x2 *>(dst) = u32x2{(s[0] & 0xFFFFu) | (s[1] << 16), (s[2] & 0xFFFFu) | (s[3] << 16)};
+        if (full && ((ldt & (KP_CPL - 1)) == 0)) {
+            if constexpr (KP_CPL == 8) {       // write-once streaming output: 16 bytes per lane, non-temporal
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 o = {(s[0] & 0xFFFFu) | (s[1] << 16), (s[2] & 0xFFFFu) | (s[3] << 16), (s[4] & 0xFFFFu) | (s[5] << 16),
+                                 (s[6] & 0xFFFFu) | (s[7] << 16)};
+                __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(dst));
+            } else {
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<u32x2 *>(dst) = u32x2{(s[0] & 0xFFFFu) | (s[1] << 16), (s[2] & 0xFFFFu) | (s[3] << 16)};
+            }
         } else {
 #pragma unroll
             for (int c = 0; c < KP_CPL; ++c)
@@ -170,11 +178,13 @@ int knn_sums_kmers(const H *kh_dev, const int32_t *label_dev, int64_t n, int k, 
     KMAP_CHECK_HIP(hipStreamSynchronize(st));                  // lab2gid is a stack buffer
     kp_gid_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(label_dev, n, tab, n_lab, gid);
     knn_profile_kernel<H><<<(unsigned)((nV + 255) / 256), 256, 0, st>>>(kh_dev, gid, nb_dev, n, k, kd, n_nb, gt, V, Vg, cg);
-    const dim3 grid((unsigned)((n + KMAP_WAVE * KP_CPL - 1) / (KMAP_WAVE * KP_CPL)),
+    const int cpl = (kd == 8 && ((uintptr_t)sums_dev % 16) == 0) ? 8 : 4;
+    const dim3 grid((unsigned)((n + KMAP_WAVE * cpl - 1) / (KMAP_WAVE * cpl)),
                     (unsigned)((nrows + KP_ROWS * KP_WAVES - 1) / (KP_ROWS * KP_WAVES)));
     KMAP_REQUIRE(grid.y <= 65535u, "knn_sums_kmers: nrows too large for one launch");
-    if (kd == 8) knn_sums_profile_kernel<8><<<grid, KMAP_WAVE * KP_WAVES, 0, st>>>(V, Vg, cg, n, k, n_nb, gt, row0, nrows, sums_dev, lds);
-    else knn_sums_profile_kernel<16><<<grid, KMAP_WAVE * KP_WAVES, 0, st>>>(V, Vg, cg, n, k, n_nb, gt, row0, nrows, sums_dev, lds);
+    if (kd == 8 && cpl == 8) knn_sums_profile_kernel<8, 8><<<grid, KMAP_WAVE * KP_WAVES, 0, st>>>(V, Vg, cg, n, k, n_nb, gt, row0, nrows, sums_dev, lds);
+    else if (kd == 8) knn_sums_profile_kernel<8, 4><<<grid, KMAP_WAVE * KP_WAVES, 0, st>>>(V, Vg, cg, n, k, n_nb, gt, row0, nrows, sums_dev, lds);
+    else knn_sums_profile_kernel<16, 4><<<grid, KMAP_WAVE * KP_WAVES, 0, st>>>(V, Vg, cg, n, k, n_nb, gt, row0, nrows, sums_dev, lds);
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;
 }

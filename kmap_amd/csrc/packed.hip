@@ -568,6 +568,12 @@ __global__ __launch_bounds__(KMAP_WAVE *DS_WAVES) void dedupe_bitmap_packed_kern
         ++it;
     }
 }
+// (r03 built and measured a quarter-wave form -- 16 lanes per read, four reads per wave in lock-step, 143 / 160 lane utilisation,
+// the read geometry paid once per four reads, each read's set an open-addressing table of its k-mers filled by LDS
+// compare-and-swap, window words fetched one iteration ahead: correct on every counting test, 5.2 ms at C3 against this
+// kernel's 3.0 ms.  The returning CAS and its divergent probe loop cost more than the lane utilisation gains -- the same
+// finding as for r02's first CAS-set kernel; an exact bitmap per read (8 KiB at k = 8) does not fit four reads per wave at a
+// useful occupancy.  Dropped.)
 __global__ __launch_bounds__(BLK) void max_read_len_kernel(const int64_t *__restrict__ borders, int64_t n_seq, int64_t n,
                                                            unsigned long long *__restrict__ out) {
     unsigned long long m = 0;
