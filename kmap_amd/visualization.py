@@ -533,11 +533,14 @@ def _visualize_kmers_impl(res_dir, debug, mode, dist, rank, neighbor_inds_mat=No
                        debug=debug, mode=mode, neighbor_inds_mat=neighbor_inds_mat)
     if rank != 0:
         return ld_data
-    lines = ["x\ty\tlabel"]
-    for x, y, label in zip(ld_data[0], ld_data[1], label_arr):
-        lines.append(f"{x:3.3f}\t{y:3.3f}\t{int(label)}")
+    # the reference's rows `f"{x:3.3f}\t{y:3.3f}\t{label}"` (visualization.py:65-72), formatted by ONE C-level % call
+    n_pts = len(label_arr)
+    flat = np.empty((n_pts, 3), object)
+    flat[:, 0] = np.asarray(ld_data[0]).tolist()
+    flat[:, 1] = np.asarray(ld_data[1]).tolist()
+    flat[:, 2] = [int(v) for v in np.asarray(label_arr).tolist()]
     with open(Path(res_dir) / FileNameDict["ld_data_file"], "w+") as fh:
-        fh.write("\n".join(lines) + "\n")
+        fh.write("x\ty\tlabel\n" + ("%3.3f\t%3.3f\t%d\n" * n_pts) % tuple(flat.ravel().tolist()))
     print("Dimensionality reduction finished. Low dimensional embeddings generated.")
     if vz.get("gen_fig_flag"):
         print("gen_fig_flag: plotting is outside the GPU hot path of kmap_amd; low_dim_data.tsv holds the embedding.")
