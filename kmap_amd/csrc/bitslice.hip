@@ -255,14 +255,19 @@ __device__ __forceinline__ void hr_count(const HrCtx &c, HrRead &r) {
     }
     const bool is_long = stop > HR_LONG;
     if (stop > 0 && !is_long) {
-        const int64_t a = r.st, b = r.st + stop;
-        const int64_t w0 = a >> 5, w1 = (b - 1) >> 5;
-        for (int64_t wi = w0; wi <= w1; ++wi) {
-            uint32_t x = c.hit32[wi] & hr_mask(wi, a, b);
+        // 32-bit arithmetic relative to the read's first hit word (a short read spans at most 33 words)
+        const uint32_t *hw = c.hit32 + (r.st >> 5);
+        const int a_off = (int)(r.st & 31), end = a_off + (int)stop;       // bit range [a_off, end) of the word stream
+        const int nw = (end + 31) >> 5;
+        const int64_t word0 = (r.st >> 5) << 5;                           // absolute position of bit 0 of the stream
+        for (int j = 0; j < nw; ++j) {
+            uint32_t x = hw[j];
+            if (j == 0) x &= ~0u >> a_off;
+            if (j == nw - 1) x &= ~0u << (32 * nw - end);
             while (x) {
                 const int tb = 31 - __builtin_clz(x);
                 x &= ~(1u << tb);
-                const int d = hr_dist<CHECK_INVALID>(c.codes, c.inval, (wi << 5) + (31 - tb), c.k, c.km, c.cons, c.rcc, c.revcom);
+                const int d = hr_dist<CHECK_INVALID>(c.codes, c.inval, word0 + (32 * j + 31 - tb), c.k, c.km, c.cons, c.rcc, c.revcom);
                 if (d < r.best) { r.mixed = r.mixed || r.count > 0; r.best = d; r.count = 1; }
                 else if (d == r.best) ++r.count;
                 else r.mixed = true;
@@ -316,16 +321,20 @@ __device__ __forceinline__ void hr_write(const HrCtx &c, const HrRead &r, uint64
     }
     const bool is_long = stop > HR_LONG;
     if (stop > 0 && !is_long) {
-        const int64_t a = r.st, b = r.st + stop;
-        const int64_t w0 = a >> 5, w1 = (b - 1) >> 5;
-        for (int64_t wi = w0; wi <= w1; ++wi) {
-            uint32_t x = c.hit32[wi] & hr_mask(wi, a, b);
+        const uint32_t *hw = c.hit32 + (r.st >> 5);
+        const int a_off = (int)(r.st & 31), end = a_off + (int)stop;
+        const int nw = (end + 31) >> 5;
+        const int64_t word0 = (r.st >> 5) << 5;
+        for (int j = 0; j < nw; ++j) {
+            uint32_t x = hw[j];
+            if (j == 0) x &= ~0u >> a_off;
+            if (j == nw - 1) x &= ~0u << (32 * nw - end);
             while (x) {                          // ascending positions: most significant bit first
                 const int tb = 31 - __builtin_clz(x);
                 x &= ~(1u << tb);
-                const int64_t p = (wi << 5) + (31 - tb);
-                if (r.mixed && hr_dist<CHECK_INVALID>(c.codes, c.inval, p, c.k, c.km, c.cons, c.rcc, c.revcom) != r.best) continue;
-                if (base < cap) pos_out[base] = (int32_t)(p - r.st);
+                const int rel = 32 * j + 31 - tb;                          // position relative to the stream's bit 0
+                if (r.mixed && hr_dist<CHECK_INVALID>(c.codes, c.inval, word0 + rel, c.k, c.km, c.cons, c.rcc, c.revcom) != r.best) continue;
+                if (base < cap) pos_out[base] = (int32_t)(rel - a_off);
                 ++base;
             }
         }
@@ -368,11 +377,31 @@ __device__ __forceinline__ void hr_write(const HrCtx &c, const HrRead &r, uint64
     }
 }
 
-// two-pass form: count kernel -> exclusive scan of the counts (caller) -> write kernel
+// two-pass form: count kernel (also: the block's hit total) -> exclusive scan of the 1 / 256 as many block totals (caller) ->
+// write kernel (the read's offset = its block's offset + the prefix of the counts inside the block, recomputed from hits[])
+__device__ __forceinline__ unsigned int hr_block_prefix(unsigned int v, unsigned int *s_wave, unsigned int &block_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    unsigned int off = 0;
+    block_total = 0;
+    for (int w = 0; w < HR_TPB / 64; ++w) {
+        if (w < wave) off += s_wave[w];
+        block_total += s_wave[w];
+    }
+    return off + inc - v;                                                  // exclusive prefix of v inside the block
+}
 template <bool WRITE, bool CHECK_INVALID>
 __global__ __launch_bounds__(HR_TPB) void scan_hits_reads_kernel(HrCtx c, const int64_t *__restrict__ borders, int64_t n_seq,
                                                                  int32_t *__restrict__ hits, int8_t *__restrict__ min_dist,
-                                                                 const uint64_t *__restrict__ offs, int32_t *__restrict__ pos_out) {
+                                                                 uint32_t *__restrict__ block_sums, const uint64_t *__restrict__ block_offs,
+                                                                 int32_t *__restrict__ pos_out) {
+    __shared__ unsigned int s_wave[HR_TPB / 64];
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     HrRead r;
     hr_setup(c, borders, s, n_seq, r);
@@ -382,11 +411,12 @@ __global__ __launch_bounds__(HR_TPB) void scan_hits_reads_kernel(HrCtx c, const 
             hits[s] = r.count;
             min_dist[s] = (int8_t)(r.best <= c.radius ? (r.best | (r.mixed ? HR_MIXED : 0)) : -1);
         }
+        unsigned int total;
+        (void)hr_block_prefix((unsigned int)r.count, s_wave, total);
+        if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
     } else {
-        uint64_t base = 0;
         if (s < n_seq) {
             r.count = hits[s];
-            base = offs[s];
             if (r.count) {
                 const int md = min_dist[s];
                 r.mixed = (md & HR_MIXED) != 0;
@@ -394,7 +424,9 @@ __global__ __launch_bounds__(HR_TPB) void scan_hits_reads_kernel(HrCtx c, const 
                 if (r.mixed) min_dist[s] = (int8_t)r.best;
             }
         }
-        hr_write<CHECK_INVALID>(c, r, base, pos_out, ~0ull);
+        unsigned int total;
+        const unsigned int in_block = hr_block_prefix((unsigned int)r.count, s_wave, total);
+        hr_write<CHECK_INVALID>(c, r, block_offs[blockIdx.x] + in_block, pos_out, ~0ull);
     }
 }
 
@@ -480,8 +512,10 @@ int kmap_bitslice_scan_reads(bool write, const uint32_t *hit32, const uint32_t *
     const HrCtx c = make_ctx(hit32, codes, inval, n, k, cons, revcom, radius);
     const unsigned grid = grid_of(n_seq, HR_TPB);
     const bool chk = c.d_inv <= radius;            // only then can a hit be a window that touches an invalid position
+    // s->offs doubles as [block offsets uint64 (n_blocks + 1) | block sums uint32 (n_blocks)]: n_seq + 1 uint64 are allocated
+    uint32_t *bsums = reinterpret_cast<uint32_t *>(s->offs + (size_t)grid + 1);
 #define KMAP_HR(W, C)                                                                                                      \
-    scan_hits_reads_kernel<W, C><<<grid, HR_TPB, 0, st>>>(c, borders, n_seq, s->hits, s->mind, (const uint64_t *)(W ? s->offs : nullptr), \
+    scan_hits_reads_kernel<W, C><<<grid, HR_TPB, 0, st>>>(c, borders, n_seq, s->hits, s->mind, bsums, (const uint64_t *)s->offs, \
                                                           W ? s->pos : nullptr)
     if (!write) { if (chk) KMAP_HR(false, true); else KMAP_HR(false, false); }
     else { if (chk) KMAP_HR(true, true); else KMAP_HR(true, false); }

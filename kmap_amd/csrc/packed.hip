@@ -1284,9 +1284,11 @@ int kmap_scan_run_packed_dev(kmap_scan *s, const uint32_t *codes_dev, const uint
         if (n > 0) KMAP_TRY(kmap_bitslice_hits(planes_dev, inval_dev, n, k, &c, &radius, 1, revcom, hit16, true, st));
         uint32_t *hit32 = reinterpret_cast<uint32_t *>(hit16);
         KMAP_TRY(kmap_bitslice_scan_reads(false, hit32, codes_dev, inval_dev, n, borders_dev, n_seq, k, c, revcom, radius, s, st));
-        KMAP_TRY(exclusive_scan_u32(reinterpret_cast<const uint32_t *>(s->hits), n_seq, s->offs, st));
+        // the count kernel left one total per block of 256 reads behind the block-offset array: scan those (1 / 256 of the reads)
+        const int64_t nblk = (n_seq + 255) / 256;
+        KMAP_TRY(exclusive_scan_u32(reinterpret_cast<const uint32_t *>(s->offs + nblk + 1), nblk, s->offs, st));
         uint64_t total = 0;
-        KMAP_CHECK_HIP(hipMemcpyAsync(&total, s->offs + n_seq, 8, hipMemcpyDeviceToHost, st));
+        KMAP_CHECK_HIP(hipMemcpyAsync(&total, s->offs + nblk, 8, hipMemcpyDeviceToHost, st));
         KMAP_CHECK_HIP(hipStreamSynchronize(st));
         KMAP_TRY(kmap_scan_reserve_pos(s, total));
         if (total) KMAP_TRY(kmap_bitslice_scan_reads(true, hit32, codes_dev, inval_dev, n, borders_dev, n_seq, k, c, revcom, radius, s, st));
