@@ -218,6 +218,7 @@ __device__ __forceinline__ uint32_t hr_mask(int64_t wi, int64_t a, int64_t b) {
 // to pos_out[base ...] -- for a read that is not mixed simply the set bits of its range; only mixed reads evaluate distances
 // again.  (Clearing the losing bits in place instead would break reads whose borders overlap -- the API allows them.)
 // Reads longer than HR_LONG positions are walked by their whole wave, 64 hit words per step, in both phases.
+constexpr int HR_CHUNK = 6;              // hit words fetched together (a 150-bp read spans 5 - 6, a 300-bp read 10 - 11)
 constexpr int HR_MIXED = 0x40;           // flag bit in the min_dist byte between the two kernels of the two-pass form
 struct HrCtx {
     const uint32_t *__restrict__ hit32;
@@ -260,17 +261,25 @@ __device__ __forceinline__ void hr_count(const HrCtx &c, HrRead &r) {
         const int a_off = (int)(r.st & 31), end = a_off + (int)stop;       // bit range [a_off, end) of the word stream
         const int nw = (end + 31) >> 5;
         const int64_t word0 = (r.st >> 5) << 5;                           // absolute position of bit 0 of the stream
-        for (int j = 0; j < nw; ++j) {
-            uint32_t x = hw[j];
-            if (j == 0) x &= ~0u >> a_off;
-            if (j == nw - 1) x &= ~0u << (32 * nw - end);
-            while (x) {
-                const int tb = 31 - __builtin_clz(x);
-                x &= ~(1u << tb);
-                const int d = hr_dist<CHECK_INVALID>(c.codes, c.inval, word0 + (32 * j + 31 - tb), c.k, c.km, c.cons, c.rcc, c.revcom);
-                if (d < r.best) { r.mixed = r.mixed || r.count > 0; r.best = d; r.count = 1; }
-                else if (d == r.best) ++r.count;
-                else r.mixed = true;
+        for (int j0 = 0; j0 < nw; j0 += HR_CHUNK) {
+            uint32_t xs[HR_CHUNK];                                          // the chunk's words in ONE round trip, not one per word
+#pragma unroll
+            for (int t = 0; t < HR_CHUNK; ++t) xs[t] = hw[min(j0 + t, nw - 1)];
+#pragma unroll
+            for (int t = 0; t < HR_CHUNK; ++t) {
+                const int j = j0 + t;
+                if (j >= nw) break;
+                uint32_t x = xs[t];
+                if (j == 0) x &= ~0u >> a_off;
+                if (j == nw - 1) x &= ~0u << (32 * nw - end);
+                while (x) {
+                    const int tb = 31 - __builtin_clz(x);
+                    x &= ~(1u << tb);
+                    const int d = hr_dist<CHECK_INVALID>(c.codes, c.inval, word0 + (32 * j + 31 - tb), c.k, c.km, c.cons, c.rcc, c.revcom);
+                    if (d < r.best) { r.mixed = r.mixed || r.count > 0; r.best = d; r.count = 1; }
+                    else if (d == r.best) ++r.count;
+                    else r.mixed = true;
+                }
             }
         }
     }
@@ -325,17 +334,25 @@ __device__ __forceinline__ void hr_write(const HrCtx &c, const HrRead &r, uint64
         const int a_off = (int)(r.st & 31), end = a_off + (int)stop;
         const int nw = (end + 31) >> 5;
         const int64_t word0 = (r.st >> 5) << 5;
-        for (int j = 0; j < nw; ++j) {
-            uint32_t x = hw[j];
-            if (j == 0) x &= ~0u >> a_off;
-            if (j == nw - 1) x &= ~0u << (32 * nw - end);
-            while (x) {                          // ascending positions: most significant bit first
-                const int tb = 31 - __builtin_clz(x);
-                x &= ~(1u << tb);
-                const int rel = 32 * j + 31 - tb;                          // position relative to the stream's bit 0
-                if (r.mixed && hr_dist<CHECK_INVALID>(c.codes, c.inval, word0 + rel, c.k, c.km, c.cons, c.rcc, c.revcom) != r.best) continue;
-                if (base < cap) pos_out[base] = (int32_t)(rel - a_off);
-                ++base;
+        for (int j0 = 0; j0 < nw; j0 += HR_CHUNK) {
+            uint32_t xs[HR_CHUNK];
+#pragma unroll
+            for (int t = 0; t < HR_CHUNK; ++t) xs[t] = hw[min(j0 + t, nw - 1)];
+#pragma unroll
+            for (int t = 0; t < HR_CHUNK; ++t) {
+                const int j = j0 + t;
+                if (j >= nw) break;
+                uint32_t x = xs[t];
+                if (j == 0) x &= ~0u >> a_off;
+                if (j == nw - 1) x &= ~0u << (32 * nw - end);
+                while (x) {                      // ascending positions: most significant bit first
+                    const int tb = 31 - __builtin_clz(x);
+                    x &= ~(1u << tb);
+                    const int rel = 32 * j + 31 - tb;                      // position relative to the stream's bit 0
+                    if (r.mixed && hr_dist<CHECK_INVALID>(c.codes, c.inval, word0 + rel, c.k, c.km, c.cons, c.rcc, c.revcom) != r.best) continue;
+                    if (base < cap) pos_out[base] = (int32_t)(rel - a_off);
+                    ++base;
+                }
             }
         }
     }
