@@ -1656,8 +1656,9 @@ int seq_tail_blocks(const kmap_embed *e) {
 }
 // How the SEQ rows are split between the quad kernel and the wide kernel.  The kernels are VALU-issue bound and every wave of a
 // SIMD shares its issue slots, so the cost of a set of waves is (waves on the fullest SIMD) x (instructions per wave); per
-// column a quad wave issues ~11 instructions, a wide wave with g lanes per row ~(36 / g + 1.2).  Whole rounds of quad waves (one
-// wave on every SIMD) are the cheapest way to do rows; what is left over is given to whichever form finishes it soonest.
+// column a quad wave issues ~9.4 instructions (8 terms x 27 + 64 adds + ~20 per 32 columns), a wide wave with g lanes per row
+// ~(30 / g + 1.2).  Whole rounds of quad waves (one wave on every SIMD) are the cheapest way to do rows; what is left over is
+// given to whichever form finishes it soonest.
 void seq_split(kmap_embed *e) {
     e->seq_main_rows = e->nrows;
     e->seq_tail_g = 0;
@@ -1671,11 +1672,11 @@ void seq_split(kmap_embed *e) {
     const int64_t rem = e->nrows - main_rows;
     if (rem == 0) return;
     auto rounds = [&](int64_t waves) { return (double)((waves + simds - 1) / simds); };
-    double best = rounds((rem + SQ_ROWS - 1) / SQ_ROWS) * 11.0;      // the remainder as quad waves
+    double best = rounds((rem + SQ_ROWS - 1) / SQ_ROWS) * 9.4;       // the remainder as quad waves
     int best_g = 0;
     for (int g : {8, 16, 32, 64}) {
         const int64_t waves = (rem + (KMAP_WAVE / g) - 1) / (KMAP_WAVE / g);
-        const double cost = rounds(waves) * (36.0 / g + 1.2);
+        const double cost = rounds(waves) * (30.0 / g + 1.2);
         if (cost < best) { best = cost; best_g = g; }
     }
     if (best_g) {
