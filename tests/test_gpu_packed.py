@@ -280,3 +280,45 @@ def test_dedupe_long_reads_both_paths(env, max_len):
         np.testing.assert_array_equal(c, oc)
     dc.close()
     ds.close()
+
+
+def test_bitsliced_scan_and_mask_fuzz_vs_oracle(env):
+    """Seeded fuzz of the bit-sliced window test (k <= 16) against the oracle: random k, radius (0 .. beyond k), strand flag,
+    consensus (random, poly-A, poly-T = the all-ones hash of invalid windows), N rate, read lengths 0 .. 1500 (short-read path,
+    whole-wave path for reads above 1024 positions, negative-slice quirk), array lengths off every 32-window boundary."""
+    _ffi, _, DeviceSeq, O = env
+    rng = np.random.default_rng(2024)
+    buf, md = np.empty(4096, np.int32), C.c_int(0)
+    for case in range(36):
+        k = int(rng.integers(1, 17))
+        r = int(rng.integers(0, k + 3))
+        revcom = bool(rng.integers(0, 2))
+        kind = case % 4
+        cons = 0 if kind == 1 else (4 ** k - 1 if kind == 2 else int(rng.integers(0, 4 ** k, dtype=np.uint64)))
+        lens = list(rng.integers(0, 90, size=60)) + list(rng.integers(100, 400, size=25)) + [int(rng.integers(1025, 1500)), k - 1 if k > 1 else 0, k, 33, 64]
+        rng.shuffle(lens)
+        p_n = float(rng.choice([0.0, 0.01, 0.1]))
+        parts, borders, st = [], [], 0
+        for L in lens:
+            L = int(L)
+            rd = rng.integers(0, 4 if rng.random() < 0.8 else 1, size=L).astype(np.uint8)
+            rd[rng.random(L) < p_n] = 255
+            parts += [rd, np.array([255], np.uint8)]
+            borders.append((st, st + L))
+            st += L + 1
+        seq, borders = np.concatenate(parts), np.array(borders, np.int64)
+        ds = DeviceSeq(seq, borders)
+        hits, pos = ds.scan(k, cons, r, revcom)
+        off = 0
+        for i, (a, b) in enumerate(borders):
+            m = O.lib().ko_scan_read(np.ascontiguousarray(seq[a:b]), b - a, k, cons, r, int(revcom), buf, C.byref(md))
+            assert hits[i] == m, (case, k, r, revcom, cons, i, int(b - a), int(hits[i]), int(m))
+            np.testing.assert_array_equal(pos[off:off + m], buf[:m])
+            off += m
+        assert off == len(pos)
+        # masking with the same consensus (+ a random second one) on the same reads
+        cons2 = np.array([cons, int(rng.integers(0, 4 ** k, dtype=np.uint64))], np.uint64)
+        rad2 = np.array([min(r, k), int(rng.integers(0, max(1, k // 2)))])
+        ds.mask(k, cons2, rad2)
+        np.testing.assert_array_equal(ds.download(), O.mask_input(seq.copy(), k, cons2, rad2), err_msg=f"case {case}: k={k} r={rad2}")
+        ds.close()
