@@ -34,4 +34,9 @@ int kmap_counts_part_hist_u32(kmap_counts *c, const uint32_t *hash_dev, int64_t 
 // the same with the keys hashed on the fly from the 2-bit packed reads (+ per-read dedupe skip bits); adds the all-T 16-mer itself
 int kmap_counts_part_hist_packed(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, const uint32_t *skip_dev,
                                  int64_t n, int k, hipStream_t st);
+// 8 <= k <= 14: the same with 16-bit keys, <= 65 536 bins per bucket and XCD-private bucket streams (counts_fine.hip); hash_dev or
+// (codes_dev, inval_dev, skip_dev) as above
+bool kmap_counts_fine_applies(int k);
+int kmap_counts_fine_hist(kmap_counts *c, const uint32_t *hash_dev, const uint32_t *codes_dev, const uint16_t *inval_dev,
+                          const uint32_t *skip_dev, int64_t n, int k, hipStream_t st);
 int kmap_counts_part_add_bin(kmap_counts *c, size_t bin, const unsigned long long *extra_dev, hipStream_t st);

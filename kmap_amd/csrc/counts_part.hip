@@ -400,6 +400,7 @@ bool kmap_counts_part_applies(int k, int64_t n) {
 // position array written and read twice: 18 GB of the ~36 GB a k = 14 count pass moved at C3)
 static int part_hist_any(kmap_counts *c, const uint32_t *hash_dev, const uint32_t *codes_dev, const uint16_t *inval_dev,
                          const uint32_t *skip_dev, int64_t n, int k, hipStream_t st) {
+    if (kmap_counts_fine_applies(k)) return kmap_counts_fine_hist(c, hash_dev, codes_dev, inval_dev, skip_dev, n, k, st);
     const size_t n_bins = (size_t)1 << (2 * k);
     KMAP_TRY(kmap_counts_reserve_bins(c, k));
     const int shift = 2 * k - PB;

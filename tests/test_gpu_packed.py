@@ -229,9 +229,10 @@ def test_two_level_partitioned_counts_vs_oracle(env, k):
 def test_lds_histogram_hot_bins(env, k):
     """LDS-pass histogram under extreme skew: 12 M positions, 85 % of them poly-A (plus poly-T and random reads), so one bin takes
     > 8 M of the counts and every wave's lanes hit the same LDS word; windows of other passes' bin ranges and invalid windows go
-    to the lanes' private bins behind the table.  k = 13 / 14 take the partitioned histogram with two 16-bit counters per LDS
-    word: the poly-A bin spills its 32 768-count chunks to the global list ~300 times.  Counts must equal the oracle's, with and
-    without per-read dedupe."""
+    to the lanes' private bins behind the table.  k >= 10 take the partitioned histogram (counts_fine.hip): the poly-A bucket holds
+    ~85 % of the keys and is cut into ~130 slices that add their bins to the table with device atomics; at k = 13 / 14 (two 16-bit
+    counters per LDS word) the poly-A bin also spills its 16 384-count chunks to the global list.  Counts must equal the oracle's,
+    with and without per-read dedupe."""
     _ffi, DeviceCounts, DeviceSeq, O = env
     rng = np.random.default_rng(500 + k)
     seq, borders = synth(rng, 60_000, 190, 210, p_n=0.001)
