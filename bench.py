@@ -14,7 +14,8 @@ Multi-GPU (--gpus G, launched by torch.distributed.run, one rank per GPU): the m
 holds all N hashes, no data-path collective.  `value` is the weak-scaling Hamming stage: N_total = 50 000 * sqrt(G)
 (rounded to 16) so that every GPU keeps 2.5e9 pairs per step.  The same line carries the STRONG-scaling legs: `embed_dist` (the
 C3 embedding, N = 50 000 fixed, sharded loop with its ONE all-reduce per iteration: ms per iteration and, from device events,
-forces / collective / apply ms) and `c4` (BASELINE config C4, N = 200 000 fixed: Hamming rows + the sharded embedding iteration).
+forces / collective / apply ms), `c4` (BASELINE config C4, N = 200 000 fixed: Hamming rows + the sharded embedding iteration) and,
+for G > 1, `count_dist` (one k = 15 count pass over read shards: all-reduce of the 4-GiB table vs bins owned by key range).
 At G = 1 `embed_dist` runs the sharded loop on a one-rank RCCL group next to the resident loop: `overhead_ms_per_iter` is what
 the multi-GPU plumbing (message kernels, collective launch, Python) costs before any link is involved.
 
@@ -334,6 +335,56 @@ def embed_dist_leg(dist, torch, world, kh, lab, conseqs, iters=200):
     return res
 
 
+def count_dist_leg(dist, torch, world, k=15, n_reads=1_000_000, read_len=150, reps=3):
+    """Multi-GPU counting at a k whose 4^k table is large (k = 15: 4 GiB): reads sharded over the ranks, one count pass with per-read
+    dedupe and reverse-complement merge -- (a) all-reduce of the whole table, every rank compacts it; (b) bins owned by key range:
+    presence all-reduce (half a byte per bin) + one SUM-reduce per slice + all-gather of the compacted shards
+    (kmap_amd.distributed.make_dist_device_seq(shard_counts=...)).  ms per pass (max over ranks, best of `reps`), and that both
+    give the same table.  1 M x 150 bp reads: 1.5e8 windows against 1.07e9 bins -- the sparse regime in which make_dist_device_seq
+    picks the key-range form by itself (every rank wants the WHOLE list, so its all-gather, 12 B per distinct k-mer, must stay
+    below what the slices save: windows < 4^k / 4).  Errors are reported in the line, not raised."""
+    from kmap_amd import _ffi, synth
+    from kmap_amd.distributed import make_dist_device_seq
+    from kmap_amd.kmer_count import DeviceCounts
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    res, err = {}, ""
+    try:
+        seq, borders = synth.synth_reads(n_reads, read_len, 11)          # the same array on every rank; a rank uploads its slice
+        sums = {}
+        for name, by_range in (("all_reduce", False), ("key_range", True)):
+            ds = make_dist_device_seq(seq, borders, dist, shard_counts=by_range)
+            dc = DeviceCounts()
+            best = None
+            for rep in range(reps + 1):                                  # the first pass allocates the table and the communicator's buffers
+                dist.barrier()
+                _ffi.sync()
+                t0 = time.perf_counter()
+                ds.count(dc, k, dedupe=True, merge_revcom=True)
+                torch.cuda.synchronize()
+                _ffi.sync()
+                dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+                if rep > 0:
+                    best = float(dt.item()) if best is None else min(best, float(dt.item()))
+            res[name + "_ms"] = best * 1e3
+            sums[name] = (int(dc.n_uniq), int(dc.total()))
+            dc.close()
+            ds.close()
+        res["same_table"] = sums["all_reduce"] == sums["key_range"]
+        res["n_uniq"], res["total_count"] = sums["key_range"]
+    except Exception as e:   # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"[:300]
+        flag.fill_(1)
+    if not _all_ok(dist, torch, flag):
+        return {"error": err or "another rank failed"}
+    tb = 4 ** k * 4
+    res.update({"k": k, "reads": n_reads, "read_len": read_len, "table_bytes": tb,
+                "bytes_received_per_rank": {"all_reduce": 2 * tb * (world - 1) // world,
+                                            "key_range": (tb + 2 * (tb // 8) + 12 * res.get("n_uniq", 0)) * (world - 1) // world,
+                                            "note": "ring estimates; key_range = table slices + presence nibbles (all-reduced) + the all-gathered shards (12 B per distinct k-mer)"}})
+    return res
+
+
 def c4_leg(dist, torch, res_dir, rank, world, barrier):
     """BASELINE config C4: N = 200 000 sampled k-mers FIXED as the GPU count grows (strong scaling).  Hamming rows of this rank
     (HIP events, no collective) and the embedding iteration (sharded FAST loop with its one all-reduce for world > 1; phases
@@ -467,6 +518,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-embed-dist", action="store_true", help="skip the sharded-embedding leg")
     ap.add_argument("--no-c4", action="store_true", help="skip the N = 200 000 strong-scaling leg")
+    ap.add_argument("--no-count-dist", action="store_true", help="skip the multi-GPU counting leg (k = 15: all-reduce vs key-range shards)")
     ap.add_argument("--no-c5", action="store_true", help="skip the full-size C5 scan leg (N=1 only)")
     ap.add_argument("--quick", action="store_true", help="smaller CPU-baseline samples (rehearsals)")
     ap.add_argument("--no-stages", action="store_true", help="skip the per-stage roofline timings")
@@ -597,6 +649,11 @@ def main():
                     dist1.destroy_process_group()
                 except Exception:   # noqa: BLE001
                     pass
+    count_dist = None
+    if dist is not None and not args.no_count_dist:
+        _ffi.check(_ffi.lib().kmap_scratch_release(1 << 30))
+        count_dist = count_dist_leg(dist, torch, world)
+        _ffi.check(_ffi.lib().kmap_scratch_release(1 << 30))
     c4 = None
     if not args.no_c4:
         if dist is not None:
@@ -641,6 +698,8 @@ def main():
                 pass
         if embed_dist is not None:
             line["embed_dist"] = embed_dist
+        if count_dist is not None:
+            line["count_dist"] = count_dist
         if c4 is not None:
             line["c4"] = c4
         if world == 1 and not args.no_stages:

@@ -165,6 +165,21 @@ int kmap_counts_hist_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const
  * counted (or kmap_scratch_release ran) since this handle's kmap_counts_hist_packed_dev. */
 int kmap_counts_bins(kmap_counts *c, void **bins_dev, int64_t *n_bins);
 int kmap_counts_finish(kmap_counts *c, int k, int merge_revcom, int64_t *n_uniq, void *stream);
+/* Key-range-sharded variant (11 <= k <= 16) of the same job: instead of all-reducing the whole table, every rank ends up with
+ * the summed counts of ITS slice of the bins and compacts that slice; the (uniq, cnt) shards are then all-gathered in rank order.
+ *   kmap_counts_hist_packed_dev                         local table
+ *   [merge_revcom] kmap_counts_presence_dev             one nibble per bin (0 / 1): bin x -> byte x / 2, low nibble for even x;
+ *                  caller: SUM all-reduce of the 4^k / 2 bytes (<= 15 ranks)
+ *                  kmap_counts_merge_presence_dev       table <- local part of the merged counts (which pair member survives is
+ *                                                        decided by the global presence), so that merged(sum) == sum(merged)
+ *   caller: SUM-reduce slice r of the table to rank r (in place)
+ *   kmap_counts_finish_range(first_bin, n_bins)         compaction of the own slice into the handle (first_bin % 8 == 0)
+ *   caller: all-gather of the shards (kmap_counts_table_dev), kmap_counts_adopt_dev(concatenation)
+ * Replaces the all-reduce of /root/reference's single-process count_uniq_hash + merge_revcom (kmer_count.py:643-760) across ranks. */
+int kmap_counts_presence_dev(kmap_counts *c, int k, void *nib_dev, void *stream);
+int kmap_counts_merge_presence_dev(kmap_counts *c, int k, const void *nib_dev, void *stream);
+int kmap_counts_finish_range(kmap_counts *c, int k, int merged, uint64_t first_bin, uint64_t n_bins, int64_t *n_uniq, void *stream);
+int kmap_counts_adopt_dev(kmap_counts *c, const void *uniq_dev, const void *cnt_dev, int64_t n_uniq, int k);
 /* planes_dev (optional, from kmap_pack_planes_dev): with it and k <= 16 the Hamming-ball test of all windows runs bit-sliced
  * over positions (csrc/bitslice.hip) instead of window by window; NULL keeps the per-window kernels.  Results are identical. */
 int kmap_mask_hamball_packed_dev(const uint32_t *codes_dev, uint16_t *inval_dev, int64_t n, int k, const uint64_t *cons,

@@ -88,6 +88,10 @@ _SIGS = {
     "kmap_counts_hist_packed_dev": (i32, [vp, vp, vp, i64, vp, i64, i32, i32, vp]),
     "kmap_counts_bins": (i32, [vp, P(vp), P(i64)]),
     "kmap_counts_finish": (i32, [vp, i32, i32, P(i64), vp]),
+    "kmap_counts_presence_dev": (i32, [vp, i32, vp, vp]),
+    "kmap_counts_merge_presence_dev": (i32, [vp, i32, vp, vp]),
+    "kmap_counts_finish_range": (i32, [vp, i32, i32, u64, u64, P(i64), vp]),
+    "kmap_counts_adopt_dev": (i32, [vp, vp, vp, i64, i32]),
     "kmap_mask_hamball_packed_dev": (i32, [vp, vp, i64, i32, vp, vp, i32, vp, vp]),
     "kmap_pack_planes_dev": (i32, [vp, i64, vp, vp]),
     "kmap_scan_run_packed_dev": (i32, [vp, vp, vp, i64, vp, i64, i32, u64, i32, i32, P(i64), vp, vp]),

@@ -112,8 +112,14 @@ __device__ __forceinline__ uint32_t rc3(uint32_t v) {   // reverse complement of
     v = 63u - v;
     return ((v & 3u) << 4) | (v & 12u) | (v >> 4);
 }
-__global__ __launch_bounds__(BLK) void rc_merge_tiles_kernel(uint32_t *__restrict__ bins, int k) {
+// PRES (key-range-sharded multi-GPU counting): `bins` holds ONE rank's counts and `nib` says, one nibble per bin (bin x: byte x / 2,
+// low nibble for even x), on how many ranks the bin is non-empty.  Which member of a pair survives is decided by that global
+// presence; the value written is the local part of the merged count (own + partner, both local), so that the SUM over the ranks of
+// the merged tables is the merged table of the summed counts: bins[x] = survives(x) ? c(x) + c(rc x) : 0.
+template <bool PRES>
+__global__ __launch_bounds__(BLK) void rc_merge_tiles_kernel(uint32_t *__restrict__ bins, int k, const uint8_t *__restrict__ nib) {
     __shared__ uint32_t A[64][65], B[64][65];
+    __shared__ uint8_t PA[PRES ? 64 : 1][68], PB[PRES ? 64 : 1][68];
     const int mg = k - 6;                                     // middle groups (k >= 7)
     const uint64_t m = blockIdx.x;
     const uint64_t m2 = revcom_hash(m, mg);
@@ -128,22 +134,32 @@ __global__ __launch_bounds__(BLK) void rc_merge_tiles_kernel(uint32_t *__restric
         const int a = s * 16 + lr;
         const u32x4 va = *reinterpret_cast<const u32x4 *>(bins + (uint64_t)a * row_stride + (m << 6) + lc);
         A[a][lc] = va.x; A[a][lc + 1] = va.y; A[a][lc + 2] = va.z; A[a][lc + 3] = va.w;
+        if (PRES) {
+            const uint32_t pa = *reinterpret_cast<const uint16_t *>(nib + (((uint64_t)a * row_stride + (m << 6) + lc) >> 1));
+            PA[a][lc] = pa & 15u; PA[a][lc + 1] = (pa >> 4) & 15u; PA[a][lc + 2] = (pa >> 8) & 15u; PA[a][lc + 3] = pa >> 12;
+        }
         if (!self) {
             const u32x4 vb = *reinterpret_cast<const u32x4 *>(bins + (uint64_t)a * row_stride + (m2 << 6) + lc);
             B[a][lc] = vb.x; B[a][lc + 1] = vb.y; B[a][lc + 2] = vb.z; B[a][lc + 3] = vb.w;
+            if (PRES) {
+                const uint32_t pb = *reinterpret_cast<const uint16_t *>(nib + (((uint64_t)a * row_stride + (m2 << 6) + lc) >> 1));
+                PB[a][lc] = pb & 15u; PB[a][lc + 1] = (pb >> 4) & 15u; PB[a][lc + 2] = (pb >> 8) & 15u; PB[a][lc + 3] = pb >> 12;
+            }
         }
     }
     __syncthreads();
     // entry (a, mm, b) against its partner (rc3(b), mo, rc3(a)): compare the tuples lexicographically
-    auto merged = [&](uint32_t (&own)[64][65], uint32_t (&oth)[64][65], uint64_t mm, uint64_t mo, int a, int b) -> uint32_t {
+    auto merged = [&](uint32_t (&own)[64][65], uint32_t (&oth)[64][65], uint8_t (&pown)[PRES ? 64 : 1][68], uint8_t (&poth)[PRES ? 64 : 1][68],
+                      uint64_t mm, uint64_t mo, int a, int b) -> uint32_t {
         const uint32_t c = own[a][b];
-        if (c == 0) return 0u;
+        if (PRES ? pown[a][b] == 0 : c == 0) return 0u;
         const uint32_t pa = rc3((uint32_t)b), pb = rc3((uint32_t)a);
         const bool eq = ((uint32_t)a == pa) && (mm == mo) && ((uint32_t)b == pb);
         if (eq) return c + c;                                // palindrome: its own partner
         const bool greater = ((uint32_t)a != pa) ? ((uint32_t)a > pa) : (mm != mo) ? (mm > mo) : ((uint32_t)b > pb);
         const uint32_t cr = oth[pa][pb];
-        return (cr > 0 && greater) ? 0u : c + cr;            // higher member of a present pair is deleted
+        const bool partner = PRES ? poth[pa][pb] != 0 : cr > 0;
+        return (partner && greater) ? 0u : c + cr;           // higher member of a present pair is deleted
     };
     uint32_t ra[4][4], rb[4][4];
 #pragma unroll
@@ -151,8 +167,8 @@ __global__ __launch_bounds__(BLK) void rc_merge_tiles_kernel(uint32_t *__restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int a = s * 16 + lr, b = lc + j;
-            ra[s][j] = self ? merged(A, A, m, m, a, b) : merged(A, B, m, m2, a, b);
-            rb[s][j] = self ? 0u : merged(B, A, m2, m, a, b);
+            ra[s][j] = self ? merged(A, A, PA, PA, m, m, a, b) : merged(A, B, PA, PB, m, m2, a, b);
+            rb[s][j] = self ? 0u : merged(B, A, PB, PA, m2, m, a, b);
         }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -161,6 +177,15 @@ __global__ __launch_bounds__(BLK) void rc_merge_tiles_kernel(uint32_t *__restric
         if (!self)
             *reinterpret_cast<u32x4 *>(bins + (uint64_t)a * row_stride + (m2 << 6) + lc) = u32x4{rb[s][0], rb[s][1], rb[s][2], rb[s][3]};
     }
+}
+// presence nibbles of the table: thread = eight bins -> four bytes
+__global__ __launch_bounds__(BLK) void presence_nibbles_kernel(const uint32_t *__restrict__ bins, uint64_t n_bins, uint32_t *__restrict__ nib) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint64_t t = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+    if (t * 8 >= n_bins) return;                              // n_bins = 4^k, k >= 2: a multiple of 8
+    const u32x4 a = *reinterpret_cast<const u32x4 *>(bins + t * 8), b = *reinterpret_cast<const u32x4 *>(bins + t * 8 + 4);
+    nib[t] = (uint32_t)(a.x != 0) | ((uint32_t)(a.y != 0) << 4) | ((uint32_t)(a.z != 0) << 8) | ((uint32_t)(a.w != 0) << 12) |
+             ((uint32_t)(b.x != 0) << 16) | ((uint32_t)(b.y != 0) << 20) | ((uint32_t)(b.z != 0) << 24) | ((uint32_t)(b.w != 0) << 28);
 }
 
 // the CT_PER_THREAD consecutive bins of a thread: 16-byte loads (element loads through the `x < n_bins` guards were eight
@@ -180,8 +205,9 @@ __device__ __forceinline__ void load_bins(const uint32_t *__restrict__ bins, uin
 // A block walks CT_TPB consecutive tiles (the per-tile counts / offsets keep their meaning): with one 8-KiB tile per block the
 // 16-GiB table of k = 16 is 2 M blocks and the pass ran at the dispatch rate (2 TB/s), not at the memory's.
 constexpr int CT_TPB = 8;
+// x_base: `bins` is the slice [x_base, x_base + n_bins) of the table (key-range-sharded counting; merge 0 or 2 only: no partner gathers)
 __global__ __launch_bounds__(BLK) void compact_count_kernel(const uint32_t *__restrict__ bins, uint64_t n_bins, int k,
-                                                            int merge, uint32_t *__restrict__ block_counts, unsigned n_tiles) {
+                                                            int merge, uint32_t *__restrict__ block_counts, unsigned n_tiles, uint64_t x_base) {
     __shared__ uint32_t wsum[CT_TPB][BLK / 64];
     uint32_t m[CT_TPB];
 #pragma unroll
@@ -195,7 +221,7 @@ __global__ __launch_bounds__(BLK) void compact_count_kernel(const uint32_t *__re
         for (int j = 0; j < CT_PER_THREAD; ++j) {
             uint64_t key;
             uint32_t cnt;
-            m[t] += bin_entry(bins, x0 + j, c8[j], k, merge, key, cnt);      // bins past the end were loaded as 0
+            m[t] += bin_entry(bins, x_base + x0 + j, c8[j], k, merge, key, cnt);      // bins past the end were loaded as 0
         }
     }
 #pragma unroll
@@ -213,7 +239,7 @@ __global__ __launch_bounds__(BLK) void compact_count_kernel(const uint32_t *__re
 template <typename H>
 __global__ __launch_bounds__(BLK) void compact_write_kernel(const uint32_t *__restrict__ bins, uint64_t n_bins, int k,
                                                             int merge, const uint64_t *__restrict__ block_off,
-                                                            H *__restrict__ uniq, uint32_t *__restrict__ cnt_out) {
+                                                            H *__restrict__ uniq, uint32_t *__restrict__ cnt_out, uint64_t x_base) {
     __shared__ uint32_t wsum[BLK / 64];
   for (int t = 0; t < CT_TPB; ++t) {                                      // the block's tiles, one after the other
     const uint64_t tile = (uint64_t)blockIdx.x * CT_TPB + t;
@@ -226,7 +252,7 @@ __global__ __launch_bounds__(BLK) void compact_write_kernel(const uint32_t *__re
     load_bins(bins, x0, n_bins, c8);
 #pragma unroll
     for (int j = 0; j < CT_PER_THREAD; ++j) {
-        if (bin_entry(bins, x0 + j, c8[j], k, merge, keys[j], cnts[j])) {
+        if (bin_entry(bins, x_base + x0 + j, c8[j], k, merge, keys[j], cnts[j])) {
             flags |= 1u << j;
             ++m;
         }
@@ -429,21 +455,17 @@ int kmap_counts_prepare_bins(kmap_counts *c, int k, hipStream_t st) {
     return KMAP_OK;
 }
 
-// order-preserving compaction of the filled histogram (+ revcom merge) into the handle's uniq/cnt arrays
-int kmap_counts_finish_hist(kmap_counts *c, int k, int merge, int64_t *n_uniq, hipStream_t st) {
-    const size_t n_bins = (size_t)1 << (2 * k);
+// order-preserving compaction of the bins [first, first + n_bins) of the table into the handle's uniq/cnt arrays; merge: 0, 1 (partner
+// gathers over the WHOLE table: first must be 0), 2 (table merged in place beforehand)
+static int compact_range(kmap_counts *c, int k, int merge, uint64_t first, uint64_t n_bins, int64_t *n_uniq, hipStream_t st) {
     const unsigned nb = grid_for((int64_t)n_bins, CT_TILE);
     uint32_t *bc = nullptr;
     uint64_t *boff = nullptr;
     KMAP_TRY(kmap_scratch((void **)&bc, (size_t)nb * 4, st, KMAP_SLOT_A));
     KMAP_TRY(kmap_scratch((void **)&boff, ((size_t)nb + 1) * 8, st, KMAP_SLOT_B));
-    static const int tiles_on = [] { const char *e = getenv("KMAP_COUNT_RCTILES"); return e ? atoi(e) : 1; }();
-    if (merge == 1 && k >= 11 && tiles_on) {   // merge the table in place first; the compaction then needs no partner gathers
-        rc_merge_tiles_kernel<<<(unsigned)((size_t)1 << (2 * (k - 6))), BLK, 0, st>>>(c->bins, k);
-        merge = 2;
-    }
+    const uint32_t *bins = c->bins + first;
     const unsigned nblk = (nb + CT_TPB - 1) / CT_TPB;
-    compact_count_kernel<<<nblk, BLK, 0, st>>>(c->bins, n_bins, k, merge, bc, nb);
+    compact_count_kernel<<<nblk, BLK, 0, st>>>(bins, n_bins, k, merge, bc, nb, first);
     KMAP_TRY(exclusive_scan_u32(bc, nb, boff, st));
     uint64_t total = 0;
     KMAP_CHECK_HIP(hipMemcpyAsync(&total, boff + nb, 8, hipMemcpyDeviceToHost, st));
@@ -460,8 +482,8 @@ int kmap_counts_finish_hist(kmap_counts *c, int k, int merge, int64_t *n_uniq, h
         c->cap = cap;
     }
     if (total) {
-        if (k < 16) compact_write_kernel<uint32_t><<<nblk, BLK, 0, st>>>(c->bins, n_bins, k, merge, boff, (uint32_t *)c->uniq, c->cnt);
-        else compact_write_kernel<uint64_t><<<nblk, BLK, 0, st>>>(c->bins, n_bins, k, merge, boff, (uint64_t *)c->uniq, c->cnt);
+        if (k < 16) compact_write_kernel<uint32_t><<<nblk, BLK, 0, st>>>(bins, n_bins, k, merge, boff, (uint32_t *)c->uniq, c->cnt, first);
+        else compact_write_kernel<uint64_t><<<nblk, BLK, 0, st>>>(bins, n_bins, k, merge, boff, (uint64_t *)c->uniq, c->cnt, first);
     }
     KMAP_CHECK_HIP(hipGetLastError());
     c->k = k;
@@ -469,6 +491,16 @@ int kmap_counts_finish_hist(kmap_counts *c, int k, int merge, int64_t *n_uniq, h
     c->n_uniq = (int64_t)total;
     if (n_uniq) *n_uniq = (int64_t)total;
     return KMAP_OK;
+}
+
+// order-preserving compaction of the filled histogram (+ revcom merge) into the handle's uniq/cnt arrays
+int kmap_counts_finish_hist(kmap_counts *c, int k, int merge, int64_t *n_uniq, hipStream_t st) {
+    static const int tiles_on = [] { const char *e = getenv("KMAP_COUNT_RCTILES"); return e ? atoi(e) : 1; }();
+    if (merge == 1 && k >= 11 && tiles_on) {   // merge the table in place first; the compaction then needs no partner gathers
+        rc_merge_tiles_kernel<false><<<(unsigned)((size_t)1 << (2 * (k - 6))), BLK, 0, st>>>(c->bins, k, nullptr);
+        merge = 2;
+    }
+    return compact_range(c, k, merge, 0, (uint64_t)1 << (2 * k), n_uniq, st);
 }
 
 namespace {
@@ -586,6 +618,67 @@ int kmap_counts_load(kmap_counts *c, const void *uniq, const void *cnt, int64_t 
             free(tmp);
             KMAP_CHECK_HIP(e);
         }
+    }
+    c->k = k;
+    c->narrow = narrow;
+    c->n_uniq = n_uniq;
+    return KMAP_OK;
+}
+
+/* ---- key-range-sharded multi-GPU counting (11 <= k <= 16; the caller owns the collectives) -------------------------------------
+ * kmap_counts_hist_packed_dev (local table) -> [merge_revcom: kmap_counts_presence_dev -> SUM all-reduce of the nibbles ->
+ * kmap_counts_merge_presence_dev] -> reduce the table slice by slice to its owner (SUM) -> kmap_counts_finish_range on the own
+ * slice -> all-gather of the (uniq, cnt) shards -> kmap_counts_adopt_dev.  Against the all-reduce of the whole table every rank
+ * receives one slice instead of the table, plus half a byte per bin of presence. */
+int kmap_counts_presence_dev(kmap_counts *c, int k, void *nib_dev, void *stream) {
+    KMAP_REQUIRE(c && c->bins && nib_dev && k >= 2 && k <= 16 && c->bins_cap >= ((size_t)1 << (2 * k)), "counts_presence: no histogram for k=%d", k);
+    KMAP_TRY(kmap_counts_bins_check(c, "counts_presence"));
+    const uint64_t n_bins = (uint64_t)1 << (2 * k);
+    presence_nibbles_kernel<<<(unsigned)((n_bins / 8 + BLK - 1) / BLK), BLK, 0, as_stream(stream)>>>(c->bins, n_bins, (uint32_t *)nib_dev);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+int kmap_counts_merge_presence_dev(kmap_counts *c, int k, const void *nib_dev, void *stream) {
+    KMAP_REQUIRE(c && c->bins && nib_dev && k >= 11 && k <= 16 && c->bins_cap >= ((size_t)1 << (2 * k)),
+                 "counts_merge_presence: needs a histogram and 11 <= k <= 16 (k=%d)", k);
+    KMAP_TRY(kmap_counts_bins_check(c, "counts_merge_presence"));
+    rc_merge_tiles_kernel<true><<<(unsigned)((size_t)1 << (2 * (k - 6))), BLK, 0, as_stream(stream)>>>(c->bins, k, (const uint8_t *)nib_dev);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+int kmap_counts_finish_range(kmap_counts *c, int k, int merged, uint64_t first_bin, uint64_t n_bins, int64_t *n_uniq, void *stream) {
+    KMAP_REQUIRE(c && c->bins && k > 0 && k <= 16 && c->bins_cap >= ((size_t)1 << (2 * k)), "counts_finish_range: no histogram for k=%d", k);
+    KMAP_REQUIRE(first_bin + n_bins <= ((uint64_t)1 << (2 * k)) && first_bin % 8 == 0, "counts_finish_range: slice [%llu, +%llu) outside the table or not 8-aligned",
+                 (unsigned long long)first_bin, (unsigned long long)n_bins);
+    KMAP_TRY(kmap_counts_bins_check(c, "counts_finish_range"));
+    return compact_range(c, k, merged ? 2 : 0, first_bin, n_bins, n_uniq, as_stream(stream));
+}
+/* the handle's table <- device arrays (uint32 / uint64 keys as k < 16 / k >= 16, uint32 counts), copied */
+int kmap_counts_adopt_dev(kmap_counts *c, const void *uniq_dev, const void *cnt_dev, int64_t n_uniq, int k) {
+    KMAP_REQUIRE(c && k > 0 && k < 32 && n_uniq >= 0, "counts_adopt: bad arguments");
+    KMAP_REQUIRE(n_uniq == 0 || (uniq_dev && cnt_dev), "counts_adopt: null pointer");
+    const int narrow = (k < 16);
+    if (n_uniq && uniq_dev != c->uniq) {
+        void *u = nullptr;
+        uint32_t *q = nullptr;
+        KMAP_CHECK_HIP(hipMalloc(&u, (size_t)n_uniq * 8));
+        if (hipMalloc((void **)&q, (size_t)n_uniq * 4) != hipSuccess) {
+            (void)hipFree(u);
+            kmap_set_error("counts_adopt: hipMalloc(%zu) failed", (size_t)n_uniq * 4);
+            return KMAP_E_NOMEM;
+        }
+        hipError_t e = hipMemcpy(u, uniq_dev, (size_t)n_uniq * (narrow ? 4 : 8), hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipMemcpy(q, cnt_dev, (size_t)n_uniq * 4, hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(u);
+            (void)hipFree(q);
+            KMAP_CHECK_HIP(e);
+        }
+        if (c->uniq) KMAP_CHECK_HIP(hipFree(c->uniq));
+        if (c->cnt) KMAP_CHECK_HIP(hipFree(c->cnt));
+        c->uniq = u;
+        c->cnt = q;
+        c->cap = (size_t)n_uniq;
     }
     c->k = k;
     c->narrow = narrow;

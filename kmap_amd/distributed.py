@@ -357,11 +357,19 @@ def _gathered_hits_cls():
     return GatheredHits
 
 
-def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None):
+def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None, shard_counts=None):
     """A DeviceSeq holding only this rank's reads whose count()/scan() results are global:
     count = local histogram -> all-reduce(SUM) of the 4^k uint32 bins -> identical compaction on every rank
     (k <= 16; per-read dedupe, masking and scanning are local to a read, hence to a rank).  Because every rank then
     sees the same counts, find_motif(dev_seq=...) makes the same decisions everywhere without further exchange.
+    shard_counts (True / False force it for 11 <= k <= 16; None = for k >= 15 when the reads of all ranks hold fewer than 4^k / 4
+    windows): the bins are owned by key range instead -- every rank receives only the summed counts of ITS slice of the table (one
+    SUM-reduce per slice), compacts that slice, and the (k-mer, count) shards are all-gathered in rank = key order.  Per rank and
+    (G-1)/G: 4^k * 4 B of slices + 4^k B of presence + 12 B per distinct k-mer, against 4^k * 8 B for the all-reduce: it pays while
+    the distinct k-mers number fewer than a quarter of the bins (every rank wants the whole list; a find_motif that kept the
+    counts sharded would not pay the last term).  The reverse-complement merge pairs
+    bins of different slices: it runs BEFORE the reduction on each rank's local table, steered by an all-reduced presence map
+    (half a byte per bin) so that merged(sum over ranks) == sum over ranks(merged); see include/kmap_hip.h.
     scan() returns the hits of ALL reads (all-gathered in read order); `out_n_seq` / `out_read_len` describe the reads those
     results cover (all of them), `n_seq` / `read_len` stay the local shard the kernels run on.
     On RCCL the hit lists never pass through the host on their way to the collective: the shards are gathered as device
@@ -388,6 +396,7 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None):
     local_seq = np.ascontiguousarray(seq_np_arr[lo:hi])
     local_borders = borders[r0:r0 + nr] - lo
     reads_of = [read_partition(borders, world, r)[1] for r in range(world)]
+    n_all_positions = len(seq_np_arr)
     GatheredHits = _gathered_hits_cls() if on_dev else None
 
     class DistDeviceSeq(DeviceSeq):
@@ -417,11 +426,59 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None):
             p, nb = _ffi.vp(), _ffi.i64(0)
             check(_ffi.lib().kmap_counts_bins(dc._h, C.byref(p), C.byref(nb)))
             bins = torch.as_tensor(_DevArray(p.value, 4 ** k, "<i4"), device="cuda")   # int32 sum wraps like uint32
+            by_range = (k >= 15 and 4 * n_all_positions < 4 ** k) if shard_counts is None else bool(shard_counts)
+            if by_range and 11 <= k <= 16 and 1 < world <= 15:
+                return self._count_by_key_range(dc, k, merge_revcom, bins)
             dist.all_reduce(bins, op=dist.ReduceOp.SUM, group=group)      # stream-ordered after the histogram kernels
             nu = _ffi.i64(0)
             check(_ffi.lib().kmap_counts_finish(dc._h, k, int(merge_revcom), C.byref(nu), None))
             dc.k, dc.n_uniq = k, nu.value
             return dc.n_uniq
+
+        def _count_by_key_range(self, dc, k, merge_revcom, bins):
+            """bins: this rank's local 4^k table (device tensor view).  Every collective below works on device tensors (gloo
+            stages them through the host itself)."""
+            lib = _ffi.lib()
+            n_bins = 4 ** k
+            if merge_revcom:
+                nib = torch.empty(n_bins // 2, dtype=torch.uint8, device="cuda")
+                check(lib.kmap_counts_presence_dev(dc._h, k, nib.data_ptr(), None))
+                dist.all_reduce(nib, op=dist.ReduceOp.SUM, group=group)   # <= 15 ranks: a nibble cannot carry
+                check(lib.kmap_counts_merge_presence_dev(dc._h, k, nib.data_ptr(), None))
+                del nib
+            bounds = [(n_bins * r // world) & ~7 for r in range(world)] + [n_bins]
+            owner = [dist.get_global_rank(group, r) if group is not None else r for r in range(world)]
+            works = [dist.reduce(bins[bounds[r]:bounds[r + 1]], dst=owner[r], op=dist.ReduceOp.SUM, group=group, async_op=True)
+                     for r in range(world)]
+            for w in works:
+                w.wait()
+            nu = _ffi.i64(0)
+            check(lib.kmap_counts_finish_range(dc._h, k, int(bool(merge_revcom)), bounds[rank], bounds[rank + 1] - bounds[rank],
+                                               C.byref(nu), None))
+            # the shards, concatenated in rank order, are the table every rank would have compacted from the all-reduced bins
+            sizes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
+            dist.all_gather(sizes, torch.tensor([nu.value], dtype=torch.int64, device="cuda"), group=group)
+            sizes = [int(t.item()) for t in sizes]
+            cap = max(max(sizes), 1)
+            up, cp, n_mine = _ffi.vp(), _ffi.vp(), _ffi.i64(0)
+            check(lib.kmap_counts_table_dev(dc._h, C.byref(up), C.byref(cp), C.byref(n_mine)))
+            kt, kdt = ("<i4", torch.int32) if k < 16 else ("<i8", torch.int64)
+            mine_u = torch.zeros(cap, dtype=kdt, device="cuda")
+            mine_c = torch.zeros(cap, dtype=torch.int32, device="cuda")
+            if nu.value:
+                mine_u[:nu.value].copy_(torch.as_tensor(_DevArray(up.value, nu.value, kt), device="cuda"))
+                mine_c[:nu.value].copy_(torch.as_tensor(_DevArray(cp.value, nu.value, "<i4"), device="cuda"))
+            parts_u = [torch.empty_like(mine_u) for _ in range(world)]
+            parts_c = [torch.empty_like(mine_c) for _ in range(world)]
+            dist.all_gather(parts_u, mine_u, group=group)
+            dist.all_gather(parts_c, mine_c, group=group)
+            all_u = torch.cat([parts_u[r][:sizes[r]] for r in range(world)]).contiguous()
+            all_c = torch.cat([parts_c[r][:sizes[r]] for r in range(world)]).contiguous()
+            total = int(all_u.numel())
+            torch.cuda.current_stream().synchronize()                     # adopt copies on the null stream's side of the library
+            check(lib.kmap_counts_adopt_dev(dc._h, all_u.data_ptr() if total else None, all_c.data_ptr() if total else None, total, k))
+            dc.k, dc.n_uniq = k, total
+            return total
 
         def _scan_gathered(self, k, consensus_kh, radius, revcom):
             """local scan -> device gather of the shards -> GatheredHits (RCCL only)"""

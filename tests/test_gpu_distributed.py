@@ -96,6 +96,65 @@ def _count_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _range_inputs():
+    from kmap_amd import synth
+    seq, borders = synth.synth_reads(20011, 75, 9)
+    for r in range(0, len(borders), 41):                     # palindromic repeats (rc(ACGTACGTACGT) = itself), poly-A / poly-T pairs
+        st, en = borders[r]
+        seq[st:en] = np.resize(np.array([0, 1, 2, 3], np.uint8), en - st) if r % 3 == 0 else (0 if r % 3 == 1 else 3)
+    return seq, borders
+
+
+def _range_count_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import pickle
+    import torch
+    import torch.distributed as dist
+    from kmap_amd.distributed import make_dist_device_seq
+    from kmap_amd.kmer_count import DeviceCounts
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seq, borders = _range_inputs()
+        ds = make_dist_device_seq(seq, borders, dist, shard_counts=True)
+        dc = DeviceCounts()
+        out = {}
+        for k in (11, 12, 15):
+            for dedupe in (True, False):
+                for merge in (True, False):
+                    ds.count(dc, k, dedupe=dedupe, merge_revcom=merge)
+                    out[(k, dedupe, merge)] = dc.fetch()
+        out["top"] = dc.topk(5)                               # the adopted table serves the handle's other queries
+        with open(Path(out_dir) / f"range_rank{rank}.pkl", "wb") as fh:
+            pickle.dump(out, fh)
+        dc.close()
+        ds.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_key_range_sharded_counting_three_ranks(tmp_path):
+    """Bins owned by key range (three ranks: unequal slices): local table -> all-reduced presence nibbles -> local revcom merge ->
+    one SUM-reduce per slice -> compaction of the own slice -> all-gather of the shards == the single-process count (oracle),
+    arrays and dtypes, with and without per-read dedupe and revcom merge, k = 11 / 12 (palindromes) / 15 (4-GiB table)."""
+    import pickle
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    mp.spawn(_range_count_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    res = [pickle.load(open(tmp_path / f"range_rank{r}.pkl", "rb")) for r in range(3)]
+    seq, borders = _range_inputs()
+    for k in (11, 12, 15):
+        for dedupe in (True, False):
+            for merge in (True, False):
+                ou, oc = O.count_kmers(seq, borders, k, rep_mode=not dedupe, revcom_mode=merge)
+                for r in res:
+                    u, c = r[(k, dedupe, merge)]
+                    np.testing.assert_array_equal(u, ou)
+                    np.testing.assert_array_equal(c, oc)
+                    assert u.dtype == ou.dtype and c.dtype == oc.dtype
+    assert res[0]["top"][0].tolist() == res[1]["top"][0].tolist() == res[2]["top"][0].tolist()
+
+
 def test_read_sharded_counting_scan_and_find_motif(tmp_path):
     """Reads sharded over two ranks (histogram all-reduce): counts, scan hits and find_motif decisions equal the
     single-GPU run and the CPU oracle."""
