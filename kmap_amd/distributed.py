@@ -427,7 +427,7 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None, shard_counts
             check(_ffi.lib().kmap_counts_bins(dc._h, C.byref(p), C.byref(nb)))
             bins = torch.as_tensor(_DevArray(p.value, 4 ** k, "<i4"), device="cuda")   # int32 sum wraps like uint32
             by_range = (k >= 15 and 4 * n_all_positions < 4 ** k) if shard_counts is None else bool(shard_counts)
-            if by_range and 11 <= k <= 16 and 1 < world <= 15:
+            if by_range and 11 <= k <= 16 and world <= 15 and (world > 1 or shard_counts):   # one rank: only when forced (tests)
                 return self._count_by_key_range(dc, k, merge_revcom, bins)
             dist.all_reduce(bins, op=dist.ReduceOp.SUM, group=group)      # stream-ordered after the histogram kernels
             nu = _ffi.i64(0)

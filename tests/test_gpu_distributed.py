@@ -412,6 +412,12 @@ def _nccl_worker(rank, world, port, out_dir):
         dc = DeviceCounts()
         ds.count(dc, 9, dedupe=True, merge_revcom=True)
         out["counts"] = dc.fetch()
+        # bins owned by key range on RCCL: uint8 SUM all-reduce of the presence nibbles, in-place reduce of table slices that
+        # live in library-owned memory, all_gather of the shards, adopt
+        ds_r = make_dist_device_seq(seq, borders, dist, shard_counts=True)
+        ds_r.count(dc, 12, dedupe=True, merge_revcom=True)
+        out["counts_range"] = dc.fetch()
+        ds_r.close()
         out["scan"] = ds.scan(8, kmer2hash("ATCGATAG"), 2, True)
         # the device-gathered hit list (GatheredHits) through the background CSV writer, fetched on the writer's thread
         from kmap_amd.kmer_count import _pkg_file, init_motif_def_dict
@@ -458,6 +464,10 @@ def test_rccl_backend_single_rank(tmp_path):
     u, c = dc.fetch()
     np.testing.assert_array_equal(got["counts"][0], u)
     np.testing.assert_array_equal(got["counts"][1], c)
+    ds.count(dc, 12, dedupe=True, merge_revcom=True)
+    u, c = dc.fetch()
+    np.testing.assert_array_equal(got["counts_range"][0], u)
+    np.testing.assert_array_equal(got["counts_range"][1], c)
     hits, pos = ds.scan(8, kmer2hash("ATCGATAG"), 2, True)
     np.testing.assert_array_equal(got["scan"][0], hits)
     np.testing.assert_array_equal(got["scan"][1], pos)
