@@ -342,10 +342,12 @@ def test_seq_forces_bit_exact_vs_oracle(V, scale):
 
 
 @pytest.mark.parametrize("n,k,lens", [(700, 8, [8, 8]), (1003, 8, [8, 6, 5]), (900, 12, [12, 7]), (1200, 16, [16, 9, 16, 4]),
-                                      (513, 5, [5, 3]), (600, 11, [11])])
+                                      (513, 5, [5, 3]), (600, 11, [11]), (640, 16, [16, 3]), (700, 8, [8, 1, 7])])
 def test_knn_sums_from_kmers_equals_matrix_sums(V, n, k, lens):
     """neighbour sums from base-count profiles (no matrix read) == the sums gathered from the Hamming matrix, incl. the
-    short-consensus prefix rule, uint32 / uint64 hashes, row blocks; unsupported requests fall back (None)."""
+    short-consensus prefix rule, uint32 / uint64 hashes, row blocks; unsupported requests fall back (None).  The matrix-core
+    kernel (v_mfma_i32_32x32x32_i8) takes every shape whose short consensuses leave it `tail` free byte slots (tail <= 4 clen);
+    (16, [16, 3]) and (8, [8, 1, 7]) do not and run the v_dot4 kernel."""
     from kmap_amd import _ffi
     from kmap_amd.hamdist import hamdist_matrix_dev, pitch_for
     from kmap_amd.kmer_count import get_hash_dtype
