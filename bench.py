@@ -510,6 +510,39 @@ def fill_rate(nbytes, reps=7):
             "what": "hipMemsetAsync of the same byte count, HIP events, same stream, same run"}
 
 
+class LegGuard:
+    """Deadline per optional multi-GPU leg: on expiry rank 0 writes the JSON line as it stands (+ "watchdog") and every rank leaves
+    with os._exit(0) -- a collective that never completes cannot be cancelled from Python, but the measured headline must get out."""
+
+    def __init__(self, active, rank, fd, line, limit_s):
+        self.active, self.rank, self.fd, self.line, self.limit = active, rank, fd, line, limit_s
+        self.timer, self.name = None, None
+
+    def _fire(self):
+        if self.rank == 0 and self.line is not None:
+            self.line["watchdog"] = f"leg '{self.name}' did not return within {self.limit:.0f} s; later legs skipped, process ended by the watchdog"
+            try:
+                os.write(self.fd, (json.dumps(self.line, default=str) + "\n").encode())
+            except Exception:   # noqa: BLE001
+                pass
+        os._exit(0)
+
+    def leg(self, name):
+        import threading
+        self.done()
+        if not self.active:
+            return
+        self.name = name
+        self.timer = threading.Timer(self.limit, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def done(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -518,6 +551,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-embed-dist", action="store_true", help="skip the sharded-embedding leg")
     ap.add_argument("--no-c4", action="store_true", help="skip the N = 200 000 strong-scaling leg")
+    ap.add_argument("--leg-limit", type=float, default=300.0, help="seconds an optional multi-GPU leg may take before the watchdog prints the line and ends the run")
     ap.add_argument("--no-count-dist", action="store_true", help="skip the multi-GPU counting leg (k = 15: all-reduce vs key-range shards)")
     ap.add_argument("--no-c5", action="store_true", help="skip the full-size C5 scan leg (N=1 only)")
     ap.add_argument("--quick", action="store_true", help="smaller CPU-baseline samples (rehearsals)")
@@ -625,42 +659,7 @@ def main():
 
     fill = fill_rate(max(nrows, 1) * ld) if rank == 0 else None
 
-    embed_dist = None
-    if not args.no_embed_dist:
-        own_group = False
-        try:
-            if dist is None:        # one GPU: the sharded loop runs on a one-rank RCCL group, so its overhead is a number in the line
-                import socket
-                import torch.distributed as dist1
-                with socket.socket() as sk:
-                    sk.bind(("127.0.0.1", 0))
-                    port = sk.getsockname()[1]
-                dist1.init_process_group("nccl" if backend == "nccl" else backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
-                                         **({"device_id": torch.device("cuda", dev)} if backend == "nccl" else {}))
-                own_group = True
-                embed_dist = embed_dist_leg(dist1, torch, 1, *c3s)
-            else:
-                embed_dist = embed_dist_leg(dist, torch, world, *c3s)
-        except Exception as e:   # noqa: BLE001 -- reported, the headline is already measured
-            embed_dist = {"error": f"{type(e).__name__}: {e}"[:300]}
-        finally:
-            if own_group:
-                try:
-                    dist1.destroy_process_group()
-                except Exception:   # noqa: BLE001
-                    pass
-    count_dist = None
-    if dist is not None and not args.no_count_dist:
-        _ffi.check(_ffi.lib().kmap_scratch_release(1 << 30))
-        count_dist = count_dist_leg(dist, torch, world)
-        _ffi.check(_ffi.lib().kmap_scratch_release(1 << 30))
-    c4 = None
-    if not args.no_c4:
-        if dist is not None:
-            box = [res_dir]
-            dist.broadcast_object_list(box, 0)
-        c4 = c4_leg(dist, torch, res_dir, rank, world, barrier)
-
+    line = None
     if rank == 0:
         pairs_total = float(n) * float(n)
         algo_bytes = nrows * n + 5 * n          # u8 out + u32 hashes + u8 group ids, per launch on this rank
@@ -696,12 +695,57 @@ def main():
                 line["roofline"]["traffic_source"] = f"profiles/{pmc[-1].name}"
             except Exception:
                 pass
-        if embed_dist is not None:
+    # ---- the optional legs (all ranks take part).  The headline above is measured and in `line`: if a leg's collective never
+    # returns on some node, the watchdog lets rank 0 print the line with what has finished and ends every rank, instead of the
+    # whole run -- headline included -- dying at the launcher's limit
+    guard = LegGuard(world > 1, rank, json_fd, line, args.leg_limit)
+    embed_dist = None
+    if not args.no_embed_dist:
+        own_group = False
+        try:
+            if dist is None:        # one GPU: the sharded loop runs on a one-rank RCCL group, so its overhead is a number in the line
+                import socket
+                import torch.distributed as dist1
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    port = sk.getsockname()[1]
+                dist1.init_process_group("nccl" if backend == "nccl" else backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                         **({"device_id": torch.device("cuda", dev)} if backend == "nccl" else {}))
+                own_group = True
+                embed_dist = embed_dist_leg(dist1, torch, 1, *c3s)
+            else:
+                guard.leg("embed_dist")
+                embed_dist = embed_dist_leg(dist, torch, world, *c3s)
+        except Exception as e:   # noqa: BLE001 -- reported, the headline is already measured
+            embed_dist = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            if own_group:
+                try:
+                    dist1.destroy_process_group()
+                except Exception:   # noqa: BLE001
+                    pass
+        if line is not None:
             line["embed_dist"] = embed_dist
-        if count_dist is not None:
+    count_dist = None
+    if dist is not None and not args.no_count_dist:
+        _ffi.check(_ffi.lib().kmap_scratch_release(1 << 30))
+        guard.leg("count_dist")
+        count_dist = count_dist_leg(dist, torch, world)
+        _ffi.check(_ffi.lib().kmap_scratch_release(1 << 30))
+        if line is not None:
             line["count_dist"] = count_dist
-        if c4 is not None:
+    c4 = None
+    if not args.no_c4:
+        guard.leg("c4")
+        if dist is not None:
+            box = [res_dir]
+            dist.broadcast_object_list(box, 0)
+        c4 = c4_leg(dist, torch, res_dir, rank, world, barrier)
+        if line is not None:
             line["c4"] = c4
+
+    guard.done()
+    if rank == 0:
         if world == 1 and not args.no_stages:
             line["roofline"]["stages"] = stage_rooflines(reads, kh, lab, lens)
         kh_d.free()
