@@ -47,7 +47,8 @@ __device__ __forceinline__ void tile_keys(const uint32_t *__restrict__ h, const 
     }
 }
 
-// (1) valid keys per (class, bucket): gcount[class * NB + bucket].  The grid is a multiple of 8, so all tiles of a block share
+// (1) valid keys per (class, bucket): gcount[class * NB + bucket].  (Measured: a bucket-only extraction -- five instead of eleven
+// vector instructions per window, byte offsets straight into the counters -- 0.48 against 0.43 ms: the pass sits at the LDS atomic rate.)  The grid is a multiple of 8, so all tiles of a block share
 // their class (tile = blockIdx + i * gridDim).
 template <bool PACKED, int GPT>
 __global__ __launch_bounds__(FS_TPB) void fine_count_kernel(const uint32_t *__restrict__ h, const uint16_t *__restrict__ inval,

@@ -13,6 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e2e_trace -- python
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/embed_trace -- python3 $R/tools/bench_embed.py --n 50000 --iters 20 > $OUT/embed_trace.txt 2> $OUT/embed_trace.err
 # (the full-size C5 scan is part of bench_trace: bench.py's c5 leg generates its 50 M x 300 bp reads in HBM)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scan_trace -- python3 $R/tools/bench_scan.py --reads 10000000 --read_len 150 --k 8 --radius 2 --reps 5 > $OUT/scan_trace.json 2> $OUT/scan_trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/count_trace -- python3 $R/tools/probes/count_only.py 14 5 0 > $OUT/count_trace.txt 2> $OUT/count_trace.err
 # counters for every kernel DESIGN.md calls "bound by ..." (C3 pipeline + SEQ micro-benchmark, four PMC passes)
 bash $R/tools/pmc_round.sh round > $OUT/pmc_round.log 2>&1 || true
 python3 $R/tools/pmc_summary.py $R/gpurun_out/pmc_round $OUT/pmc_summary.json > $OUT/pmc_summary.txt 2>&1 || true
