@@ -1679,6 +1679,15 @@ void seq_split(kmap_embed *e) {
         const double cost = rounds(waves) * (30.0 / g + 1.2);
         if (cost < best) { best = cost; best_g = g; }
     }
+    if (main_rows == 0) {
+        // fewer rows than one round of quad waves (N < 16 384 on this part): the waves are dependent-add chains, not issue slots, and
+        // whole-round counting misjudges 1.2 waves per SIMD as two rounds.  Measured (tools/bench_embed.py --modes seq, ms per
+        // iteration, g = quad / 8 / 16 / 32 / 64): N = 1000: .036 .035 .026 .022 .021; 3000: .085 .073 .049 .051 .060;
+        // 5000: .138 .115 .105 .105 .133; 8000: .214 .174 .155 .199 .307; 10 000: .265 .293 .249 .297 .462; 14 000: .372 .412 .429 ...
+        best_g = rem <= 1500 ? 64 : rem <= 2500 ? 32 : rem <= 12000 ? 16 : 0;
+    }
+    static const int force_g = [] { const char *v = getenv("KMAP_SEQ_G"); return v ? atoi(v) : -1; }();   // measurements: 0 = quad, 8 .. 64
+    if (force_g >= 0) best_g = force_g;
     if (best_g) {
         e->seq_main_rows = main_rows;
         e->seq_tail_g = best_g;
