@@ -1234,6 +1234,85 @@ __device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *_
 // alone for a full millisecond (N = 49 152: 3.00 ms, N = 49 216: 3.98 ms).  As 848 one-row waves they take ~0.16 ms.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // wide form, block `bid` of the local rows [lrow0, nrows); xch_all: SQ_WAVES x 64 x 8 (t dx, t dy) pairs of LDS
+// acc + (value of `v` in lane K of the caller's 16-lane DPP row), valid in lane 0 of the row: row_ror:(16 - K) makes lane L read lane
+// (L + K) mod 16.
+template <int K>
+__device__ __forceinline__ float add_row16_lane(float acc, float v) {
+    float r;
+    if constexpr (K == 0) { r = acc + v; return r; }
+#define KMAP_ROR(KK, N) if constexpr (K == KK) asm("v_add_f32_dpp %0, %1, %2 row_ror:" #N " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "v"(acc));
+    KMAP_ROR(1, 15) KMAP_ROR(2, 14) KMAP_ROR(3, 13) KMAP_ROR(4, 12) KMAP_ROR(5, 11) KMAP_ROR(6, 10) KMAP_ROR(7, 9) KMAP_ROR(8, 8)
+    KMAP_ROR(9, 7) KMAP_ROR(10, 6) KMAP_ROR(11, 5) KMAP_ROR(12, 4) KMAP_ROR(13, 3) KMAP_ROR(14, 2) KMAP_ROR(15, 1)
+#undef KMAP_ROR
+    return r;
+}
+// Sixteen lanes per row (one DPP row), four rows per wave, no LDS: for sessions with fewer rows than one round of quad waves, where
+// a wave is a chain of dependent adds and not a share of issue slots.  Lane s of a row computes the terms of columns
+// j0 + 8 s .. + 7 of a 128-column batch; lane 0 of the row adds them in column order through row_ror sources (the other lanes
+// execute the same adds on rotated operands and are ignored).  The x and y chains alternate, so consecutive adds of one chain are
+// two instructions apart -- their latency -- and nothing waits for an LDS round trip as in the strip-exchange form.
+constexpr int SR_SUB = 16, SR_ROWS = KMAP_WAVE / SR_SUB, SR_BATCH = SR_SUB * SQ_CPL;
+template <bool LUTSRC>
+__device__ __forceinline__ void seq_row16_body(const ProbSrc &src, const float *__restrict__ Y, int64_t n, int64_t row0, int64_t lrow0,
+                                               int64_t nrows, float *__restrict__ G, double *__restrict__ loss_part, int64_t bid,
+                                               const float *__restrict__ lut_s, double *wl) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & (SR_SUB - 1);
+    const int64_t wave_lr = lrow0 + (bid * SQ_WAVES + wave) * SR_ROWS;    // first local row of the wave
+    const int64_t lr = wave_lr + (lane / SR_SUB);
+    const bool valid = lr < nrows;
+    const int64_t lrc = valid ? lr : nrows - 1;
+    const int64_t i = row0 + lrc;
+    const float *X = Y, *Yy = Y + n;
+    const float xi = X[i], yi = Yy[i];
+    const bool vec = ((n & 3) == 0) && (!LUTSRC || (src.ld % 8 == 0));
+    const int i32 = (int)i;
+    const int64_t wave_row_min = row0 + wave_lr;
+    float gx = 0.0f, gy = 0.0f, ce_acc = 0.0f;
+    double loss = 0.0;
+    // (computing the terms of batch b + 1 in the same loop body as the adds of batch b -- a software pipeline for the scheduler to
+    // interleave -- measured slower: 0.066 vs 0.058 ms at N = 4000)
+    SeqBatch cur, nxt;
+    seq_load<LUTSRC>(cur, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n, vec);
+    for (int64_t j0 = 0; j0 < n; j0 += SR_BATCH) {
+        const int64_t jl = j0 + (int64_t)sub * SQ_CPL;
+        if (j0 + SR_BATCH < n) seq_load<LUTSRC>(nxt, src, X, Yy, lrc, jl + SR_BATCH, n, vec);   // prefetch
+        float tx[SQ_CPL], ty[SQ_CPL];
+        float ce2;
+        seq_terms_dispatch<LUTSRC>(cur, lut_s, xi, yi, i32, n, j0, SR_BATCH, wave_row_min, SR_ROWS, (int)jl, tx, ty, ce2);
+        ce_acc += ce2;
+        asm volatile("s_nop 1");
+#define SEQ_ADD16(K)                                                                                  \
+        _Pragma("unroll") for (int c = 0; c < SQ_CPL; ++c) {                                          \
+            gx = add_row16_lane<K>(gx, tx[c]);                                                        \
+            gy = add_row16_lane<K>(gy, ty[c]);                                                        \
+        }
+        SEQ_ADD16(0) SEQ_ADD16(1) SEQ_ADD16(2) SEQ_ADD16(3) SEQ_ADD16(4) SEQ_ADD16(5) SEQ_ADD16(6) SEQ_ADD16(7)
+        SEQ_ADD16(8) SEQ_ADD16(9) SEQ_ADD16(10) SEQ_ADD16(11) SEQ_ADD16(12) SEQ_ADD16(13) SEQ_ADD16(14) SEQ_ADD16(15)
+#undef SEQ_ADD16
+        if (((j0 / SR_BATCH) & 7) == 7) {
+            loss += (double)ce_acc;
+            ce_acc = 0.0f;
+        }
+        cur = nxt;
+    }
+    loss += (double)ce_acc;
+    loss *= -0.6931471805599453;   // log2 units -> -ln
+    if (valid && sub == 0) {
+        G[i] = gx;
+        G[n + i] = gy;
+    }
+    if (!valid) loss = 0.0;
+    for (int o = 32; o > 0; o >>= 1) loss += __shfl_down(loss, o);
+    if (lane == 0) wl[wave] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < SQ_WAVES; ++w) t += wl[w];
+        loss_part[bid] = t;
+    }
+}
+
 template <bool LUTSRC, int GW>
 __device__ __forceinline__ void seq_wide_body(const ProbSrc &src, const float *__restrict__ Y, int64_t n, int64_t row0, int64_t lrow0,
                                               int64_t nrows, float *__restrict__ G, double *__restrict__ loss_part, int64_t bid,
@@ -1326,8 +1405,11 @@ __global__ __launch_bounds__(KMAP_WAVE *SQ_WAVES) void forces_seq_kernel(ProbSrc
     __shared__ double wl[SQ_WAVES];
     if constexpr (GW != 0) {
         if ((int)blockIdx.x < nb_tail) {   // block-uniform
-            seq_wide_body<LUTSRC, GW>(src, Y, n, row0, main_rows, nrows, G, loss_part + nb_main, (int64_t)blockIdx.x, lut_s, wl,
-                                      reinterpret_cast<f32x2 *>(smem));
+            if constexpr (GW == 16)   // one DPP row per matrix row: no exchange through LDS
+                seq_row16_body<LUTSRC>(src, Y, n, row0, main_rows, nrows, G, loss_part + nb_main, (int64_t)blockIdx.x, lut_s, wl);
+            else
+                seq_wide_body<LUTSRC, GW>(src, Y, n, row0, main_rows, nrows, G, loss_part + nb_main, (int64_t)blockIdx.x, lut_s, wl,
+                                          reinterpret_cast<f32x2 *>(smem));
             return;
         }
     }
