@@ -1062,6 +1062,27 @@ __device__ __forceinline__ float add_quad_bcast(float acc, float v) {
     if constexpr (S == 3) asm("v_add_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "v"(acc));
     return r;
 }
+// the eight columns of quad lane S, x and y chains alternating, as ONE asm statement: between single-instruction asm statements the
+// compiler puts an s_nop behind every other pair of adds (24 per 64-add batch; it guards the accumulator, written two instructions
+// earlier, as if it were the DPP source -- only src0 goes through the DPP network, and the terms are written long before)
+template <int S>
+__device__ __forceinline__ void add_quad_block(float &gx, float &gy, const float (&tx)[8], const float (&ty)[8]) {
+#define KMAP_QP8(SS, P)                                                                                                            \
+    if constexpr (S == SS)                                                                                                        \
+        asm("v_add_f32_dpp %0, %2, %0 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %10, %1 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %3, %0 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %11, %1 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %4, %0 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %12, %1 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %5, %0 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %13, %1 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %6, %0 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %14, %1 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %7, %0 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %15, %1 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %8, %0 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %16, %1 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %9, %0 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %17, %1 quad_perm:" P " row_mask:0xf bank_mask:0xf"        \
+            : "+v"(gx), "+v"(gy)                                                                                                  \
+            : "v"(tx[0]), "v"(tx[1]), "v"(tx[2]), "v"(tx[3]), "v"(tx[4]), "v"(tx[5]), "v"(tx[6]), "v"(tx[7]), "v"(ty[0]), "v"(ty[1]), "v"(ty[2]),  \
+              "v"(ty[3]), "v"(ty[4]), "v"(ty[5]), "v"(ty[6]), "v"(ty[7]));
+    KMAP_QP8(0, "[0,0,0,0]") KMAP_QP8(1, "[1,1,1,1]") KMAP_QP8(2, "[2,2,2,2]") KMAP_QP8(3, "[3,3,3,3]")
+#undef KMAP_QP8
+}
 constexpr int SQ_CPL = 8;                       // consecutive columns per lane per batch (one 16-byte load of u16 sums)
 constexpr int SQ_BATCH = SQ_SUB * SQ_CPL;       // 32 columns per quad per batch
 
@@ -1195,13 +1216,10 @@ __device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *_
         ce_acc += ce2;
         // ordered accumulation over the batch's 32 columns: column j0 + 8*s2 + c lives in sub-lane s2, slot c
         asm volatile("s_nop 1");
-#define SEQ_ADD(S2)                                                                                   \
-        _Pragma("unroll") for (int c = 0; c < SQ_CPL; ++c) {                                          \
-            gx = add_quad_bcast<S2>(gx, tx[c]);                                                       \
-            gy = add_quad_bcast<S2>(gy, ty[c]);                                                       \
-        }
-        SEQ_ADD(0) SEQ_ADD(1) SEQ_ADD(2) SEQ_ADD(3)
-#undef SEQ_ADD
+        add_quad_block<0>(gx, gy, tx, ty);
+        add_quad_block<1>(gx, gy, tx, ty);
+        add_quad_block<2>(gx, gy, tx, ty);
+        add_quad_block<3>(gx, gy, tx, ty);
         if (((j0 / SQ_BATCH) & 7) == 7) {
             loss += (double)ce_acc;
             ce_acc = 0.0f;
@@ -1246,6 +1264,29 @@ __device__ __forceinline__ float add_row16_lane(float acc, float v) {
 #undef KMAP_ROR
     return r;
 }
+// the eight columns of source lane K (K >= 1) of a batch, x and y chains alternating, as ONE asm statement: left to itself the
+// compiler puts an s_nop behind every pair of these adds (it treats the accumulator, written two instructions earlier, as if it
+// were the DPP source: 112 s_nop for the 240 adds of a batch).  Only src0 goes through the DPP network, and tx / ty are written
+// long before.
+template <int K>
+__device__ __forceinline__ void add_row16_block(float &gx, float &gy, const float (&tx)[SQ_CPL], const float (&ty)[SQ_CPL]) {
+#define KMAP_ROR8(KK, N)                                                                                                          \
+    if constexpr (K == KK)                                                                                                        \
+        asm("v_add_f32_dpp %0, %2, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %10, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %3, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %11, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %4, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %12, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %5, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %13, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %6, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %14, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %7, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %15, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %8, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %16, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %9, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %17, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf"        \
+            : "+v"(gx), "+v"(gy)                                                                                                  \
+            : "v"(tx[0]), "v"(tx[1]), "v"(tx[2]), "v"(tx[3]), "v"(tx[4]), "v"(tx[5]), "v"(tx[6]), "v"(tx[7]), "v"(ty[0]), "v"(ty[1]), "v"(ty[2]),  \
+              "v"(ty[3]), "v"(ty[4]), "v"(ty[5]), "v"(ty[6]), "v"(ty[7]));
+    KMAP_ROR8(1, 15) KMAP_ROR8(2, 14) KMAP_ROR8(3, 13) KMAP_ROR8(4, 12) KMAP_ROR8(5, 11) KMAP_ROR8(6, 10) KMAP_ROR8(7, 9) KMAP_ROR8(8, 8)
+    KMAP_ROR8(9, 7) KMAP_ROR8(10, 6) KMAP_ROR8(11, 5) KMAP_ROR8(12, 4) KMAP_ROR8(13, 3) KMAP_ROR8(14, 2) KMAP_ROR8(15, 1)
+#undef KMAP_ROR8
+}
 // Sixteen lanes per row (one DPP row), four rows per wave, no LDS: for sessions with fewer rows than one round of quad waves, where
 // a wave is a chain of dependent adds and not a share of issue slots.  Lane s of a row computes the terms of columns
 // j0 + 8 s .. + 7 of a 128-column batch; lane 0 of the row adds them in column order through row_ror sources (the other lanes
@@ -1287,9 +1328,13 @@ __device__ __forceinline__ void seq_row16_body(const ProbSrc &src, const float *
             gx = add_row16_lane<K>(gx, tx[c]);                                                        \
             gy = add_row16_lane<K>(gy, ty[c]);                                                        \
         }
-        SEQ_ADD16(0) SEQ_ADD16(1) SEQ_ADD16(2) SEQ_ADD16(3) SEQ_ADD16(4) SEQ_ADD16(5) SEQ_ADD16(6) SEQ_ADD16(7)
-        SEQ_ADD16(8) SEQ_ADD16(9) SEQ_ADD16(10) SEQ_ADD16(11) SEQ_ADD16(12) SEQ_ADD16(13) SEQ_ADD16(14) SEQ_ADD16(15)
+        SEQ_ADD16(0)
 #undef SEQ_ADD16
+        add_row16_block<1>(gx, gy, tx, ty); add_row16_block<2>(gx, gy, tx, ty); add_row16_block<3>(gx, gy, tx, ty);
+        add_row16_block<4>(gx, gy, tx, ty); add_row16_block<5>(gx, gy, tx, ty); add_row16_block<6>(gx, gy, tx, ty);
+        add_row16_block<7>(gx, gy, tx, ty); add_row16_block<8>(gx, gy, tx, ty); add_row16_block<9>(gx, gy, tx, ty);
+        add_row16_block<10>(gx, gy, tx, ty); add_row16_block<11>(gx, gy, tx, ty); add_row16_block<12>(gx, gy, tx, ty);
+        add_row16_block<13>(gx, gy, tx, ty); add_row16_block<14>(gx, gy, tx, ty); add_row16_block<15>(gx, gy, tx, ty);
         if (((j0 / SR_BATCH) & 7) == 7) {
             loss += (double)ce_acc;
             ce_acc = 0.0f;
