@@ -265,21 +265,34 @@ __device__ __forceinline__ void hr_count(const HrCtx &c, HrRead &r) {
             uint32_t xs[HR_CHUNK];                                          // the chunk's words in ONE round trip, not one per word
 #pragma unroll
             for (int t = 0; t < HR_CHUNK; ++t) xs[t] = hw[min(j0 + t, nw - 1)];
+            // ONE loop over the chunk's hits (three 64-bit words, earliest position in the top bit): a wave runs it as often as its
+            // busiest read has hits.  One loop per 32-bit word ran each of the six as often as ITS busiest lane had hits -- about
+            // twice the divergent iterations, each with the round trip of hr_dist's code loads inside.
+            uint64_t q[HR_CHUNK / 2];
 #pragma unroll
             for (int t = 0; t < HR_CHUNK; ++t) {
                 const int j = j0 + t;
-                if (j >= nw) break;
-                uint32_t x = xs[t];
+                uint32_t x = j < nw ? xs[t] : 0u;
                 if (j == 0) x &= ~0u >> a_off;
                 if (j == nw - 1) x &= ~0u << (32 * nw - end);
-                while (x) {
-                    const int tb = 31 - __builtin_clz(x);
-                    x &= ~(1u << tb);
-                    const int d = hr_dist<CHECK_INVALID>(c.codes, c.inval, word0 + (32 * j + 31 - tb), c.k, c.km, c.cons, c.rcc, c.revcom);
-                    if (d < r.best) { r.mixed = r.mixed || r.count > 0; r.best = d; r.count = 1; }
-                    else if (d == r.best) ++r.count;
-                    else r.mixed = true;
-                }
+                if (t & 1) q[t >> 1] |= x;
+                else q[t >> 1] = (uint64_t)x << 32;
+            }
+            static_assert(HR_CHUNK == 6, "three 64-bit words");
+            for (;;) {
+                const int sel = q[0] ? 0 : (q[1] ? 1 : 2);
+                const uint64_t cur = q[0] ? q[0] : (q[1] ? q[1] : q[2]);
+                if (!cur) break;
+                const int tb = 63 - __builtin_clzll(cur);
+                const uint64_t clr = ~(1ull << tb);
+                q[0] &= sel == 0 ? clr : ~0ull;
+                q[1] &= sel == 1 ? clr : ~0ull;
+                q[2] &= sel == 2 ? clr : ~0ull;
+                const int rel = 32 * j0 + 64 * sel + 63 - tb;
+                const int d = hr_dist<CHECK_INVALID>(c.codes, c.inval, word0 + rel, c.k, c.km, c.cons, c.rcc, c.revcom);
+                if (d < r.best) { r.mixed = r.mixed || r.count > 0; r.best = d; r.count = 1; }
+                else if (d == r.best) ++r.count;
+                else r.mixed = true;
             }
         }
     }
@@ -338,21 +351,29 @@ __device__ __forceinline__ void hr_write(const HrCtx &c, const HrRead &r, uint64
             uint32_t xs[HR_CHUNK];
 #pragma unroll
             for (int t = 0; t < HR_CHUNK; ++t) xs[t] = hw[min(j0 + t, nw - 1)];
+            uint64_t q[HR_CHUNK / 2];                                       // one loop over the chunk's hits, as in hr_count
 #pragma unroll
             for (int t = 0; t < HR_CHUNK; ++t) {
                 const int j = j0 + t;
-                if (j >= nw) break;
-                uint32_t x = xs[t];
+                uint32_t x = j < nw ? xs[t] : 0u;
                 if (j == 0) x &= ~0u >> a_off;
                 if (j == nw - 1) x &= ~0u << (32 * nw - end);
-                while (x) {                      // ascending positions: most significant bit first
-                    const int tb = 31 - __builtin_clz(x);
-                    x &= ~(1u << tb);
-                    const int rel = 32 * j + 31 - tb;                      // position relative to the stream's bit 0
-                    if (r.mixed && hr_dist<CHECK_INVALID>(c.codes, c.inval, word0 + rel, c.k, c.km, c.cons, c.rcc, c.revcom) != r.best) continue;
-                    if (base < cap) pos_out[base] = (int32_t)(rel - a_off);
-                    ++base;
-                }
+                if (t & 1) q[t >> 1] |= x;
+                else q[t >> 1] = (uint64_t)x << 32;
+            }
+            for (;;) {                           // ascending positions: most significant bit first
+                const int sel = q[0] ? 0 : (q[1] ? 1 : 2);
+                const uint64_t cur = q[0] ? q[0] : (q[1] ? q[1] : q[2]);
+                if (!cur) break;
+                const int tb = 63 - __builtin_clzll(cur);
+                const uint64_t clr = ~(1ull << tb);
+                q[0] &= sel == 0 ? clr : ~0ull;
+                q[1] &= sel == 1 ? clr : ~0ull;
+                q[2] &= sel == 2 ? clr : ~0ull;
+                const int rel = 32 * j0 + 64 * sel + 63 - tb;              // position relative to the stream's bit 0
+                if (r.mixed && hr_dist<CHECK_INVALID>(c.codes, c.inval, word0 + rel, c.k, c.km, c.cons, c.rcc, c.revcom) != r.best) continue;
+                if (base < cap) pos_out[base] = (int32_t)(rel - a_off);
+                ++base;
             }
         }
     }
