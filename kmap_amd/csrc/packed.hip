@@ -360,12 +360,20 @@ struct DbRaw {
     uint32_t c0, c1;                    // codes of groups g, g + 1
     uint16_t f0, f1;                    // their invalid flags
 };
+// The read's pointers reach the wave through v_readlane (Batch / pick below), so the compiler no longer knows them to be global and
+// emits FLAT loads -- which count in lgkmcnt as well as vmcnt: every wait for an LDS atomic's result then also waited for the window
+// loads prefetched for the NEXT read, the very stall the vector border loads were introduced to remove.  The address-space casts
+// make them global_load again.
+typedef const __attribute__((address_space(1))) uint32_t *db_g32;
+typedef const __attribute__((address_space(1))) uint16_t *db_g16;
 __device__ __forceinline__ void db_load(const DbRead &g, int o, DbRaw &w) {
     const int gi = min(o >> 4, g.gmax);
-    w.c0 = g.crd[gi];
-    w.c1 = g.crd[gi + 1];
-    w.f0 = g.ird[gi];
-    w.f1 = g.ird[gi + 1];
+    const db_g32 crd = (db_g32)g.crd;
+    const db_g16 ird = (db_g16)g.ird;
+    w.c0 = crd[gi];
+    w.c1 = crd[gi + 1];
+    w.f0 = ird[gi];
+    w.f1 = ird[gi + 1];
 }
 __device__ __forceinline__ bool db_window(const DbRead &g, int o, const DbRaw &w, int k, uint32_t kbits, uint64_t kones, uint32_t &h) {
     const int i = o & 15;
@@ -541,8 +549,10 @@ __global__ __launch_bounds__(KMAP_WAVE *DS_WAVES) void dedupe_bitmap_packed_kern
                             const uint32_t bits = __builtin_bitreverse32(lane ? (uint32_t)(m >> 32) : (uint32_t)m);   // lane l of the half -> bit 31-l
                             const int w0 = cs * 64 + 32 * lane;           // first position (offset) of this word
                             if (bits) {
-                                if (w0 < G.lo || w0 + 32 > G.hi) atomicOr(&G.srd[w0 >> 5], bits);   // shared with a neighbouring read
-                                else G.srd[w0 >> 5] = bits;
+                                typedef __attribute__((address_space(1))) uint32_t *db_gw32;      // global, not flat (see db_load)
+                                const db_gw32 sw = (db_gw32)G.srd + (w0 >> 5);
+                                if (w0 < G.lo || w0 + 32 > G.hi) __hip_atomic_fetch_or(sw, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // shared with a neighbouring read
+                                else *sw = bits;
                             }
                         }
                     }
