@@ -367,7 +367,7 @@ struct DbRaw {
 typedef const __attribute__((address_space(1))) uint32_t *db_g32;
 typedef const __attribute__((address_space(1))) uint16_t *db_g16;
 __device__ __forceinline__ void db_load(const DbRead &g, int o, DbRaw &w) {
-    const int gi = min(o >> 4, g.gmax);
+    const uint32_t gi = (uint32_t)min(o >> 4, g.gmax);                      // unsigned: scalar base + 32-bit lane offset addressing
     const db_g32 crd = (db_g32)g.crd;
     const db_g16 ird = (db_g16)g.ird;
     w.c0 = crd[gi];
@@ -378,9 +378,10 @@ __device__ __forceinline__ void db_load(const DbRead &g, int o, DbRaw &w) {
 __device__ __forceinline__ bool db_window(const DbRead &g, int o, const DbRaw &w, int k, uint32_t kbits, uint64_t kones, uint32_t &h) {
     const int i = o & 15;
     const uint64_t t0 = ((uint64_t)w.c0 << 32) | w.c1;
-    const uint64_t fl = ((uint64_t)w.f0 << 16) | w.f1;                    // 32 invalid flags, position 0 in bit 31
-    h = (uint32_t)((t0 << (2 * i)) >> (64 - 2 * k)) & kbits;              // k <= 16: the window lies in groups g, g + 1
-    const bool bad = ((fl >> (32 - i - k)) & kones) != 0;
+    const uint32_t fl = ((uint32_t)w.f0 << 16) | w.f1;                    // 32 invalid flags, position 0 in bit 31
+    const uint32_t top = (uint32_t)(t0 >> (32 - 2 * i));                  // the 16 bases from position i on (one 64-bit shift, not two)
+    h = (top >> (32 - 2 * k)) & kbits;                                    // k <= 16: the window lies in groups g, g + 1
+    const bool bad = ((fl >> (32 - i - k)) & (uint32_t)kones) != 0;       // 1 <= 32 - i - k <= 31
     return o >= g.lo && o < g.hi && !bad;
 }
 
