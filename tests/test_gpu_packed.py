@@ -323,3 +323,39 @@ def test_bitsliced_scan_and_mask_fuzz_vs_oracle(env):
         ds.mask(k, cons2, rad2)
         np.testing.assert_array_equal(ds.download(), O.mask_input(seq.copy(), k, cons2, rad2), err_msg=f"case {case}: k={k} r={rad2}")
         ds.close()
+
+
+@pytest.mark.parametrize("case", ["all_invalid", "one_kmer", "two_hot_buckets", "ragged_tail"])
+def test_fine_partition_edge_inputs(env, case):
+    """counts_fine.hip (k = 10 .. 14 above 2^20 positions) on inputs that stress its bookkeeping: no valid window at all; one k-mer
+    only (every key in bucket 0: the bucket is cut into ~2000 slices, the bin spills its 16-bit counter ~70 times); two planted
+    k-mers in otherwise random reads (two heavy buckets among 4094 ordinary ones); a length that ends inside a tile and inside a
+    16-position group.  Counts == oracle, with and without dedupe / revcom merge."""
+    _ffi, DeviceCounts, DeviceSeq, O = env
+    rng = np.random.default_rng(77)
+    n_reads, L = 7000, 160
+    seq, borders = synth(rng, n_reads, L, L, p_n=0.0)
+    if case == "all_invalid":
+        seq[:] = 255
+    elif case == "one_kmer":
+        for st, en in borders:
+            seq[st:en] = 0
+    elif case == "two_hot_buckets":
+        for r in range(0, n_reads, 2):
+            st, en = borders[r]
+            seq[st:en] = np.resize(np.array([1, 2, 3, 0, 2, 1, 1, 3, 0, 0, 2, 3, 1, 2], np.uint8), en - st) if r % 4 == 0 else \
+                np.resize(np.array([3, 3, 0, 1, 2, 0, 3, 1], np.uint8), en - st)
+    else:
+        seq, borders = seq[:borders[-1][1] - 37], borders.copy()
+        borders[-1][1] = len(seq)
+    assert len(seq) > (1 << 20)
+    ds, dc = DeviceSeq(seq, borders), DeviceCounts()
+    for k in (10, 12, 13, 14):
+        for dedupe, merge in ((False, True), (True, False)):
+            ds.count(dc, k, dedupe=dedupe, merge_revcom=merge)
+            u, c = dc.fetch()
+            ou, oc = O.count_kmers(seq, borders, k, rep_mode=not dedupe, revcom_mode=merge)
+            np.testing.assert_array_equal(u, ou)
+            np.testing.assert_array_equal(c, oc)
+    dc.close()
+    ds.close()
