@@ -164,7 +164,8 @@ __global__ __launch_bounds__(FS_TPB) void fine_offsets_kernel(const uint32_t *__
 // reservations 0.45, placement 0.63, write-out 1.38 -- the last is the rate the memory system takes 16-byte appends at (the
 // probe's 1.6 TB/s): halving the write-out's instructions (rank from a per-word popcount prefix), halving its active lanes
 // (4-byte stores) and overlapping it with the next tile's extraction (software-pipelined loop, two counter sets: 2.95 ms) each
-// left the pass where it was.  LDS: sorted 16-bit keys (2 B x FT), bucket counters / cursors (NB), dense
+// left the pass where it was; so did branch-free atomics (invalid windows to per-lane spare counters instead of an exec-mask
+// save / restore around each of the 2 x 32 atomics).  LDS: sorted 16-bit keys (2 B x FT), bucket counters / cursors (NB), dense
 // bases of the non-empty buckets (8 B x NB), run-start bitmap (FT bits) + its words paired with their popcount prefix (8 B / word).
 template <int GPT, int BPT>
 constexpr size_t fine_scatter_lds() {
