@@ -1081,10 +1081,10 @@ __device__ __forceinline__ void add_quad_block(float &gx, float &gy, const float
             : "v"(tx[0]), "v"(tx[1]), "v"(tx[2]), "v"(tx[3]), "v"(tx[4]), "v"(tx[5]), "v"(tx[6]), "v"(tx[7]), "v"(ty[0]), "v"(ty[1]), "v"(ty[2]),  \
               "v"(ty[3]), "v"(ty[4]), "v"(ty[5]), "v"(ty[6]), "v"(ty[7]));
     KMAP_QP8(0, "[0,0,0,0]") KMAP_QP8(1, "[1,1,1,1]") KMAP_QP8(2, "[2,2,2,2]") KMAP_QP8(3, "[3,3,3,3]")
+    KMAP_QP8(4, "[0,0,2,2]") KMAP_QP8(5, "[1,1,3,3]")        // two sub-lanes per row (pair form): lane 0 / 1 of each lane pair
 #undef KMAP_QP8
 }
 constexpr int SQ_CPL = 8;                       // consecutive columns per lane per batch (one 16-byte load of u16 sums)
-constexpr int SQ_BATCH = SQ_SUB * SQ_CPL;       // 32 columns per quad per batch
 
 struct SeqBatch {                                // raw operands of one batch of one lane
     uint32_t w[4];                               // 8 u16 sums (LUT source) ...
@@ -1188,13 +1188,17 @@ __device__ __forceinline__ void seq_terms_dispatch(const SeqBatch &cur, const fl
 }
 
 // quad form, block `bid` of the rows [0, nrows) (lut_s: the block's LUT copy in LDS, already filled; wl: SQ_WAVES doubles of LDS)
-template <bool LUTSRC>
-__device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *__restrict__ Y, int64_t n, int64_t row0, int64_t nrows,
-                                              float *__restrict__ G, double *__restrict__ loss_part, int64_t bid,
+// SUB = 4: the quad form.  SUB = 2 (pair form): two sub-lanes per row, 32 rows per wave -- every ordered add then serves 32 rows instead
+// of 16 (4 instead of 8 add instructions per pair), at twice the columns per lane; one round of pair waves replaces two rounds of quad
+// waves (12.6 N against 2 x 7.3 N instructions per SIMD).  Rows [lrow0, lrow0 + ...) of the local range, bounded by `nrows`.
+template <bool LUTSRC, int SUB>
+__device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *__restrict__ Y, int64_t n, int64_t row0, int64_t lrow0,
+                                              int64_t nrows, float *__restrict__ G, double *__restrict__ loss_part, int64_t bid,
                                               const float *__restrict__ lut_s, double *wl) {
+    constexpr int SQ_SUB = SUB, SQ_ROWS = KMAP_WAVE / SUB, SQ_BATCH = SUB * SQ_CPL;   // shadow the quad form's constants
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane & (SQ_SUB - 1);
-    const int64_t lr = (bid * SQ_WAVES + wave) * SQ_ROWS + (lane / SQ_SUB);
+    const int64_t lr = lrow0 + (bid * SQ_WAVES + wave) * SQ_ROWS + (lane / SQ_SUB);
     const bool valid = lr < nrows;
     const int64_t lrc = valid ? lr : nrows - 1;
     const int64_t i = row0 + lrc;
@@ -1202,7 +1206,7 @@ __device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *_
     const float xi = X[i], yi = Yy[i];
     const bool vec = ((n & 3) == 0) && (!LUTSRC || (src.ld % 8 == 0));
     const int i32 = (int)i;                      // n < 2^31 (checked by the host)
-    const int64_t wave_row_min = row0 + (bid * SQ_WAVES + wave) * SQ_ROWS;   // smallest global row of the wave
+    const int64_t wave_row_min = row0 + lrow0 + (bid * SQ_WAVES + wave) * SQ_ROWS;   // smallest global row of the wave
     float gx = 0.0f, gy = 0.0f, ce_acc = 0.0f;
     double loss = 0.0;
     SeqBatch cur, nxt;
@@ -1216,10 +1220,15 @@ __device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *_
         ce_acc += ce2;
         // ordered accumulation over the batch's 32 columns: column j0 + 8*s2 + c lives in sub-lane s2, slot c
         asm volatile("s_nop 1");
-        add_quad_block<0>(gx, gy, tx, ty);
-        add_quad_block<1>(gx, gy, tx, ty);
-        add_quad_block<2>(gx, gy, tx, ty);
-        add_quad_block<3>(gx, gy, tx, ty);
+        if constexpr (SUB == 4) {
+            add_quad_block<0>(gx, gy, tx, ty);
+            add_quad_block<1>(gx, gy, tx, ty);
+            add_quad_block<2>(gx, gy, tx, ty);
+            add_quad_block<3>(gx, gy, tx, ty);
+        } else {
+            add_quad_block<4>(gx, gy, tx, ty);
+            add_quad_block<5>(gx, gy, tx, ty);
+        }
         if (((j0 / SQ_BATCH) & 7) == 7) {
             loss += (double)ce_acc;
             ce_acc = 0.0f;
@@ -1438,8 +1447,9 @@ __device__ __forceinline__ void seq_wide_body(const ProbSrc &src, const float *_
 // blocks come first in the grid so that they are placed before the CUs fill up.
 template <bool LUTSRC, int GW>
 __global__ __launch_bounds__(KMAP_WAVE *SQ_WAVES) void forces_seq_kernel(ProbSrc src, const float *__restrict__ Y, int64_t n,
-                                                               int64_t row0, int64_t main_rows, int64_t nrows, int nb_tail,
-                                                               int nb_main, float *__restrict__ G, double *__restrict__ loss_part) {
+                                                               int64_t row0, int64_t pair_rows, int64_t main_rows, int64_t nrows,
+                                                               int nb_tail, int nb_pair, int nb_main, float *__restrict__ G,
+                                                               double *__restrict__ loss_part) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr size_t XCH_FLOATS = GW ? (size_t)SQ_WAVES * KMAP_WAVE * SQ_CPL * 2 : 0;   // exchange strips first, the LUT behind them
     float *lut_s = smem + XCH_FLOATS;
@@ -1458,7 +1468,11 @@ __global__ __launch_bounds__(KMAP_WAVE *SQ_WAVES) void forces_seq_kernel(ProbSrc
             return;
         }
     }
-    seq_quad_body<LUTSRC>(src, Y, n, row0, main_rows, G, loss_part, (int64_t)blockIdx.x - nb_tail, lut_s, wl);
+    // grid order: wide blocks, pair blocks (rows [0, pair_rows)), quad blocks (rows [pair_rows, main_rows)); loss partials: quad |
+    // pair | wide (nb_main = quad + pair blocks)
+    const int b = (int)blockIdx.x - nb_tail;
+    if (b < nb_pair) seq_quad_body<LUTSRC, 2>(src, Y, n, row0, 0, pair_rows, G, loss_part + (nb_main - nb_pair), (int64_t)b, lut_s, wl);
+    else seq_quad_body<LUTSRC, 4>(src, Y, n, row0, pair_rows, main_rows, G, loss_part, (int64_t)(b - nb_pair), lut_s, wl);
 }
 
 // deterministic reduction of the per-block loss partials inside the fused apply kernel (every block computes the same total):
@@ -1751,6 +1765,7 @@ struct kmap_embed {
     // form a last, nearly empty round of blocks -- to the wide kernel with seq_tail_g lanes per row (0: no tail)
     int64_t seq_main_rows = 0;
     int seq_tail_g = 0;
+    int64_t seq_pair_rows = 0;      // of the main rows, [0, seq_pair_rows) run in the pair form (32 rows per wave); multiple of 128
     // symmetric FAST path (all rows local): partial buffers
     float *rowpart = nullptr, *colpart = nullptr;
     int64_t symI = 0, symJ = 0;
@@ -1775,7 +1790,11 @@ void drop_graph(kmap_embed *e) {   // kernel arguments changed: the captured ite
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     e->gexec = nullptr;
 }
-int seq_main_blocks(const kmap_embed *e) { return (int)((e->seq_main_rows + SQ_ROWS * SQ_WAVES - 1) / (SQ_ROWS * SQ_WAVES)); }
+int seq_pair_blocks(const kmap_embed *e) { return (int)(e->seq_pair_rows / (2 * SQ_ROWS * SQ_WAVES)); }
+// quad + pair blocks
+int seq_main_blocks(const kmap_embed *e) {
+    return seq_pair_blocks(e) + (int)((e->seq_main_rows - e->seq_pair_rows + SQ_ROWS * SQ_WAVES - 1) / (SQ_ROWS * SQ_WAVES));
+}
 int seq_tail_blocks(const kmap_embed *e) {
     if (!e->seq_tail_g) return 0;
     const int64_t rows_per_block = (int64_t)SQ_WAVES * (KMAP_WAVE / e->seq_tail_g);
@@ -1789,6 +1808,7 @@ int seq_tail_blocks(const kmap_embed *e) {
 void seq_split(kmap_embed *e) {
     e->seq_main_rows = e->nrows;
     e->seq_tail_g = 0;
+    e->seq_pair_rows = 0;
     static const int off = [] { const char *v = getenv("KMAP_SEQ_TAIL"); return v && v[0] == '0'; }();   // A/B switch
     if (off || e->nrows <= 0) return;
     int dev = 0, cus = 256;
@@ -1797,6 +1817,16 @@ void seq_split(kmap_embed *e) {
     const int64_t round_rows = simds * SQ_ROWS;                       // rows of one wave on every SIMD
     const int64_t main_rows = (e->nrows / round_rows) * round_rows;
     const int64_t rem = e->nrows - main_rows;
+    // two rounds of quad waves -> one round of pair waves (every ordered add serves 32 rows: 12.6 N against 14.6 N instructions per
+    // SIMD); an odd round stays in the quad form and shares the SIMDs with the pair round
+    static const int pair_on = [] { const char *v = getenv("KMAP_SEQ_PAIR"); return !(v && v[0] == '0'); }();   // A/B switch
+    // ... but only next to quad waves: a pair round alone on the SIMDs (one wave each) exposes its add chain (N = 33 000: 1.52 against
+    // 1.29 ms for two quad rounds), so at least one quad round stays -- R rounds of quad rows become (R - 1) / 2 pair rounds + the rest
+    const int64_t rounds_q = main_rows / round_rows;
+    static const int force_pr = [] { const char *v = getenv("KMAP_SEQ_PAIR_ROUNDS"); return v ? atoi(v) : -1; }();   // measurements
+    int64_t pair_rounds = rounds_q >= 3 ? (rounds_q - 1) / 2 : 0;
+    if (force_pr >= 0 && 2 * (int64_t)force_pr <= rounds_q) pair_rounds = force_pr;
+    e->seq_pair_rows = pair_on ? pair_rounds * 2 * round_rows : 0;
     if (rem == 0) return;
     auto rounds = [&](int64_t waves) { return (double)((waves + simds - 1) / simds); };
     double best = rounds((rem + SQ_ROWS - 1) / SQ_ROWS) * 9.4;       // the remainder as quad waves
@@ -2075,8 +2105,9 @@ int launch_forces(kmap_embed *e, float *G, bool reduce_sym, hipStream_t st) {
 #define KMAP_SEQ(LUT, GW)                                                                                                          \
         do {                                                                                                                       \
             KMAP_TRY(kmap_allow_lds((const void *)forces_seq_kernel<LUT, GW>, (int)lds_w));                                        \
-            forces_seq_kernel<LUT, GW><<<nb_tail + nb_main, KMAP_WAVE * SQ_WAVES, lds_w, st>>>(e->src, e->Y, e->n, e->row0, e->seq_main_rows, \
-                                                                                              e->nrows, nb_tail, nb_main, G, e->loss_part); \
+            forces_seq_kernel<LUT, GW><<<nb_tail + nb_main, KMAP_WAVE * SQ_WAVES, lds_w, st>>>(e->src, e->Y, e->n, e->row0, e->seq_pair_rows, \
+                                                                                              e->seq_main_rows, e->nrows, nb_tail,      \
+                                                                                              seq_pair_blocks(e), nb_main, G, e->loss_part); \
         } while (0)
 #define KMAP_SEQ_G(LUT)                                                                                       \
         do {                                                                                                  \
