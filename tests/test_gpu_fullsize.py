@@ -381,3 +381,37 @@ def test_c4_embedding_force_evaluation_full_size():
     np.testing.assert_allclose(msum[:2 * n].reshape(2, n), gf, rtol=0, atol=3e-6 * np.abs(gf).max())
     for b in (sums_d, nb_d, kh_d, lab_d):
         b.free()
+
+
+def test_seq_pair_form_is_bit_identical(tmp_path):
+    """N = 3 x 16 384 + 640: the SEQ split turns two of the three quad rounds into one round of pair-form waves (two sub-lanes per
+    row) next to the remaining quad round and the wide left-over rows; the gradient must equal the run without the pair form
+    (KMAP_SEQ_PAIR=0) bit for bit.  One force evaluation per process (the switch is read once); the 5-GB sums matrix is
+    generated in the child from a seed."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    n = 3 * 16384 + 640
+    code = ("import numpy as np, sys; sys.path.insert(0, sys.argv[1]); from kmap_amd import _ffi, visualization as V;"
+            "n = int(sys.argv[2]); lds = (n + 127) & ~127; rng = np.random.default_rng(5);"
+            "sd = _ffi.DeviceBuffer(n * lds * 2);\n"
+            "for r0 in range(0, n, 4096):\n"
+            "    m = min(4096, n - r0); blk = rng.integers(0, 3201, size=(m, lds), dtype=np.uint16);"
+            " _ffi.check(_ffi.lib().kmap_memcpy_h2d(sd.ptr + r0 * lds * 2, _ffi.ptr(blk), m * lds * 2, None)); _ffi.sync()\n"
+            "lut = V.hd_prob_lut(8, 20, 3200); ld = (rng.standard_normal((2, n)) * 5).astype(np.float32);"
+            "s = V.EmbedSession(n, 10, 0.01, V.EMBED_SEQ);"
+            "_ffi.check(_ffi.lib().kmap_embed_set_prob_lut(s._h, sd.ptr, lds, _ffi.ptr(lut), len(lut))); s.set_coords(ld);"
+            "g = _ffi.DeviceBuffer(2 * n * 4); l = _ffi.DeviceBuffer(8); g.zero(); s.forces(g.ptr, l.ptr); _ffi.sync();"
+            "np.savez(sys.argv[3], g=g.to_numpy(np.float32, (2, n)), l=l.to_numpy(np.float64, (1,)))")
+    root = str(Path(__file__).resolve().parent.parent)
+    outs = {}
+    for tag, env in (("pair", {}), ("quad", {"KMAP_SEQ_PAIR": "0"})):
+        r = subprocess.run([sys.executable, "-c", code, root, str(n), str(tmp_path / f"{tag}.npz")],
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(tmp_path / f"{tag}.npz")
+    np.testing.assert_array_equal(outs["pair"]["g"].view(np.uint32), outs["quad"]["g"].view(np.uint32))
+    assert outs["pair"]["g"].any()
+    lp, lq = float(outs["pair"]["l"][0]), float(outs["quad"]["l"][0])
+    assert abs(lp - lq) <= 1e-8 * abs(lq)        # the loss is not bit-pinned: f32 partial sums over batches of different width
