@@ -512,7 +512,8 @@ def fill_rate(nbytes, reps=7):
 
 class LegGuard:
     """Deadline per optional multi-GPU leg: on expiry rank 0 writes the JSON line as it stands (+ "watchdog") and every rank leaves
-    with os._exit(0) -- a collective that never completes cannot be cancelled from Python, but the measured headline must get out."""
+    with os._exit(WATCHDOG_RC) (3: the launcher and the driver see a failed run, and the line -- which carries the measured headline --
+    says which leg hung; a collective that never completes cannot be cancelled from Python)."""
 
     def __init__(self, active, rank, fd, line, limit_s):
         self.active, self.rank, self.fd, self.line, self.limit = active, rank, fd, line, limit_s
@@ -525,7 +526,7 @@ class LegGuard:
                 os.write(self.fd, (json.dumps(self.line, default=str) + "\n").encode())
             except Exception:   # noqa: BLE001
                 pass
-        os._exit(0)
+        os._exit(WATCHDOG_RC)
 
     def leg(self, name):
         import threading
@@ -541,6 +542,70 @@ class LegGuard:
         if self.timer is not None:
             self.timer.cancel()
             self.timer = None
+
+
+WATCHDOG_RC = 3         # exit code of every rank when a multi-GPU leg's collective never returned (the partial line is still printed)
+
+
+def self_launch(n_gpus):
+    """`python3 bench.py --gpus N` without a launcher around it: start `python -m torch.distributed.run --nproc-per-node N bench.py
+    <same arguments>` as a CHILD process -- nothing in this process has touched HIP or torch.cuda yet, and nothing will: a process
+    that has initialised the GPU must never exec another program on this pool -- relay the child's one JSON line to stdout
+    (anything else the launcher or a library wrote there goes to stderr) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_gpus)))
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True)
+    line = None
+    try:
+        for out in proc.stdout:
+            if out.lstrip().startswith('{"metric"'):
+                line = out.strip()
+            else:
+                sys.stderr.write(out)
+        rc = proc.wait()
+    except BaseException:
+        try:
+            os.killpg(proc.pid, 15)      # exactly the process group started above
+        except ProcessLookupError:
+            pass
+        raise
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 4                           # the launcher succeeded but no line came out: not a result
+    return rc
+
+
+def rank_identity(dist, torch, dev, world):
+    """what proves that N ranks on N different GPUs produced the line: world size as the process group reports it, every rank's
+    device name / PCI bus id / uuid (all-gathered), and the collective library's version"""
+    p = torch.cuda.get_device_properties(dev)
+    bus = "%04x:%02x:%02x" % tuple(int(getattr(p, a, -1)) & 0xffff for a in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    me = {"rank": int(os.environ.get("RANK", "0")), "device_index": dev, "device_name": p.name, "pci_bus": bus, "uuid": str(getattr(p, "uuid", "")),
+          "arch": getattr(p, "gcnArchName", ""), "pid": os.getpid()}
+    ranks = [me]
+    seen = 1
+    backend = "none"
+    if dist is not None:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+        seen = dist.get_world_size()
+        backend = dist.get_backend()
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:   # noqa: BLE001
+        ver = None
+    return {"ranks_seen": seen, "backend": backend, "rccl_version": ver, "ranks": ranks,
+            "distinct_gpus": len({(r["pci_bus"], r["uuid"]) for r in ranks})}
 
 
 def main():
@@ -559,6 +624,8 @@ def main():
     ap.add_argument("--e2e", default="full", choices=["none", "k9", "full"],
                     help="end-to-end timings on C3 (rank 0, N=1 only): k9 = k 6..9 in both embedding modes; full = also the default k 6..16")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
 
     # stdout carries ONE JSON line and nothing else: libraries that print to fd 1 (RCCL's version banner at communicator
     # creation, for one) are sent to stderr for the rest of the run; the line itself goes to the saved descriptor
@@ -570,8 +637,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
     import torch
@@ -659,6 +724,7 @@ def main():
 
     fill = fill_rate(max(nrows, 1) * ld) if rank == 0 else None
 
+    ident = rank_identity(dist, torch, dev, world)      # all ranks (an all-gather of small objects, outside the timed region)
     line = None
     if rank == 0:
         pairs_total = float(n) * float(n)
@@ -684,6 +750,8 @@ def main():
                                         f"the {args.warmup} warm-up steps: after an idle gap the GPU needs ~20-40 ms to restore its clocks, and the first ~40 "
                                         f"launches take 0.50 instead of 0.395 ms (tools/hamdist_trend.py, profiles/r03_hamdist_trend.txt)")},
         }
+        line.update({"ranks_seen": ident["ranks_seen"], "distinct_gpus": ident["distinct_gpus"], "dist_backend": ident["backend"],
+                     "rccl_version": ident["rccl_version"], "ranks": ident["ranks"]})
         # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate
         # runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); collected offline, stored under profiles/
         pmc = sorted((ROOT / "profiles").glob("r*_bench_pmc.json"))

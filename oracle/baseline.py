@@ -35,6 +35,7 @@ def lib():
             "kb_fill_prob": (None, [_u32p, i64, _f32p, i32, _f32p, i32]),
             "kb_embed_forces": (f64, [_f32p, _f32p, i64, i64, i64, _f32p, i32]),
             "kb_embed_forces_src": (f64, [C.c_void_p, _u32p, _f32p, i32, _f32p, i64, i64, i64, _f32p, i32]),
+            "kb_embed_forces_rows": (None, [_f32p, _i64p, i64, _f32p, i64, _f32p, i32]),
             "kb_set_threads": (None, [i32]),
             "kb_embed_update": (None, [_f32p, _f32p, i64, C.c_float]),
             "kb_max_threads": (i32, []),
@@ -123,3 +124,14 @@ def embed_forces_kmers(kh, lut, per_mismatch, y, r0=0, r1=None, threads=0):
     loss = lib().kb_embed_forces_src(None, np.ascontiguousarray(kh, np.uint32), np.ascontiguousarray(lut, np.float32), per_mismatch,
                                      np.ascontiguousarray(y, np.float32), n, r0, r1, g, threads)
     return g, loss
+
+
+def embed_forces_rows(Pslab, rows, y, threads=0):
+    """raw gradient float32[2, len(rows)] of the sampled rows; Pslab[r, :] = the probabilities of row rows[r] (no N x N matrix)"""
+    rows = np.ascontiguousarray(rows, np.int64)
+    Pslab = np.ascontiguousarray(Pslab, np.float32)
+    n = Pslab.shape[1]
+    assert Pslab.shape[0] == len(rows) and y.shape == (2, n)
+    g = np.zeros((2, len(rows)), np.float32)
+    lib().kb_embed_forces_rows(Pslab, rows, len(rows), np.ascontiguousarray(y, np.float32), n, g, threads)
+    return g

@@ -275,6 +275,32 @@ double kb_embed_forces_src(const float *P, const uint32_t *kh, const float *lut,
     return loss;
 }
 
+/* The same row sums for a SAMPLE of rows whose probabilities arrive as a slab: Pslab[r * n + j] = p(rows[r], j), g = float[2][n_rows]
+ * (g[r], g[n_rows + r] of row rows[r]).  The checker of the device's SEQ kernel at sizes where no N x N matrix fits the host
+ * (tests/test_gpu_fullsize.py); the loop body is the one above (taichi_core.py:305-326, visualization.py:131-145). */
+void kb_embed_forces_rows(const float *Pslab, const int64_t *rows, int64_t n_rows, const float *y, int64_t n, float *g, int threads) {
+    kb_threads(threads);
+    const float lo = 1e-3f, hi = 0.999f, one = 1.0f;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int64_t i = rows[r];
+        const float xi = y[i], yi = y[n + i];
+        const float *p = Pslab + r * n;
+        float gx = 0.0f, gy = 0.0f;
+        for (int64_t j = 0; j < n; ++j) {
+            if (j == i) continue;
+            const float dx = xi - y[j], dy = yi - y[n + j];
+            float q = one / (one + (dx * dx + dy * dy));
+            q = q < lo ? lo : (q > hi ? hi : q);
+            const float t = q / (one - q) * (p[j] - q);
+            gx = gx + t * dx;
+            gy = gy + t * dy;
+        }
+        g[r] = gx;
+        g[n_rows + r] = gy;
+    }
+}
+
 /* y += -(4 g) lr (visualization.py:145,316) */
 void kb_embed_update(float *y, const float *g, int64_t n, float lr) {
     for (int64_t i = 0; i < 2 * n; ++i) y[i] = y[i] + (-(4.0f * g[i]) * lr);

@@ -204,6 +204,41 @@ def test_c4_hamming_full_size():
     assert np.all(np.diag(sub) == 0) and got.max() <= K
 
 
+def _seq_form_rows(n, round_rows=16384):
+    """>= 128 rows covering the three forms of the SEQ split (embed.hip seq_split: R whole rounds of 16 384 rows -> (R - 1) / 2 pair
+    rounds of 2 x 16 384 rows first, the other whole rounds in the quad form, the remainder in the wide form), with the first / last
+    row of each region, wave and block edges, and a random fill"""
+    rounds = n // round_rows
+    pair = ((rounds - 1) // 2) * 2 * round_rows if rounds >= 3 else 0
+    main = rounds * round_rows
+    rng = np.random.default_rng(11)
+    rows = set()
+    for lo, hi in ((0, pair), (pair, main), (main, n)):
+        if hi > lo:
+            edge = [lo, lo + 1, lo + 15, lo + 16, lo + 31, lo + 32, lo + 63, lo + 64, lo + 127, lo + 128, hi - 129, hi - 65, hi - 33, hi - 2, hi - 1]
+            rows |= {r for r in edge if lo <= r < hi}
+            rows |= set(rng.integers(lo, hi, 40).tolist())
+    rows = np.array(sorted(rows), np.int64)
+    assert len(rows) >= 128 and (pair == 0 or (rows < pair).sum() >= 40) and ((rows >= pair) & (rows < main)).sum() >= 40 and (rows >= main).sum() >= 30
+    return rows
+
+
+def _assert_seq_rows_equal_oracle(g, sums_d, lds, lut, coords, rows):
+    """device SEQ gradient rows == the CPU restatement of the reference's row sum (taichi_core.py:305-326 with T from
+    visualization.py:131-145: IEEE f32, j ascending, j != i, no FMA), BIT for bit.  The rows' probabilities are rebuilt on the
+    host from the rows' u16 neighbour sums through the same LUT (len(rows) x N floats -- no N x N matrix)."""
+    from oracle import baseline as B
+    n = coords.shape[1]
+    P = np.empty((len(rows), n), np.float32)
+    for t, r in enumerate(rows):
+        P[t] = lut[sums_d.to_numpy(np.uint16, (lds,), offset=int(r) * lds * 2)[:n]]
+    want = B.embed_forces_rows(P, rows, coords, threads=8)
+    got = np.ascontiguousarray(g[:, rows])
+    bad = np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(axis=0))[0]
+    assert len(bad) == 0, f"SEQ rows differ from the oracle: rows {rows[bad][:10].tolist()} got {got[:, bad[:3]]} want {want[:, bad[:3]]}"
+    assert np.abs(want).max() > 0
+
+
 def test_c3_embedding_force_evaluation_full_size():
     """N = 50 000 with the hand-over's label structure: the symmetric FAST kernel (the C3 default) against the SEQ kernel (the
     reference's summation order) on one force evaluation -- loss to 2e-6, gradient to 2e-5 of its scale -- and 20 FAST
@@ -234,6 +269,10 @@ def test_c3_embedding_force_evaluation_full_size():
         sess.forces(g_d.ptr, l_d.ptr)
         _ffi.sync()
         outs[tag] = (g_d.to_numpy(np.float32, (2, n)), float(l_d.to_numpy(np.float64, (1,))[0]))
+        if tag == "seq":
+            # the SEQ kernel's large-N forms against the ORACLE's arithmetic, bit for bit, on sampled rows of every form: at
+            # N = 50 000 rows [0, 32 768) run in the pair form, [32 768, 49 152) in the quad form, the last 848 in the wide form
+            _assert_seq_rows_equal_oracle(outs[tag][0], sums_d, lds, lut, coords, _seq_form_rows(n))
         if tag == "fast":
             sess.set_jitter(np.random.default_rng(8).normal(0, 0.01, 4096))
             sess.step(20)
@@ -350,6 +389,8 @@ def test_c4_embedding_force_evaluation_full_size():
         sess.close()
         g_d.free()
     (gs, ls), (gf, lf) = outs["seq"], outs["fast"]
+    # SEQ at N = 200 000 (5 pair rounds, 2 quad rounds, 3392 wide rows) against the oracle's row sums, bit for bit, on sampled rows
+    _assert_seq_rows_equal_oracle(gs, sums_d, lds, lut, coords, _seq_form_rows(n))
     assert abs(lf - ls) <= 2e-6 * abs(ls)
     # f32 row sums of 200 000 terms in two different orders: 15 of the 400 000 entries differ by 2.0 .. 2.4e-5 of the gradient's
     # scale (N = 50 000: all within 2e-5; the round-off of a sum grows with its length)
@@ -403,15 +444,23 @@ def test_seq_pair_form_is_bit_identical(tmp_path):
             "s = V.EmbedSession(n, 10, 0.01, V.EMBED_SEQ);"
             "_ffi.check(_ffi.lib().kmap_embed_set_prob_lut(s._h, sd.ptr, lds, _ffi.ptr(lut), len(lut))); s.set_coords(ld);"
             "g = _ffi.DeviceBuffer(2 * n * 4); l = _ffi.DeviceBuffer(8); g.zero(); s.forces(g.ptr, l.ptr); _ffi.sync();"
-            "np.savez(sys.argv[3], g=g.to_numpy(np.float32, (2, n)), l=l.to_numpy(np.float64, (1,)))")
+            "rows = np.array([int(t) for t in sys.argv[4].split(',')]);"
+            "sr = np.stack([sd.to_numpy(np.uint16, (lds,), offset=int(r) * lds * 2)[:n] for r in rows]);"
+            "np.savez(sys.argv[3], g=g.to_numpy(np.float32, (2, n)), l=l.to_numpy(np.float64, (1,)), sr=sr, lut=lut, ld=ld)")
     root = str(Path(__file__).resolve().parent.parent)
     outs = {}
+    rows = _seq_form_rows(n)
     for tag, env in (("pair", {}), ("quad", {"KMAP_SEQ_PAIR": "0"})):
-        r = subprocess.run([sys.executable, "-c", code, root, str(n), str(tmp_path / f"{tag}.npz")],
+        r = subprocess.run([sys.executable, "-c", code, root, str(n), str(tmp_path / f"{tag}.npz"), ",".join(str(t) for t in rows)],
                            env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[tag] = np.load(tmp_path / f"{tag}.npz")
     np.testing.assert_array_equal(outs["pair"]["g"].view(np.uint32), outs["quad"]["g"].view(np.uint32))
     assert outs["pair"]["g"].any()
+    # ... and both equal the oracle's row sums on sampled rows of the pair, quad and wide regions (not only each other)
+    from oracle import baseline as B
+    o = outs["pair"]
+    want = B.embed_forces_rows(o["lut"][o["sr"]], rows, o["ld"], threads=8)
+    np.testing.assert_array_equal(np.ascontiguousarray(o["g"][:, rows]).view(np.uint32), want.view(np.uint32))
     lp, lq = float(outs["pair"]["l"][0]), float(outs["quad"]["l"][0])
     assert abs(lp - lq) <= 1e-8 * abs(lq)        # the loss is not bit-pinned: f32 partial sums over batches of different width

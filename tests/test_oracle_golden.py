@@ -386,6 +386,9 @@ def test_cpu_baseline_equals_oracle():
     np.testing.assert_array_equal((np.float32(4.0) * g).view(np.uint32), O.gradient_loss(P, q, y).view(np.uint32))
     ref = float(O.cross_entropy(P, q))
     assert abs(2.0 * loss - ref) <= 3e-6 * abs(ref)
+    rows = np.array([0, 3, 100, 256, 17], np.int64)             # the row-slab form (checker of the SEQ kernel at sizes without a host matrix)
+    gr = B.embed_forces_rows(P[rows], rows, y, threads=2)
+    np.testing.assert_array_equal(gr.view(np.uint32), g[:, rows].view(np.uint32))
     P_off = P.copy()                                            # the on-the-fly form bench.py times: p from the k-mers, no matrix
     g3, l3 = B.embed_forces_kmers(kh, lut, 1, y, threads=3)
     B.lib().kb_fill_prob(kh, n, lut, 1, P_off, 2)              # (its diagonal is lut[0]; the pass skips j == i either way)
