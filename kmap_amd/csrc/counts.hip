@@ -514,8 +514,7 @@ static int compact_range(kmap_counts *c, int k, int merge, uint64_t first, uint6
 
 // order-preserving compaction of the filled histogram (+ revcom merge) into the handle's uniq/cnt arrays
 int kmap_counts_finish_hist(kmap_counts *c, int k, int merge, int64_t *n_uniq, hipStream_t st) {
-    static const int tiles_on = [] { const char *e = getenv("KMAP_COUNT_RCTILES"); return e ? atoi(e) : 1; }();
-    if (merge == 1 && k >= 11 && tiles_on)     // merge the table in place first; the compaction then needs no partner gathers
+    if (merge == 1 && k >= 11)                 // merge the table in place first; the compaction then needs no partner gathers
         return compact_range(c, k, 2, 0, (uint64_t)1 << (2 * k), n_uniq, st, true);
     return compact_range(c, k, merge, 0, (uint64_t)1 << (2 * k), n_uniq, st);
 }

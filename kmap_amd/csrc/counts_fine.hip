@@ -1,9 +1,9 @@
-// counts_fine.hip -- partitioned histogram for 8 <= k <= 14 with 16-bit keys and XCD-private bucket streams.
+// counts_fine.hip -- partitioned histogram for 10 <= k <= 14 with 16-bit keys and XCD-private bucket streams.
 //
 // counts_part.hip's first version of this path sorted 4-byte keys into 1024 buckets; at k = 14 a bucket then spans 2^18 bins
 // and the LDS histogram needed four range passes over every bucket's keys (3.3 of the count pass's 8.6 ms at C3, all of it L2
 // re-reads), and the key array was 4 B per k-mer written once and read four times.  Here
-//   * a bucket spans at most 65 536 bins (4096 buckets for k >= 10, 1024 below), so the histogram step is ONE pass;
+//   * a bucket spans at most 65 536 bins (4096 buckets), so the histogram step is ONE pass;
 //   * a key inside its bucket is 16 bits: the key array is 2 B per k-mer (bucket = position in the array);
 //   * more buckets mean shorter runs per tile (a 32 768-window tile holds ~8 keys = 16 B of every one of 4096 buckets).  Short
 //     appends to a stream that all eight XCDs write leave partially written lines in eight L2s (tools/probes/append_streams.hip:
@@ -377,8 +377,8 @@ int fine_scatter_launch(const uint32_t *src, const uint16_t *inval, const uint32
 
 template <bool PACKED, int GPT>
 int fine_hist(kmap_counts *c, const uint32_t *src, const uint16_t *inval, const uint32_t *skip, int64_t n, int k, hipStream_t st) {
-    const int nb_bits = k >= 10 ? 12 : 10, NB = 1 << nb_bits, low_bits = 2 * k - nb_bits;   // 4096 buckets of 4^k / 4096 <= 65 536 bins (k < 10: 1024)
-    KMAP_REQUIRE(low_bits >= 2 && low_bits <= 16 && NB <= 4096, "counts: fine partition needs 6 <= k <= 14 (k=%d)", k);
+    const int nb_bits = 12, NB = 1 << nb_bits, low_bits = 2 * k - nb_bits;   // 4096 buckets of 4^k / 4096 <= 65 536 bins
+    KMAP_REQUIRE(k >= 10 && k <= 14, "counts: fine partition needs 10 <= k <= 14 (k=%d)", k);
     KMAP_TRY(kmap_counts_reserve_bins(c, k));
     const size_t m = (size_t)NB * FC;
     void *small = nullptr;
@@ -397,9 +397,7 @@ int fine_hist(kmap_counts *c, const uint32_t *src, const uint16_t *inval, const 
     KMAP_TRY(kmap_allow_lds((const void *)fine_count_kernel<PACKED, GPT>, (NB + 64) * 4));
     fine_count_kernel<PACKED, GPT><<<grid, FS_TPB, (size_t)(NB + 64) * 4, st>>>(src, inval, skip, k, n, low_bits, NB, gcb);
     fine_offsets_kernel<<<1, FS_TPB, 0, st>>>(gcb, NB, goff, cursor, plan);        // goff[m] = number of valid keys
-    if (NB == 1024) KMAP_TRY((fine_scatter_launch<PACKED, GPT, 1>(src, inval, skip, k, n, low_bits, cursor, keys, grid, st)));
-    else if (NB == 2048) KMAP_TRY((fine_scatter_launch<PACKED, GPT, 2>(src, inval, skip, k, n, low_bits, cursor, keys, grid, st)));
-    else KMAP_TRY((fine_scatter_launch<PACKED, GPT, 4>(src, inval, skip, k, n, low_bits, cursor, keys, grid, st)));
+    KMAP_TRY((fine_scatter_launch<PACKED, GPT, 4>(src, inval, skip, k, n, low_bits, cursor, keys, grid, st)));
     if (low_bits == 16) {
         void *sp = nullptr;
         const size_t cap = (size_t)(n / (int64_t)FH_LIMIT) + 16;
@@ -420,10 +418,7 @@ int fine_hist(kmap_counts *c, const uint32_t *src, const uint16_t *inval, const 
 }
 }  // namespace
 
-bool kmap_counts_fine_applies(int k) {
-    static const int on = [] { const char *e = getenv("KMAP_COUNT_FINE"); return e ? atoi(e) : 1; }();      // A/B switch
-    return on && k >= 8 && k <= 14;
-}
+bool kmap_counts_fine_applies(int k) { return k >= 10 && k <= 14; }
 int kmap_counts_fine_hist(kmap_counts *c, const uint32_t *hash_dev, const uint32_t *codes_dev, const uint16_t *inval_dev,
                           const uint32_t *skip_dev, int64_t n, int k, hipStream_t st) {
     // two 16-position groups per thread: 32 768-window tiles (three: 24-byte runs at k = 14, but 29 spilled registers -- 6.9 against 6.5 ms)

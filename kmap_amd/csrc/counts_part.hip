@@ -1,16 +1,16 @@
-// counts_part.hip -- partitioned histogram for 11 <= k <= 16 (hashes as uint32).
+// counts_part.hip -- partitioned histogram for k = 15, 16 (hashes as uint32) and the dispatch of the partitioned paths.
 //
-// A 4^k-bin table (16 MiB .. 4 GiB) does not fit LDS, and device-scope atomics into it run at ~20 G updates/s (74 ms for
+// A 4^k-bin table (4 / 16 GiB) does not fit LDS, and device-scope atomics into it run at ~20 G updates/s (k = 16: 112 ms for
 // 1.5e9 k-mers, random bins: every update is a read-modify-write of a DRAM sector).  Instead:
 //   (1) count the valid hashes per bucket (bucket = top 10 bits of the 2k-bit hash; 1024-bin LDS histogram per block);
 //   (2) exclusive scan -> bucket offsets; (3) counting-sort tiles of 32768 hashes into bucket order (LDS counts, one global
 //   fetch-add per non-empty bucket per tile, LDS cursors) -> a bucket-ordered key array (4 B per valid k-mer);
-//   (4) one block per (bucket, 32768-bin range): stream the bucket's keys, LDS histogram of the range, plain coalesced stores
-//   of the LDS bins into the table.  Every bin of the table is written exactly once (no memset, no global atomics).
-// k = 15, 16: one bucket level would need 32 / 128 range passes over every bucket's keys in step (4) (41 ms at k = 15; k = 16
-// used device atomics into the 16-GiB table: 112 ms).  A second level splits every bucket into S = 32 / 128 sub-buckets of 32768
-// bins with the same tile-staged counting sort, run on 32768-key tiles that never cross a bucket border; step (4) is then one
-// pass per sub-bucket.
+//   (4) a second level splits every bucket into S = 32 / 128 sub-buckets of 32768 bins with the same tile-staged counting sort,
+//   run on 32768-key tiles that never cross a bucket border;
+//   (5) one block per sub-bucket: stream its keys, LDS histogram, plain coalesced stores of the LDS bins into the table.  Every
+//   bin of the table is written exactly once (no memset, no global atomics).
+// 10 <= k <= 14 take counts_fine.hip (4096 buckets of <= 65 536 bins, 16-bit keys, one level); this file's one-level forms for
+// those k (1024 buckets, 4-byte keys, 2 - 8 range passes over every bucket) were removed in round 4 (CHANGELOG.md).
 // The table then goes through the usual compaction / reverse-complement merge (counts.hip).
 #include <stdlib.h>
 
@@ -142,32 +142,19 @@ __global__ __launch_bounds__(PS_TPB) void part_scatter_kernel(const uint32_t *__
     }
 }
 
-// block = (bucket, bin range): LDS histogram of the bucket's keys restricted to the range, then plain stores into the table
+// block = sub-bucket (`bins_per_bucket` = 32768 consecutive bins): LDS histogram of its keys, then plain stores into the table
 __global__ __launch_bounds__(PH_TPB) void part_hist_kernel(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ goff,
-                                                           uint32_t bins_per_bucket, int passes, uint32_t sub,
-                                                           uint32_t *__restrict__ table) {
+                                                           uint32_t bins_per_bucket, uint32_t *__restrict__ table) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lb[];
-    // The range passes of one bucket read the same keys: they get block ids that the dispatcher sends to the SAME XCD, one after the
-    // other (block b runs on XCD b mod 8), so that the first one's misses fill the L2 the others read.  With plain (bucket, pass)
-    // = (b / passes, b mod passes) the eight passes of a k = 14 bucket sat on eight different XCDs: 46 GB through the fabric.
-    uint32_t bucket = blockIdx.x / passes, p = blockIdx.x % passes;
-    if (passes > 1 && (gridDim.x / passes) % 8 == 0) {
-        const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
-        bucket = (j / passes) * 8 + xcd;
-        p = j % passes;
-    }
-    for (uint32_t j = threadIdx.x; j < sub; j += PH_TPB) lb[j] = 0;
+    const uint32_t bucket = blockIdx.x;
+    for (uint32_t j = threadIdx.x; j < bins_per_bucket; j += PH_TPB) lb[j] = 0;
     __syncthreads();
     const uint64_t lo = goff[bucket], hi = goff[bucket + 1];
-    const uint32_t low = bins_per_bucket - 1u, r0 = p * sub;
-    const uint32_t dummy = sub + (threadIdx.x & 63u);                     // 64 private bins behind the range (never read)
+    const uint32_t low = bins_per_bucket - 1u;
     // 16-byte loads over the 4-key-aligned interior of [lo, hi), scalar head and tail
     const uint64_t lo4 = (lo + 3) & ~(uint64_t)3, hi4 = hi & ~(uint64_t)3;
     if (lo4 < hi4) {
-        for (uint64_t i = lo + threadIdx.x; i < lo4; i += PH_TPB) {
-            const uint32_t a = (keys[i] & low) - r0;
-            if (a < sub) atomicAdd(&lb[a], 1u);
-        }
+        for (uint64_t i = lo + threadIdx.x; i < lo4; i += PH_TPB) atomicAdd(&lb[keys[i] & low], 1u);
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys);
         // two loads ahead of the keys being counted (one block per CU: 16 waves; a plain load -> count loop exposed one memory
@@ -179,100 +166,18 @@ __global__ __launch_bounds__(PH_TPB) void part_hist_kernel(const uint32_t *__res
             const u32x4 kv = k0;
             k0 = k1;
             k1 = k4[q + 2 * PH_TPB < qend ? q + 2 * PH_TPB : qlast];
-            // no branch per key: a key of another range lands, by one unsigned min, in the lane's private bin behind the range's
-            // bins (range passes > 1: seven of eight keys at k = 14 -- the exec-mask juggling cost more than their atomics do)
-            const uint32_t a0 = (kv.x & low) - r0, a1 = (kv.y & low) - r0, a2 = (kv.z & low) - r0, a3 = (kv.w & low) - r0;
-            atomicAdd(&lb[a0 < dummy ? a0 : dummy], 1u);
-            atomicAdd(&lb[a1 < dummy ? a1 : dummy], 1u);
-            atomicAdd(&lb[a2 < dummy ? a2 : dummy], 1u);
-            atomicAdd(&lb[a3 < dummy ? a3 : dummy], 1u);
+            atomicAdd(&lb[kv.x & low], 1u);
+            atomicAdd(&lb[kv.y & low], 1u);
+            atomicAdd(&lb[kv.z & low], 1u);
+            atomicAdd(&lb[kv.w & low], 1u);
         }
-        for (uint64_t i = hi4 + threadIdx.x; i < hi; i += PH_TPB) {
-            const uint32_t a = (keys[i] & low) - r0;
-            if (a < sub) atomicAdd(&lb[a], 1u);
-        }
+        for (uint64_t i = hi4 + threadIdx.x; i < hi; i += PH_TPB) atomicAdd(&lb[keys[i] & low], 1u);
     } else {
-        for (uint64_t i = lo + threadIdx.x; i < hi; i += PH_TPB) {
-            const uint32_t a = (keys[i] & low) - r0;
-            if (a < sub) atomicAdd(&lb[a], 1u);
-        }
+        for (uint64_t i = lo + threadIdx.x; i < hi; i += PH_TPB) atomicAdd(&lb[keys[i] & low], 1u);
     }
     __syncthreads();
-    uint32_t *dst = table + (size_t)bucket * bins_per_bucket + r0;
-    for (uint32_t j = threadIdx.x; j < sub; j += PH_TPB) dst[j] = lb[j];
-}
-// The same with two 16-bit counters per LDS word: 65 536 bins per block, half the range passes over a bucket's keys (k = 13: one
-// instead of two, k = 14: four instead of eight).  A counter must never carry into its neighbour: the thread whose returning
-// ds_add (same LDS rate as the plain one on this part) SETS bit 14 of the counter (0x3FFF -> 0x4000, or, if an earlier
-// withdrawal is still in flight, 0xBFFF -> 0xC000) takes 0x4000 counts out again and notes the bin in a global list;
-// part_spill_kernel adds them to the finished table.  Margin: a carry needs 0xC000 = 49 152 further adds to ONE bin between a
-// thread's ds_add and its ds_sub (a block has 1024 threads with four keys in flight each); the r02 version spilled at 0x8000
-// with a 32 768 margin and an equality test that a delayed withdrawal could step over.  Between two spills of a bin lie at
-// least 0x4000 adds to it, so the list holds at most n / 16 384 entries (the write is bounds-checked all the same).
-constexpr uint32_t PH_HALF_BINS = 2 * PH_BINS, PH_HALF_LIMIT = 0x4000u;
-__global__ __launch_bounds__(PH_TPB) void part_hist_half_kernel(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ goff,
-                                                                uint32_t bins_per_bucket, int passes, uint32_t *__restrict__ table,
-                                                                unsigned long long *__restrict__ spill_n, uint32_t *__restrict__ spill,
-                                                                unsigned long long spill_cap) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lb[];
-    uint32_t bucket = blockIdx.x / passes, p = blockIdx.x % passes;
-    if (passes > 1 && (gridDim.x / passes) % 8 == 0) {                    // range passes of a bucket on one XCD (see part_hist_kernel)
-        const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
-        bucket = (j / passes) * 8 + xcd;
-        p = j % passes;
-    }
-    for (uint32_t j = threadIdx.x; j < PH_BINS; j += PH_TPB) lb[j] = 0;
-    __syncthreads();
-    const uint64_t lo = goff[bucket], hi = goff[bucket + 1];
-    const uint32_t low = bins_per_bucket - 1u, r0 = p * PH_HALF_BINS;
-    const uint32_t bin_base = bucket * bins_per_bucket + r0;             // < 4^14: fits 32 bits
-    const uint32_t dummy = PH_HALF_BINS + 2u * (threadIdx.x & 63u);       // the lane's private counter behind the range
-    auto count = [&](uint32_t key) {
-        const uint32_t a = (key & low) - r0;
-        const uint32_t b = a < dummy ? a : dummy;
-        const int hs = (int)(b & 1u) * 16;
-        const uint32_t old = atomicAdd(&lb[b >> 1], 1u << hs);
-        const uint32_t o16 = (old >> hs) & 0xFFFFu;
-        if ((~o16 & (o16 + 1u) & PH_HALF_LIMIT) && a < PH_HALF_BINS) {   // this add set bit 14: take 0x4000 out, note the bin
-            atomicSub(&lb[b >> 1], PH_HALF_LIMIT << hs);
-            const unsigned long long at = atomicAdd(spill_n, 1ull);
-            if (at < spill_cap) spill[at] = bin_base + a;
-        }
-    };
-    const uint64_t lo4 = (lo + 3) & ~(uint64_t)3, hi4 = hi & ~(uint64_t)3;
-    if (lo4 < hi4) {
-        for (uint64_t i = lo + threadIdx.x; i < lo4; i += PH_TPB) count(keys[i]);
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 *k4 = reinterpret_cast<const u32x4 *>(keys);
-        const uint64_t qend = hi4 >> 2, qlast = qend - 1;
-        uint64_t q = (lo4 >> 2) + threadIdx.x;
-        u32x4 k0 = k4[q < qend ? q : qlast], k1 = k4[q + PH_TPB < qend ? q + PH_TPB : qlast];
-        for (; q < qend; q += PH_TPB) {
-            const u32x4 kv = k0;
-            k0 = k1;
-            k1 = k4[q + 2 * PH_TPB < qend ? q + 2 * PH_TPB : qlast];
-            count(kv.x);
-            count(kv.y);
-            count(kv.z);
-            count(kv.w);
-        }
-        for (uint64_t i = hi4 + threadIdx.x; i < hi; i += PH_TPB) count(keys[i]);
-    } else {
-        for (uint64_t i = lo + threadIdx.x; i < hi; i += PH_TPB) count(keys[i]);
-    }
-    __syncthreads();
-    uint2 *dst = reinterpret_cast<uint2 *>(table + (size_t)bucket * bins_per_bucket + r0);
-    for (uint32_t j = threadIdx.x; j < PH_BINS; j += PH_TPB) {
-        const uint32_t w = lb[j];
-        dst[j] = make_uint2(w & 0xFFFFu, w >> 16);
-    }
-}
-__global__ void part_spill_kernel(uint32_t *__restrict__ table, const unsigned long long *__restrict__ spill_n,
-                                  const uint32_t *__restrict__ spill, unsigned long long spill_cap) {
-    unsigned long long m = *spill_n;
-    if (m > spill_cap) m = spill_cap;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (unsigned long long)gridDim.x * blockDim.x)
-        atomicAdd(&table[spill[i]], PH_HALF_LIMIT);
+    uint32_t *dst = table + (size_t)bucket * bins_per_bucket;
+    for (uint32_t j = threadIdx.x; j < bins_per_bucket; j += PH_TPB) dst[j] = lb[j];
 }
 // ---- second level: tiles of <= 32768 keys inside one first-level bucket ---------------------------------------------------
 constexpr int P2_MAX = 128;        // sub-buckets per bucket (k = 16); 32 at k = 15
@@ -389,11 +294,9 @@ __global__ void part_add_bin_kernel(uint32_t *__restrict__ table, size_t bin, co
 }
 }  // namespace
 
-bool kmap_counts_part_applies(int k, int64_t n) {
-    static const int on = [] { const char *e = getenv("KMAP_COUNT_PART"); return e ? atoi(e) : 1; }();
-    static const int min_k = [] { const char *e = getenv("KMAP_COUNT_PART_MINK"); return e ? atoi(e) : 10; }();   // k = 10: 32 LDS passes (13.7 ms at C3) against ~6 ms here; k = 9: 8 passes (3.7 ms) win
-    return on && k >= min_k && k >= 8 && k <= 16 && n >= ((int64_t)1 << 20);
-}
+// k = 10: 32 LDS passes over the reads (13.7 ms at C3) against ~5 ms partitioned; k = 9: 8 passes (3.7 ms) win.  Few keys: the
+// fixed cost of the partition (scans, 4096-block histogram pass) exceeds device atomics.
+bool kmap_counts_part_applies(int k, int64_t n) { return k >= 10 && k <= 16 && n >= ((int64_t)1 << 20); }
 
 // bins of c <- histogram of the valid (!= 0xFFFFFFFF) keys; the whole table is written (no prior memset needed).  Keys: a hash
 // array (hash_dev), or -- hash_dev null -- hashed on the fly from the packed reads in the count and the scatter pass (no 4 B /
@@ -437,54 +340,33 @@ static int part_hist_any(kmap_counts *c, const uint32_t *hash_dev, const uint32_
         part_scatter_kernel<false><<<(unsigned)tiles, PS_TPB, (size_t)PT_TILE * 4, st>>>(hash_dev, nullptr, nullptr, k, n, shift, cursor, keys);
     }
     const uint32_t bins_per_bucket = (uint32_t)(n_bins >> PB);
-    const uint32_t sub = bins_per_bucket < (uint32_t)PH_BINS ? bins_per_bucket : (uint32_t)PH_BINS;
-    const int passes = (int)(bins_per_bucket / sub);
+    const int passes = (int)(bins_per_bucket / (uint32_t)PH_BINS);
+    KMAP_REQUIRE(k >= 15 && passes <= P2_MAX, "counts: the two-level partition serves k = 15, 16 (k=%d)", k);
     KMAP_TRY(kmap_allow_lds((const void *)part_hist_kernel, (PH_BINS + 64) * 4));
-    static const int two_level = [] { const char *e = getenv("KMAP_COUNT_PART2"); return e ? atoi(e) : 1; }();   // A/B switch
-    if (k >= 15 && two_level && passes <= P2_MAX) {
-        // second level: S = passes sub-buckets of 32768 bins per bucket; keys re-sorted tile by tile inside their bucket
-        const int S = passes, shift2 = 15;                           // sub-bucket = bits [15, 15 + log2 S) of the hash
-        uint32_t *gcount2 = nullptr, *keys2 = nullptr, *ntile = nullptr;
-        uint64_t *goff2 = nullptr, *tile_off = nullptr;
-        unsigned long long *cursor2 = nullptr;
-        const size_t m = (size_t)NBK * S;
-        void *aux = nullptr;
-        KMAP_TRY(kmap_scratch(&aux, (m + 1) * 8 + m * 8 + ((size_t)NBK + 1) * 8 + m * 4 + (size_t)NBK * 4, st, KMAP_SLOT_B));
-        goff2 = reinterpret_cast<uint64_t *>(aux);
-        cursor2 = reinterpret_cast<unsigned long long *>(goff2 + m + 1);
-        tile_off = reinterpret_cast<uint64_t *>(cursor2 + m);
-        gcount2 = reinterpret_cast<uint32_t *>(tile_off + NBK + 1);
-        ntile = gcount2 + m;
-        KMAP_TRY(kmap_scratch((void **)&keys2, (size_t)n * 4, st, KMAP_SLOT_HASH));   // the hash array is dead: its slot takes the re-sorted keys
-        KMAP_CHECK_HIP(hipMemsetAsync(gcount2, 0, m * 4, st));
-        part2_ntiles_kernel<<<NBK / 256, 256, 0, st>>>(goff, ntile);
-        KMAP_TRY(exclusive_scan_u32(ntile, NBK, tile_off, st));
-        part2_count_kernel<<<2048, PS_TPB, 0, st>>>(keys, goff, tile_off, shift2, S, gcount2);
-        KMAP_TRY(exclusive_scan_u32(gcount2, (int64_t)m, goff2, st));
-        part2_init_cursor_kernel<<<(unsigned)((m + 255) / 256), 256, 0, st>>>(goff2, (int64_t)m, cursor2);
-        KMAP_TRY(kmap_allow_lds((const void *)part2_scatter_kernel, PT_TILE * 4));
-        part2_scatter_kernel<<<1024, PS_TPB, (size_t)PT_TILE * 4, st>>>(keys, goff, tile_off, shift2, S, cursor2, keys2);
-        // one pass per sub-bucket: "bucket" = sub-bucket index, 32768 bins each
-        part_hist_kernel<<<(unsigned)m, PH_TPB, (size_t)(PH_BINS + 64) * 4, st>>>(keys2, goff2, (uint32_t)PH_BINS, 1, (uint32_t)PH_BINS, c->bins);
-        if (packed && k == 16) part_add_bin_kernel<<<1, 1, 0, st>>>(c->bins, (size_t)0xFFFFFFFFu, all_ones);
-        KMAP_CHECK_HIP(hipGetLastError());
-        return KMAP_OK;
-    }
-    static const bool half = [] { const char *e = getenv("KMAP_COUNT_PART_HALF"); return !(e && e[0] == '0'); }();   // A/B switch
-    if (half && passes > 1 && bins_per_bucket % PH_HALF_BINS == 0) {     // k = 13, 14: 16-bit counters, half the range passes
-        void *sp = nullptr;
-        const size_t cap = (size_t)(n / (int64_t)PH_HALF_LIMIT) + 16;
-        KMAP_TRY(kmap_scratch(&sp, 16 + cap * 4, st, KMAP_SLOT_B));
-        unsigned long long *spill_n = reinterpret_cast<unsigned long long *>(sp);
-        uint32_t *spill = reinterpret_cast<uint32_t *>(spill_n + 2);
-        KMAP_CHECK_HIP(hipMemsetAsync(spill_n, 0, 16, st));
-        const int hp = (int)(bins_per_bucket / PH_HALF_BINS);
-        KMAP_TRY(kmap_allow_lds((const void *)part_hist_half_kernel, (PH_BINS + 64) * 4));
-        part_hist_half_kernel<<<(unsigned)(NBK * hp), PH_TPB, (size_t)(PH_BINS + 64) * 4, st>>>(keys, goff, bins_per_bucket, hp, c->bins, spill_n, spill, (unsigned long long)cap);
-        part_spill_kernel<<<64, 256, 0, st>>>(c->bins, spill_n, spill, (unsigned long long)cap);
-    } else {
-        part_hist_kernel<<<(unsigned)(NBK * passes), PH_TPB, (size_t)(sub + 64) * 4, st>>>(keys, goff, bins_per_bucket, passes, sub, c->bins);
-    }
+    // second level: S = passes sub-buckets of 32768 bins per bucket; keys re-sorted tile by tile inside their bucket
+    const int S = passes, shift2 = 15;                               // sub-bucket = bits [15, 15 + log2 S) of the hash
+    uint32_t *gcount2 = nullptr, *keys2 = nullptr, *ntile = nullptr;
+    uint64_t *goff2 = nullptr, *tile_off = nullptr;
+    unsigned long long *cursor2 = nullptr;
+    const size_t m = (size_t)NBK * S;
+    void *aux = nullptr;
+    KMAP_TRY(kmap_scratch(&aux, (m + 1) * 8 + m * 8 + ((size_t)NBK + 1) * 8 + m * 4 + (size_t)NBK * 4, st, KMAP_SLOT_B));
+    goff2 = reinterpret_cast<uint64_t *>(aux);
+    cursor2 = reinterpret_cast<unsigned long long *>(goff2 + m + 1);
+    tile_off = reinterpret_cast<uint64_t *>(cursor2 + m);
+    gcount2 = reinterpret_cast<uint32_t *>(tile_off + NBK + 1);
+    ntile = gcount2 + m;
+    KMAP_TRY(kmap_scratch((void **)&keys2, (size_t)n * 4, st, KMAP_SLOT_HASH));   // the hash array is dead: its slot takes the re-sorted keys
+    KMAP_CHECK_HIP(hipMemsetAsync(gcount2, 0, m * 4, st));
+    part2_ntiles_kernel<<<NBK / 256, 256, 0, st>>>(goff, ntile);
+    KMAP_TRY(exclusive_scan_u32(ntile, NBK, tile_off, st));
+    part2_count_kernel<<<2048, PS_TPB, 0, st>>>(keys, goff, tile_off, shift2, S, gcount2);
+    KMAP_TRY(exclusive_scan_u32(gcount2, (int64_t)m, goff2, st));
+    part2_init_cursor_kernel<<<(unsigned)((m + 255) / 256), 256, 0, st>>>(goff2, (int64_t)m, cursor2);
+    KMAP_TRY(kmap_allow_lds((const void *)part2_scatter_kernel, PT_TILE * 4));
+    part2_scatter_kernel<<<1024, PS_TPB, (size_t)PT_TILE * 4, st>>>(keys, goff, tile_off, shift2, S, cursor2, keys2);
+    // one pass per sub-bucket: "bucket" = sub-bucket index, 32768 bins each
+    part_hist_kernel<<<(unsigned)m, PH_TPB, (size_t)(PH_BINS + 64) * 4, st>>>(keys2, goff2, (uint32_t)PH_BINS, c->bins);
     if (packed && k == 16) part_add_bin_kernel<<<1, 1, 0, st>>>(c->bins, (size_t)0xFFFFFFFFu, all_ones);
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;

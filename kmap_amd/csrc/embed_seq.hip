@@ -1,0 +1,523 @@
+// embed_seq.hip -- SEQ forces of the embedding iteration: the reference's arithmetic and summation order, bit for bit
+// (taichi_core.py:305-326 with T from visualization.py:131-145: IEEE f32, j ascending, j != i, no FMA).
+#include <math.h>
+#include <stdlib.h>
+
+#include "embed_internal.h"
+#include "seq_div.h"
+
+namespace {
+// =================================================================================================
+// SEQ forces: the reference's summation order (taichi_core.py:305-326: ret_val += diff[i,j] * (y[k,i] - y[k,j]),
+// j ascending, j != i), IEEE f32, no FMA.  A row is owned by the 4 lanes of a quad: for a group of 4 columns
+// each sub-lane evaluates one term (q, t, t*dx, t*dy -- independent work), then ALL lanes of the row add the
+// 4 terms in column order (DPP quad broadcasts), so they carry identical accumulators and the sum order is exactly
+// j = 0, 1, 2, ...  The loss needs no order (f64 accumulation of f32 terms), each sub-lane keeps its own.
+// =================================================================================================
+// acc + (value of `v` in lane S of the caller's quad) as ONE v_add_f32 with a DPP quad_perm source.
+// hipcc does not fold __builtin_amdgcn_update_dpp into the add, so the instruction is written out; the DPP operand
+// `v` is always produced more than 2 VALU instructions earlier (the DPP read-after-VALU-write hazard, cdna_hip 5.7).
+template <int S>
+__device__ __forceinline__ float add_quad_bcast(float acc, float v) {
+    float r;
+    if constexpr (S == 0) asm("v_add_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "v"(acc));
+    if constexpr (S == 1) asm("v_add_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "v"(acc));
+    if constexpr (S == 2) asm("v_add_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "v"(acc));
+    if constexpr (S == 3) asm("v_add_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "v"(acc));
+    return r;
+}
+// the eight columns of quad lane S, x and y chains alternating, as ONE asm statement: between single-instruction asm statements the
+// compiler puts an s_nop behind every other pair of adds (24 per 64-add batch; it guards the accumulator, written two instructions
+// earlier, as if it were the DPP source -- only src0 goes through the DPP network, and the terms are written long before)
+template <int S>
+__device__ __forceinline__ void add_quad_block(float &gx, float &gy, const float (&tx)[8], const float (&ty)[8]) {
+#define KMAP_QP8(SS, P)                                                                                                            \
+    if constexpr (S == SS)                                                                                                        \
+        asm("v_add_f32_dpp %0, %2, %0 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %10, %1 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %3, %0 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %11, %1 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %4, %0 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %12, %1 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %5, %0 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %13, %1 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %6, %0 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %14, %1 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %7, %0 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %15, %1 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %8, %0 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %16, %1 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %9, %0 quad_perm:" P " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %17, %1 quad_perm:" P " row_mask:0xf bank_mask:0xf"        \
+            : "+v"(gx), "+v"(gy)                                                                                                  \
+            : "v"(tx[0]), "v"(tx[1]), "v"(tx[2]), "v"(tx[3]), "v"(tx[4]), "v"(tx[5]), "v"(tx[6]), "v"(tx[7]), "v"(ty[0]), "v"(ty[1]), "v"(ty[2]),  \
+              "v"(ty[3]), "v"(ty[4]), "v"(ty[5]), "v"(ty[6]), "v"(ty[7]));
+    KMAP_QP8(0, "[0,0,0,0]") KMAP_QP8(1, "[1,1,1,1]") KMAP_QP8(2, "[2,2,2,2]") KMAP_QP8(3, "[3,3,3,3]")
+    KMAP_QP8(4, "[0,0,2,2]") KMAP_QP8(5, "[1,1,3,3]")        // two sub-lanes per row (pair form): lane 0 / 1 of each lane pair
+#undef KMAP_QP8
+}
+constexpr int SQ_CPL = 8;                       // consecutive columns per lane per batch (one 16-byte load of u16 sums)
+
+struct SeqBatch {                                // raw operands of one batch of one lane
+    uint32_t w[4];                               // 8 u16 sums (LUT source) ...
+    float pf[SQ_CPL];                            // ... or 8 f32 probabilities
+    float x[SQ_CPL], y[SQ_CPL];
+};
+template <bool LUTSRC>
+__device__ __forceinline__ void seq_load(SeqBatch &b, const ProbSrc &src, const float *__restrict__ X,
+                                         const float *__restrict__ Yy, int64_t lrc, int64_t jl, int64_t n, bool vec) {
+    if (vec && jl + SQ_CPL <= n) {
+        if (LUTSRC) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(src.ps + lrc * src.ld + jl);
+            b.w[0] = v.x; b.w[1] = v.y; b.w[2] = v.z; b.w[3] = v.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < SQ_CPL; ++c) b.pf[c] = src.pf[lrc * src.ld + jl + c];
+        }
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(X + jl), a1 = *reinterpret_cast<const f32x4 *>(X + jl + 4);
+        const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Yy + jl), c1 = *reinterpret_cast<const f32x4 *>(Yy + jl + 4);
+        b.x[0] = a0.x; b.x[1] = a0.y; b.x[2] = a0.z; b.x[3] = a0.w; b.x[4] = a1.x; b.x[5] = a1.y; b.x[6] = a1.z; b.x[7] = a1.w;
+        b.y[0] = c0.x; b.y[1] = c0.y; b.y[2] = c0.z; b.y[3] = c0.w; b.y[4] = c1.x; b.y[5] = c1.y; b.y[6] = c1.z; b.y[7] = c1.w;
+    } else {
+#pragma unroll
+        for (int c = 0; c < SQ_CPL; ++c) {
+            const int64_t j = (jl + c < n) ? jl + c : n - 1;
+            if (LUTSRC) {
+                const uint32_t v = src.ps[lrc * src.ld + j];
+                if (c & 1) b.w[c >> 1] |= v << 16;
+                else b.w[c >> 1] = v;
+            } else {
+                b.pf[c] = src.pf[lrc * src.ld + j];
+            }
+            b.x[c] = X[j];
+            b.y[c] = Yy[j];
+        }
+    }
+}
+
+
+// The 8 terms of one lane's batch: t * dx, t * dy of columns jl32 .. jl32 + 7 against point (xi, yi) = row i32, and the batch's
+// cross-entropy contribution in log2 units.  SLOW: generic IEEE divisions (some squared distance beyond 1e30); LOSS: the batch has
+// columns right of the wave's rows; MASK: per-term predicates (the batch reaches past column n - 1 or contains the diagonal of
+// one of the wave's rows).  The two divisions are the exhaustively verified short sequences of seq_div.h.
+template <bool LUTSRC, bool SLOW, bool LOSS, bool MASK>
+__device__ __forceinline__ void seq_terms(const SeqBatch &cur, const float *__restrict__ lut_s, float xi, float yi, int i32, int n32,
+                                          int jl32, float (&tx)[SQ_CPL], float (&ty)[SQ_CPL], float &ce2) {
+    float prod = 1.0f, esum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < SQ_CPL; ++c) {                               // 8 independent terms
+        const int j = jl32 + c;
+        const float p = LUTSRC ? lut_s[(cur.w[c >> 1] >> (16 * (c & 1))) & 0xFFFFu] : cur.pf[c];
+        const float dx = xi - cur.x[c], dy = yi - cur.y[c];
+        const float d2 = dx * dx + dy * dy;                          // (dx*dx) + (dy*dy), no FMA (taichi_core.py:254)
+        float q = SLOW ? 1.0f / (1.0f + d2) : seq_rcp<KMAP_SEQ_RCP_STEPS>(1.0f + d2);        // :255
+        q = __builtin_amdgcn_fmed3f(q, 0.001f, 0.999f);              // np.minimum(.., 1 - 1e-3), np.maximum(.., 1e-3)
+        const float omq = 1.0f - q;
+        const float u = SLOW ? q / omq : seq_quo<KMAP_SEQ_QUO_RSTEPS, KMAP_SEQ_QUO_STEPS>(q, omq);   // visualization.py:132-134
+        const float t = u * (p - q);
+        const bool use = !MASK || ((j < n32) && (j != i32));
+        tx[c] = use ? t * dx : 0.0f;                                 // products rounded on their own (-ffp-contract=off)
+        ty[c] = use ? t * dy : 0.0f;
+        if (LOSS) {
+            // -(p ln q + (1-p) ln(1-q)) = -ln2 (log2(1-q) + p log2(q/(1-q))): one log per pair + one log of the product
+            // of the eight (1-q); the reference's eps branches change a term by < 1e-9 relative (p < 1e-10) or not at
+            // all (p = 1), and the loss is not part of the bit-pinned path
+            const bool live = !MASK || ((j < n32) && (j > i32));     // a plain batch with loss lies right of all the wave's rows
+            esum += live ? p * __builtin_amdgcn_logf(u) : 0.0f;
+            prod *= live ? omq : 1.0f;
+        }
+    }
+    if (LOSS) ce2 = __builtin_amdgcn_logf(prod) + esum;
+}
+// wave-uniform dispatch over the variants.  rows_in_wave consecutive rows from wave_row_min; batch = columns [j0, j0 + batch_cols)
+template <bool LUTSRC>
+__device__ __forceinline__ void seq_terms_dispatch(const SeqBatch &cur, const float *__restrict__ lut_s, float xi, float yi, int i32,
+                                                   int64_t n, int64_t j0, int batch_cols, int64_t wave_row_min, int rows_in_wave,
+                                                   int jl32, float (&tx)[SQ_CPL], float (&ty)[SQ_CPL], float &ce2) {
+    // (a) no column of the batch lies right of any of the wave's rows -> no loss terms (each unordered pair is charged to its
+    // j > i side); (b) some squared distance is too large for the short divisions -> generic division
+    const bool want_loss = (j0 + batch_cols - 1) > wave_row_min;
+    float d2max = 0.0f;
+#pragma unroll
+    for (int c = 0; c < SQ_CPL; ++c) {
+        const float dx = xi - cur.x[c], dy = yi - cur.y[c];
+        d2max = fmaxf(d2max, dx * dx + dy * dy);
+    }
+    const bool slow = __any(!(d2max < 1e30f));
+    // (c) the batch neither reaches past column n-1 nor contains the diagonal of any of the wave's rows -> no per-term masks
+    const bool plain = (j0 + batch_cols <= n) && (j0 + batch_cols - 1 < wave_row_min || j0 > wave_row_min + rows_in_wave - 1);
+    const int n32 = (int)n;
+    ce2 = 0.0f;
+    if (slow) {   // rare (coordinates beyond 1e15): one generic instantiation
+        seq_terms<LUTSRC, true, true, true>(cur, lut_s, xi, yi, i32, n32, jl32, tx, ty, ce2);
+    } else if (plain) {
+        if (want_loss) seq_terms<LUTSRC, false, true, false>(cur, lut_s, xi, yi, i32, n32, jl32, tx, ty, ce2);
+        else seq_terms<LUTSRC, false, false, false>(cur, lut_s, xi, yi, i32, n32, jl32, tx, ty, ce2);
+    } else {
+        seq_terms<LUTSRC, false, true, true>(cur, lut_s, xi, yi, i32, n32, jl32, tx, ty, ce2);
+    }
+}
+
+// quad form, block `bid` of the rows [0, nrows) (lut_s: the block's LUT copy in LDS, already filled; wl: SQ_WAVES doubles of LDS)
+// SUB = 4: the quad form.  SUB = 2 (pair form): two sub-lanes per row, 32 rows per wave -- every ordered add then serves 32 rows instead
+// of 16 (4 instead of 8 add instructions per pair), at twice the columns per lane; one round of pair waves replaces two rounds of quad
+// waves (12.6 N against 2 x 7.3 N instructions per SIMD).  Rows [lrow0, lrow0 + ...) of the local range, bounded by `nrows`.
+template <bool LUTSRC, int SUB>
+__device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *__restrict__ Y, int64_t n, int64_t row0, int64_t lrow0,
+                                              int64_t nrows, float *__restrict__ G, double *__restrict__ loss_part, int64_t bid,
+                                              const float *__restrict__ lut_s, double *wl) {
+    constexpr int SQ_SUB = SUB, SQ_ROWS = KMAP_WAVE / SUB, SQ_BATCH = SUB * SQ_CPL;   // shadow the quad form's constants
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & (SQ_SUB - 1);
+    const int64_t lr = lrow0 + (bid * SQ_WAVES + wave) * SQ_ROWS + (lane / SQ_SUB);
+    const bool valid = lr < nrows;
+    const int64_t lrc = valid ? lr : nrows - 1;
+    const int64_t i = row0 + lrc;
+    const float *X = Y, *Yy = Y + n;
+    const float xi = X[i], yi = Yy[i];
+    const bool vec = ((n & 3) == 0) && (!LUTSRC || (src.ld % 8 == 0));
+    const int i32 = (int)i;                      // n < 2^31 (checked by the host)
+    const int64_t wave_row_min = row0 + lrow0 + (bid * SQ_WAVES + wave) * SQ_ROWS;   // smallest global row of the wave
+    float gx = 0.0f, gy = 0.0f, ce_acc = 0.0f;
+    double loss = 0.0;
+    SeqBatch cur, nxt;
+    seq_load<LUTSRC>(cur, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n, vec);
+    for (int64_t j0 = 0; j0 < n; j0 += SQ_BATCH) {
+        const int64_t jl = j0 + (int64_t)sub * SQ_CPL;                       // this lane's first column of the batch
+        if (j0 + SQ_BATCH < n) seq_load<LUTSRC>(nxt, src, X, Yy, lrc, jl + SQ_BATCH, n, vec);   // prefetch
+        float tx[SQ_CPL], ty[SQ_CPL];
+        float ce2;                                                           // loss terms in log2 units (order-free)
+        seq_terms_dispatch<LUTSRC>(cur, lut_s, xi, yi, i32, n, j0, SQ_BATCH, wave_row_min, SQ_ROWS, (int)jl, tx, ty, ce2);
+        ce_acc += ce2;
+        // ordered accumulation over the batch's 32 columns: column j0 + 8*s2 + c lives in sub-lane s2, slot c
+        asm volatile("s_nop 1");
+        if constexpr (SUB == 4) {
+            add_quad_block<0>(gx, gy, tx, ty);
+            add_quad_block<1>(gx, gy, tx, ty);
+            add_quad_block<2>(gx, gy, tx, ty);
+            add_quad_block<3>(gx, gy, tx, ty);
+        } else {
+            add_quad_block<4>(gx, gy, tx, ty);
+            add_quad_block<5>(gx, gy, tx, ty);
+        }
+        if (((j0 / SQ_BATCH) & 7) == 7) {
+            loss += (double)ce_acc;
+            ce_acc = 0.0f;
+        }
+        cur = nxt;
+    }
+    loss += (double)ce_acc;
+    loss *= -0.6931471805599453;   // log2 units -> -ln
+    if (valid && sub == 0) {
+        G[i] = gx;
+        G[n + i] = gy;
+    }
+    if (!valid) loss = 0.0;
+    for (int o = 32; o > 0; o >>= 1) loss += __shfl_down(loss, o);
+    if (lane == 0) wl[wave] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < SQ_WAVES; ++w) t += wl[w];
+        loss_part[bid] = t;
+    }
+}
+
+// SEQ forces, WIDE form: a row is owned by GW lanes (GW = 8 .. 64; 64 / GW rows per wave).  Same terms, same order of the row
+// sum; what differs is how the terms reach the accumulator: every lane writes its 8 (t dx, t dy) pairs to a per-wave LDS strip,
+// and the row's first lane then adds the strip's 8 GW pairs in column order (one packed f32 add per pair).
+// Per column and wave that costs 288 / (8 GW) + 1 VALU instructions instead of the quad form's 11 -- but GW / 4 times the lanes
+// per row, i.e. more total work: it is for the rows that do NOT fill the machine.  With 16 rows per quad wave and 3 waves per SIMD
+// (145 VGPRs), 49 152 rows fill an MI355X exactly; the 848 remaining rows of N = 50 000 were a fourth round of 14 blocks that ran
+// alone for a full millisecond (N = 49 152: 3.00 ms, N = 49 216: 3.98 ms).  As 848 one-row waves they take ~0.16 ms.
+// wide form, block `bid` of the local rows [lrow0, nrows); xch_all: SQ_WAVES x 64 x 8 (t dx, t dy) pairs of LDS
+// acc + (value of `v` in lane K of the caller's 16-lane DPP row), valid in lane 0 of the row: row_ror:(16 - K) makes lane L read lane
+// (L + K) mod 16.
+template <int K>
+__device__ __forceinline__ float add_row16_lane(float acc, float v) {
+    float r;
+    if constexpr (K == 0) { r = acc + v; return r; }
+#define KMAP_ROR(KK, N) if constexpr (K == KK) asm("v_add_f32_dpp %0, %1, %2 row_ror:" #N " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "v"(acc));
+    KMAP_ROR(1, 15) KMAP_ROR(2, 14) KMAP_ROR(3, 13) KMAP_ROR(4, 12) KMAP_ROR(5, 11) KMAP_ROR(6, 10) KMAP_ROR(7, 9) KMAP_ROR(8, 8)
+    KMAP_ROR(9, 7) KMAP_ROR(10, 6) KMAP_ROR(11, 5) KMAP_ROR(12, 4) KMAP_ROR(13, 3) KMAP_ROR(14, 2) KMAP_ROR(15, 1)
+#undef KMAP_ROR
+    return r;
+}
+// the eight columns of source lane K (K >= 1) of a batch, x and y chains alternating, as ONE asm statement: left to itself the
+// compiler puts an s_nop behind every pair of these adds (it treats the accumulator, written two instructions earlier, as if it
+// were the DPP source: 112 s_nop for the 240 adds of a batch).  Only src0 goes through the DPP network, and tx / ty are written
+// long before.
+template <int K>
+__device__ __forceinline__ void add_row16_block(float &gx, float &gy, const float (&tx)[SQ_CPL], const float (&ty)[SQ_CPL]) {
+#define KMAP_ROR8(KK, N)                                                                                                          \
+    if constexpr (K == KK)                                                                                                        \
+        asm("v_add_f32_dpp %0, %2, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %10, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %3, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %11, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %4, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %12, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %5, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %13, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %6, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %14, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %7, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %15, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %8, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %16, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"   \
+            "v_add_f32_dpp %0, %9, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %17, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf"        \
+            : "+v"(gx), "+v"(gy)                                                                                                  \
+            : "v"(tx[0]), "v"(tx[1]), "v"(tx[2]), "v"(tx[3]), "v"(tx[4]), "v"(tx[5]), "v"(tx[6]), "v"(tx[7]), "v"(ty[0]), "v"(ty[1]), "v"(ty[2]),  \
+              "v"(ty[3]), "v"(ty[4]), "v"(ty[5]), "v"(ty[6]), "v"(ty[7]));
+    KMAP_ROR8(1, 15) KMAP_ROR8(2, 14) KMAP_ROR8(3, 13) KMAP_ROR8(4, 12) KMAP_ROR8(5, 11) KMAP_ROR8(6, 10) KMAP_ROR8(7, 9) KMAP_ROR8(8, 8)
+    KMAP_ROR8(9, 7) KMAP_ROR8(10, 6) KMAP_ROR8(11, 5) KMAP_ROR8(12, 4) KMAP_ROR8(13, 3) KMAP_ROR8(14, 2) KMAP_ROR8(15, 1)
+#undef KMAP_ROR8
+}
+// Sixteen lanes per row (one DPP row), four rows per wave, no LDS: for sessions with fewer rows than one round of quad waves, where
+// a wave is a chain of dependent adds and not a share of issue slots.  Lane s of a row computes the terms of columns
+// j0 + 8 s .. + 7 of a 128-column batch; lane 0 of the row adds them in column order through row_ror sources (the other lanes
+// execute the same adds on rotated operands and are ignored).  The x and y chains alternate, so consecutive adds of one chain are
+// two instructions apart -- their latency -- and nothing waits for an LDS round trip as in the strip-exchange form.
+constexpr int SR_SUB = 16, SR_ROWS = KMAP_WAVE / SR_SUB, SR_BATCH = SR_SUB * SQ_CPL;
+template <bool LUTSRC>
+__device__ __forceinline__ void seq_row16_body(const ProbSrc &src, const float *__restrict__ Y, int64_t n, int64_t row0, int64_t lrow0,
+                                               int64_t nrows, float *__restrict__ G, double *__restrict__ loss_part, int64_t bid,
+                                               const float *__restrict__ lut_s, double *wl) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & (SR_SUB - 1);
+    const int64_t wave_lr = lrow0 + (bid * SQ_WAVES + wave) * SR_ROWS;    // first local row of the wave
+    const int64_t lr = wave_lr + (lane / SR_SUB);
+    const bool valid = lr < nrows;
+    const int64_t lrc = valid ? lr : nrows - 1;
+    const int64_t i = row0 + lrc;
+    const float *X = Y, *Yy = Y + n;
+    const float xi = X[i], yi = Yy[i];
+    const bool vec = ((n & 3) == 0) && (!LUTSRC || (src.ld % 8 == 0));
+    const int i32 = (int)i;
+    const int64_t wave_row_min = row0 + wave_lr;
+    float gx = 0.0f, gy = 0.0f, ce_acc = 0.0f;
+    double loss = 0.0;
+    // (computing the terms of batch b + 1 in the same loop body as the adds of batch b -- a software pipeline for the scheduler to
+    // interleave -- measured slower: 0.066 vs 0.058 ms at N = 4000)
+    SeqBatch cur, nxt;
+    seq_load<LUTSRC>(cur, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n, vec);
+    for (int64_t j0 = 0; j0 < n; j0 += SR_BATCH) {
+        const int64_t jl = j0 + (int64_t)sub * SQ_CPL;
+        if (j0 + SR_BATCH < n) seq_load<LUTSRC>(nxt, src, X, Yy, lrc, jl + SR_BATCH, n, vec);   // prefetch
+        float tx[SQ_CPL], ty[SQ_CPL];
+        float ce2;
+        seq_terms_dispatch<LUTSRC>(cur, lut_s, xi, yi, i32, n, j0, SR_BATCH, wave_row_min, SR_ROWS, (int)jl, tx, ty, ce2);
+        ce_acc += ce2;
+        asm volatile("s_nop 1");
+#define SEQ_ADD16(K)                                                                                  \
+        _Pragma("unroll") for (int c = 0; c < SQ_CPL; ++c) {                                          \
+            gx = add_row16_lane<K>(gx, tx[c]);                                                        \
+            gy = add_row16_lane<K>(gy, ty[c]);                                                        \
+        }
+        SEQ_ADD16(0)
+#undef SEQ_ADD16
+        add_row16_block<1>(gx, gy, tx, ty); add_row16_block<2>(gx, gy, tx, ty); add_row16_block<3>(gx, gy, tx, ty);
+        add_row16_block<4>(gx, gy, tx, ty); add_row16_block<5>(gx, gy, tx, ty); add_row16_block<6>(gx, gy, tx, ty);
+        add_row16_block<7>(gx, gy, tx, ty); add_row16_block<8>(gx, gy, tx, ty); add_row16_block<9>(gx, gy, tx, ty);
+        add_row16_block<10>(gx, gy, tx, ty); add_row16_block<11>(gx, gy, tx, ty); add_row16_block<12>(gx, gy, tx, ty);
+        add_row16_block<13>(gx, gy, tx, ty); add_row16_block<14>(gx, gy, tx, ty); add_row16_block<15>(gx, gy, tx, ty);
+        if (((j0 / SR_BATCH) & 7) == 7) {
+            loss += (double)ce_acc;
+            ce_acc = 0.0f;
+        }
+        cur = nxt;
+    }
+    loss += (double)ce_acc;
+    loss *= -0.6931471805599453;   // log2 units -> -ln
+    if (valid && sub == 0) {
+        G[i] = gx;
+        G[n + i] = gy;
+    }
+    if (!valid) loss = 0.0;
+    for (int o = 32; o > 0; o >>= 1) loss += __shfl_down(loss, o);
+    if (lane == 0) wl[wave] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < SQ_WAVES; ++w) t += wl[w];
+        loss_part[bid] = t;
+    }
+}
+
+template <bool LUTSRC, int GW>
+__device__ __forceinline__ void seq_wide_body(const ProbSrc &src, const float *__restrict__ Y, int64_t n, int64_t row0, int64_t lrow0,
+                                              int64_t nrows, float *__restrict__ G, double *__restrict__ loss_part, int64_t bid,
+                                              const float *__restrict__ lut_s, double *wl, f32x2 *xch_all) {
+    constexpr int RW = KMAP_WAVE / GW;                       // rows per wave
+    constexpr int BC = GW * SQ_CPL;                          // columns per batch
+    f32x2 *xch = xch_all + (size_t)(threadIdx.x >> 6) * (KMAP_WAVE * SQ_CPL);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & (GW - 1), grp = lane / GW;
+    const int64_t wave_lr = lrow0 + (bid * SQ_WAVES + wave) * RW;    // first local row of the wave
+    const int64_t lr = wave_lr + grp;
+    const bool valid = lr < nrows;
+    const int64_t lrc = valid ? lr : nrows - 1;
+    const int64_t i = row0 + lrc;
+    const float *X = Y, *Yy = Y + n;
+    const float xi = X[i], yi = Yy[i];
+    const bool vec = ((n & 3) == 0) && (!LUTSRC || (src.ld % 8 == 0));
+    const int i32 = (int)i;
+    const int64_t wave_row_min = row0 + wave_lr;
+    f32x2 acc = {0.0f, 0.0f};
+    float ce_acc = 0.0f;
+    double loss = 0.0;
+    SeqBatch cur, nxt;
+    seq_load<LUTSRC>(cur, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n, vec);
+    f32x2 *mine = xch + (size_t)lane * SQ_CPL;                         // = strip of row grp, columns sub * 8 .. + 7
+    const f32x4 *strip = reinterpret_cast<const f32x4 *>(xch + (size_t)grp * BC);
+    int batch = 0;
+    for (int64_t j0 = 0; j0 < n; j0 += BC, ++batch) {
+        const int64_t jl = j0 + (int64_t)sub * SQ_CPL;
+        if (j0 + BC < n) seq_load<LUTSRC>(nxt, src, X, Yy, lrc, jl + BC, n, vec);          // prefetch
+        float tx[SQ_CPL], ty[SQ_CPL];
+        float ce2;
+        seq_terms_dispatch<LUTSRC>(cur, lut_s, xi, yi, i32, n, j0, BC, wave_row_min, RW, (int)jl, tx, ty, ce2);
+        ce_acc += ce2;
+#pragma unroll
+        for (int c = 0; c < SQ_CPL; c += 2) {
+            const f32x4 v = {tx[c], ty[c], tx[c + 1], ty[c + 1]};
+            *reinterpret_cast<f32x4 *>(mine + c) = v;
+        }
+        // same wave writes and reads: LDS operations of a wave execute in order; the compiler must not move the reads up
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (sub == 0) {   // ONE lane per row carries the sum: 64 lanes reading the same 16 bytes made the strip reads LDS-bandwidth bound
+#pragma unroll 16
+            for (int m = 0; m < BC / 2; ++m) {                               // ordered: columns j0 + 2m, j0 + 2m + 1
+                const f32x4 v = strip[m];
+                acc += f32x2{v.x, v.y};
+                acc += f32x2{v.z, v.w};
+            }
+        }
+        asm volatile("" ::: "memory");                                       // the next batch's writes stay behind these reads
+        if ((batch & 7) == 7) {
+            loss += (double)ce_acc;
+            ce_acc = 0.0f;
+        }
+        cur = nxt;
+    }
+    loss += (double)ce_acc;
+    loss *= -0.6931471805599453;
+    if (valid && sub == 0) {
+        G[i] = acc.x;
+        G[n + i] = acc.y;
+    }
+    if (!valid) loss = 0.0;
+    for (int o = 32; o > 0; o >>= 1) loss += __shfl_down(loss, o);
+    if (lane == 0) wl[wave] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < SQ_WAVES; ++w) t += wl[w];
+        loss_part[bid] = t;
+    }
+}
+
+// One launch for both forms: blocks [0, nb_tail) take the left-over rows in the wide form (GW lanes per row; GW = 0: none), the
+// blocks behind them the whole rounds in the quad form.  Launched together the wide waves share their SIMDs with three quad
+// waves each, which hides the latency of their N-step dependent add chain (alone on the machine -- as a second launch -- the
+// 848 one-row waves of N = 50 000 took 0.5 - 0.6 ms; as a fourth wave per SIMD they cost their ~8 % of issue slots).  Wide
+// blocks come first in the grid so that they are placed before the CUs fill up.
+template <bool LUTSRC, int GW>
+__global__ __launch_bounds__(KMAP_WAVE *SQ_WAVES) void forces_seq_kernel(ProbSrc src, const float *__restrict__ Y, int64_t n,
+                                                               int64_t row0, int64_t pair_rows, int64_t main_rows, int64_t nrows,
+                                                               int nb_tail, int nb_pair, int nb_main, float *__restrict__ G,
+                                                               double *__restrict__ loss_part) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr size_t XCH_FLOATS = GW ? (size_t)SQ_WAVES * KMAP_WAVE * SQ_CPL * 2 : 0;   // exchange strips first, the LUT behind them
+    float *lut_s = smem + XCH_FLOATS;
+    if (LUTSRC) {
+        for (int t = threadIdx.x; t < src.lut_len && t < F_LUT_LDS; t += blockDim.x) lut_s[t] = src.lut[t];
+        __syncthreads();
+    }
+    __shared__ double wl[SQ_WAVES];
+    if constexpr (GW != 0) {
+        if ((int)blockIdx.x < nb_tail) {   // block-uniform
+            if constexpr (GW == 16)   // one DPP row per matrix row: no exchange through LDS
+                seq_row16_body<LUTSRC>(src, Y, n, row0, main_rows, nrows, G, loss_part + nb_main, (int64_t)blockIdx.x, lut_s, wl);
+            else
+                seq_wide_body<LUTSRC, GW>(src, Y, n, row0, main_rows, nrows, G, loss_part + nb_main, (int64_t)blockIdx.x, lut_s, wl,
+                                          reinterpret_cast<f32x2 *>(smem));
+            return;
+        }
+    }
+    // grid order: wide blocks, pair blocks (rows [0, pair_rows)), quad blocks (rows [pair_rows, main_rows)); loss partials: quad |
+    // pair | wide (nb_main = quad + pair blocks)
+    const int b = (int)blockIdx.x - nb_tail;
+    if (b < nb_pair) seq_quad_body<LUTSRC, 2>(src, Y, n, row0, 0, pair_rows, G, loss_part + (nb_main - nb_pair), (int64_t)b, lut_s, wl);
+    else seq_quad_body<LUTSRC, 4>(src, Y, n, row0, pair_rows, main_rows, G, loss_part, (int64_t)(b - nb_pair), lut_s, wl);
+}
+}  // namespace
+
+int kmap_embed_seq_pair_blocks(const kmap_embed *e) { return (int)(e->seq_pair_rows / (2 * SQ_ROWS * SQ_WAVES)); }
+// quad + pair blocks
+static int seq_main_blocks(const kmap_embed *e) {
+    return kmap_embed_seq_pair_blocks(e) + (int)((e->seq_main_rows - e->seq_pair_rows + SQ_ROWS * SQ_WAVES - 1) / (SQ_ROWS * SQ_WAVES));
+}
+static int seq_tail_blocks(const kmap_embed *e) {
+    if (!e->seq_tail_g) return 0;
+    const int64_t rows_per_block = (int64_t)SQ_WAVES * (KMAP_WAVE / e->seq_tail_g);
+    return (int)((e->nrows - e->seq_main_rows + rows_per_block - 1) / rows_per_block);
+}
+int kmap_embed_seq_blocks(const kmap_embed *e) { return seq_main_blocks(e) + seq_tail_blocks(e); }
+
+// How the SEQ rows are split between the quad kernel and the wide kernel.  The kernels are VALU-issue bound and every wave of a
+// SIMD shares its issue slots, so the cost of a set of waves is (waves on the fullest SIMD) x (instructions per wave); per
+// column a quad wave issues ~9.4 instructions (8 terms x 27 + 64 adds + ~20 per 32 columns), a wide wave with g lanes per row
+// ~(30 / g + 1.2).  Whole rounds of quad waves (one wave on every SIMD) are the cheapest way to do rows; what is left over is
+// given to whichever form finishes it soonest.
+void kmap_embed_seq_split(kmap_embed *e) {
+    e->seq_main_rows = e->nrows;
+    e->seq_tail_g = 0;
+    e->seq_pair_rows = 0;
+    static const int off = [] { const char *v = getenv("KMAP_SEQ_TAIL"); return v && v[0] == '0'; }();   // A/B switch
+    if (off || e->nrows <= 0) return;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const int64_t simds = 4 * (int64_t)cus;
+    const int64_t round_rows = simds * SQ_ROWS;                       // rows of one wave on every SIMD
+    const int64_t main_rows = (e->nrows / round_rows) * round_rows;
+    const int64_t rem = e->nrows - main_rows;
+    // two rounds of quad waves -> one round of pair waves (every ordered add serves 32 rows: 12.6 N against 14.6 N instructions per
+    // SIMD); an odd round stays in the quad form and shares the SIMDs with the pair round
+    static const int pair_on = [] { const char *v = getenv("KMAP_SEQ_PAIR"); return !(v && v[0] == '0'); }();   // A/B switch
+    // ... but only next to quad waves: a pair round alone on the SIMDs (one wave each) exposes its add chain (N = 33 000: 1.52 against
+    // 1.29 ms for two quad rounds), so at least one quad round stays -- R rounds of quad rows become (R - 1) / 2 pair rounds + the rest
+    const int64_t rounds_q = main_rows / round_rows;
+    const int64_t pair_rounds = rounds_q >= 3 ? (rounds_q - 1) / 2 : 0;
+    e->seq_pair_rows = pair_on ? pair_rounds * 2 * round_rows : 0;
+    if (rem == 0) return;
+    auto rounds = [&](int64_t waves) { return (double)((waves + simds - 1) / simds); };
+    double best = rounds((rem + SQ_ROWS - 1) / SQ_ROWS) * 9.4;       // the remainder as quad waves
+    int best_g = 0;
+    for (int g : {8, 16, 32, 64}) {
+        const int64_t waves = (rem + (KMAP_WAVE / g) - 1) / (KMAP_WAVE / g);
+        const double cost = rounds(waves) * (30.0 / g + 1.2);
+        if (cost < best) { best = cost; best_g = g; }
+    }
+    if (main_rows == 0) {
+        // fewer rows than one round of quad waves (N < 16 384 on this part): the waves are dependent-add chains, not issue slots, and
+        // whole-round counting misjudges 1.2 waves per SIMD as two rounds.  Measured (tools/bench_embed.py --modes seq, ms per
+        // iteration, g = quad / 8 / 16 / 32 / 64): N = 1000: .036 .035 .026 .022 .021; 3000: .085 .073 .049 .051 .060;
+        // 5000: .138 .115 .105 .105 .133; 8000: .214 .174 .155 .199 .307; 10 000: .265 .293 .249 .297 .462; 14 000: .372 .412 .429 ...
+        best_g = rem <= 1500 ? 64 : rem <= 2500 ? 32 : rem <= 12000 ? 16 : 0;
+    }
+    if (best_g) {
+        e->seq_main_rows = main_rows;
+        e->seq_tail_g = best_g;
+    }
+}
+
+int kmap_embed_launch_seq(kmap_embed *e, float *G, hipStream_t st) {
+    const bool lut = e->src.ps != nullptr;
+    const size_t lds = lut ? (((size_t)e->src.lut_len * 4 + 15) & ~(size_t)15) : 16;
+    const int nb_main = seq_main_blocks(e), nb_tail = seq_tail_blocks(e);
+    const size_t lds_w = (nb_tail ? (size_t)SQ_WAVES * KMAP_WAVE * SQ_CPL * 8 : 0) + lds;
+#define KMAP_SEQ(LUT, GW)                                                                                                          \
+    do {                                                                                                                           \
+        KMAP_TRY(kmap_allow_lds((const void *)forces_seq_kernel<LUT, GW>, (int)lds_w));                                            \
+        forces_seq_kernel<LUT, GW><<<nb_tail + nb_main, KMAP_WAVE * SQ_WAVES, lds_w, st>>>(e->src, e->Y, e->n, e->row0, e->seq_pair_rows, \
+                                                                                          e->seq_main_rows, e->nrows, nb_tail,      \
+                                                                                          kmap_embed_seq_pair_blocks(e), nb_main, G, e->loss_part); \
+    } while (0)
+#define KMAP_SEQ_G(LUT)                                                                                       \
+    do {                                                                                                      \
+        const int g = nb_tail ? e->seq_tail_g : 0;                                                            \
+        if (g == 0) KMAP_SEQ(LUT, 0); else if (g == 8) KMAP_SEQ(LUT, 8); else if (g == 16) KMAP_SEQ(LUT, 16); \
+        else if (g == 32) KMAP_SEQ(LUT, 32); else KMAP_SEQ(LUT, 64);                                            \
+    } while (0)
+    if (lut) KMAP_SEQ_G(true); else KMAP_SEQ_G(false);
+#undef KMAP_SEQ_G
+#undef KMAP_SEQ
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}

@@ -62,7 +62,7 @@ constexpr uint32_t pack_bias() {   // removes the +16/+32 of four packed p2() re
 }
 
 // the row loop of one wave; VEC = the lane's 16 columns are in range and 16-byte aligned
-template <typename H, bool NT, bool VEC>
+template <typename H, bool VEC>
 __device__ __forceinline__ void run_rows(const H (&b)[COLS_PER_LANE], const uint32_t (&gcol)[COLS_PER_LANE / 4], H arow,
                                          uint32_t grow, uint32_t srow, int rcount, uint8_t *orow, int64_t ld,
                                          int64_t col0, int64_t n) {
@@ -96,8 +96,7 @@ __device__ __forceinline__ void run_rows(const H (&b)[COLS_PER_LANE], const uint
         }
         if constexpr (VEC) {
             u32x4 o = {w[0], w[1], w[2], w[3]};
-            if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(orow));
-            else *reinterpret_cast<u32x4 *>(orow) = o;
+            __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(orow));   // write-once streaming output (5.02 vs 4.77 TB/s at N = 50 k)
         } else {
 #pragma unroll
             for (int c = 0; c < COLS_PER_LANE; ++c)
@@ -106,7 +105,7 @@ __device__ __forceinline__ void run_rows(const H (&b)[COLS_PER_LANE], const uint
     }
 }
 
-template <typename H, bool NT>
+template <typename H>
 __global__ __launch_bounds__(KMAP_WAVE *WAVES_PER_BLOCK) void hamdist_matrix_kernel(
     const H *__restrict__ kh, const uint8_t *__restrict__ gid, ByteTab gshift, int64_t n, H mask,
     int64_t row0, int64_t nrows, uint8_t *__restrict__ out, int64_t ld, int vec_ok, int rpw, int row_major, int wpb) {
@@ -148,7 +147,7 @@ __global__ __launch_bounds__(KMAP_WAVE *WAVES_PER_BLOCK) void hamdist_matrix_ker
         gcol[0] = g.x; gcol[1] = g.y; gcol[2] = g.z; gcol[3] = g.w;
 #pragma unroll
         for (int c = 0; c < COLS_PER_LANE; ++c) b[c] &= mask;
-        run_rows<H, NT, true>(b, gcol, arow, grow, srow, rcount, orow, ld, col0, n);
+        run_rows<H, true>(b, gcol, arow, grow, srow, rcount, orow, ld, col0, n);
     } else {
 #pragma unroll
         for (int c = 0; c < COLS_PER_LANE; ++c) b[c] = (col0 + c < n) ? (H)(kh[col0 + c] & mask) : (H)0;
@@ -160,7 +159,7 @@ __global__ __launch_bounds__(KMAP_WAVE *WAVES_PER_BLOCK) void hamdist_matrix_ker
                 if (col0 + 4 * v + c < n) w |= (uint32_t)gid[col0 + 4 * v + c] << (8 * c);
             gcol[v] = w;
         }
-        run_rows<H, NT, false>(b, gcol, arow, grow, srow, rcount, orow, ld, col0, n);
+        run_rows<H, false>(b, gcol, arow, grow, srow, rcount, orow, ld, col0, n);
     }
 }
 
@@ -178,6 +177,7 @@ __global__ __launch_bounds__(KMAP_WAVE *WAVES_PER_BLOCK) void hamdist_matrix_ker
 // Tile = one 4-KiB column block x R rows spaced 8 apart (all its chunks share one residue); requires ld % 4096 == 0 and
 // ld / 4096 odd (kmap_amd.hamdist.pitch_for provides it).
 constexpr int T_TPB = 256;
+constexpr int T_LDS_THROTTLE = 40 * 1024;   // dynamic LDS reserved per block: four resident blocks per CU (rule (c) above)
 
 template <typename H>
 __global__ void build_codes_kernel(const H *__restrict__ kh, int64_t n, int k, H mask, int onehot, uint32_t *__restrict__ c0,
@@ -200,7 +200,7 @@ __global__ void build_codes_kernel(const H *__restrict__ kh, int64_t n, int k, H
 
 __device__ __forceinline__ uint32_t bcnt(uint32_t x, uint32_t acc) { return (uint32_t)__builtin_popcount(x) + acc; }
 
-template <int CW, int R, bool NT>
+template <int CW, int R>
 __global__ __launch_bounds__(T_TPB) void hamdist_tile_kernel(const uint32_t *__restrict__ c0, const uint32_t *__restrict__ c1,
                                                              const uint8_t *__restrict__ gid, ByteTab gshift, int k, int64_t n,
                                                              int64_t row0, int64_t nrows, uint8_t *__restrict__ out, int64_t ld,
@@ -358,8 +358,7 @@ __global__ __launch_bounds__(T_TPB) void hamdist_tile_kernel(const uint32_t *__r
         uint8_t *orow = out + rloc * ld + col0;
         if (full) {
             u32x4 o = {w[0], w[1], w[2], w[3]};
-            if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(orow));
-            else *reinterpret_cast<u32x4 *>(orow) = o;
+            __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(orow));   // write-once streaming output (5.02 vs 4.77 TB/s at N = 50 k)
         } else {
 #pragma unroll
             for (int cc = 0; cc < COLS_PER_LANE; ++cc)
@@ -370,7 +369,7 @@ __global__ __launch_bounds__(T_TPB) void hamdist_tile_kernel(const uint32_t *__r
 
 template <int CW, int R>
 int launch_tile(const uint32_t *c0, const uint32_t *c1, const uint8_t *gid, const ByteTab &gshift, int k, int64_t n, int64_t row0,
-                int64_t nrows, uint8_t *out, int64_t ld, bool nt, int lds_bytes, hipStream_t st) {
+                int64_t nrows, uint8_t *out, int64_t ld, hipStream_t st) {
     const int cb = (int)((n + 4095) / 4096);
     const int cpr = (int)(ld >> 12);
     int inv = 1;
@@ -380,12 +379,8 @@ int launch_tile(const uint32_t *c0, const uint32_t *c1, const uint8_t *gid, cons
     const int64_t groups = (nrows + 8 * R - 1) / (8 * R);
     KMAP_REQUIRE(groups <= 65535, "hamdist_matrix: nrows too large for one launch (%lld)", (long long)nrows);
     const dim3 blocks((unsigned)(8 * cb), (unsigned)groups);
-    KMAP_TRY(kmap_allow_lds((const void *)hamdist_tile_kernel<CW, R, true>, 160 * 1024));
-    KMAP_TRY(kmap_allow_lds((const void *)hamdist_tile_kernel<CW, R, false>, 160 * 1024));
-    if (nt)
-        hamdist_tile_kernel<CW, R, true><<<blocks, T_TPB, lds_bytes, st>>>(c0, c1, gid, gshift, k, n, row0, nrows, out, ld, cb, inv, shift);
-    else
-        hamdist_tile_kernel<CW, R, false><<<blocks, T_TPB, lds_bytes, st>>>(c0, c1, gid, gshift, k, n, row0, nrows, out, ld, cb, inv, shift);
+    KMAP_TRY(kmap_allow_lds((const void *)hamdist_tile_kernel<CW, R>, 160 * 1024));
+    hamdist_tile_kernel<CW, R><<<blocks, T_TPB, T_LDS_THROTTLE, st>>>(c0, c1, gid, gshift, k, n, row0, nrows, out, ld, cb, inv, shift);
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;
 }
@@ -419,14 +414,9 @@ int launch_matrix(const H *kh_dev, const int32_t *label_dev, int64_t n, int k, c
     uint8_t *gid = nullptr;
     KMAP_TRY(kmap_scratch((void **)&gid, ((size_t)n + 15) & ~(size_t)15, st, KMAP_SLOT_A));
 
-    static const bool nt = !(getenv("KMAP_HAMDIST_NT") && getenv("KMAP_HAMDIST_NT")[0] == '0');
-    // tiled one-hot path: k <= 16, 4-KiB row pitch with an odd number of chunks per row, at least one full column block
-    static const int tile_on = [] { const char *e = getenv("KMAP_HAMDIST_TILE"); return e ? atoi(e) : 1; }();
-    // rows per tile: 4 for the one-word one-hot compare (2.75 ops per byte), 8 for the heavier compares (k = 12: 0.428 vs 0.464 ms)
-    static const int tile_r_env = [] { const char *e = getenv("KMAP_HAMDIST_TILE_R"); int v = e ? atoi(e) : 0; return (v == 2 || v == 4 || v == 8 || v == 16) ? v : 0; }();
-    const int tile_r = tile_r_env ? tile_r_env : (k <= 8 ? 4 : 8);
-    static const int tile_lds = [] { const char *e = getenv("KMAP_HAMDIST_TILE_LDS_KB"); int v = e ? atoi(e) : 40; return (v >= 0 && v <= 160) ? v : 40; }();
-    if (tile_on && k <= 16 && (ld % 4096) == 0 && ((ld >> 12) & 1) && n >= 4096 && ((uintptr_t)out_dev % 4096) == 0) {
+    // tiled one-hot path: k <= 16, 4-KiB row pitch with an odd number of chunks per row, at least one full column block.
+    // Rows per tile: 4 for the one-word one-hot compare (2.75 ops per byte), 8 for the heavier compares (k = 12: 0.428 vs 0.464 ms)
+    if (k <= 16 && (ld % 4096) == 0 && ((ld >> 12) & 1) && n >= 4096 && ((uintptr_t)out_dev % 4096) == 0) {
         uint32_t *codes = nullptr;
         const size_t npad = ((size_t)n + 63) & ~(size_t)63;
         KMAP_TRY(kmap_scratch((void **)&codes, npad * 8, st, KMAP_SLOT_B));
@@ -434,30 +424,19 @@ int launch_matrix(const H *kh_dev, const int32_t *label_dev, int64_t n, int k, c
         uint32_t *c0 = codes, *c1 = (onehot == 2) ? codes + npad : nullptr;
         build_codes_kernel<H><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(kh_dev, n, k, low_mask<H>(k), onehot, c0, c1,
                                                                                        label_dev, lab2gid, n_lab, gid);
-        const int lds = tile_lds * 1024;
-#define KMAP_TILE(CW, R) launch_tile<CW, R>(c0, c1, gid, gshift, k, n, row0, nrows, out_dev, ld, nt, lds, st)
-        if (onehot == 1) return tile_r == 2 ? KMAP_TILE(1, 2) : tile_r == 8 ? KMAP_TILE(1, 8) : tile_r == 16 ? KMAP_TILE(1, 16) : KMAP_TILE(1, 4);
-        if (onehot == 0) return tile_r == 2 ? KMAP_TILE(0, 2) : tile_r == 8 ? KMAP_TILE(0, 8) : tile_r == 16 ? KMAP_TILE(0, 16) : KMAP_TILE(0, 4);
-        return tile_r == 2 ? KMAP_TILE(2, 2) : tile_r == 8 ? KMAP_TILE(2, 8) : tile_r == 16 ? KMAP_TILE(2, 16) : KMAP_TILE(2, 4);
-#undef KMAP_TILE
+        if (onehot == 1) return launch_tile<1, 4>(c0, c1, gid, gshift, k, n, row0, nrows, out_dev, ld, st);
+        if (onehot == 0) return launch_tile<0, 8>(c0, c1, gid, gshift, k, n, row0, nrows, out_dev, ld, st);
+        return launch_tile<2, 8>(c0, c1, gid, gshift, k, n, row0, nrows, out_dev, ld, st);
     }
+    // general kernel: k > 16, small or unaligned outputs
     build_gid_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(label_dev, n, lab2gid, n_lab, gid);
     const int vec_ok = ((uintptr_t)kh_dev % 16 == 0) && ((uintptr_t)out_dev % 16 == 0) && (ld % 16 == 0);
-    static const int rpw = [] { const char *e = getenv("KMAP_HAMDIST_RPW"); int v = e ? atoi(e) : ROWS_PER_WAVE; return (v >= 1 && v <= 64) ? v : ROWS_PER_WAVE; }();
-    static const int row_major = [] { const char *e = getenv("KMAP_HAMDIST_ROWMAJOR"); return e ? atoi(e) : 0; }();
+    constexpr int rpw = ROWS_PER_WAVE, wpb = 2;
     const unsigned gx = (unsigned)((n + COLS_PER_WAVE - 1) / COLS_PER_WAVE);
-    static const int wpb = [] { const char *e = getenv("KMAP_HAMDIST_WPB"); int v = e ? atoi(e) : 2; return (v >= 1 && v <= WAVES_PER_BLOCK) ? v : 2; }();
     const unsigned gy = (unsigned)((nrows + (int64_t)rpw * wpb - 1) / ((int64_t)rpw * wpb));
-    dim3 grid = row_major ? dim3(gy, gx) : dim3(gx, gy);
-    KMAP_REQUIRE(grid.y <= 65535u, "hamdist_matrix: nrows too large for one launch (%lld)", (long long)nrows);
-    // non-temporal stores by default (write-once streaming output: 5.02 vs 4.77 TB/s measured at N=50k);
-    // KMAP_HAMDIST_NT=0 switches back to default-policy stores for A/B runs
-    if (nt)
-        hamdist_matrix_kernel<H, true><<<grid, dim3(KMAP_WAVE * wpb), 0, st>>>(
-            kh_dev, gid, gshift, n, low_mask<H>(k), row0, nrows, out_dev, ld, vec_ok, rpw, row_major, wpb);
-    else
-        hamdist_matrix_kernel<H, false><<<grid, dim3(KMAP_WAVE * wpb), 0, st>>>(
-            kh_dev, gid, gshift, n, low_mask<H>(k), row0, nrows, out_dev, ld, vec_ok, rpw, row_major, wpb);
+    KMAP_REQUIRE(gy <= 65535u, "hamdist_matrix: nrows too large for one launch (%lld)", (long long)nrows);
+    hamdist_matrix_kernel<H><<<dim3(gx, gy), dim3(KMAP_WAVE * wpb), 0, st>>>(kh_dev, gid, gshift, n, low_mask<H>(k), row0, nrows, out_dev, ld,
+                                                                             vec_ok, rpw, 0, wpb);
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;
 }

@@ -72,12 +72,6 @@ int write_occurrence_csv_impl(const char *path, const char *header, int64_t n_se
     }
     fputs(header, fh);
     fputc('\n', fh);
-    static const bool trace = getenv("KMAP_IO_TRACE") != nullptr;
-    const auto t_begin = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (trace) fprintf(stderr, "[csv %s] %s at %.1f ms\n", path, what,
-                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
-    };
     // format in parallel: reads are cut into chunks, every chunk gets its own cursor (prefix of hits) and buffer,
     // buffers are written in chunk order
     static const int thread_cap = getenv("KMAP_IO_THREADS") ? std::max(1, atoi(getenv("KMAP_IO_THREADS"))) : 16;   // several writers run at once (scan_motif)
@@ -110,7 +104,6 @@ int write_occurrence_csv_impl(const char *path, const char *header, int64_t n_se
                 cur[(size_t)c] += s2;
             }
     }
-    lap("hit sums");
     // uninitialised buffers: a vector<char>::resize would zero-fill (and page-fault) every byte before it is formatted over
     struct Chunk {
         std::unique_ptr<char[]> mem;
@@ -167,7 +160,6 @@ int write_occurrence_csv_impl(const char *path, const char *header, int64_t n_se
         for (int t = 0; t < n_threads; ++t) pool.emplace_back(worker);
         for (auto &t : pool) t.join();
     }
-    lap("formatted");
     // the chunks go to their final offsets with parallel pwrite()s (one memcpy into the page cache per thread instead of
     // one serial stream: 185 MB per file at C3)
     int64_t rows = 0;
@@ -205,9 +197,7 @@ int write_occurrence_csv_impl(const char *path, const char *header, int64_t n_se
         for (int t = 0; t < std::min(n_threads, 2); ++t) pool.emplace_back(write_worker);   // one inode lock: more threads only wait (measured 4..64: 21-27 ms)
         for (auto &t : pool) t.join();
     }
-    lap("written");
     const int rc = fclose(fh);
-    lap("closed");
     if (rows_written) *rows_written = rows;
     if (rc != 0 || !write_ok) {
         kmap_set_error("write_occurrence_csv: write to %s failed", path);

@@ -330,8 +330,8 @@ int knn_sums_kmers(const H *kh_dev, const int32_t *label_dev, int64_t n, int k, 
     hipStream_t st = as_stream(stream);
     const int kd = (k <= 8) ? 8 : 16;
     // matrix-core form: byte counters must be signed bytes, and the rank-one term of every short group needs `tail` free byte slots
-    static const int mfma_on = [] { const char *e = getenv("KMAP_KNN_MFMA"); return e ? atoi(e) : 1; }();     // A/B switch
-    bool mfma = mfma_on && n_nb <= 127;
+    // (otherwise -- more than 127 neighbours, or a consensus so short that its tail does not fit -- the v_dot4 kernel above)
+    bool mfma = n_nb <= 127;
     for (int g = 0; g < gt.n; ++g) mfma = mfma && (k - gt.clen[g]) <= 4 * gt.clen[g];
     // scratch: V [n][kd] u32 | Vg [g][n][kd] u32 | GA, GB [g][n][kd] u32 (MFMA form) | cg [g][n] u8 | gid [n] u8 | lab2gid table
     const size_t nV = (size_t)n * kd, ng = (size_t)(gt.n ? gt.n : 1);

@@ -12,6 +12,7 @@
 // packed stream, Hamming-ball mask (flag + coverage), and the per-read occurrence scan.
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include "common.h"
 #include "counts_internal.h"
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(BLK) void unpack_kernel(const uint32_t *__restrict_
 }
 
 // ---- hash materialisation (one thread per group, 16 hashes, 64/128 contiguous bytes out) -------------------------
-// skip bits of per-read de-duplication (dedupe_skip_packed_kernel): word w covers positions 32w .. 32w+31, position 32w+j in bit
+// skip bits of per-read de-duplication (dedupe_bitmap_packed_kernel): word w covers positions 32w .. 32w+31, position 32w+j in bit
 // 31-j; a set bit = "the k-mer starting here already occurred in its read".  Group g's 16 bits, window i in bit 15-i:
 __device__ __forceinline__ uint32_t skip16_of(const uint32_t *__restrict__ skip, int64_t g) {
     return skip ? ((skip[g >> 1] >> ((g & 1) ? 0 : 16)) & 0xFFFFu) : 0u;
@@ -242,86 +243,17 @@ __global__ __launch_bounds__(LDSMODE ? HP_TPB : BLK) void hist_packed_kernel(con
 // ---- per-read de-duplication as skip bits (remove_duplicate_hash_per_seq, kmer_count.py:743-760, fused with counting) -----------
 // The reference invalidates every repeated hash of a read before counting; only the COUNTS are used afterwards, so which of the
 // equal windows survives does not matter.  One wave per read: the windows are hashed straight from the packed codes, 64 at a
-// time, and inserted into a per-wave open-addressing set in LDS with one atomicCAS per probe -- the lane whose CAS claims an
-// empty slot owns the k-mer, a lane that finds its own key there is a duplicate.  The duplicates leave as one bit per position
-// (ballot -> two 32-bit words per step; words that straddle a read border are shared with the neighbouring read's wave and are
-// ORed atomically, the others are plain stores into the zeroed array), which the histogram / hash kernels OR into their
-// invalid-window masks.  No 4-8 B/position hash array is written, de-duplicated in place and read back any more.
+// time, and looked up in a per-wave set in LDS.  The duplicates leave as one bit per position (ballot -> two 32-bit words per
+// step; words that straddle a read border are shared with the neighbouring read's wave and are ORed atomically, the others are
+// plain stores into the zeroed array), which the histogram / hash kernels OR into their invalid-window masks.  No 4-8 B/position
+// hash array is written, de-duplicated in place and read back.
+// (The round-2 kernel kept the set as an open-addressing table filled by LDS compare-and-swap: 349 scalar + 206 vector
+// instructions per read against 18 LDS instructions -- the CU's single scalar unit was the bound, not the LDS atomics:
+// wave-uniform values were computed per lane in 64 bits under divergent loops, and every probe round is a dozen mask operations.
+// A set without atomics -- store, read back, lanes decide who owns the slot -- was measured too: 3.3 rounds per 64 windows,
+// 7.5 ms.  Both are gone; CHANGELOG.md has the numbers.)
 constexpr int DS_CAP = 512;             // longest read handled here (longer ones: the hash-array path of kmer_ops.hip)
-constexpr int DS_SLOTS = 2 * DS_CAP;
 constexpr int DS_WAVES = 4;
-template <bool K64>
-__global__ __launch_bounds__(KMAP_WAVE *DS_WAVES) void dedupe_skip_packed_kernel(const uint32_t *__restrict__ codes,
-                                                                                 const uint16_t *__restrict__ inval, int64_t n,
-                                                                                 const int64_t *__restrict__ borders, int64_t n_seq,
-                                                                                 int k, uint32_t *__restrict__ skip) {
-    typedef typename std::conditional<K64, unsigned long long, unsigned int>::type K;
-    __shared__ K keys[DS_WAVES][DS_SLOTS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t s = (int64_t)blockIdx.x * DS_WAVES + wave;
-    if (s >= n_seq) return;
-    int64_t st = borders[2 * s], en = borders[2 * s + 1];
-    if (st < 0) st = 0;
-    if (en > n) en = n;
-    const int64_t L = en - st;
-    if (L <= 1 || L > DS_CAP) return;       // a read of one window has no duplicate; longer reads never get here (host check)
-    int T = 64;
-    while (T < 2 * L) T <<= 1;
-    K *kt = keys[wave];
-    const K EMPTY = (K)~(K)0;               // never a valid hash (k <= 15 in 32 bits, k = 16 in 64 bits)
-    for (int t = lane; t < T; t += 64) kt[t] = EMPTY;
-    __builtin_amdgcn_wave_barrier();
-    const uint64_t kmask = low_mask<uint64_t>(k);
-    // three 64-position steps per batch: their window loads are issued together (a wave is latency-bound otherwise: one
-    // dependent global load per step and only a few steps per read)
-    constexpr int NB = 3;
-    for (int64_t pb = st & ~(int64_t)31; pb < en; pb += 64 * NB) {
-        Win w[NB];
-        bool act[NB];
-#pragma unroll
-        for (int c = 0; c < NB; ++c) {
-            const int64_t p = pb + 64 * c + lane;
-            act[c] = p >= st && p < en;
-            if (act[c]) w[c] = load_win(codes, inval, p >> 4);
-        }
-#pragma unroll
-        for (int c = 0; c < NB; ++c) {
-            const int64_t p0 = pb + 64 * c;
-            if (p0 >= en) break;                                          // wave-uniform
-            const int64_t p = p0 + lane;
-            bool dup = false;
-            if (act[c]) {
-                bool bad;
-                const uint64_t h = win_hash<false>(w[c], (int)(p & 15), k, kmask, bad);   // k <= 16: the window lies in groups g, g+1
-                if (!bad) {
-                    uint64_t x = h * 0x9E3779B97F4A7C15ull;
-                    int slot = (int)((x ^ (x >> 29)) & (uint64_t)(T - 1));
-                    for (;;) {
-                        const K prev = atomicCAS(&kt[slot], EMPTY, (K)h);
-                        if (prev == EMPTY) break;
-                        if (prev == (K)h) { dup = true; break; }
-                        slot = (slot + 1) & (T - 1);
-                    }
-                }
-            }
-            const unsigned long long m = __ballot(dup);
-            if (lane < 2) {
-                const uint32_t bits = __builtin_bitreverse32(lane ? (uint32_t)(m >> 32) : (uint32_t)m);   // lane l of the half -> bit 31-l
-                if (bits) {
-                    const int64_t w0 = p0 + 32 * lane;                    // first position of this word
-                    if (w0 < st || w0 + 32 > en) atomicOr(&skip[w0 >> 5], bits);   // shared with a neighbouring read
-                    else skip[w0 >> 5] = bits;
-                }
-            }
-        }
-    }
-}
-
-// Second kernel, written after the PMC passes on the one above (tools/pmc_dedupe.sh): 349 scalar + 206 vector instructions
-// per read against 18 LDS instructions -- the CU's single scalar unit was the bound (0.86 scalar instructions per clock and
-// CU), not the LDS atomics: wave-uniform values (read index, borders, table size) were computed per lane in 64 bits under
-// divergent loops, and every probe round of the open-addressing set is a dozen mask operations.  (A set without atomics --
-// store, read back, lanes decide who owns the slot -- was built and measured too: 3.3 rounds per 64 windows, 7.5 ms.)
 // Here: * the set is a BITMAP in LDS indexed by the k-mer itself (4^k bits, k <= 8: exact) or by 16 hashed bits (k >= 9),
 //         one returning ds_or per window: the lane that finds its bit clear keeps the k-mer, no probing, no loop;
 //       * hashed mode: a lane that finds its bit set is only a candidate (143 windows in 65 536 bits: ~0.15 false positives
@@ -609,7 +541,7 @@ struct ConsTabP {
 };
 // hit16[g]: bit (15-i) set when the window at position 16g+i (invalid = all ones, compared as is) is within radius of
 // any consensus.  Reads the CURRENT invalid mask; the coverage pass below writes it.
-template <bool WIDE>
+// k > 16 only: k <= 16 is tested bit-sliced on the reads' bit planes (bitslice.hip)
 __global__ __launch_bounds__(BLK) void mask_flag_packed_kernel(const uint32_t *__restrict__ codes,
                                                                const uint16_t *__restrict__ inval, int64_t n, int k,
                                                                ConsTabP t, uint16_t *__restrict__ hit16) {
@@ -619,41 +551,10 @@ __global__ __launch_bounds__(BLK) void mask_flag_packed_kernel(const uint32_t *_
     const Win w = load_win(codes, inval, g);
     const uint64_t kmask = low_mask<uint64_t>(k);
     uint32_t hits = 0;
-    if constexpr (!WIDE) {   // k <= 16: 32-bit windows (v_alignbit + shift), validity of the 16 windows from one doubling pass
-        uint64_t bad = w.m;
-        for (int have = 1; have < k;) {
-            const int step = (have <= k - have) ? have : k - have;
-            bad |= bad << step;
-            have += step;
-        }
-        const uint32_t bad16 = (uint32_t)(bad >> 32), km = (uint32_t)kmask;
-        const uint32_t hi = (uint32_t)(w.t0 >> 32), lo = (uint32_t)w.t0;
-        const int sh = 32 - 2 * k;
-        uint32_t h[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const uint32_t top = (i == 0) ? hi : __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * i);
-            h[i] = ((top >> sh) | (uint32_t)__builtin_amdgcn_sbfe((int)bad16, 15 - i, 1)) & km;   // invalid window: all ones, compared as is
-        }
-        // consensus outside (scalar operands, one loop test per consensus instead of per window and consensus), the 16 windows
-        // unrolled inside; the flags shift in from the right, so window i ends in bit 15 - i
-        for (int c = 0; c < t.n; ++c) {
-            const uint32_t cc = (uint32_t)t.cons[c];
-            const int r = t.radius[c];
-            uint32_t acc = 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc = (acc << 1) | (uint32_t)(popc2(h[i] ^ cc) <= r);
-            hits |= acc;
-        }
-        const int64_t left = n - 16 * g;          // positions past the end do not exist
-        if (left < 16) hits &= ~((1u << (16 - (int)left)) - 1u);
-        hit16[g] = (uint16_t)hits;
-        return;
-    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         bool bad;
-        const uint64_t h = win_hash<WIDE>(w, i, k, kmask, bad);
+        const uint64_t h = win_hash<true>(w, i, k, kmask, bad);
         bool f = false;
         for (int c = 0; c < t.n; ++c) f |= (popc2((h ^ t.cons[c]) & kmask) <= t.radius[c]);
         if (16 * g + i >= n) f = false;           // positions past the end do not exist
@@ -796,6 +697,7 @@ __global__ __launch_bounds__(KMAP_WAVE *SC_WAVES) void scan_packed_kernel(const 
 // ---- occurrence scan, flat formulation ---------------------------------------------------------------------------
 // The wave-per-read kernel above spends its time on per-read latency chains (borders -> codes -> reduce -> ballot): 10^7
 // waves of ~3 positions per lane.  Split instead into
+// (k > 16 only: k <= 16 scans the bit-sliced hit words of bitslice.hip.)
 //   (1) a flat pass, thread per 16-position group, that stores the capped distance of EVERY window as a nibble
 //       (d <= radius ? d : 15; 8 B per group = 0.5 B per position) -- independent of read borders because a window that
 //       the scan may use (p < L-k+1) lies entirely inside its read;
@@ -820,7 +722,6 @@ __device__ __forceinline__ int nib_min(uint64_t x) {
     }
     return m;
 }
-template <bool WIDE>
 __global__ __launch_bounds__(BLK) void scan_nibble_kernel(const uint32_t *__restrict__ codes, const uint16_t *__restrict__ inval,
                                                           int64_t n, int k, uint64_t cons, uint64_t rcc, int radius, int revcom,
                                                           uint64_t *__restrict__ nib, uint8_t *__restrict__ wmin) {
@@ -829,51 +730,16 @@ __global__ __launch_bounds__(BLK) void scan_nibble_kernel(const uint32_t *__rest
     const Win w = load_win(codes, inval, g);
     const uint64_t kmask = low_mask<uint64_t>(k);
     uint64_t out = 0;
-    if (!WIDE) {   // k <= 16: the hash fits 32 bits
-        // 32-bit windows as in the histogram kernel: v_alignbit + shift, the 16 "window touches an invalid position" flags from
-        // one doubling pass, nibbles packed into two 32-bit halves, the minimum kept on the way (the first version shifted the
-        // 64-bit stream and the 48-bit flag word per window and re-read the 16 nibbles for the minimum: ~30 vector instructions
-        // per window on a kernel that is bound by instruction issue)
-        const uint32_t km = (uint32_t)kmask, c32 = (uint32_t)cons, r32 = (uint32_t)rcc;
-        uint64_t bad = w.m;
-        for (int have = 1; have < k;) {
-            const int step = (have <= k - have) ? have : k - have;
-            bad |= bad << step;
-            have += step;
-        }
-        const uint32_t bad16 = (uint32_t)(bad >> 32);                        // windows 0..15 in bits 15..0
-        const uint32_t hi = (uint32_t)(w.t0 >> 32), lo = (uint32_t)w.t0;
-        const int sh = 32 - 2 * k;
-        uint32_t half[2] = {0u, 0u};
-        int mn = 15;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const uint32_t top = (i == 0) ? hi : __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * i);
-            const uint32_t h = ((top >> sh) | (uint32_t)__builtin_amdgcn_sbfe((int)bad16, 15 - i, 1)) & km;   // invalid: all ones
-            int d = popc2(h ^ c32);
-            if (revcom) {
-                const int d2 = popc2(h ^ r32);
-                d = d2 < d ? d2 : d;
-            }
-            d = d <= radius ? d : 15;
-            mn = d < mn ? d : mn;
-            half[i >> 3] |= (uint32_t)d << (4 * (i & 7));
+    for (int i = 0; i < 16; ++i) {
+        bool bad;
+        const uint64_t h = win_hash<true>(w, i, k, kmask, bad);
+        int d = popc2((h ^ cons) & kmask);
+        if (revcom) {
+            const int d2 = popc2((h ^ rcc) & kmask);
+            d = d2 < d ? d2 : d;
         }
-        nib[g] = ((uint64_t)half[1] << 32) | half[0];
-        wmin[g] = (uint8_t)mn;
-        return;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            bool bad;
-            const uint64_t h = win_hash<true>(w, i, k, kmask, bad);
-            int d = popc2((h ^ cons) & kmask);
-            if (revcom) {
-                const int d2 = popc2((h ^ rcc) & kmask);
-                d = d2 < d ? d2 : d;
-            }
-            out |= (uint64_t)(d <= radius ? d : 15) << (4 * i);
-        }
+        out |= (uint64_t)(d <= radius ? d : 15) << (4 * i);
     }
     nib[g] = out;
     wmin[g] = (uint8_t)nib_min(out);   // smallest nibble of the word: the per-read passes skip words that cannot matter
@@ -1075,8 +941,7 @@ namespace {
 int dedupe_skip_bits(const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n, const int64_t *borders_dev, int64_t n_seq, int k,
                      hipStream_t st, uint32_t **skip_out) {
     *skip_out = nullptr;
-    static const bool on = [] { const char *e = getenv("KMAP_DEDUPE_SKIP"); return !(e && e[0] == '0'); }();   // A/B switch
-    if (!on || n_seq == 0 || n == 0) return KMAP_OK;
+    if (n_seq == 0 || n == 0) return KMAP_OK;
     const size_t words = (size_t)((n + 31) >> 5) + 4;
     uint32_t *skip = nullptr;
     KMAP_TRY(kmap_scratch((void **)&skip, words * 4 + 16, st, KMAP_SLOT_C));
@@ -1087,32 +952,20 @@ int dedupe_skip_bits(const uint32_t *codes_dev, const uint16_t *inval_dev, int64
     KMAP_CHECK_HIP(hipMemcpyAsync(&max_len, mx, 8, hipMemcpyDeviceToHost, st));
     KMAP_CHECK_HIP(hipStreamSynchronize(st));
     if (max_len > (unsigned long long)DS_CAP) return KMAP_OK;
-    const unsigned grid = (unsigned)((n_seq + DS_WAVES - 1) / DS_WAVES);
-    static const bool cas_set = [] { const char *e = getenv("KMAP_DEDUPE_SET"); return e && !strcmp(e, "cas"); }();   // A/B: r02's first kernel
-    if (cas_set) {
-        if (k == 16) dedupe_skip_packed_kernel<true><<<grid, KMAP_WAVE * DS_WAVES, 0, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, skip);
-        else dedupe_skip_packed_kernel<false><<<grid, KMAP_WAVE * DS_WAVES, 0, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, skip);
-    } else {
-        static const int exact_max_k = getenv("KMAP_DEDUPE_EXACT_MAXK") ? atoi(getenv("KMAP_DEDUPE_EXACT_MAXK")) : 8;
-        const bool exact = k <= std::min(8, exact_max_k);                 // 4^k bits fit the per-wave bitmap
-        const int bw = exact ? std::max(4, (int)((1u << (2 * k)) >> 5)) : DB_HASH_WORDS;
-        const int per_wave = (bw + (exact ? 0 : 2 * DB_MAXSTEPS + 2) + 3) & ~3;
-        const size_t lds = (size_t)DS_WAVES * per_wave * 4;
-        // persistent grid = exactly the blocks that are resident at once (one more would run as a second round)
-        int dev = 0, cus = 0, per_cu = 0;
-        KMAP_CHECK_HIP(hipGetDevice(&dev));
-        KMAP_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        if (exact) KMAP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dedupe_bitmap_packed_kernel<true>, KMAP_WAVE * DS_WAVES, lds));
-        else KMAP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dedupe_bitmap_packed_kernel<false>, KMAP_WAVE * DS_WAVES, lds));
-        static const int per_cu_env = getenv("KMAP_DEDUPE_BLOCKS_PER_CU") ? atoi(getenv("KMAP_DEDUPE_BLOCKS_PER_CU")) : 0;
-        per_cu = std::max(1, std::min(per_cu, (int)((size_t)(156 << 10) / lds)));   // the query says 5 x 32 KiB fit a CU; measured: 4 do (the fifth block runs as a second round, 6.3 -> 8.2 ms)
-        if (per_cu_env > 0) per_cu = per_cu_env;
-        const unsigned pgrid = (unsigned)std::min<int64_t>((n_seq + DS_WAVES - 1) / DS_WAVES, (int64_t)cus * per_cu);
-        static const bool trace = getenv("KMAP_DEDUPE_TRACE") != nullptr;
-        if (trace) fprintf(stderr, "[dedupe] k=%d exact=%d lds=%zu blocks/CU=%d grid=%u\n", k, (int)exact, lds, per_cu, pgrid);
-        if (exact) dedupe_bitmap_packed_kernel<true><<<pgrid, KMAP_WAVE * DS_WAVES, lds, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, skip, bw);
-        else dedupe_bitmap_packed_kernel<false><<<pgrid, KMAP_WAVE * DS_WAVES, lds, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, skip, bw);
-    }
+    const bool exact = k <= 8;                                            // 4^k bits fit the per-wave bitmap
+    const int bw = exact ? std::max(4, (int)((1u << (2 * k)) >> 5)) : DB_HASH_WORDS;
+    const int per_wave = (bw + (exact ? 0 : 2 * DB_MAXSTEPS + 2) + 3) & ~3;
+    const size_t lds = (size_t)DS_WAVES * per_wave * 4;
+    // persistent grid = exactly the blocks that are resident at once (one more would run as a second round)
+    int dev = 0, cus = 0, per_cu = 0;
+    KMAP_CHECK_HIP(hipGetDevice(&dev));
+    KMAP_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (exact) KMAP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dedupe_bitmap_packed_kernel<true>, KMAP_WAVE * DS_WAVES, lds));
+    else KMAP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dedupe_bitmap_packed_kernel<false>, KMAP_WAVE * DS_WAVES, lds));
+    per_cu = std::max(1, std::min(per_cu, (int)((size_t)(156 << 10) / lds)));   // the query says 5 x 32 KiB fit a CU; measured: 4 do (the fifth block runs as a second round, 6.3 -> 8.2 ms)
+    const unsigned pgrid = (unsigned)std::min<int64_t>((n_seq + DS_WAVES - 1) / DS_WAVES, (int64_t)cus * per_cu);
+    if (exact) dedupe_bitmap_packed_kernel<true><<<pgrid, KMAP_WAVE * DS_WAVES, lds, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, skip, bw);
+    else dedupe_bitmap_packed_kernel<false><<<pgrid, KMAP_WAVE * DS_WAVES, lds, st>>>(codes_dev, inval_dev, n, borders_dev, n_seq, k, skip, bw);
     KMAP_CHECK_HIP(hipGetLastError());
     *skip_out = skip;
     return KMAP_OK;
@@ -1141,29 +994,9 @@ int kmap_counts_hist_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const
         return kmap_counts_hist_hashes(c, hash, n, k, st);
     }
     if (kmap_counts_part_applies(k, n)) {
-        // 11 <= k <= 16: bucket-partitioned histogram, keys hashed from the packed reads inside its count and scatter passes
-        // (KMAP_COUNT_PART_FUSED=0: materialise the 4 B/position hash array first, the r01 / early r02 arrangement)
-        static const bool fused = [] { const char *e = getenv("KMAP_COUNT_PART_FUSED"); return !(e && e[0] == '0'); }();
-        if (fused) return kmap_counts_part_hist_packed(c, codes_dev, inval_dev, skip, n, k, st);
-        void *hash = nullptr;
-        KMAP_TRY(kmap_scratch(&hash, (size_t)n * 4 + 16, st, KMAP_SLOT_HASH));
-        unsigned long long *all_ones = nullptr;
-        if (k == 16) {
-            void *cnt8 = nullptr;
-            KMAP_TRY(kmap_scratch(&cnt8, 64, st, KMAP_SLOT_D));
-            all_ones = (unsigned long long *)cnt8;
-            KMAP_CHECK_HIP(hipMemsetAsync(all_ones, 0, 8, st));
-        }
-        hash_packed_kernel<uint32_t, false><<<grid_for((n + 15) >> 4, BLK), BLK, 0, st>>>(codes_dev, inval_dev, n, k, (uint32_t *)hash, skip, all_ones);
-        KMAP_CHECK_HIP(hipGetLastError());
-        if (k == 16) {   // the scan inside the partitioned path re-uses slot D: move the count next to the hash array first
-            unsigned long long *keep = (unsigned long long *)((char *)hash + (((size_t)n * 4 + 7) & ~(size_t)7));
-            KMAP_CHECK_HIP(hipMemcpyAsync(keep, all_ones, 8, hipMemcpyDeviceToDevice, st));
-            all_ones = keep;
-        }
-        KMAP_TRY(kmap_counts_part_hist_u32(c, (const uint32_t *)hash, n, k, st));
-        if (k == 16) KMAP_TRY(kmap_counts_part_add_bin(c, (size_t)0xFFFFFFFFu, all_ones, st));
-        return KMAP_OK;
+        // 10 <= k <= 16: bucket-partitioned histogram, keys hashed from the packed reads inside its count and scatter passes (no
+        // 4 B / position hash array written and read back)
+        return kmap_counts_part_hist_packed(c, codes_dev, inval_dev, skip, n, k, st);
     }
     KMAP_TRY(kmap_counts_prepare_bins(c, k, st));
     if (n > 0) {
@@ -1219,11 +1052,8 @@ int kmap_counts_run_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const 
     return kmap_counts_finish_hist(c, k, merge_revcom, n_uniq, st);
 }
 
-// does the bit-sliced formulation (bitslice.hip) serve this call?  KMAP_BITSLICE=0 keeps the per-window kernels (A/B runs)
-static bool bitslice_on(const uint32_t *planes_dev, int k) {
-    static const bool on = !(getenv("KMAP_BITSLICE") && getenv("KMAP_BITSLICE")[0] == '0');
-    return on && planes_dev && k <= 16;
-}
+// k <= 16: the bit-sliced formulation (bitslice.hip) on the reads' bit planes; the per-window kernels of this file serve k > 16
+static bool bitslice_on(int k) { return k <= 16; }
 
 int kmap_mask_hamball_packed_dev(const uint32_t *codes_dev, uint16_t *inval_dev, int64_t n, int k, const uint64_t *cons,
                                  const int32_t *radius, int n_cons, const uint32_t *planes_dev, void *stream) {
@@ -1231,9 +1061,23 @@ int kmap_mask_hamball_packed_dev(const uint32_t *codes_dev, uint16_t *inval_dev,
     KMAP_REQUIRE(n_cons >= 0 && (n_cons == 0 || (cons && radius)), "mask_hamball_packed: null consensus list");
     if (n <= 0 || n_cons == 0) return KMAP_OK;
     KMAP_REQUIRE(codes_dev && inval_dev, "mask_hamball_packed: null pointer");
+    KMAP_REQUIRE(k > 16 || planes_dev, "mask_hamball_packed: k <= 16 needs the bit planes (kmap_pack_planes_dev)");
+    // a negative radius matches nothing (the reference's `ham_dist <= r`, kmer_count.py:594-603): such entries are dropped here --
+    // the bit-sliced "count > r" test is built for r >= 0
+    std::vector<uint64_t> cons_v;
+    std::vector<int32_t> rad_v;
+    for (int c = 0; c < n_cons; ++c)
+        if (radius[c] >= 0) {
+            cons_v.push_back(cons[c]);
+            rad_v.push_back(radius[c]);
+        }
+    if (cons_v.empty()) return KMAP_OK;
+    cons = cons_v.data();
+    radius = rad_v.data();
+    n_cons = (int)cons_v.size();
     hipStream_t st = as_stream(stream);
     const int64_t ng = (n + 15) >> 4;
-    if (bitslice_on(planes_dev, k)) {
+    if (bitslice_on(k)) {
         // 16 consensuses per flag pass, all passes on the mask as it is on entry, then the coverage passes
         const int nb = (n_cons + 15) / 16;
         uint16_t *hitb = nullptr;
@@ -1260,8 +1104,7 @@ int kmap_mask_hamball_packed_dev(const uint32_t *codes_dev, uint16_t *inval_dev,
             t.cons[c] = cons[32 * b + c] & low_mask<uint64_t>(k);
             t.radius[c] = radius[32 * b + c];
         }
-        if (k <= 16) mask_flag_packed_kernel<false><<<grid_for(ng, BLK), BLK, 0, st>>>(codes_dev, inval_dev, n, k, t, hit + (size_t)b * ngp);
-        else mask_flag_packed_kernel<true><<<grid_for(ng, BLK), BLK, 0, st>>>(codes_dev, inval_dev, n, k, t, hit + (size_t)b * ngp);
+        mask_flag_packed_kernel<<<grid_for(ng, BLK), BLK, 0, st>>>(codes_dev, inval_dev, n, k, t, hit + (size_t)b * ngp);
     }
     // ... then the coverage passes OR into it
     for (int b = 0; b < batches; ++b)
@@ -1281,13 +1124,14 @@ int kmap_scan_run_packed_dev(kmap_scan *s, const uint32_t *codes_dev, const uint
     if (total_hits) *total_hits = 0;
     if (n_seq == 0) return KMAP_OK;
     KMAP_REQUIRE(codes_dev && inval_dev && borders_dev, "scan_run_packed: null pointer");
+    KMAP_REQUIRE(k > 16 || planes_dev, "scan_run_packed: k <= 16 needs the bit planes (kmap_pack_planes_dev)");
     hipStream_t st = as_stream(stream);
     KMAP_TRY(kmap_scan_reserve(s, n_seq));
     const uint64_t m = low_mask<uint64_t>(k);
     const uint64_t c = cons & m;
     uint64_t com = m - c, rcc = com & 3u;
     for (int i = 0; i < k - 1; ++i) { rcc <<= 2; com >>= 2; rcc += com & 3u; }
-    if (bitslice_on(planes_dev, k)) {
+    if (bitslice_on(k)) {
         // hit bit per window (bit-sliced, 0.125 B per position written), then the per-read passes evaluate the few hits exactly
         const int64_t ng = (n + 15) >> 4;
         uint16_t *hit16 = nullptr;
@@ -1307,8 +1151,7 @@ int kmap_scan_run_packed_dev(kmap_scan *s, const uint32_t *codes_dev, const uint
         if (total_hits) *total_hits = (int64_t)total;
         return KMAP_OK;
     }
-    static const bool flat_ok = !(getenv("KMAP_SCAN_FLAT") && getenv("KMAP_SCAN_FLAT")[0] == '0');
-    const bool flat = flat_ok && radius <= 14;
+    const bool flat = radius <= 14;                 // k > 16: nibble pass + thread-per-read passes; larger radii: wave per read
     const unsigned grid = (unsigned)((n_seq + SC_WAVES - 1) / SC_WAVES);
     const unsigned fgrid = (unsigned)((n_seq + FL_TPB - 1) / FL_TPB);
     uint64_t *nib = nullptr;
@@ -1320,8 +1163,7 @@ int kmap_scan_run_packed_dev(kmap_scan *s, const uint32_t *codes_dev, const uint
         KMAP_TRY(kmap_scratch((void **)&nib, ngp * 9, st, KMAP_SLOT_HASH));   // 8 B of nibbles + 1 B minimum per group
         wmin = reinterpret_cast<uint8_t *>(nib + ngp);
         if (ng) {
-            if (k <= 16) scan_nibble_kernel<false><<<grid_for(ng, BLK), BLK, 0, st>>>(codes_dev, inval_dev, n, k, c, rcc, radius, revcom, nib, wmin);
-            else scan_nibble_kernel<true><<<grid_for(ng, BLK), BLK, 0, st>>>(codes_dev, inval_dev, n, k, c, rcc, radius, revcom, nib, wmin);
+            scan_nibble_kernel<<<grid_for(ng, BLK), BLK, 0, st>>>(codes_dev, inval_dev, n, k, c, rcc, radius, revcom, nib, wmin);
         }
         // distance of an invalid window (all ones, compared like any value)
         auto pc2 = [](uint64_t x) { return __builtin_popcountll((x | (x >> 1)) & 0x5555555555555555ull); };

@@ -597,11 +597,8 @@ def write_occurence_file(per, conseq_list, output_file, n_out, read_len, writers
     n_cons = len(conseq_list)
 
     def emit():
-        t0 = time.perf_counter()
         narrow = bool(per) and all(isinstance(r, ScanHits) and r.unfetched and r.max_hits <= 255 for r in per)
         host = [r.host_u8() if narrow else tuple(r) for r in per]
-        if os.environ.get("KMAP_IO_TRACE"):
-            print(f"[csv {output_file}] lists fetched in {1e3 * (time.perf_counter() - t0):.1f} ms (start at {t0:.3f})", file=sys.stderr)
         assert all(len(h) == n_out for h, _ in host)
         hits_ptrs = (C.c_void_p * max(n_cons, 1))(*[h.ctypes.data for h, _ in host])
         pos_keep = [np.ascontiguousarray(p, np.int32) if len(p) else np.zeros(1, np.int32) for _, p in host]

@@ -434,6 +434,8 @@ def kmap_from_kmers(samp_kh, samp_cnts, samp_label, conseq_list, kmer_len, n_nei
                 check(_ffi.lib().kmap_memcpy2d_d2h(ptr(rows), n, D_d.ptr + r0 * ldd, ldd, n, r1 - r0, None))
                 nbs.append(np.argpartition(rows.astype(np.int64), n_neighbour, axis=1)[:, :n_neighbour])
             neighbor_inds_mat = np.concatenate(nbs)
+    if trace is not None and not isinstance(neighbor_inds_mat, _ffi.DeviceBuffer):
+        trace["nb"] = np.asarray(neighbor_inds_mat)            # the host-chosen neighbours (numpy mode / injected)
     with _stage("knn_sums"):
         res = knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, kmer_len, lens, neighbor_inds_mat, n_neighbour)
         sums_d, lds = res if res is not None else knn_sums_dev(D_d.ptr, ldd, neighbor_inds_mat, n, n_neighbour)

@@ -245,11 +245,14 @@ def _cyclic_worker(rank, world, port, out_dir, n, iters):
         dist.destroy_process_group()
 
 
-def test_cyclic_symmetric_shards_match_single_gpu(tmp_path):
+@pytest.mark.parametrize("cyclic", ["1", "0"])
+def test_cyclic_symmetric_shards_match_single_gpu(tmp_path, monkeypatch, cyclic):
     """FAST at N >= 16384 under torch.distributed: the ranks own cyclic 256-row blocks and evaluate each unordered pair once;
-    the all-reduced gradient equals the single-GPU symmetric kernel's up to the order of the partial sums."""
+    the all-reduced gradient equals the single-GPU symmetric kernel's up to the order of the partial sums.  KMAP_DIST_CYCLIC=0:
+    the same run on contiguous row blocks (the row-wise FAST kernel, every ordered pair) -- the layout below N = 16 384."""
     import torch.multiprocessing as mp
     import kmap_amd.visualization as V
+    monkeypatch.setenv("KMAP_DIST_CYCLIC", cyclic)  # inherited by the spawned ranks
     n, iters = 16384 + 3 * 256 + 77, 6            # 68 row blocks, the last one ragged; odd split over 3 ranks
     mp.spawn(_cyclic_worker, args=(3, _free_port(), str(tmp_path), n, iters), nprocs=3, join=True)
     r = [np.load(tmp_path / f"cyc_rank{i}.npz") for i in range(3)]

@@ -99,6 +99,25 @@ def test_packed_mask_vs_oracle_incl_quirks(env):
     ds.close()
 
 
+def test_packed_mask_negative_radius_matches_nothing(env):
+    """max_ham_dist < 0: `ham_dist <= r` (kmer_count.py:594-603) holds for no window, so nothing is masked -- on the bit-sliced path
+    (k <= 16, where "count > r" is built for r >= 0) and on the per-window path (k > 16) alike; mixed with a real entry only that
+    entry masks."""
+    _ffi, _, DeviceSeq, O = env
+    rng = np.random.default_rng(17)
+    seq, borders = synth(rng, 400, 25, 120)
+    for k in (6, 8, 14, 18):
+        cons = rng.integers(0, 4 ** k, size=3, dtype=np.uint64)
+        cons[1] = int(O.kmer2hash("T" * k))            # would match every invalid window at any radius >= 0
+        ds = DeviceSeq(seq, borders)
+        ds.mask(k, cons, np.array([-1, -1, -3]))
+        np.testing.assert_array_equal(ds.download(), seq)
+        rad = np.array([-1, 0, 1 if k < 16 else 4])
+        ds.mask(k, cons, rad)
+        np.testing.assert_array_equal(ds.download(), O.mask_input(seq.copy(), k, cons, rad))
+        ds.close()
+
+
 def test_packed_mask_many_consensuses(env):
     _ffi, _, DeviceSeq, O = env
     rng = np.random.default_rng(13)
