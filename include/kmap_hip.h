@@ -144,7 +144,7 @@ int kmap_counts_hamball_mass(kmap_counts *c, const uint64_t *cands, int n_cand, 
 
 /* ---- 2-bit-packed reads (device resident): the uint8 array contract (kmer_count.py:244-347) packed 16 positions per
  * group: codes uint32[groups] (first base most significant) + invalid bitmask uint16[groups] (255 / past the end),
- * groups = kmap_packed_groups(n) incl. two all-invalid halo groups.  Masking ORs bits into the invalid mask; the
+ * groups = kmap_packed_groups(n): the data groups, at least two all-invalid halo groups, an even total.  Masking ORs bits into the invalid mask; the
  * codes never change.  The packed entry points do what their uint8 counterparts above do, on the packed stream. */
 int64_t kmap_packed_groups(int64_t n);
 int kmap_pack_reads_dev(const uint8_t *seq_dev, int64_t n, uint32_t *codes_dev, uint16_t *inval_dev, void *stream);

@@ -12,12 +12,15 @@
 //   * a thread takes 32 positions: H, L (and the following 32 for the window tails).  For consensus base j the mismatch plane
 //     over the 32 windows is M_j = ((H << j) ^ CH_j) | ((L << j) ^ CL_j) with CH_j / CL_j = 0 or ~0 (scalar): 2 funnel shifts
 //     shared by both strands + 3 logic ops per strand;
-//   * the K mismatch planes are added bit-sliced by a balanced adder tree (compile-time K: ~3.3 ops per plane) into a 4..5-bit
-//     counter per window, and "count > r" is the carry out of adding the constant 2^B - 1 - r (2 ops per counter bit);
+//   * the K mismatch planes are added bit-sliced by a carry-save tree of two-instruction full adders (compile-time K: ~1.6 ops
+//     per plane) into a 4..5-bit counter per window, and "count > r" is the carry out of adding the constant 2^B - 1 - r (one
+//     majority per counter bit);
 //   * hit = (le_fwd | le_rc) for valid windows; a window that touches an invalid position has the reference's all-ones hash
 //     ("compared like any value"), i.e. the same distance d_inv for all of them: hit = (d_inv <= r), a scalar.
-// ~5.2 vector instructions per window at k = 8 with both strands, ~8.5 at k = 14, and the intermediate shrinks from 0.56 B
+// ~3.5 vector instructions per window at k = 8 with both strands, ~5.5 at k = 14 (r03's ripple-adder tree: 5.2 / 8.5), and the intermediate shrinks from 0.56 B
 // (nibble + minimum) to 0.125 B (one bit) per position.
+#include <algorithm>
+
 #include "common.h"
 #include "scan_internal.h"
 #include "scan_util.h"
@@ -43,55 +46,57 @@ __global__ __launch_bounds__(BS_TPB) void planes_kernel(const uint32_t *__restri
 }
 
 // ---- bit-sliced counters --------------------------------------------------------------------------------------------
-template <int B>
-struct Num {
-    uint32_t b[B];     // b[i] = bit i of the count of each of the 32 windows
-};
+// The K mismatch planes of a strand are counted by a carry-save tree of full adders, each TWO instructions on gfx950
+// (v_bitop3_b32: sum = a ^ b ^ c, carry = majority): planes of equal weight are taken three at a time until one is left -- the
+// count's bit of that weight -- and the carries form the next weight's planes.  K = 14: 10 full adders + 1 half adder = 22
+// instructions (the r03 balanced tree of ripple adders: 46), K = 8: 13.
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+__device__ __forceinline__ uint32_t maj3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); }
 constexpr int bits_for(int n) {   // bits that hold 0..n
     int b = 0;
     while ((1 << b) <= n) ++b;
     return b;
 }
-// x + y, result truncated to BR bits (the caller knows the sum fits).  Missing high bits are literal zeros: the optimiser folds
-// the adder cells they feed, and the carry out of the last cell is never computed.
-template <int BA, int BB, int BR>
-__device__ __forceinline__ Num<BR> add_num(const Num<BA> &x, const Num<BB> &y) {
-    Num<BR> r;
-    uint32_t carry = 0;
+// N planes of one weight in cur[0 .. N) -> the count's bit of that weight (returned) and N / 2 carry planes in nxt[0 .. N / 2)
+template <int N>
+__device__ __forceinline__ uint32_t csa_level(uint32_t (&cur)[16], uint32_t (&nxt)[16]) {
+    if constexpr (N == 0) return 0u;
+    constexpr int FA = (N - 1) / 2;
 #pragma unroll
-    for (int i = 0; i < BR; ++i) {
-        const uint32_t xi = (i < BA) ? x.b[i < BA ? i : 0] : 0u, yi = (i < BB) ? y.b[i < BB ? i : 0] : 0u;
-        const uint32_t t = xi ^ yi;
-        r.b[i] = t ^ carry;
-        carry = (xi & yi) | (carry & t);
+    for (int it = 0; it < FA; ++it) {                                       // live planes: cur[0 .. N - 2 it)
+        const int top = N - 2 * it - 1;
+        const uint32_t x = cur[top], y = cur[top - 1], z = cur[top - 2];
+        cur[top - 2] = xor3(x, y, z);
+        nxt[it] = maj3(x, y, z);
     }
-    return r;
-}
-template <int LO, int HI, int K>
-__device__ __forceinline__ Num<bits_for(HI - LO)> tree_sum(const uint32_t (&m)[K]) {
-    constexpr int N = HI - LO;
-    if constexpr (N == 1) {
-        Num<1> r;
-        r.b[0] = m[LO];
-        return r;
-    } else {
-        constexpr int MID = LO + N / 2;
-        const auto x = tree_sum<LO, MID, K>(m);
-        const auto y = tree_sum<MID, HI, K>(m);
-        return add_num<bits_for(MID - LO), bits_for(HI - MID), bits_for(N)>(x, y);
+    if constexpr (N >= 2 && N % 2 == 0) {                                   // two planes left: half adder
+        const uint32_t x = cur[0], y = cur[1];
+        cur[0] = x ^ y;
+        nxt[FA] = x & y;
     }
+    return cur[0];
 }
-// windows whose count exceeds r: the carry out of count + (2^B - 1 - r), r clamped to 2^B - 1.  kmask[b] = 0 / ~0 for bit b of
-// that constant (scalars): carry' = majority(count_b, carry, kmask_b)
-template <int B>
-__device__ __forceinline__ uint32_t greater_than(const Num<B> &c, int r) {
+// windows whose mismatch count over the K planes exceeds r: the carry out of count + (2^B - 1 - r), r clamped to 2^B - 1
+// (r >= 0: the callers drop entries with a negative radius, which match nothing).  Bit b of that constant as a scalar 0 / ~0:
+// carry' = majority(count_b, carry, const_b) -- one instruction per counter bit.
+template <int K>
+__device__ __forceinline__ uint32_t count_greater_than(const uint32_t (&m)[K], int r) {
+    constexpr int B = bits_for(K);
+    uint32_t l0[16], l1[16], l2[16], l3[16], l4[16], cnt[5];
+#pragma unroll
+    for (int j = 0; j < K; ++j) l0[j] = m[j];
+    cnt[0] = csa_level<K>(l0, l1);
+    cnt[1] = csa_level<K / 2>(l1, l2);
+    cnt[2] = csa_level<K / 4>(l2, l3);
+    cnt[3] = csa_level<K / 8>(l3, l4);
+    cnt[4] = csa_level<K / 16>(l4, l0);
     const int rr = r > (1 << B) - 1 ? (1 << B) - 1 : r;
     const uint32_t konst = (uint32_t)((1 << B) - 1 - rr);
     uint32_t carry = 0;
 #pragma unroll
     for (int b = 0; b < B; ++b) {
         const uint32_t kb = 0u - ((konst >> b) & 1u);
-        carry = (c.b[b] & carry) | (kb & (c.b[b] | carry));
+        carry = b == 0 ? (cnt[0] & kb) : maj3(cnt[b], carry, kb);
     }
     return carry;
 }
@@ -117,12 +122,11 @@ __device__ __forceinline__ uint32_t strand_gt(const uint32_t (&hs)[K], const uin
         const uint32_t ch = 0u - (base >> 1), cl = 0u - (base & 1u);
         m[j] = (hs[j] ^ ch) | (ls[j] ^ cl);
     }
-    const auto cnt = tree_sum<0, K, K>(m);
-    return greater_than<bits_for(K)>(cnt, radius);
+    return count_greater_than<K>(m, radius);
 }
 
 // hit16[g]: bit (15 - i) set when the window at position 16 g + i is within radius of any table entry (invalid windows: the
-// entry's inv_hit).  Thread = groups 2t, 2t + 1.  planes / inval are read up to group 2t + 3 (guarded against n_alloc_groups).
+// entry's inv_hit).  Thread = groups 2t, 2t + 1.  planes / inval are read up to group 2t + 3 (inside the array: see kmap_packed_groups).
 // WORDS: store the 32 hit bits as ONE word, window i in bit 31 - i (hit32[t], the scan's per-read passes); otherwise as the
 // two uint16 of the mask's coverage pass.
 template <int K, bool WORDS>
@@ -132,17 +136,16 @@ __global__ __launch_bounds__(BS_TPB) void hits_planes_kernel(const uint32_t *__r
     const int64_t t = (int64_t)blockIdx.x * BS_TPB + threadIdx.x;
     const int64_t g0 = 2 * t;
     if (16 * g0 >= n) return;
-    uint32_t pl[4], iv[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const bool in = g0 + q < n_alloc_groups;
-        pl[q] = in ? planes[g0 + q] : 0u;
-        iv[q] = in ? (uint32_t)inval[g0 + q] : 0xFFFFu;
-    }
+    // groups g0 .. g0 + 3 as two aligned pairs: g0 is even and < the number of data groups, and the array holds an even number of
+    // groups of which at least the last two are all-invalid halo groups (kmap_packed_groups), so g0 + 3 is inside it
+    const uint2 pa = *reinterpret_cast<const uint2 *>(planes + g0), pb = *reinterpret_cast<const uint2 *>(planes + g0 + 2);
+    const uint32_t ia = *reinterpret_cast<const uint32_t *>(inval + g0), ib = *reinterpret_cast<const uint32_t *>(inval + g0 + 2);
+    const uint32_t pl[4] = {pa.x, pa.y, pb.x, pb.y};
     const uint32_t H = (pl[0] & 0xFFFF0000u) | (pl[1] >> 16), L = (pl[0] << 16) | (pl[1] & 0xFFFFu);
     const uint32_t H2 = (pl[2] & 0xFFFF0000u) | (pl[3] >> 16), L2 = (pl[2] << 16) | (pl[3] & 0xFFFFu);
-    // windows that touch an invalid position: OR of the invalid flags of positions p .. p + K - 1 (doubling on the 64-bit stream)
-    uint64_t acc = ((uint64_t)((iv[0] << 16) | iv[1]) << 32) | ((iv[2] << 16) | iv[3]);
+    // windows that touch an invalid position: OR of the invalid flags of positions p .. p + K - 1 (doubling on the 64-bit stream);
+    // a little-endian pair of flag words has the first group in its low half: rotate by 16
+    uint64_t acc = ((uint64_t)__builtin_amdgcn_alignbit(ia, ia, 16) << 32) | __builtin_amdgcn_alignbit(ib, ib, 16);
 #pragma unroll
     for (int have = 1; have < K;) {
         const int step = (have <= K - have) ? have : K - have;
@@ -468,10 +471,53 @@ __global__ __launch_bounds__(HR_TPB) void scan_hits_reads_kernel(HrCtx c, const 
     }
 }
 
-// (A fused form -- counts -> block scan -> decoupled look-back over the blocks' published aggregates -> positions in ONE kernel --
-// was built and measured in r03: 5.1 ms at C3 against 0.32 + 0.09 + 0.28 ms for the three launches.  On a part with eight L2s
-// every agent-scope release / acquire of the status words is an L2 write-back / invalidate; 39 000 blocks of 256 reads pay
-// for it 39 000 times.  Larger blocks amortise it only linearly.  Dropped.)
+// One-pass form (the default): the per-read work is done ONCE.  A block counts its 256 reads, reserves room for all their positions
+// with one fetch-add on a global cursor -- blocks therefore land in the buffer in the order they happen to finish -- and writes the
+// positions right away (the hit words are still in L1; reads that are not "mixed" need no second distance evaluation).  What is
+// left for after the scan of the block totals is a copy of every block's contiguous segment to its place in read order: 4 B per
+// HIT instead of a second walk over every read's borders, hit words and codes (C5: 1.3 ms of 6.2).
+// (A decoupled look-back over published block aggregates, which would keep read order in a single kernel, was built and measured
+// in r03: 5.1 ms at C3 against 0.7 ms for the three launches -- on a part with eight L2s every agent-scope release / acquire of
+// the status words is an L2 write-back / invalidate, paid once per block.  The unordered reservation needs no such hand-over.)
+template <bool CHECK_INVALID>
+__global__ __launch_bounds__(HR_TPB) void scan_hits_reads_fused_kernel(HrCtx c, const int64_t *__restrict__ borders, int64_t n_seq,
+                                                                       int32_t *__restrict__ hits, int8_t *__restrict__ min_dist,
+                                                                       uint32_t *__restrict__ block_sums, uint64_t *__restrict__ block_ubase,
+                                                                       unsigned long long *__restrict__ cursor, int32_t *__restrict__ tmp_pos,
+                                                                       uint64_t cap) {
+    __shared__ unsigned int s_wave[HR_TPB / 64];
+    __shared__ unsigned long long s_base;
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    HrRead r;
+    hr_setup(c, borders, s, n_seq, r);
+    hr_count<CHECK_INVALID>(c, r);
+    if (s < n_seq) {
+        hits[s] = r.count;
+        min_dist[s] = (int8_t)(r.best <= c.radius ? r.best : -1);
+    }
+    unsigned int total;
+    const unsigned int in_block = hr_block_prefix((unsigned int)r.count, s_wave, total);
+    if (threadIdx.x == 0) {
+        const unsigned long long base = total ? atomicAdd(cursor, (unsigned long long)total) : 0ull;
+        s_base = base;
+        block_sums[blockIdx.x] = total;
+        block_ubase[blockIdx.x] = base;
+    }
+    __syncthreads();
+    hr_write<CHECK_INVALID>(c, r, s_base + in_block, tmp_pos, cap);         // writes behind `cap` are dropped (the caller falls back)
+}
+// segment of block b: tmp[ubase[b] .. + sums[b]) -> pos[offs[b] ..]; one wave per segment
+__global__ __launch_bounds__(256) void scan_reorder_kernel(const int32_t *__restrict__ tmp, const uint64_t *__restrict__ ubase,
+                                                           const uint64_t *__restrict__ offs, const uint32_t *__restrict__ sums, int64_t n_blocks,
+                                                           int32_t *__restrict__ pos) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < n_blocks; b += (int64_t)gridDim.x * 4) {
+        const uint32_t m = sums[b];
+        const int32_t *src = tmp + ubase[b];
+        int32_t *dst = pos + offs[b];
+        for (uint32_t i = lane; i < m; i += 64) dst[i] = src[i];
+    }
+}
 
 unsigned grid_of(int64_t n, int64_t per) {
     const int64_t g = (n + per - 1) / per;
@@ -560,6 +606,47 @@ int kmap_bitslice_scan_reads(bool write, const uint32_t *hit32, const uint32_t *
 #undef KMAP_HR
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;
+}
+
+// The whole per-read part of the scan: hits[] / min_dist[] per read, positions in read order in s->pos, *total_out hits.
+// One pass + a segment copy when the hits fit the temporary buffer (2 n_seq entries, at least 2^20), else the two-pass form.
+int kmap_bitslice_scan_reads_all(const uint32_t *hit32, const uint32_t *codes, const uint16_t *inval, int64_t n, const int64_t *borders,
+                                 int64_t n_seq, int k, uint64_t cons, int revcom, int radius, kmap_scan *s, uint64_t *total_out,
+                                 hipStream_t st) {
+    const HrCtx c = make_ctx(hit32, codes, inval, n, k, cons, revcom, radius);
+    const int64_t nblk = (n_seq + HR_TPB - 1) / HR_TPB;
+    const bool chk = c.d_inv <= radius;
+    // s->offs ((n_seq + 1) uint64 + 128 B) holds: block offsets uint64[nblk + 1] | block sums uint32[nblk] (padded to 8 B) |
+    // unordered block bases uint64[nblk] | cursor uint64
+    uint64_t *boffs = s->offs;
+    uint32_t *bsums = reinterpret_cast<uint32_t *>(s->offs + nblk + 1);
+    uint64_t *ubase = s->offs + nblk + 1 + (nblk + 1) / 2;
+    unsigned long long *cursor = reinterpret_cast<unsigned long long *>(ubase + nblk);
+    KMAP_REQUIRE((size_t)(nblk + 1 + (nblk + 1) / 2 + nblk + 1) * 8 <= ((size_t)n_seq + 1) * 8 + 128, "scan: block bookkeeping does not fit");
+    const uint64_t cap = (uint64_t)std::max<int64_t>(2 * n_seq, (int64_t)1 << 20);
+    int32_t *tmp = nullptr;
+    KMAP_TRY(kmap_scratch((void **)&tmp, cap * 4, st, KMAP_SLOT_PART));
+    KMAP_CHECK_HIP(hipMemsetAsync(cursor, 0, 8, st));
+    if (chk) scan_hits_reads_fused_kernel<true><<<(unsigned)nblk, HR_TPB, 0, st>>>(c, borders, n_seq, s->hits, s->mind, bsums, ubase, cursor, tmp, cap);
+    else scan_hits_reads_fused_kernel<false><<<(unsigned)nblk, HR_TPB, 0, st>>>(c, borders, n_seq, s->hits, s->mind, bsums, ubase, cursor, tmp, cap);
+    KMAP_CHECK_HIP(hipGetLastError());
+    KMAP_TRY(exclusive_scan_u32(bsums, nblk, boffs, st));
+    uint64_t total = 0;
+    KMAP_CHECK_HIP(hipMemcpyAsync(&total, boffs + nblk, 8, hipMemcpyDeviceToHost, st));
+    KMAP_CHECK_HIP(hipStreamSynchronize(st));
+    KMAP_TRY(kmap_scan_reserve_pos(s, total));
+    *total_out = total;
+    if (total == 0) return KMAP_OK;
+    if (total <= cap) {
+        const unsigned grid = (unsigned)std::min<int64_t>((nblk + 3) / 4, 8192);
+        scan_reorder_kernel<<<grid, 256, 0, st>>>(tmp, ubase, boffs, bsums, nblk, s->pos);
+        KMAP_CHECK_HIP(hipGetLastError());
+        return KMAP_OK;
+    }
+    // more hits than the temporary buffer holds (> 2 per read on average): count again with the mixed flags kept, then write in order
+    KMAP_TRY(kmap_bitslice_scan_reads(false, hit32, codes, inval, n, borders, n_seq, k, cons, revcom, radius, s, st));
+    KMAP_TRY(exclusive_scan_u32(bsums, nblk, boffs, st));
+    return kmap_bitslice_scan_reads(true, hit32, codes, inval, n, borders, n_seq, k, cons, revcom, radius, s, st);
 }
 
 extern "C" {

@@ -50,10 +50,10 @@ __device__ __forceinline__ void add_quad_block(float &gx, float &gy, const float
 }
 constexpr int SQ_CPL = 8;                       // consecutive columns per lane per batch (one 16-byte load of u16 sums)
 
-struct SeqBatch {                                // raw operands of one batch of one lane
+struct SeqBatch {                                // raw operands of one batch of one lane, as column pairs (c, c + 1)
     uint32_t w[4];                               // 8 u16 sums (LUT source) ...
-    float pf[SQ_CPL];                            // ... or 8 f32 probabilities
-    float x[SQ_CPL], y[SQ_CPL];
+    f32x2 pf[SQ_CPL / 2];                        // ... or 8 f32 probabilities
+    f32x2 x[SQ_CPL / 2], y[SQ_CPL / 2];
 };
 template <bool LUTSRC>
 __device__ __forceinline__ void seq_load(SeqBatch &b, const ProbSrc &src, const float *__restrict__ X,
@@ -64,62 +64,92 @@ __device__ __forceinline__ void seq_load(SeqBatch &b, const ProbSrc &src, const 
             b.w[0] = v.x; b.w[1] = v.y; b.w[2] = v.z; b.w[3] = v.w;
         } else {
 #pragma unroll
-            for (int c = 0; c < SQ_CPL; ++c) b.pf[c] = src.pf[lrc * src.ld + jl + c];
+            for (int d = 0; d < SQ_CPL / 2; ++d) b.pf[d] = f32x2{src.pf[lrc * src.ld + jl + 2 * d], src.pf[lrc * src.ld + jl + 2 * d + 1]};
         }
         const f32x4 a0 = *reinterpret_cast<const f32x4 *>(X + jl), a1 = *reinterpret_cast<const f32x4 *>(X + jl + 4);
         const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Yy + jl), c1 = *reinterpret_cast<const f32x4 *>(Yy + jl + 4);
-        b.x[0] = a0.x; b.x[1] = a0.y; b.x[2] = a0.z; b.x[3] = a0.w; b.x[4] = a1.x; b.x[5] = a1.y; b.x[6] = a1.z; b.x[7] = a1.w;
-        b.y[0] = c0.x; b.y[1] = c0.y; b.y[2] = c0.z; b.y[3] = c0.w; b.y[4] = c1.x; b.y[5] = c1.y; b.y[6] = c1.z; b.y[7] = c1.w;
+        b.x[0] = f32x2{a0.x, a0.y}; b.x[1] = f32x2{a0.z, a0.w}; b.x[2] = f32x2{a1.x, a1.y}; b.x[3] = f32x2{a1.z, a1.w};
+        b.y[0] = f32x2{c0.x, c0.y}; b.y[1] = f32x2{c0.z, c0.w}; b.y[2] = f32x2{c1.x, c1.y}; b.y[3] = f32x2{c1.z, c1.w};
     } else {
 #pragma unroll
-        for (int c = 0; c < SQ_CPL; ++c) {
-            const int64_t j = (jl + c < n) ? jl + c : n - 1;
-            if (LUTSRC) {
-                const uint32_t v = src.ps[lrc * src.ld + j];
-                if (c & 1) b.w[c >> 1] |= v << 16;
-                else b.w[c >> 1] = v;
-            } else {
-                b.pf[c] = src.pf[lrc * src.ld + j];
-            }
-            b.x[c] = X[j];
-            b.y[c] = Yy[j];
+        for (int d = 0; d < SQ_CPL / 2; ++d) {
+            const int64_t ja = (jl + 2 * d < n) ? jl + 2 * d : n - 1, jb = (jl + 2 * d + 1 < n) ? jl + 2 * d + 1 : n - 1;
+            if (LUTSRC) b.w[d] = (uint32_t)src.ps[lrc * src.ld + ja] | ((uint32_t)src.ps[lrc * src.ld + jb] << 16);
+            else b.pf[d] = f32x2{src.pf[lrc * src.ld + ja], src.pf[lrc * src.ld + jb]};
+            b.x[d] = f32x2{X[ja], X[jb]};
+            b.y[d] = f32x2{Yy[ja], Yy[jb]};
         }
     }
 }
 
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // The 8 terms of one lane's batch: t * dx, t * dy of columns jl32 .. jl32 + 7 against point (xi, yi) = row i32, and the batch's
 // cross-entropy contribution in log2 units.  SLOW: generic IEEE divisions (some squared distance beyond 1e30); LOSS: the batch has
 // columns right of the wave's rows; MASK: per-term predicates (the batch reaches past column n - 1 or contains the diagonal of
 // one of the wave's rows).  The two divisions are the exhaustively verified short sequences of seq_div.h.
+// Everything is written on column PAIRS as v_pk_{add,mul,fma}_f32 -- the same IEEE operations, two columns per issue slot: per
+// pair of terms 2 SDWA shifts (LUT byte offsets), dx, dy, dx^2, dy^2, +, 1 +, 2 rcp, 2 pk_fma, 2 med3, 1 -, 2 rcp, pk_mul,
+// 2 pk_fma, p - q, t, t dx, t dy = 26 instructions (13 per term; left to its own vectoriser the compiler reached 17.6).
+// dx, dy come from the dispatcher, which needs them for its range test anyway.
 template <bool LUTSRC, bool SLOW, bool LOSS, bool MASK>
-__device__ __forceinline__ void seq_terms(const SeqBatch &cur, const float *__restrict__ lut_s, float xi, float yi, int i32, int n32,
-                                          int jl32, float (&tx)[SQ_CPL], float (&ty)[SQ_CPL], float &ce2) {
-    float prod = 1.0f, esum = 0.0f;
+__device__ __forceinline__ void seq_terms(const SeqBatch &cur, const float *__restrict__ lut_s, const f32x2 (&dx)[SQ_CPL / 2],
+                                          const f32x2 (&dy)[SQ_CPL / 2], const f32x2 (&d2)[SQ_CPL / 2], int i32, int n32, int jl32,
+                                          float (&tx)[SQ_CPL], float (&ty)[SQ_CPL], float &ce2) {
+    const f32x2 one2 = {1.0f, 1.0f};
+    f32x2 es2 = {0.0f, 0.0f};
+    float prod = 1.0f;
 #pragma unroll
-    for (int c = 0; c < SQ_CPL; ++c) {                               // 8 independent terms
-        const int j = jl32 + c;
-        const float p = LUTSRC ? lut_s[(cur.w[c >> 1] >> (16 * (c & 1))) & 0xFFFFu] : cur.pf[c];
-        const float dx = xi - cur.x[c], dy = yi - cur.y[c];
-        const float d2 = dx * dx + dy * dy;                          // (dx*dx) + (dy*dy), no FMA (taichi_core.py:254)
-        float q = SLOW ? 1.0f / (1.0f + d2) : seq_rcp<KMAP_SEQ_RCP_STEPS>(1.0f + d2);        // :255
-        q = __builtin_amdgcn_fmed3f(q, 0.001f, 0.999f);              // np.minimum(.., 1 - 1e-3), np.maximum(.., 1e-3)
-        const float omq = 1.0f - q;
-        const float u = SLOW ? q / omq : seq_quo<KMAP_SEQ_QUO_RSTEPS, KMAP_SEQ_QUO_STEPS>(q, omq);   // visualization.py:132-134
-        const float t = u * (p - q);
-        const bool use = !MASK || ((j < n32) && (j != i32));
-        tx[c] = use ? t * dx : 0.0f;                                 // products rounded on their own (-ffp-contract=off)
-        ty[c] = use ? t * dy : 0.0f;
+    for (int d = 0; d < SQ_CPL / 2; ++d) {                               // 4 independent pairs of terms
+        const f32x2 p = LUTSRC ? f32x2{lut_s[cur.w[d] & 0xFFFFu], lut_s[cur.w[d] >> 16]} : cur.pf[d];
+        const f32x2 s1 = one2 + d2[d];                                   // d2 = (dx*dx) + (dy*dy), no FMA (taichi_core.py:254)
+        f32x2 q;                                                         // 1 / (1 + d2)   :255
+        if (SLOW) {
+            q = f32x2{1.0f / s1.x, 1.0f / s1.y};
+        } else {                                                         // seq_rcp<1>: v_rcp_f32 + one Newton step
+            static_assert(KMAP_SEQ_RCP_STEPS == 1 && KMAP_SEQ_QUO_RSTEPS == 0 && KMAP_SEQ_QUO_STEPS == 1, "the packed sequences below");
+            const f32x2 r = {__builtin_amdgcn_rcpf(s1.x), __builtin_amdgcn_rcpf(s1.y)};
+            q = pk_fma(pk_fma(-s1, r, one2), r, r);
+        }
+        q = f32x2{__builtin_amdgcn_fmed3f(q.x, 0.001f, 0.999f), __builtin_amdgcn_fmed3f(q.y, 0.001f, 0.999f)};   // np.minimum(.., 1 - 1e-3), np.maximum(.., 1e-3)
+        const f32x2 omq = one2 - q;
+        f32x2 u;                                                         // q / (1 - q)   visualization.py:132-134
+        if (SLOW) {
+            u = f32x2{q.x / omq.x, q.y / omq.y};
+        } else {                                                         // seq_quo<0, 1>: q * rcp(1 - q) + one residual correction
+            const f32x2 r2 = {__builtin_amdgcn_rcpf(omq.x), __builtin_amdgcn_rcpf(omq.y)};
+            const f32x2 u0 = q * r2;
+            u = pk_fma(pk_fma(-omq, u0, q), r2, u0);
+        }
+        const f32x2 t = u * (p - q);
+        f32x2 tx2 = t * dx[d], ty2 = t * dy[d];                          // products rounded on their own (-ffp-contract=off)
+        const int ja = jl32 + 2 * d, jb = ja + 1;
+        if (MASK) {
+            const bool ua = (ja < n32) && (ja != i32), ub = (jb < n32) && (jb != i32);
+            tx2 = f32x2{ua ? tx2.x : 0.0f, ub ? tx2.y : 0.0f};
+            ty2 = f32x2{ua ? ty2.x : 0.0f, ub ? ty2.y : 0.0f};
+        }
+        tx[2 * d] = tx2.x; tx[2 * d + 1] = tx2.y;
+        ty[2 * d] = ty2.x; ty[2 * d + 1] = ty2.y;
         if (LOSS) {
             // -(p ln q + (1-p) ln(1-q)) = -ln2 (log2(1-q) + p log2(q/(1-q))): one log per pair + one log of the product
             // of the eight (1-q); the reference's eps branches change a term by < 1e-9 relative (p < 1e-10) or not at
             // all (p = 1), and the loss is not part of the bit-pinned path
-            const bool live = !MASK || ((j < n32) && (j > i32));     // a plain batch with loss lies right of all the wave's rows
-            esum += live ? p * __builtin_amdgcn_logf(u) : 0.0f;
-            prod *= live ? omq : 1.0f;
+            const f32x2 lg = {__builtin_amdgcn_logf(u.x), __builtin_amdgcn_logf(u.y)};
+            f32x2 pl = p, om = omq;
+            if (MASK) {                                                  // a plain batch with loss lies right of all the wave's rows
+                const bool la = (ja < n32) && (ja > i32), lb = (jb < n32) && (jb > i32);
+                pl = f32x2{la ? p.x : 0.0f, lb ? p.y : 0.0f};
+                om = f32x2{la ? omq.x : 1.0f, lb ? omq.y : 1.0f};
+            }
+            es2 = pk_fma(pl, lg, es2);
+            // ONE chain in column order, not two packed half-products: near the loss floor every (1 - q) is the same float
+            // (0.999), the rounding of its powers is then systematic, and the chain's happens to sit 2.4e-6 from the reference's
+            // per-term logs where the pairwise product sits 9.6e-6 (tests/test_gpu_embed.py::test_early_stop_golden)
+            prod = (prod * om.x) * om.y;
         }
     }
-    if (LOSS) ce2 = __builtin_amdgcn_logf(prod) + esum;
+    if (LOSS) ce2 = __builtin_amdgcn_logf(prod) + (es2.x + es2.y);
 }
 // wave-uniform dispatch over the variants.  rows_in_wave consecutive rows from wave_row_min; batch = columns [j0, j0 + batch_cols)
 template <bool LUTSRC>
@@ -129,24 +159,28 @@ __device__ __forceinline__ void seq_terms_dispatch(const SeqBatch &cur, const fl
     // (a) no column of the batch lies right of any of the wave's rows -> no loss terms (each unordered pair is charged to its
     // j > i side); (b) some squared distance is too large for the short divisions -> generic division
     const bool want_loss = (j0 + batch_cols - 1) > wave_row_min;
-    float d2max = 0.0f;
+    const f32x2 xi2 = {xi, xi}, yi2 = {yi, yi};
+    f32x2 dx[SQ_CPL / 2], dy[SQ_CPL / 2], d2[SQ_CPL / 2];
 #pragma unroll
-    for (int c = 0; c < SQ_CPL; ++c) {
-        const float dx = xi - cur.x[c], dy = yi - cur.y[c];
-        d2max = fmaxf(d2max, dx * dx + dy * dy);
+    for (int d = 0; d < SQ_CPL / 2; ++d) {
+        dx[d] = xi2 - cur.x[d];
+        dy[d] = yi2 - cur.y[d];
+        d2[d] = dx[d] * dx[d] + dy[d] * dy[d];
     }
-    const bool slow = __any(!(d2max < 1e30f));
+    const f32x2 m01 = __builtin_elementwise_max(d2[0], d2[1]), m23 = __builtin_elementwise_max(d2[2], d2[3]);
+    const f32x2 m = __builtin_elementwise_max(m01, m23);
+    const bool slow = __any(!(fmaxf(m.x, m.y) < 1e30f));
     // (c) the batch neither reaches past column n-1 nor contains the diagonal of any of the wave's rows -> no per-term masks
     const bool plain = (j0 + batch_cols <= n) && (j0 + batch_cols - 1 < wave_row_min || j0 > wave_row_min + rows_in_wave - 1);
     const int n32 = (int)n;
     ce2 = 0.0f;
     if (slow) {   // rare (coordinates beyond 1e15): one generic instantiation
-        seq_terms<LUTSRC, true, true, true>(cur, lut_s, xi, yi, i32, n32, jl32, tx, ty, ce2);
+        seq_terms<LUTSRC, true, true, true>(cur, lut_s, dx, dy, d2, i32, n32, jl32, tx, ty, ce2);
     } else if (plain) {
-        if (want_loss) seq_terms<LUTSRC, false, true, false>(cur, lut_s, xi, yi, i32, n32, jl32, tx, ty, ce2);
-        else seq_terms<LUTSRC, false, false, false>(cur, lut_s, xi, yi, i32, n32, jl32, tx, ty, ce2);
+        if (want_loss) seq_terms<LUTSRC, false, true, false>(cur, lut_s, dx, dy, d2, i32, n32, jl32, tx, ty, ce2);
+        else seq_terms<LUTSRC, false, false, false>(cur, lut_s, dx, dy, d2, i32, n32, jl32, tx, ty, ce2);
     } else {
-        seq_terms<LUTSRC, false, true, true>(cur, lut_s, xi, yi, i32, n32, jl32, tx, ty, ce2);
+        seq_terms<LUTSRC, false, true, true>(cur, lut_s, dx, dy, d2, i32, n32, jl32, tx, ty, ce2);
     }
 }
 
@@ -172,9 +206,10 @@ __device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *_
     const int64_t wave_row_min = row0 + lrow0 + (bid * SQ_WAVES + wave) * SQ_ROWS;   // smallest global row of the wave
     float gx = 0.0f, gy = 0.0f, ce_acc = 0.0f;
     double loss = 0.0;
-    SeqBatch cur, nxt;
-    seq_load<LUTSRC>(cur, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n, vec);
-    for (int64_t j0 = 0; j0 < n; j0 += SQ_BATCH) {
+    // two batch buffers in alternating roles (no register copies between batches): while `cur` is evaluated, `nxt` is in flight
+    SeqBatch bufA, bufB;
+    seq_load<LUTSRC>(bufA, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n, vec);
+    auto step = [&](const SeqBatch &cur, SeqBatch &nxt, int64_t j0) {
         const int64_t jl = j0 + (int64_t)sub * SQ_CPL;                       // this lane's first column of the batch
         if (j0 + SQ_BATCH < n) seq_load<LUTSRC>(nxt, src, X, Yy, lrc, jl + SQ_BATCH, n, vec);   // prefetch
         float tx[SQ_CPL], ty[SQ_CPL];
@@ -196,7 +231,10 @@ __device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *_
             loss += (double)ce_acc;
             ce_acc = 0.0f;
         }
-        cur = nxt;
+    };
+    for (int64_t j0 = 0; j0 < n; j0 += 2 * SQ_BATCH) {
+        step(bufA, bufB, j0);
+        if (j0 + SQ_BATCH < n) step(bufB, bufA, j0 + SQ_BATCH);
     }
     loss += (double)ce_acc;
     loss *= -0.6931471805599453;   // log2 units -> -ln
@@ -284,9 +322,9 @@ __device__ __forceinline__ void seq_row16_body(const ProbSrc &src, const float *
     double loss = 0.0;
     // (computing the terms of batch b + 1 in the same loop body as the adds of batch b -- a software pipeline for the scheduler to
     // interleave -- measured slower: 0.066 vs 0.058 ms at N = 4000)
-    SeqBatch cur, nxt;
-    seq_load<LUTSRC>(cur, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n, vec);
-    for (int64_t j0 = 0; j0 < n; j0 += SR_BATCH) {
+    SeqBatch bufA, bufB;
+    seq_load<LUTSRC>(bufA, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n, vec);
+    auto step = [&](const SeqBatch &cur, SeqBatch &nxt, int64_t j0) {
         const int64_t jl = j0 + (int64_t)sub * SQ_CPL;
         if (j0 + SR_BATCH < n) seq_load<LUTSRC>(nxt, src, X, Yy, lrc, jl + SR_BATCH, n, vec);   // prefetch
         float tx[SQ_CPL], ty[SQ_CPL];
@@ -310,7 +348,10 @@ __device__ __forceinline__ void seq_row16_body(const ProbSrc &src, const float *
             loss += (double)ce_acc;
             ce_acc = 0.0f;
         }
-        cur = nxt;
+    };
+    for (int64_t j0 = 0; j0 < n; j0 += 2 * SR_BATCH) {
+        step(bufA, bufB, j0);
+        if (j0 + SR_BATCH < n) step(bufB, bufA, j0 + SR_BATCH);
     }
     loss += (double)ce_acc;
     loss *= -0.6931471805599453;   // log2 units -> -ln
@@ -351,12 +392,12 @@ __device__ __forceinline__ void seq_wide_body(const ProbSrc &src, const float *_
     f32x2 acc = {0.0f, 0.0f};
     float ce_acc = 0.0f;
     double loss = 0.0;
-    SeqBatch cur, nxt;
-    seq_load<LUTSRC>(cur, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n, vec);
+    SeqBatch bufA, bufB;
+    seq_load<LUTSRC>(bufA, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n, vec);
     f32x2 *mine = xch + (size_t)lane * SQ_CPL;                         // = strip of row grp, columns sub * 8 .. + 7
     const f32x4 *strip = reinterpret_cast<const f32x4 *>(xch + (size_t)grp * BC);
     int batch = 0;
-    for (int64_t j0 = 0; j0 < n; j0 += BC, ++batch) {
+    auto step = [&](const SeqBatch &cur, SeqBatch &nxt, int64_t j0) {
         const int64_t jl = j0 + (int64_t)sub * SQ_CPL;
         if (j0 + BC < n) seq_load<LUTSRC>(nxt, src, X, Yy, lrc, jl + BC, n, vec);          // prefetch
         float tx[SQ_CPL], ty[SQ_CPL];
@@ -383,7 +424,11 @@ __device__ __forceinline__ void seq_wide_body(const ProbSrc &src, const float *_
             loss += (double)ce_acc;
             ce_acc = 0.0f;
         }
-        cur = nxt;
+        ++batch;
+    };
+    for (int64_t j0 = 0; j0 < n; j0 += 2 * BC) {
+        step(bufA, bufB, j0);
+        if (j0 + BC < n) step(bufB, bufA, j0 + BC);
     }
     loss += (double)ce_acc;
     loss *= -0.6931471805599453;

@@ -902,7 +902,9 @@ static inline unsigned grid_for(int64_t n, int64_t per) {
 
 extern "C" {
 
-int64_t kmap_packed_groups(int64_t n) { return ((n + 15) >> 4) + 2; }
+// data groups + two all-invalid halo groups, rounded up to an EVEN number of groups: kernels that take group pairs (bitslice.hip:
+// thread = groups 2t .. 2t + 3) read whole aligned pairs without a bounds test
+int64_t kmap_packed_groups(int64_t n) { return ((((n + 15) >> 4) + 2) + 1) & ~(int64_t)1; }
 
 int kmap_pack_reads_dev(const uint8_t *seq_dev, int64_t n, uint32_t *codes_dev, uint16_t *inval_dev, void *stream) {
     KMAP_REQUIRE(n >= 0 && (n == 0 || seq_dev) && codes_dev && inval_dev, "pack_reads: bad arguments");
@@ -1138,15 +1140,8 @@ int kmap_scan_run_packed_dev(kmap_scan *s, const uint32_t *codes_dev, const uint
         KMAP_TRY(kmap_scratch((void **)&hit16, (size_t)((ng + 9) & ~(int64_t)7) * 2, st, KMAP_SLOT_HASH));
         if (n > 0) KMAP_TRY(kmap_bitslice_hits(planes_dev, inval_dev, n, k, &c, &radius, 1, revcom, hit16, true, st));
         uint32_t *hit32 = reinterpret_cast<uint32_t *>(hit16);
-        KMAP_TRY(kmap_bitslice_scan_reads(false, hit32, codes_dev, inval_dev, n, borders_dev, n_seq, k, c, revcom, radius, s, st));
-        // the count kernel left one total per block of 256 reads behind the block-offset array: scan those (1 / 256 of the reads)
-        const int64_t nblk = (n_seq + 255) / 256;
-        KMAP_TRY(exclusive_scan_u32(reinterpret_cast<const uint32_t *>(s->offs + nblk + 1), nblk, s->offs, st));
         uint64_t total = 0;
-        KMAP_CHECK_HIP(hipMemcpyAsync(&total, s->offs + nblk, 8, hipMemcpyDeviceToHost, st));
-        KMAP_CHECK_HIP(hipStreamSynchronize(st));
-        KMAP_TRY(kmap_scan_reserve_pos(s, total));
-        if (total) KMAP_TRY(kmap_bitslice_scan_reads(true, hit32, codes_dev, inval_dev, n, borders_dev, n_seq, k, c, revcom, radius, s, st));
+        KMAP_TRY(kmap_bitslice_scan_reads_all(hit32, codes_dev, inval_dev, n, borders_dev, n_seq, k, c, revcom, radius, s, &total, st));
         s->total = (int64_t)total;
         if (total_hits) *total_hits = (int64_t)total;
         return KMAP_OK;

@@ -19,3 +19,8 @@ int kmap_bitslice_hits(const uint32_t *planes, const uint16_t *inval, int64_t n,
 int kmap_bitslice_scan_reads(bool write, const uint32_t *hit32, const uint32_t *codes, const uint16_t *inval, int64_t n,
                              const int64_t *borders, int64_t n_seq, int k, uint64_t cons, int revcom, int radius, kmap_scan *s,
                              hipStream_t st);
+// the whole per-read part in one call: one pass + a copy of the blocks' segments into read order (two passes when the hits do not
+// fit the temporary buffer)
+int kmap_bitslice_scan_reads_all(const uint32_t *hit32, const uint32_t *codes, const uint16_t *inval, int64_t n, const int64_t *borders,
+                                 int64_t n_seq, int k, uint64_t cons, int revcom, int radius, kmap_scan *s, uint64_t *total_out,
+                                 hipStream_t st);

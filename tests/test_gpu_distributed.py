@@ -265,7 +265,8 @@ def test_cyclic_symmetric_shards_match_single_gpu(tmp_path, monkeypatch, cyclic)
     tr = {}
     V.kmap_from_kmers(kh, np.ones(n, np.int64), lab, ["ACGTACGT", "ACGTAC"], K, n_max_iter=iters, random_seed=SEED,
                       mode=V.EMBED_FAST, trace=tr)
-    np.testing.assert_allclose(r[0]["losses"], tr["losses"], rtol=2e-6)
+    # (the row-wise kernel takes one log per 8 (1 - q) factors in another grouping than the tile kernel: a systematic ~3e-6)
+    np.testing.assert_allclose(r[0]["losses"], tr["losses"], rtol=2e-6 if cyclic == "1" else 6e-6)
     # FAST sums are order-dependent in the last bits and the first steps from a random start are violent (the loss falls
     # 100x in one step), so a handful of coordinates drift to ~1e-4 of the embedding's extent within 6 iterations
     scale = np.abs(tr["last_coords"]).max()
