@@ -408,6 +408,7 @@ static uint64_t host_revcom(uint64_t h, int k, int narrow) {
 #include <mutex>
 
 #include "counts_internal.h"
+#include "host_pool.h"
 
 namespace {
 
@@ -714,21 +715,8 @@ int kmap_counts_fetch(kmap_counts *c, void *uniq_out, void *cnt_out) {
         uint32_t *tmp = (uint32_t *)malloc(n * 4);
         KMAP_REQUIRE(tmp, "counts_fetch: host malloc");
         hipError_t e = hipMemcpy(tmp, c->cnt, n * 4, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) {   // widen uint32 -> int64 on several host threads (10^9 entries at k = 16)
-            const unsigned nt = n > ((size_t)1 << 22) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-            std::vector<std::thread> pool;
-            size_t done_to = 0;                                     // entries [0, done_to) are covered by started threads
-            try {
-                for (unsigned t = 0; t < nt; ++t) {
-                    const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
-                    pool.emplace_back([=]() { for (size_t i = lo; i < hi; ++i) ((int64_t *)cnt_out)[i] = (int64_t)tmp[i]; });
-                    done_to = hi;
-                }
-            } catch (...) {                                         // no exception may cross the C ABI: finish on this thread
-            }
-            for (auto &th : pool) th.join();
-            for (size_t i = done_to; i < n; ++i) ((int64_t *)cnt_out)[i] = (int64_t)tmp[i];
-        }
+        if (e == hipSuccess)   // widen uint32 -> int64 on several host threads (10^9 entries at k = 16)
+            kmap_convert_pool<uint32_t, int64_t>((int64_t *)cnt_out, tmp, n, std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
         free(tmp);
         KMAP_CHECK_HIP(e);
     }
@@ -789,25 +777,7 @@ int staged_fetch(DST *dst, const SRC *src_dev, size_t n, hipStream_t st) {
         if (err != hipSuccess) break;
         const size_t next_off = off + len, next_len = next_off < n ? std::min(chunk, n - next_off) : 0;
         if (next_len) err = hipMemcpyAsync(stage[b ^ 1], src_dev + next_off, next_len * sizeof(SRC), hipMemcpyDeviceToHost, st);
-        try {
-            std::vector<std::thread> pool;
-            const SRC *sp = stage[b];
-            DST *dp = dst + off;
-            for (unsigned t = 0; t < nt; ++t)
-                pool.emplace_back([=]() {
-                    const size_t lo = len * t / nt, hi = len * (t + 1) / nt;
-                    // the destination may be an unaligned view into a memory-mapped pickle file (TableSaver): byte-wise typed stores
-                    typedef DST __attribute__((aligned(1))) DSTu;
-                    DSTu *du = (DSTu *)dp;
-                    if (std::is_same<SRC, DST>::value) memcpy((void *)(dp + lo), (const void *)(sp + lo), (hi - lo) * sizeof(SRC));
-                    else for (size_t i = lo; i < hi; ++i) du[i] = (DST)sp[i];
-                });
-            for (auto &th : pool) th.join();
-        } catch (...) {                                           // thread creation failed: convert on this thread
-            typedef DST __attribute__((aligned(1))) DSTu;
-            DSTu *du = (DSTu *)(dst + off);
-            for (size_t i = 0; i < len; ++i) du[i] = (DST)stage[b][i];
-        }
+        kmap_convert_pool<SRC, DST>(dst + off, stage[b], len, nt);  // the destination may be an unaligned view into a memory-mapped pickle file (TableSaver)
         off = next_off;
         len = next_len;
         b ^= 1;
