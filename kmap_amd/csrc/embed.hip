@@ -363,7 +363,7 @@ static int embed_create_impl(kmap_embed **out, int64_t n, int64_t row0, int64_t 
     e->n_part = kmap_embed_force_blocks(e) > 0 ? kmap_embed_force_blocks(e) : 1;
     hipError_t err = hipSuccess;
     auto A = [&](void **p, size_t b) { if (err == hipSuccess) err = hipMalloc(p, b ? b : 16); };
-    A((void **)&e->Y, (size_t)2 * n * 4);
+    A((void **)&e->Y, ((size_t)2 * n + 64) * 4);            // + 64 floats: embed_seq.hip's 16-byte coordinate loads may run 7 floats past Yy
     A((void **)&e->G, (size_t)2 * n * 4);
     A((void **)&e->snaps, (size_t)n_best * 2 * n * 4);
     A((void **)&e->loss_log, (size_t)e->loss_log_cap * 4);
@@ -395,6 +395,7 @@ static int embed_create_impl(kmap_embed **out, int64_t n, int64_t row0, int64_t 
     KMAP_CHECK_HIP(hipMemcpy(&e->states[0], &s0, sizeof s0, hipMemcpyHostToDevice));
     KMAP_CHECK_HIP(hipMemcpy(&e->states[1], &s0, sizeof s0, hipMemcpyHostToDevice));
     KMAP_CHECK_HIP(hipMemset(e->G, 0, (size_t)2 * n * 4));
+    KMAP_CHECK_HIP(hipMemset(e->Y + 2 * n, 0, 64 * 4));
     KMAP_CHECK_HIP(hipMemset(e->loss_part, 0, (size_t)e->n_part * 8));
     KMAP_CHECK_HIP(hipMemset(e->n_normals_dev, 0, 16));
     *out = e;

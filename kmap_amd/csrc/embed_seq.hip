@@ -3,6 +3,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "embed_internal.h"
 #include "seq_div.h"
 
@@ -55,19 +57,32 @@ struct SeqBatch {                                // raw operands of one batch of
     f32x2 pf[SQ_CPL / 2];                        // ... or 8 f32 probabilities
     f32x2 x[SQ_CPL / 2], y[SQ_CPL / 2];
 };
-template <bool LUTSRC>
+// One batch of one lane.  The SAME number of load instructions on every path through a step -- no branch around or inside this
+// function: the waitcnt pass counts outstanding loads, loads return in order, and at a control-flow join it must assume the
+// smaller count was issued after the loads it waits for.  With a conditional prefetch (or a vector / scalar choice per batch) the
+// wait in front of the CURRENT batch's first use became vmcnt(0): it also waited for the prefetch just issued, one exposed L2
+// round trip per batch -- 2.5 of the kernel's 6.4 SIMD cycles per instruction (r04 what-if run without the loads: 1.0 instead of
+// 2.5 ms).  So the prefetch is unconditional (behind the last batch it re-reads the current one) and VEC is a compile-time choice.
+// VEC (n % 4 == 0, sums pitch % 8 == 0): one 16-byte load of sums, four of coordinates.  A lane's 8 columns may reach past column
+// n - 1 (the terms are masked there): the sums row is read inside its pitch, the coordinates up to 7 floats behind X / Yy -- X is
+// followed by Yy, Yy by the session's 64 floats of padding.  A lane entirely behind column n - 1 reads the last lane that is not.
+template <bool LUTSRC, bool VEC>
 __device__ __forceinline__ void seq_load(SeqBatch &b, const ProbSrc &src, const float *__restrict__ X,
-                                         const float *__restrict__ Yy, int64_t lrc, int64_t jl, int64_t n, bool vec) {
-    if (vec && jl + SQ_CPL <= n) {
+                                         const float *__restrict__ Yy, int64_t lrc, int64_t jl, int64_t n) {
+    if constexpr (VEC) {
+        const int64_t jv = jl < n ? jl : ((n - 1) & ~(int64_t)7);
         if (LUTSRC) {
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(src.ps + lrc * src.ld + jl);
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(src.ps + lrc * src.ld + jv);
             b.w[0] = v.x; b.w[1] = v.y; b.w[2] = v.z; b.w[3] = v.w;
         } else {
 #pragma unroll
-            for (int d = 0; d < SQ_CPL / 2; ++d) b.pf[d] = f32x2{src.pf[lrc * src.ld + jl + 2 * d], src.pf[lrc * src.ld + jl + 2 * d + 1]};
+            for (int d = 0; d < SQ_CPL / 2; ++d) {
+                const int64_t ja = (jv + 2 * d < n) ? jv + 2 * d : n - 1, jb = (jv + 2 * d + 1 < n) ? jv + 2 * d + 1 : n - 1;
+                b.pf[d] = f32x2{src.pf[lrc * src.ld + ja], src.pf[lrc * src.ld + jb]};
+            }
         }
-        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(X + jl), a1 = *reinterpret_cast<const f32x4 *>(X + jl + 4);
-        const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Yy + jl), c1 = *reinterpret_cast<const f32x4 *>(Yy + jl + 4);
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(X + jv), a1 = *reinterpret_cast<const f32x4 *>(X + jv + 4);
+        const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Yy + jv), c1 = *reinterpret_cast<const f32x4 *>(Yy + jv + 4);
         b.x[0] = f32x2{a0.x, a0.y}; b.x[1] = f32x2{a0.z, a0.w}; b.x[2] = f32x2{a1.x, a1.y}; b.x[3] = f32x2{a1.z, a1.w};
         b.y[0] = f32x2{c0.x, c0.y}; b.y[1] = f32x2{c0.z, c0.w}; b.y[2] = f32x2{c1.x, c1.y}; b.y[3] = f32x2{c1.z, c1.w};
     } else {
@@ -201,17 +216,19 @@ __device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *_
     const int64_t i = row0 + lrc;
     const float *X = Y, *Yy = Y + n;
     const float xi = X[i], yi = Yy[i];
-    const bool vec = ((n & 3) == 0) && (!LUTSRC || (src.ld % 8 == 0));
+    const bool vec = ((n & 3) == 0) && (src.ld % 8 == 0);
     const int i32 = (int)i;                      // n < 2^31 (checked by the host)
     const int64_t wave_row_min = row0 + lrow0 + (bid * SQ_WAVES + wave) * SQ_ROWS;   // smallest global row of the wave
     float gx = 0.0f, gy = 0.0f, ce_acc = 0.0f;
     double loss = 0.0;
+    auto run = [&](auto vec_tag) {
+    constexpr bool VEC = decltype(vec_tag)::value;
     // two batch buffers in alternating roles (no register copies between batches): while `cur` is evaluated, `nxt` is in flight
     SeqBatch bufA, bufB;
-    seq_load<LUTSRC>(bufA, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n, vec);
+    seq_load<LUTSRC, VEC>(bufA, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n);
     auto step = [&](const SeqBatch &cur, SeqBatch &nxt, int64_t j0) {
         const int64_t jl = j0 + (int64_t)sub * SQ_CPL;                       // this lane's first column of the batch
-        if (j0 + SQ_BATCH < n) seq_load<LUTSRC>(nxt, src, X, Yy, lrc, jl + SQ_BATCH, n, vec);   // prefetch
+        seq_load<LUTSRC, VEC>(nxt, src, X, Yy, lrc, (j0 + SQ_BATCH < n) ? jl + SQ_BATCH : jl, n);   // prefetch, always (see seq_load)
         float tx[SQ_CPL], ty[SQ_CPL];
         float ce2;                                                           // loss terms in log2 units (order-free)
         seq_terms_dispatch<LUTSRC>(cur, lut_s, xi, yi, i32, n, j0, SQ_BATCH, wave_row_min, SQ_ROWS, (int)jl, tx, ty, ce2);
@@ -236,6 +253,9 @@ __device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *_
         step(bufA, bufB, j0);
         if (j0 + SQ_BATCH < n) step(bufB, bufA, j0 + SQ_BATCH);
     }
+    };
+    if (vec) run(std::true_type{});
+    else run(std::false_type{});
     loss += (double)ce_acc;
     loss *= -0.6931471805599453;   // log2 units -> -ln
     if (valid && sub == 0) {
@@ -315,18 +335,20 @@ __device__ __forceinline__ void seq_row16_body(const ProbSrc &src, const float *
     const int64_t i = row0 + lrc;
     const float *X = Y, *Yy = Y + n;
     const float xi = X[i], yi = Yy[i];
-    const bool vec = ((n & 3) == 0) && (!LUTSRC || (src.ld % 8 == 0));
+    const bool vec = ((n & 3) == 0) && (src.ld % 8 == 0);
     const int i32 = (int)i;
     const int64_t wave_row_min = row0 + wave_lr;
     float gx = 0.0f, gy = 0.0f, ce_acc = 0.0f;
     double loss = 0.0;
+    auto run = [&](auto vec_tag) {
+    constexpr bool VEC = decltype(vec_tag)::value;
     // (computing the terms of batch b + 1 in the same loop body as the adds of batch b -- a software pipeline for the scheduler to
     // interleave -- measured slower: 0.066 vs 0.058 ms at N = 4000)
     SeqBatch bufA, bufB;
-    seq_load<LUTSRC>(bufA, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n, vec);
+    seq_load<LUTSRC, VEC>(bufA, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n);
     auto step = [&](const SeqBatch &cur, SeqBatch &nxt, int64_t j0) {
         const int64_t jl = j0 + (int64_t)sub * SQ_CPL;
-        if (j0 + SR_BATCH < n) seq_load<LUTSRC>(nxt, src, X, Yy, lrc, jl + SR_BATCH, n, vec);   // prefetch
+        seq_load<LUTSRC, VEC>(nxt, src, X, Yy, lrc, (j0 + SR_BATCH < n) ? jl + SR_BATCH : jl, n);   // prefetch, always (see seq_load)
         float tx[SQ_CPL], ty[SQ_CPL];
         float ce2;
         seq_terms_dispatch<LUTSRC>(cur, lut_s, xi, yi, i32, n, j0, SR_BATCH, wave_row_min, SR_ROWS, (int)jl, tx, ty, ce2);
@@ -353,6 +375,9 @@ __device__ __forceinline__ void seq_row16_body(const ProbSrc &src, const float *
         step(bufA, bufB, j0);
         if (j0 + SR_BATCH < n) step(bufB, bufA, j0 + SR_BATCH);
     }
+    };
+    if (vec) run(std::true_type{});
+    else run(std::false_type{});
     loss += (double)ce_acc;
     loss *= -0.6931471805599453;   // log2 units -> -ln
     if (valid && sub == 0) {
@@ -386,20 +411,22 @@ __device__ __forceinline__ void seq_wide_body(const ProbSrc &src, const float *_
     const int64_t i = row0 + lrc;
     const float *X = Y, *Yy = Y + n;
     const float xi = X[i], yi = Yy[i];
-    const bool vec = ((n & 3) == 0) && (!LUTSRC || (src.ld % 8 == 0));
+    const bool vec = ((n & 3) == 0) && (src.ld % 8 == 0);
     const int i32 = (int)i;
     const int64_t wave_row_min = row0 + wave_lr;
     f32x2 acc = {0.0f, 0.0f};
     float ce_acc = 0.0f;
     double loss = 0.0;
+    auto run = [&](auto vec_tag) {
+    constexpr bool VEC = decltype(vec_tag)::value;
     SeqBatch bufA, bufB;
-    seq_load<LUTSRC>(bufA, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n, vec);
+    seq_load<LUTSRC, VEC>(bufA, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n);
     f32x2 *mine = xch + (size_t)lane * SQ_CPL;                         // = strip of row grp, columns sub * 8 .. + 7
     const f32x4 *strip = reinterpret_cast<const f32x4 *>(xch + (size_t)grp * BC);
     int batch = 0;
     auto step = [&](const SeqBatch &cur, SeqBatch &nxt, int64_t j0) {
         const int64_t jl = j0 + (int64_t)sub * SQ_CPL;
-        if (j0 + BC < n) seq_load<LUTSRC>(nxt, src, X, Yy, lrc, jl + BC, n, vec);          // prefetch
+        seq_load<LUTSRC, VEC>(nxt, src, X, Yy, lrc, (j0 + BC < n) ? jl + BC : jl, n);      // prefetch, always (see seq_load)
         float tx[SQ_CPL], ty[SQ_CPL];
         float ce2;
         seq_terms_dispatch<LUTSRC>(cur, lut_s, xi, yi, i32, n, j0, BC, wave_row_min, RW, (int)jl, tx, ty, ce2);
@@ -430,6 +457,9 @@ __device__ __forceinline__ void seq_wide_body(const ProbSrc &src, const float *_
         step(bufA, bufB, j0);
         if (j0 + BC < n) step(bufB, bufA, j0 + BC);
     }
+    };
+    if (vec) run(std::true_type{});
+    else run(std::false_type{});
     loss += (double)ce_acc;
     loss *= -0.6931471805599453;
     if (valid && sub == 0) {
