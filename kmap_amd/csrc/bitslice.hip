@@ -479,6 +479,104 @@ __global__ __launch_bounds__(HR_TPB) void scan_hits_reads_kernel(HrCtx c, const 
 // (A decoupled look-back over published block aggregates, which would keep read order in a single kernel, was built and measured
 // in r03: 5.1 ms at C3 against 0.7 ms for the three launches -- on a part with eight L2s every agent-scope release / acquire of
 // the status words is an L2 write-back / invalidate, paid once per block.  The unordered reservation needs no such hand-over.)
+// Short reads in the one-pass form: all hit words of the read (up to HF_WORDS = 12: 352 positions) arrive in ONE round trip of six
+// 8-byte loads, the masked words stay in registers for the write phase, and the first HF_KEEP positions at the running minimum are
+// kept in registers while counting -- a read whose hits all lie at one distance (nearly all: one planted hit) is written from
+// them without a second walk.  (r04 counters on the general form at the C5 shape: 1213 vector + 365 scalar instructions per 64
+// reads at 57 % issue utilisation -- instruction-bound as much as latency-bound: two chunks of six word loads, mask building and
+// the hit loop ran once for the counts and again for the positions.)
+constexpr int HF_WORDS = 12, HF_KEEP = 4, HF_CURSORS = 64;
+typedef uint32_t hf_u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+struct HfRead {
+    uint64_t q[HF_WORDS / 2];            // the read's hit bits, position p of the word stream in bit 63 - (p & 63) of q[p >> 6]
+    int keep[HF_KEEP];                   // first positions (relative to the read) at the minimum, ascending
+    int a_off;                           // bit offset of the read's first position in the word stream
+    int64_t word0;                       // absolute position of the stream's bit 0
+};
+__device__ __forceinline__ bool hf_applies(const HrRead &r) {
+    const int end = (int)(r.st & 31) + (int)r.stop;
+    return !r.quirk && r.stop > 0 && r.stop <= 32 * HF_WORDS && ((end + 31) >> 5) <= HF_WORDS;
+}
+// pops the earliest hit of the six words (0 words: returns false); rel = its position in the word stream
+__device__ __forceinline__ bool hf_pop(uint64_t (&q)[HF_WORDS / 2], int &rel) {
+    int sel = -1;
+    uint64_t cur = 0;
+#pragma unroll
+    for (int t = HF_WORDS / 2 - 1; t >= 0; --t)
+        if (q[t]) { sel = t; cur = q[t]; }
+    if (sel < 0) return false;
+    const int tb = 63 - __builtin_clzll(cur);
+    const uint64_t clr = ~(1ull << tb);
+#pragma unroll
+    for (int t = 0; t < HF_WORDS / 2; ++t) q[t] &= (sel == t) ? clr : ~0ull;
+    rel = 64 * sel + 63 - tb;
+    return true;
+}
+template <bool CHECK_INVALID>
+__device__ __forceinline__ void hf_count(const HrCtx &c, HrRead &r, HfRead &f, bool active) {
+    f.a_off = (int)(r.st & 31);
+    f.word0 = (r.st >> 5) << 5;
+    const int end = f.a_off + (int)r.stop;
+    const int nw = active ? (end + 31) >> 5 : 0;
+    const uint32_t *hw = c.hit32 + (r.st >> 5);
+    uint32_t x[HF_WORDS];
+#pragma unroll
+    for (int t = 0; t < HF_WORDS / 2; ++t) {   // word pairs behind the read's last word repeat its last pair (inside the array)
+        const int at = (2 * t < nw) ? 2 * t : (nw > 0 ? (nw - 1) & ~1 : 0);
+        const hf_u32x2 v = *reinterpret_cast<const hf_u32x2 *>(hw + at);
+        x[2 * t] = v.x;
+        x[2 * t + 1] = v.y;
+    }
+#pragma unroll
+    for (int j = 0; j < HF_WORDS; ++j) {
+        uint32_t m = j < nw ? ~0u : 0u;
+        if (j == 0) m &= ~0u >> f.a_off;
+        if (j == nw - 1) m &= ~0u << (32 * nw - end);
+        x[j] &= m;
+    }
+#pragma unroll
+    for (int t = 0; t < HF_WORDS / 2; ++t) f.q[t] = ((uint64_t)x[2 * t] << 32) | x[2 * t + 1];
+    uint64_t w[HF_WORDS / 2];
+#pragma unroll
+    for (int t = 0; t < HF_WORDS / 2; ++t) w[t] = f.q[t];
+#pragma unroll
+    for (int t = 0; t < HF_KEEP; ++t) f.keep[t] = 0;
+    int rel;
+    while (hf_pop(w, rel)) {                // a wave runs this as often as its busiest read has hits
+        const int d = hr_dist<CHECK_INVALID>(c.codes, c.inval, f.word0 + rel, c.k, c.km, c.cons, c.rcc, c.revcom);
+        const int p = rel - f.a_off;
+        if (d < r.best) {
+            r.mixed = r.mixed || r.count > 0;
+            r.best = d;
+            r.count = 1;
+            f.keep[0] = p;
+        } else if (d == r.best) {
+#pragma unroll
+            for (int t = 1; t < HF_KEEP; ++t)
+                if (r.count == t) f.keep[t] = p;
+            ++r.count;
+        } else {
+            r.mixed = true;
+        }
+    }
+}
+template <bool CHECK_INVALID>
+__device__ __forceinline__ void hf_write(const HrCtx &c, const HrRead &r, HfRead &f, uint64_t base, int32_t *__restrict__ pos_out, uint64_t cap) {
+    if (r.count == 0) return;
+    if (r.count <= HF_KEEP) {               // the positions are in registers
+#pragma unroll
+        for (int t = 0; t < HF_KEEP; ++t)
+            if (t < r.count && base + t < cap) pos_out[base + t] = f.keep[t];
+        return;
+    }
+    int rel;
+    while (hf_pop(f.q, rel)) {              // many hits (or several distances): walk the saved words again
+        if (r.mixed && hr_dist<CHECK_INVALID>(c.codes, c.inval, f.word0 + rel, c.k, c.km, c.cons, c.rcc, c.revcom) != r.best) continue;
+        if (base < cap) pos_out[base] = rel - f.a_off;
+        ++base;
+    }
+}
+
 template <bool CHECK_INVALID>
 __global__ __launch_bounds__(HR_TPB) void scan_hits_reads_fused_kernel(HrCtx c, const int64_t *__restrict__ borders, int64_t n_seq,
                                                                        int32_t *__restrict__ hits, int8_t *__restrict__ min_dist,
@@ -490,7 +588,16 @@ __global__ __launch_bounds__(HR_TPB) void scan_hits_reads_fused_kernel(HrCtx c, 
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     HrRead r;
     hr_setup(c, borders, s, n_seq, r);
-    hr_count<CHECK_INVALID>(c, r);
+    const bool fast = hf_applies(r);
+    const bool general = !fast && (r.stop > 0 || r.quirk);                  // long reads, the negative-slice quirk
+    HfRead f;
+    hf_count<CHECK_INVALID>(c, r, f, fast);
+    if (__any(general)) {                                                   // wave-uniform: the general form for the lanes that need it
+        HrRead g = r;
+        if (!general) { g.stop = 0; g.quirk = false; }
+        hr_count<CHECK_INVALID>(c, g);
+        if (general) r = g;
+    }
     if (s < n_seq) {
         hits[s] = r.count;
         min_dist[s] = (int8_t)(r.best <= c.radius ? r.best : -1);
@@ -498,13 +605,28 @@ __global__ __launch_bounds__(HR_TPB) void scan_hits_reads_fused_kernel(HrCtx c, 
     unsigned int total;
     const unsigned int in_block = hr_block_prefix((unsigned int)r.count, s_wave, total);
     if (threadIdx.x == 0) {
-        const unsigned long long base = total ? atomicAdd(cursor, (unsigned long long)total) : 0ull;
+        // HF_CURSORS reservation counters, each with its own region of the buffer (a block takes counter blockIdx mod HF_CURSORS):
+        // tens of thousands of device-scope fetch-adds on ONE address serialise at the memory side
+        const unsigned cu = blockIdx.x % HF_CURSORS;
+        const unsigned long long region = cap / HF_CURSORS;
+        unsigned long long base = 0;
+        if (total) {
+            const unsigned long long at = atomicAdd(&cursor[cu], (unsigned long long)total);
+            base = at + total <= region ? (unsigned long long)cu * region + at : cap;     // region full: dropped, and *overflow says so
+            if (at + total > region) atomicMax(&cursor[HF_CURSORS], 1ull);
+        }
         s_base = base;
         block_sums[blockIdx.x] = total;
         block_ubase[blockIdx.x] = base;
     }
     __syncthreads();
-    hr_write<CHECK_INVALID>(c, r, s_base + in_block, tmp_pos, cap);         // writes behind `cap` are dropped (the caller falls back)
+    const uint64_t base = s_base + in_block;
+    if (fast) hf_write<CHECK_INVALID>(c, r, f, base, tmp_pos, cap);         // writes behind `cap` are dropped (the caller falls back)
+    if (__any(general)) {
+        HrRead g = r;
+        if (!general) { g.count = 0; g.stop = 0; g.quirk = false; }
+        hr_write<CHECK_INVALID>(c, g, base, tmp_pos, cap);
+    }
 }
 // segment of block b: tmp[ubase[b] .. + sums[b]) -> pos[offs[b] ..]; one wave per segment
 __global__ __launch_bounds__(256) void scan_reorder_kernel(const int32_t *__restrict__ tmp, const uint64_t *__restrict__ ubase,
@@ -621,29 +743,33 @@ int kmap_bitslice_scan_reads_all(const uint32_t *hit32, const uint32_t *codes, c
     uint64_t *boffs = s->offs;
     uint32_t *bsums = reinterpret_cast<uint32_t *>(s->offs + nblk + 1);
     uint64_t *ubase = s->offs + nblk + 1 + (nblk + 1) / 2;
-    unsigned long long *cursor = reinterpret_cast<unsigned long long *>(ubase + nblk);
-    KMAP_REQUIRE((size_t)(nblk + 1 + (nblk + 1) / 2 + nblk + 1) * 8 <= ((size_t)n_seq + 1) * 8 + 128, "scan: block bookkeeping does not fit");
-    const uint64_t cap = (uint64_t)std::max<int64_t>(2 * n_seq, (int64_t)1 << 20);
+    // the reservation counters (+ overflow flag) live in the scratch arena behind the temporary positions
+    const size_t book = (size_t)(nblk + 1 + (nblk + 1) / 2 + nblk) * 8;
+    KMAP_REQUIRE(book <= ((size_t)n_seq + 1) * 8 + 128, "scan: block bookkeeping does not fit");
+    const uint64_t cap = ((uint64_t)std::max<int64_t>(2 * n_seq, (int64_t)1 << 20) + 2 * HF_CURSORS - 1) / (2 * HF_CURSORS) * (2 * HF_CURSORS);   // HF_CURSORS even regions
     int32_t *tmp = nullptr;
-    KMAP_TRY(kmap_scratch((void **)&tmp, cap * 4, st, KMAP_SLOT_PART));
-    KMAP_CHECK_HIP(hipMemsetAsync(cursor, 0, 8, st));
+    KMAP_TRY(kmap_scratch((void **)&tmp, cap * 4 + (HF_CURSORS + 1) * 8, st, KMAP_SLOT_PART));
+    unsigned long long *cursor = reinterpret_cast<unsigned long long *>(tmp + cap);       // cap is even: 8-byte aligned
+    KMAP_CHECK_HIP(hipMemsetAsync(cursor, 0, (HF_CURSORS + 1) * 8, st));
     if (chk) scan_hits_reads_fused_kernel<true><<<(unsigned)nblk, HR_TPB, 0, st>>>(c, borders, n_seq, s->hits, s->mind, bsums, ubase, cursor, tmp, cap);
     else scan_hits_reads_fused_kernel<false><<<(unsigned)nblk, HR_TPB, 0, st>>>(c, borders, n_seq, s->hits, s->mind, bsums, ubase, cursor, tmp, cap);
     KMAP_CHECK_HIP(hipGetLastError());
     KMAP_TRY(exclusive_scan_u32(bsums, nblk, boffs, st));
     uint64_t total = 0;
+    unsigned long long overflow = 0;
     KMAP_CHECK_HIP(hipMemcpyAsync(&total, boffs + nblk, 8, hipMemcpyDeviceToHost, st));
+    KMAP_CHECK_HIP(hipMemcpyAsync(&overflow, cursor + HF_CURSORS, 8, hipMemcpyDeviceToHost, st));
     KMAP_CHECK_HIP(hipStreamSynchronize(st));
     KMAP_TRY(kmap_scan_reserve_pos(s, total));
     *total_out = total;
     if (total == 0) return KMAP_OK;
-    if (total <= cap) {
+    if (!overflow) {
         const unsigned grid = (unsigned)std::min<int64_t>((nblk + 3) / 4, 8192);
         scan_reorder_kernel<<<grid, 256, 0, st>>>(tmp, ubase, boffs, bsums, nblk, s->pos);
         KMAP_CHECK_HIP(hipGetLastError());
         return KMAP_OK;
     }
-    // more hits than the temporary buffer holds (> 2 per read on average): count again with the mixed flags kept, then write in order
+    // more hits than a region of the temporary buffer holds (> 2 per read on average): count again with the mixed flags kept, then write in order
     KMAP_TRY(kmap_bitslice_scan_reads(false, hit32, codes, inval, n, borders, n_seq, k, cons, revcom, radius, s, st));
     KMAP_TRY(exclusive_scan_u32(bsums, nblk, boffs, st));
     return kmap_bitslice_scan_reads(true, hit32, codes, inval, n, borders, n_seq, k, cons, revcom, radius, s, st);
