@@ -90,6 +90,58 @@ def all_gather_rows_dev(dist, local_dev, n, world, rank, row_elems, group=None):
     return _ffi.DeviceView(full.data_ptr(), full.numel() * 4, keep=full)
 
 
+class CountShard:
+    """What a DeviceCounts handle that holds only this rank's KEY RANGE of a count table needs to answer find_motif's questions
+    (reference motif_discovery.py:648,661-673) without any rank receiving the whole (k-mer, count) list: the sizes of all ranks'
+    shards (shards are in key order = rank order, so a k-mer's index in the whole sorted table is its shard's offset + its local
+    index), and three tiny collectives -- a SUM of one integer (total count), a SUM of top_k float64 masses per trial, an
+    all-gather of <= top_k candidates per rank.  All ranks take identical decisions because all see identical merged values."""
+
+    def __init__(self, dist, group, sizes):
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.sizes = [int(v) for v in sizes]
+        self.n_local = self.sizes[self.rank]
+        self.offset = int(sum(self.sizes[:self.rank]))
+        self.n_global = int(sum(self.sizes))
+        self.dev = _coll_device(dist, group)
+
+    def sum_int(self, v):
+        import torch
+        t = torch.tensor([int(v)], dtype=torch.int64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return int(t.item())
+
+    def sum_f64(self, arr):
+        """element-wise sum over the ranks of integer-valued float64 partials (exact below 2^53 in any order)"""
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(arr, np.float64)).to(self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+    def merge_topk(self, top_k, idx, kh, cnt):
+        """every rank's local top-k (count descending, local index ascending) -> the top-k of the whole table by the same rule
+        (count descending, index in the whole sorted table ascending): identical on every rank"""
+        import torch
+        mine = np.full((top_k, 3), -1, np.int64)
+        m = len(idx)
+        mine[:m, 0] = np.asarray(cnt, np.int64)
+        mine[:m, 1] = np.asarray(idx, np.int64) + self.offset
+        mine[:m, 2] = np.asarray(kh, np.uint64).view(np.int64)
+        t = torch.from_numpy(mine.reshape(-1)).to(self.dev)
+        parts = torch.empty(self.world * top_k * 3, dtype=torch.int64, device=self.dev)
+        self.dist.all_gather_into_tensor(parts, t, group=self.group)
+        allc = parts.cpu().numpy().reshape(-1, 3)
+        allc = allc[allc[:, 0] > 0]                                   # kmap_counts_topk never returns a non-positive count
+        order = np.lexsort((allc[:, 1], -allc[:, 0]))[:top_k]
+        sel = allc[order]
+        return sel[:, 1].copy(), sel[:, 2].copy().view(np.uint64), sel[:, 0].copy()
+
+    def gather_host(self, u, c):
+        """the whole table on every rank's host (the top_k > 16 path of find_motif: numpy's argpartition on the full arrays)"""
+        return all_gather_concat(self.dist, u, self.sizes, self.group), all_gather_concat(self.dist, c, self.sizes, self.group)
+
+
 def broadcast_seed(dist, random_seed, group=None):
     """`random_seed = "default"` (None) means OS entropy in the reference (np.random.seed(None)); under a multi-rank launch
     every rank must still start from the same coordinates, placeholders and jitter stream, so rank 0 draws the seed and
@@ -366,8 +418,8 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None, shard_counts
     windows): the bins are owned by key range instead -- every rank receives only the summed counts of ITS slice of the table (one
     SUM-reduce per slice), compacts that slice, and the (k-mer, count) shards are all-gathered in rank = key order.  Per rank and
     (G-1)/G: 4^k * 4 B of slices + 4^k B of presence + 12 B per distinct k-mer, against 4^k * 8 B for the all-reduce: it pays while
-    the distinct k-mers number fewer than a quarter of the bins (every rank wants the whole list; a find_motif that kept the
-    counts sharded would not pay the last term).  The reverse-complement merge pairs
+    the distinct k-mers number fewer than a quarter of the bins -- and above TOPK_DEVICE_MIN unique k-mers the last term is not paid
+    at all: the table stays sharded (DeviceCounts._shard / CountShard) and find_motif works on local partials.  The reverse-complement merge pairs
     bins of different slices: it runs BEFORE the reduction on each rank's local table, steered by an all-reduced presence map
     (half a byte per bin) so that merged(sum over ranks) == sum over ranks(merged); see include/kmap_hip.h.
     scan() returns the hits of ALL reads (all-gathered in read order); `out_n_seq` / `out_read_len` describe the reads those
@@ -379,7 +431,7 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None, shard_counts
     import torch
     from . import _ffi
     from ._ffi import check
-    from .motif_discovery import DeviceSeq
+    from .motif_discovery import TOPK_DEVICE_MIN, DeviceSeq
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     on_dev = _coll_device(dist, group) == "cuda"
@@ -402,6 +454,8 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None, shard_counts
     class DistDeviceSeq(DeviceSeq):
         first_read, n_local_reads, n_all_reads = r0, nr, len(borders)
         _all_read_len = None
+        keep_sharded = None         # key-range counting: None = keep the table sharded above TOPK_DEVICE_MIN unique k-mers; True / False force it
+        full_table_rank = None      # ... and gather the whole table on this rank as well (the writer of k{k}.pkl)
 
         @property
         def out_read_len(self):
@@ -415,12 +469,37 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None, shard_counts
         def out_read_len(self, value):      # DeviceSeq.__init__ assigns the local shard's lengths: not what scan() covers here
             pass
 
+        def mask(self, k, consensus_kh_arr, max_ham_dist_arr):
+            """mask_input on this rank's reads, plus the one effect that crosses a shard boundary: a window that touches a separator
+            has the reference's all-ones hash ("compared like any value", kmer_count.py:580-610), so a consensus within its radius
+            of the all-T k-mer also masks the window that STARTS AT the separator in front of this shard -- on the rank before --
+            and with it the first k - 1 positions here."""
+            DeviceSeq.mask(self, k, consensus_kh_arr, max_ham_dist_arr)
+            if self.first_read == 0 or self.n == 0:
+                return
+            kmask = (1 << (2 * k)) - 1
+            hit = False
+            for c, r in zip(np.asarray(consensus_kh_arr).tolist(), np.asarray(max_ham_dist_arr).tolist()):
+                x = (kmask ^ int(c)) & kmask
+                hit = hit or bin((x | (x >> 1)) & 0x5555555555555555).count("1") <= int(r)
+            if not hit:
+                return
+            m = min(k - 1, self.n)                                       # positions [0, m) become invalid
+            ng = (m + 15) // 16
+            flags = np.zeros(ng, np.uint16)
+            check(_ffi.lib().kmap_memcpy_d2h(_ffi.ptr(flags), self.inval_work.ptr, ng * 2, None))
+            for p in range(m):
+                flags[p >> 4] |= np.uint16(1 << (15 - (p & 15)))         # position i of a group in bit 15 - i
+            check(_ffi.lib().kmap_memcpy_h2d(self.inval_work.ptr, _ffi.ptr(flags), ng * 2, None))
+            _ffi.sync()
+
         def count(self, dc, k, dedupe, merge_revcom, use_work=True):
             if k > 16:
                 raise ValueError("sharded counting all-reduces the 4^k histogram and needs k <= 16")
             if on_dev:
                 assert_default_stream()
             inval = self.inval_work if use_work else self.inval_orig
+            dc._unshard()
             check(_ffi.lib().kmap_counts_hist_packed_dev(dc._h, self.codes.ptr, inval.ptr, self.n, self.borders.ptr,
                                                          self.n_seq, k, int(dedupe), None))
             p, nb = _ffi.vp(), _ffi.i64(0)
@@ -456,29 +535,74 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None, shard_counts
             check(lib.kmap_counts_finish_range(dc._h, k, int(bool(merge_revcom)), bounds[rank], bounds[rank + 1] - bounds[rank],
                                                C.byref(nu), None))
             # the shards, concatenated in rank order, are the table every rank would have compacted from the all-reduced bins
-            sizes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
-            dist.all_gather(sizes, torch.tensor([nu.value], dtype=torch.int64, device="cuda"), group=group)
-            sizes = [int(t.item()) for t in sizes]
-            cap = max(max(sizes), 1)
-            up, cp, n_mine = _ffi.vp(), _ffi.vp(), _ffi.i64(0)
-            check(lib.kmap_counts_table_dev(dc._h, C.byref(up), C.byref(cp), C.byref(n_mine)))
-            kt, kdt = ("<i4", torch.int32) if k < 16 else ("<i8", torch.int64)
-            mine_u = torch.zeros(cap, dtype=kdt, device="cuda")
-            mine_c = torch.zeros(cap, dtype=torch.int32, device="cuda")
-            if nu.value:
-                mine_u[:nu.value].copy_(torch.as_tensor(_DevArray(up.value, nu.value, kt), device="cuda"))
-                mine_c[:nu.value].copy_(torch.as_tensor(_DevArray(cp.value, nu.value, "<i4"), device="cuda"))
-            parts_u = [torch.empty_like(mine_u) for _ in range(world)]
-            parts_c = [torch.empty_like(mine_c) for _ in range(world)]
-            dist.all_gather(parts_u, mine_u, group=group)
-            dist.all_gather(parts_c, mine_c, group=group)
-            all_u = torch.cat([parts_u[r][:sizes[r]] for r in range(world)]).contiguous()
-            all_c = torch.cat([parts_c[r][:sizes[r]] for r in range(world)]).contiguous()
-            total = int(all_u.numel())
+            sizes = torch.empty(world, dtype=torch.int64, device="cuda")
+            dist.all_gather_into_tensor(sizes, torch.tensor([nu.value], dtype=torch.int64, device="cuda"), group=group)
+            sizes = [int(v) for v in sizes.cpu().numpy()]
+            total = int(sum(sizes))
+            dc._unshard()
+            keep = self.keep_sharded if self.keep_sharded is not None else total > TOPK_DEVICE_MIN
+            if keep:
+                # the table STAYS sharded: find_motif's top-k and Hamming-ball masses are local partials + tiny collectives
+                # (CountShard); only the rank that writes k{k}.pkl -- if any -- receives the other ranks' shards
+                if self.full_table_rank is not None:
+                    full = self._gather_table(dc, k, sizes, nu.value, dst=self.full_table_rank)
+                    if full is not None:
+                        dc._full = full
+                dc._shard = CountShard(dist, group, sizes)
+                dc.k, dc.n_uniq = k, total
+                return total
+            all_u, all_c = self._gather_table_tensors(dc, k, sizes, nu.value, dst=None)
             torch.cuda.current_stream().synchronize()                     # adopt copies on the null stream's side of the library
             check(lib.kmap_counts_adopt_dev(dc._h, all_u.data_ptr() if total else None, all_c.data_ptr() if total else None, total, k))
             dc.k, dc.n_uniq = k, total
             return total
+
+        def _gather_table_tensors(self, dc, k, sizes, n_mine, dst):
+            """this rank's shard [uniq | cnt] and the others' -> (all_u, all_c) device tensors in key order; dst = None: on every
+            rank (all-gather), else only on rank `dst` (the others return (None, None)).  One padded buffer per rank carries
+            keys and counts together."""
+            lib = _ffi.lib()
+            up, cp, n_tab = _ffi.vp(), _ffi.vp(), _ffi.i64(0)
+            check(lib.kmap_counts_table_dev(dc._h, C.byref(up), C.byref(cp), C.byref(n_tab)))
+            kt, kdt, kw = ("<i4", torch.int32, 1) if k < 16 else ("<i8", torch.int64, 2)       # key width in int32 words
+            cap = max(max(sizes), 1)
+            mine = torch.zeros((kw + 1) * cap, dtype=torch.int32, device="cuda")
+            if n_mine:
+                mine[:kw * n_mine].copy_(torch.as_tensor(_DevArray(up.value, kw * n_mine, "<i4"), device="cuda"))
+                mine[kw * cap:kw * cap + n_mine].copy_(torch.as_tensor(_DevArray(cp.value, n_mine, "<i4"), device="cuda"))
+            if dst is None:
+                flat = torch.empty(world * (kw + 1) * cap, dtype=torch.int32, device="cuda")   # flat: gloo takes no 2-D output
+                dist.all_gather_into_tensor(flat, mine, group=group)
+                parts = flat.view(world, (kw + 1) * cap)
+            else:
+                glist = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
+                if on_dev:
+                    dist.gather(mine, glist, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
+                else:                                                    # gloo gathers host tensors
+                    hl = [torch.empty(mine.shape, dtype=torch.int32) for _ in range(world)] if rank == dst else None
+                    dist.gather(mine.cpu(), hl, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
+                    if rank == dst:
+                        glist = [t.cuda() for t in hl]
+                if rank != dst:
+                    return None, None
+                parts = torch.stack(glist)
+            all_u32 = torch.cat([parts[r, :kw * sizes[r]] for r in range(world)]).contiguous()
+            all_c = torch.cat([parts[r, kw * cap:kw * cap + sizes[r]] for r in range(world)]).contiguous()
+            all_u = all_u32.view(kdt) if kw == 2 else all_u32
+            return all_u, all_c
+
+        def _gather_table(self, dc, k, sizes, n_mine, dst):
+            """the whole table as a NEW DeviceCounts on rank dst (None elsewhere)"""
+            from .kmer_count import DeviceCounts
+            all_u, all_c = self._gather_table_tensors(dc, k, sizes, n_mine, dst)
+            if all_u is None:
+                return None
+            full = DeviceCounts()
+            total = int(all_c.numel())
+            torch.cuda.current_stream().synchronize()
+            check(_ffi.lib().kmap_counts_adopt_dev(full._h, all_u.data_ptr() if total else None, all_c.data_ptr() if total else None, total, k))
+            full.k, full.n_uniq = k, total
+            return full
 
         def _scan_gathered(self, k, consensus_kh, radius, revcom):
             """local scan -> device gather of the shards -> GatheredHits (RCCL only)"""

@@ -159,7 +159,12 @@ def remove_duplicate_hash_per_seq(hash_arr: np.ndarray, boarder_mat: np.ndarray,
 
 
 class DeviceCounts:
-    """Owns a kmap_counts handle: unique k-mers + counts resident in HBM."""
+    """Owns a kmap_counts handle: unique k-mers + counts resident in HBM.
+    Multi-GPU, large tables (distributed.make_dist_device_seq, bins owned by key range): the handle may hold only THIS rank's key
+    range of the table (`_shard`, a distributed.CountShard); n_uniq is then the global number of unique k-mers, and total / topk /
+    hamball_mass -- everything find_motif asks of the table (reference motif_discovery.py:648,661-673) -- are local partials
+    combined by one tiny collective each, so no rank ever receives the whole (k-mer, count) list.  `_full` (optional, on the rank
+    that writes k{k}.pkl): a second handle holding the gathered table."""
 
     def __init__(self):
         h = _ffi.vp()
@@ -167,50 +172,75 @@ class DeviceCounts:
         self._h = h.value
         self.k = 0
         self.n_uniq = 0
+        self._shard = None
+        self._full = None
+
+    def _unshard(self):
+        self._shard = None
+        if self._full is not None:
+            self._full.close()
+            self._full = None
 
     def run_hashes(self, hash_dev_ptr, n, k, merge_revcom, stream=None):
+        self._unshard()
         nu = _ffi.i64(0)
         check(_ffi.lib().kmap_counts_run_hashes_dev(self._h, hash_dev_ptr, n, k, int(merge_revcom), C.byref(nu), stream))
         self.k, self.n_uniq = k, nu.value
         return self.n_uniq
 
     def run_seq(self, seq_dev_ptr, n, borders_dev_ptr, n_seq, k, dedupe, merge_revcom, stream=None):
+        self._unshard()
         nu = _ffi.i64(0)
         check(_ffi.lib().kmap_counts_run_seq_dev(self._h, seq_dev_ptr, n, borders_dev_ptr, n_seq, k, int(dedupe),
                                                  int(merge_revcom), C.byref(nu), stream))
         self.k, self.n_uniq = k, nu.value
         return self.n_uniq
 
+    def _fetch_local(self, n, stream=None):
+        u = np.empty(n, get_hash_dtype(self.k))
+        c = np.empty(n, get_cnt_dtype(self.k))
+        if n:
+            if stream is None:
+                check(_ffi.lib().kmap_counts_fetch(self._h, ptr(u), ptr(c)))
+            else:
+                check(_ffi.lib().kmap_counts_fetch_stream(self._h, ptr(u), ptr(c), stream))
+        return u, c
+
     def fetch(self, stream=None):
         """(unique hashes, counts) as the reference's numpy arrays.  stream: a non-default stream handle -> the copy runs there
-        through pinned staging buffers (a background thread can then drain this table while the default stream keeps working)."""
-        u = np.empty(self.n_uniq, get_hash_dtype(self.k))
-        c = np.empty(self.n_uniq, get_cnt_dtype(self.k))
-        if stream is None:
-            check(_ffi.lib().kmap_counts_fetch(self._h, ptr(u), ptr(c)))
-        else:
-            check(_ffi.lib().kmap_counts_fetch_stream(self._h, ptr(u), ptr(c), stream))
-        return u, c
+        through pinned staging buffers (a background thread can then drain this table while the default stream keeps working).
+        Sharded table: every rank must call it (the shards are all-gathered on the host)."""
+        if self._shard is not None:
+            if self._full is not None:
+                return self._full.fetch(stream)
+            return self._shard.gather_host(*self._fetch_local(self._shard.n_local))
+        return self._fetch_local(self.n_uniq, stream)
 
     def total(self):
         t = _ffi.i64(0)
         check(_ffi.lib().kmap_counts_total(self._h, C.byref(t)))
-        return t.value
+        return t.value if self._shard is None else self._shard.sum_int(t.value)
 
     def topk(self, top_k):
         """device top-k by count (largest first, ties by lowest index): (indices, hashes, counts)"""
         idx, kh, cnt = np.empty(top_k, np.int64), np.empty(top_k, np.uint64), np.empty(top_k, np.int64)
         m = _ffi.i32(0)
         check(_ffi.lib().kmap_counts_topk(self._h, top_k, ptr(idx), ptr(kh), ptr(cnt), C.byref(m)))
+        if self._shard is not None:    # the ranks' candidates (<= world x top_k) merged by the same rule: count descending, index ascending
+            idx, kh, cnt = self._shard.merge_topk(top_k, idx[:m.value], kh[:m.value], cnt[:m.value])
+            return idx, kh.astype(get_hash_dtype(self.k)), cnt
         return idx[:m.value], kh[:m.value].astype(get_hash_dtype(self.k)), cnt[:m.value]
 
     def hamball_mass(self, cands, radius, revcom=True):
         cands = np.ascontiguousarray(cands, dtype=np.uint64)
         out = np.zeros(len(cands), np.float64)
         check(_ffi.lib().kmap_counts_hamball_mass(self._h, ptr(cands), len(cands), int(radius), int(revcom), ptr(out)))
-        return out
+        return out if self._shard is None else self._shard.sum_f64(out)   # integer-valued float64 partials: exact in any order
 
     def close(self):
+        if self._full is not None:
+            self._full.close()
+            self._full = None
         if self._h:
             _ffi.lib().kmap_counts_destroy(self._h)
             self._h = None

@@ -112,6 +112,7 @@ class DeviceSeq:
     def count(self, dc: DeviceCounts, k, dedupe, merge_revcom, use_work=True):
         inval = self.inval_work if use_work else self.inval_orig
         nu = _ffi.i64(0)
+        dc._unshard()
         check(_ffi.lib().kmap_counts_run_packed_dev(dc._h, self.codes.ptr, inval.ptr, self.n, self.borders.ptr, self.n_seq, k,
                                                     int(dedupe), int(merge_revcom), C.byref(nu), None))
         dc.k, dc.n_uniq = k, nu.value
@@ -426,6 +427,7 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
         dev_seq = DeviceSeq(seq_np_arr, boarder_mat)
     dc = take()
     saver = None
+    detached = False                    # the saver owns a gathered copy, not `first`
     try:
         cached = save_kmer_cnt_flag and kmer_cnt_pkl_file and Path(kmer_cnt_pkl_file).exists()
         if cached:
@@ -434,6 +436,7 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
             assert kmer_len == k_pkl
             u = np.ascontiguousarray(uniq_kh_arr, get_hash_dtype(kmer_len))
             c = np.ascontiguousarray(uniq_kh_cnt_arr, get_cnt_dtype(kmer_len))
+            dc._unshard()
             check(_ffi.lib().kmap_counts_load(dc._h, ptr(u), ptr(c), len(u), kmer_len))
             dc.k, dc.n_uniq = kmer_len, len(u)
         else:
@@ -448,7 +451,12 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
                 dev = _ffi.i32(0)
                 check(_ffi.lib().kmap_get_device(C.byref(dev)))
                 _ffi.sync()
-                saver = TableSaver(first, kmer_len, kmer_cnt_pkl_file, device=dev.value)
+                table = first
+                if first._shard is not None:      # sharded table: the saver takes the copy that was gathered on this rank
+                    assert first._full is not None, "sharded counts: the rank that saves k{k}.pkl must be the gather target"
+                    table, first._full = first._full, None
+                    detached = True
+                saver = TableSaver(table, kmer_len, kmer_cnt_pkl_file, device=dev.value)
                 dc = take()
             else:
                 uniq_kh_arr, uniq_kh_cnt_arr = dc.fetch()
@@ -509,6 +517,8 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
         else:
             if dc is not first:
                 give(dc)
+            if detached:
+                give(first)
             if table_savers is not None:
                 table_savers[kmer_len] = saver               # the caller joins (errors surface there) and closes; table stays resident
             else:
@@ -965,6 +975,8 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
         found, hit_lists, occ_written = {}, {}, set()
         occ_writers = savers.setdefault("occurrence", [])
         n_out, out_read_len = scan_seq.out_n_seq, scan_seq.out_read_len
+        if dist is not None:      # tables that stay sharded (distributed.CountShard): only the writer of k{k}.pkl receives all shards
+            count_seq.full_table_rank = 0 if save_kmer_cnt_flag else None
         for kmer_len in sorted(range(min_k, max_k + 1), key=lambda k: (k != max_k, k)):
             count_seq.reset()
             d = motif_def_dict[kmer_len]

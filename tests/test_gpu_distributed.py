@@ -96,12 +96,15 @@ def _count_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def _range_inputs():
+def _range_inputs(poly=True):
     from kmap_amd import synth
     seq, borders = synth.synth_reads(20011, 75, 9)
     for r in range(0, len(borders), 41):                     # palindromic repeats (rc(ACGTACGTACGT) = itself), poly-A / poly-T pairs
         st, en = borders[r]
-        seq[st:en] = np.resize(np.array([0, 1, 2, 3], np.uint8), en - st) if r % 3 == 0 else (0 if r % 3 == 1 else 3)
+        if r % 3 == 0 or not poly:
+            seq[st:en] = np.resize(np.array([0, 1, 2, 3], np.uint8), en - st)
+        else:
+            seq[st:en] = 0 if r % 3 == 1 else 3
     return seq, borders
 
 
@@ -153,6 +156,90 @@ def test_key_range_sharded_counting_three_ranks(tmp_path):
                     np.testing.assert_array_equal(c, oc)
                     assert u.dtype == ou.dtype and c.dtype == oc.dtype
     assert res[0]["top"][0].tolist() == res[1]["top"][0].tolist() == res[2]["top"][0].tolist()
+
+
+def _kept_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import pickle
+    import torch
+    import torch.distributed as dist
+    import kmap_amd.motif_discovery as md
+    from kmap_amd.distributed import make_dist_device_seq
+    from kmap_amd.kmer_count import DeviceCounts
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        md.TOPK_DEVICE_MIN = 1000                            # find_motif takes its candidates from the device top-k above this size
+        seq, borders = _range_inputs()
+        ds = make_dist_device_seq(seq, borders, dist, shard_counts=True)
+        ds.keep_sharded, ds.full_table_rank = True, 0
+        dc = DeviceCounts()
+        out = {}
+        cands = {13: [0, 5, 0x1B1B1B1, 4 ** 13 - 1], 16: [0, 0x1B1B1B1B, 4 ** 16 - 1]}
+        for k in (13, 16):                                   # 16: int64 keys, 16-GiB tables
+            ds.count(dc, k, dedupe=True, merge_revcom=True)
+            assert dc._shard is not None and (dc._full is not None) == (rank == 0)
+            out[k] = {"n_uniq": dc.n_uniq, "n_local": dc._shard.n_local, "total": dc.total(), "top": dc.topk(7),
+                      "mass": dc.hamball_mass(np.array(cands[k], np.uint64), 3, True)}
+            if rank == 0:
+                out[k]["full"] = dc.fetch()
+        ds.reset()
+        # the reads hold poly-A / poly-T stretches: a consensus within the radius of the all-T k-mer also matches the windows that touch a
+        # separator (the reference's all-ones invalid hash, kmer_count.py:580-610) and masks k - 1 positions into the NEXT read --
+        # across a shard boundary too (DistDeviceSeq.mask)
+        r = md.find_motif(None, 13, 3, 3.0e-6, 1.0, 0.05, 1.3, top_k=5, n_trial=3, save_kmer_cnt_flag=False, dev_seq=ds)
+        out["motifs"] = {int(h): v for h, v in r.items()}
+        with open(Path(out_dir) / f"kept_rank{rank}.pkl", "wb") as fh:
+            pickle.dump(out, fh)
+        dc.close()
+        ds.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_find_motif_on_counts_that_stay_sharded(tmp_path):
+    """Key-range counting with the table LEFT sharded (three ranks; distributed.CountShard): no rank but the k{k}.pkl writer receives
+    the (k-mer, count) list; n_uniq / total / top-k (count descending, index in the whole table ascending) / Hamming-ball masses are
+    local partials + one tiny collective each and equal the oracle's on the whole table; find_motif on such a table == find_motif of
+    one GPU on all reads (same device top-k rule) on every rank.  k = 13 and k = 16 (int64 keys; reference motif_discovery.py:655-701)."""
+    import pickle
+    import torch.multiprocessing as mp
+    import kmap_amd.motif_discovery as md
+    from kmap_amd.motif_discovery import DeviceSeq
+    from oracle import oracle as O
+    mp.spawn(_kept_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    res = [pickle.load(open(tmp_path / f"kept_rank{r}.pkl", "rb")) for r in range(3)]
+    seq, borders = _range_inputs()
+    cands = {13: [0, 5, 0x1B1B1B1, 4 ** 13 - 1], 16: [0, 0x1B1B1B1B, 4 ** 16 - 1]}
+    for k in (13, 16):
+        ou, oc = O.count_kmers(seq, borders, k, rep_mode=False, revcom_mode=True)
+        order = np.lexsort((np.arange(len(oc)), -oc.astype(np.int64)))[:7]
+        mass = O.hamball_mass(ou, oc, k, np.array(cands[k], np.uint64), 3, True)
+        assert sum(r[k]["n_local"] for r in res) == len(ou) and min(r[k]["n_local"] for r in res) > 0
+        for r in res:
+            assert r[k]["n_uniq"] == len(ou) and r[k]["total"] == int(oc.sum())
+            idx, kh, cnt = r[k]["top"]
+            assert idx.tolist() == order.tolist() and kh.tolist() == ou[order].tolist() and cnt.tolist() == oc[order].tolist()
+            assert kh.dtype == ou.dtype
+            np.testing.assert_array_equal(r[k]["mass"], mass)
+        fu, fc = res[0][k]["full"]                           # the writer rank holds the gathered table as well
+        np.testing.assert_array_equal(fu, ou)
+        np.testing.assert_array_equal(fc, oc)
+        assert fu.dtype == ou.dtype and fc.dtype == oc.dtype
+    old = md.TOPK_DEVICE_MIN
+    md.TOPK_DEVICE_MIN = 1000
+    try:
+        ds = DeviceSeq(seq, borders)
+        single = md.find_motif(None, 13, 3, 3.0e-6, 1.0, 0.05, 1.3, top_k=5, n_trial=3, save_kmer_cnt_flag=False, dev_seq=ds)
+        ds.close()
+    finally:
+        md.TOPK_DEVICE_MIN = old
+    single = {int(h): v for h, v in single.items()}
+    assert len(single) >= 1
+    for r in res:
+        assert list(r["motifs"]) == list(single)
+        for h in single:
+            assert r["motifs"][h] == single[h]
 
 
 def test_read_sharded_counting_scan_and_find_motif(tmp_path):
