@@ -403,6 +403,13 @@ def _gathered_hits_cls():
                 assert self._host is None and self._ph is not None and self.max_hits <= 255
                 return self._cat(True)
 
+        def release(self):
+            """a rank that will never write this list (everyone but the owner of the occurrence files) drops the gathered device
+            tensors at once -- world x (reads + positions) int32 per consensus otherwise stay in HBM until the list object dies;
+            the summary numbers (total, n_reads_hit, max_hits) stay"""
+            with self._lock:
+                self._ph = self._pp = None
+
         def __del__(self):
             pass
 

@@ -996,6 +996,9 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
                 tmp_list = [hash2kmer(kh, kmer_len) for kh in found[kmer_len]]
                 with _stage("occurrence_per_k"):
                     hit_lists[kmer_len] = scan_hit_lists(scan_seq, tmp_list, motif_def_dict, revcom_mode)
+                    if not lead:                              # only the owner of the files ever fetches a gathered list
+                        for r in hit_lists[kmer_len]:
+                            getattr(r, "release", lambda: None)()
                     if lead and not needs_draws(hit_lists[kmer_len]):
                         write_occurence_file(hit_lists[kmer_len], tmp_list, res / FileNameDict["kmer_count_dir"] /
                                              f"k{kmer_len}.motif_occurence.csv", n_out, out_read_len, occ_writers)
@@ -1077,6 +1080,9 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
     want_occ = md["motif_pos_density_flag"] or md["motif_co_occurence_flag"]
     with _stage("occurrence_final"):
         per_final = scan_motif_occurence(scan_seq, final_conseq_list, motif_def_dict, revcom_mode, subsample=lead)
+        if not lead:
+            for r in per_final:
+                getattr(r, "release", lambda: None)()
         if lead:
             if want_occ:
                 per_final = [list(r) for r in per_final]       # the report stages below read the lists on this thread
