@@ -371,6 +371,23 @@ int kmap_embed_apply(kmap_embed *e, const float *grad_dev_2xn, const double *los
  * row-sharded sessions, zeroes every entry it has read, so the next message again starts from x + 0 + ... + 0.  The buffer must
  * be zero before the first call. */
 int64_t kmap_embed_msg_floats(int64_t n);
+/* Peer-direct exchange of the iteration message ("one-hop direct all-gather over the xGMI links" instead of a
+ * collective-library call per iteration).  Every rank owns a fine-grained receive area of 2 (iteration parity) x world slots
+ * of kmap_embed_msg_floats(n) floats + one flag word per slot, exported through an IPC handle; after kmap_peer_connect it holds
+ * device pointers to all peers' areas.  kmap_embed_step_peer runs n_iter iterations without any host involvement between them:
+ * forces_msg into a local buffer -> push kernel (the message is copied into slot [parity][rank] of EVERY rank's area, then a
+ * system-scope release store of the iteration number into the slot's flag) -> apply kernel (waits -- bounded -- for the world
+ * flags of the iteration, adds the world slots in rank order, decodes the loss limbs, applies).  Sums in rank order are the
+ * same on every rank, so all ranks take identical decisions.  A wait that exceeds its bound sets a sticky flag
+ * (kmap_peer_status) and the iteration proceeds with whatever it has: the host raises, no kernel spins for ever. */
+typedef struct kmap_peer kmap_peer;
+#define KMAP_PEER_HANDLE_BYTES 64
+int kmap_peer_create(kmap_peer **p, int world, int rank, int64_t msg_floats);
+int kmap_peer_handle(kmap_peer *p, void *handle_out /* KMAP_PEER_HANDLE_BYTES */);
+int kmap_peer_connect(kmap_peer *p, const void *handles /* world x KMAP_PEER_HANDLE_BYTES, rank order */);
+int kmap_peer_status(kmap_peer *p, int *timed_out, int64_t *iterations);
+int kmap_peer_destroy(kmap_peer *p);
+int kmap_embed_step_peer(kmap_embed *e, kmap_peer *p, int n_iter, void *stream);
 int kmap_embed_forces_msg(kmap_embed *e, float *msg_dev, void *stream);
 int kmap_embed_apply_msg(kmap_embed *e, float *msg_dev, void *stream);
 /* single-GPU convenience: n_iter iterations of forces+apply on `stream` */

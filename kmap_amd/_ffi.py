@@ -131,6 +131,12 @@ _SIGS = {
     "kmap_embed_msg_floats": (i64, [i64]),
     "kmap_embed_forces_msg": (i32, [vp, vp, vp]),
     "kmap_embed_apply_msg": (i32, [vp, vp, vp]),
+    "kmap_peer_create": (i32, [C.POINTER(vp), i32, i32, i64]),
+    "kmap_peer_handle": (i32, [vp, vp]),
+    "kmap_peer_connect": (i32, [vp, vp]),
+    "kmap_peer_status": (i32, [vp, C.POINTER(i32), C.POINTER(i64)]),
+    "kmap_peer_destroy": (i32, [vp]),
+    "kmap_embed_step_peer": (i32, [vp, vp, i32, vp]),
     "kmap_embed_step": (i32, [vp, i32, vp]),
     "kmap_embed_state": (i32, [vp, P(i64), P(i32), P(f32), P(f32), P(i32), vp]),
     "kmap_embed_get_coords": (i32, [vp, vp, vp]),

@@ -264,6 +264,76 @@ __global__ __launch_bounds__(BLK) void apply_msg_kernel(LoopState *__restrict__ 
     }
 }
 
+// ---- peer-direct exchange (kmap_hip.h: kmap_embed_step_peer) -------------------------------------------------------------------
+// push: this rank's message -> slot [parity][rank] of EVERY rank's receive area (own included), 16 bytes per thread and peer;
+// every block fences its stores system-wide and counts itself done; the block that finds itself last publishes the iteration
+// number in the slot's flag on every rank (release, system scope).
+__global__ __launch_bounds__(BLK) void peer_push_kernel(PeerTab tab, const float *__restrict__ msg, int64_t msg_floats, int world, int rank,
+                                                        int parity, unsigned long long iter_tag, unsigned long long *__restrict__ done) {
+    const int64_t i4 = ((int64_t)blockIdx.x * BLK + threadIdx.x) * 4;
+    const size_t slot = ((size_t)parity * world + rank) * (size_t)msg_floats;
+    if (i4 < msg_floats) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(msg + i4);
+        for (int q = 0; q < world; ++q) *reinterpret_cast<f32x4 *>(tab.slots[q] + slot + i4) = v;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long before = atomicAdd(done, 1ull);
+        if (before == (unsigned long long)gridDim.x - 1) {                 // every block's stores are fenced: publish
+            *done = 0;
+            __threadfence_system();
+            for (int q = 0; q < world; ++q)
+                __hip_atomic_store(tab.flags[q] + (size_t)parity * world + rank, iter_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+// apply for the peer protocol: wait for the iteration's world flags in the own area (bounded: ~2 s of the 100 MHz wall clock,
+// then the sticky time-out word is set and the iteration goes on with what is there), add the world slots in rank order,
+// decode the loss limbs of the sum, apply.
+__global__ __launch_bounds__(BLK) void apply_peer_kernel(LoopState *__restrict__ states, int cur, float *__restrict__ Y,
+                                                         const float *__restrict__ slots, const unsigned long long *__restrict__ flags,
+                                                         int world, int parity, unsigned long long iter_tag, int64_t msg_floats,
+                                                         unsigned long long *__restrict__ timed_out, float *__restrict__ snaps, int64_t n,
+                                                         float lr, const double *__restrict__ normals, const int *__restrict__ n_normals_dev,
+                                                         float *__restrict__ loss_log, int64_t loss_log_cap) {
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = wall_clock64();
+        for (int q = 0; q < world; ++q) {
+            const unsigned long long *f = flags + (size_t)parity * world + q;
+            while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != iter_tag) {
+                if (wall_clock64() - t0 > 200000000ull) {                   // 2 s at 100 MHz: a peer is gone
+                    atomicMax(timed_out, 1ull);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        __threadfence_system();
+    }
+    __syncthreads();
+    const float *base = slots + (size_t)parity * world * (size_t)msg_floats;
+    auto summed = [&](int64_t i) {
+        float s = base[i];
+        for (int q = 1; q < world; ++q) s += base[(size_t)q * msg_floats + i];   // rank order: the same float sum on every rank
+        return s;
+    };
+    float tail[MSG_EXTRA];
+#pragma unroll
+    for (int t = 0; t < MSG_EXTRA; ++t) tail[t] = summed(2 * n + t);
+    const double total = loss_from_limbs(tail);
+    const StepDecision d = step_decide(&states[cur], total);
+    const int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    const bool special = (idx == 0 || idx == 1 || idx == n || idx == n + 1);   // owned by the leader (jitter)
+    if (idx < 2 * n && !special && !d.halted) step_element(d, idx, summed(idx), Y, snaps, n, lr);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float gsp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int c = 0; c < 2; ++c)
+            for (int p = 0; p < 2 && p < n; ++p) gsp[2 * c + p] = summed((int64_t)c * n + p);
+        step_leader(states, cur, d, Y, gsp, snaps, n, lr, normals, n_normals_dev, loss_log, loss_log_cap);
+    }
+}
+
 // symmetric FAST kernel, single GPU: the sum of the row / column partials (sym_reduce_kernel's order: 8 lanes per element, lane l
 // adds partials l, l + 8, ..., fixed butterfly) fused with apply -- the gradient never goes to memory.  The first four 8-lane
 // groups of block 0 take x0, x1, y0, y1 and hand them to the leader through LDS; the other groups take the remaining 2N - 4
@@ -591,6 +661,35 @@ int kmap_embed_apply_msg(kmap_embed *e, float *msg_dev, void *stream) {
                                                       e->loss_log, e->loss_log_cap);
     KMAP_CHECK_HIP(hipGetLastError());
     e->cur ^= 1;
+    return KMAP_OK;
+}
+
+int kmap_embed_step_peer(kmap_embed *e, kmap_peer *p, int n_iter, void *stream) {
+    KMAP_REQUIRE(e && p && e->have_prob && e->have_coords, "embed_step_peer: session / exchange not ready");
+    KMAP_REQUIRE(p->msg_floats == kmap_embed_msg_floats(e->n), "embed_step_peer: the exchange was created for another message length");
+    for (int q = 0; q < p->world; ++q) KMAP_REQUIRE(p->peer_area[q], "embed_step_peer: rank %d's receive area is not connected", q);
+    hipStream_t st = as_stream(stream);
+    PeerTab tab;
+    memset(&tab, 0, sizeof tab);
+    for (int q = 0; q < p->world; ++q) {
+        tab.slots[q] = (float *)p->peer_area[q];
+        tab.flags[q] = (unsigned long long *)((char *)p->peer_area[q] + kmap_peer_slots_bytes(p));
+    }
+    const unsigned pgrid = (unsigned)((p->slot_floats / 4 + BLK - 1) / BLK);
+    const unsigned agrid = (unsigned)((2 * e->n + BLK - 1) / BLK);
+    for (int it = 0; it < n_iter; ++it) {
+        const int parity = (int)(p->iter & 1);
+        const unsigned long long tag = p->iter + 1;
+        KMAP_TRY(kmap_embed_forces_msg(e, p->msg_local, stream));
+        peer_push_kernel<<<pgrid, BLK, 0, st>>>(tab, p->msg_local, p->slot_floats, p->world, p->rank, parity, tag, p->done);
+        apply_peer_kernel<<<agrid, BLK, 0, st>>>(e->states, e->cur, e->Y, (const float *)p->area,
+                                                 (const unsigned long long *)((char *)p->area + kmap_peer_slots_bytes(p)), p->world, parity, tag,
+                                                 p->slot_floats, p->done + 1, e->snaps, e->n, e->lr, e->normals, e->n_normals_dev, e->loss_log,
+                                                 e->loss_log_cap);
+        KMAP_CHECK_HIP(hipGetLastError());
+        e->cur ^= 1;
+        p->iter += 1;
+    }
     return KMAP_OK;
 }
 

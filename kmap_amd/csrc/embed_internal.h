@@ -106,3 +106,23 @@ inline int kmap_embed_force_blocks(const kmap_embed *e) {
     if (e->mode == KMAP_EMBED_SEQ) return kmap_embed_seq_blocks(e);
     return (int)((e->nrows + F_RPW * F_WAVES - 1) / (F_RPW * F_WAVES));
 }
+
+// ---- peer-direct exchange (peer_exchange.hip owns the object; embed.hip's kmap_embed_step_peer drives it) ------------------------
+constexpr int KMAP_PEER_MAX = 16;
+struct kmap_peer {
+    int world = 0, rank = 0;
+    int64_t msg_floats = 0;                    // floats of a message (2 N + MSG_EXTRA)
+    int64_t slot_floats = 0;                   // ... rounded up to a multiple of 4: slot stride (16-byte copies)
+    size_t area_bytes = 0;
+    void *area = nullptr;                      // this rank's receive area: slots float[2][world][slot_floats] | flags u64[2][world]
+    void *peer_area[KMAP_PEER_MAX] = {};       // every rank's area as mapped here (own entry = area)
+    bool opened[KMAP_PEER_MAX] = {};
+    float *msg_local = nullptr;                // the message forces_msg writes (entries of other ranks' rows stay zero)
+    unsigned long long *done = nullptr;        // push kernel's finished-blocks counter | sticky time-out flag
+    uint64_t iter = 0;                         // iterations issued so far
+};
+struct PeerTab {                               // kernel argument
+    float *slots[KMAP_PEER_MAX];               // base of rank q's slots
+    unsigned long long *flags[KMAP_PEER_MAX];  // base of rank q's flags
+};
+inline size_t kmap_peer_slots_bytes(const kmap_peer *p) { return (size_t)2 * p->world * p->slot_floats * 4; }

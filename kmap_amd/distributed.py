@@ -198,6 +198,56 @@ def assert_default_stream():
                            "stream; collectives on another stream would not be ordered after its kernels)")
 
 
+PEER_HANDLE_BYTES = 64
+
+
+class PeerExchange:
+    """The peer-direct transport of the iteration message (kmap_hip.h kmap_peer_*): every rank exports a fine-grained receive area
+    through a HIP IPC handle, the handles are all-gathered once, and from then on an iteration is three kernels and no library
+    call: forces into a local message -> push (the message into slot [rank] of every rank's area over the xGMI links + a release
+    store of the iteration number) -> apply (waits for the world flags, adds the slots in rank order).  Works between the GPUs of
+    a node and between processes that share one GPU (the rehearsal on a one-GPU box)."""
+
+    def __init__(self, session, n, dist, group=None):
+        import ctypes as C
+        import torch
+        from . import _ffi
+        self.s, self.dist, self.group = session, dist, group
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        lib = _ffi.lib()
+        h = _ffi.vp()
+        _ffi.check(lib.kmap_peer_create(C.byref(h), world, rank, int(lib.kmap_embed_msg_floats(n))))
+        self._p = h.value
+        mine = np.zeros(PEER_HANDLE_BYTES, np.uint8)
+        _ffi.check(lib.kmap_peer_handle(self._p, _ffi.ptr(mine)))
+        dev = _coll_device(dist, group)
+        allh = torch.empty(world * PEER_HANDLE_BYTES, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(allh, torch.from_numpy(mine).to(dev), group=group)
+        self._handles = np.ascontiguousarray(allh.cpu().numpy())
+        _ffi.check(lib.kmap_peer_connect(self._p, _ffi.ptr(self._handles)))
+        dist.barrier(group=group)                 # nobody pushes before everybody's area is mapped everywhere
+
+    def step(self, n_iter):
+        from . import _ffi
+        _ffi.check(_ffi.lib().kmap_embed_step_peer(self.s._h, self._p, int(n_iter), None))
+
+    def check(self):
+        """after a segment: did a wait run into its bound (a peer that never pushed)?  Blocks until the issued iterations ran."""
+        import ctypes as C
+        from . import _ffi
+        t, it = _ffi.i32(0), _ffi.i64(0)
+        _ffi.check(_ffi.lib().kmap_peer_status(self._p, C.byref(t), C.byref(it)))
+        if t.value:
+            raise RuntimeError(f"peer exchange: a rank's message did not arrive within the wait bound (after {it.value} iterations issued)")
+
+    def close(self):
+        from . import _ffi
+        if self._p:
+            self.dist.barrier(group=self.group)   # no rank unmaps an area a peer may still push into
+            _ffi.lib().kmap_peer_destroy(self._p)
+            self._p = None
+
+
 class DistEmbedLoop:
     """Drives a (row-sharded) embedding session with ONE collective per iteration:
         forces_msg -> all_reduce(SUM, float32 message) -> apply_msg.
@@ -208,16 +258,21 @@ class DistEmbedLoop:
     zero-initialised float32 torch tensor of 2 N + MSG_EXTRA elements on the session's device.
     always_collective: issue the all-reduce even on a one-rank group (bench.py measures the loop's overhead that way)."""
 
-    def __init__(self, session, msg_t, dist=None, group=None, always_collective=False):
+    def __init__(self, session, msg_t, dist=None, group=None, always_collective=False, peer: "PeerExchange" = None):
         self.s, self.m, self.dist, self.group = session, msg_t, dist, group
         self.mp = msg_t.data_ptr()
         self.n_collectives = 0
         self.coll = dist is not None and (always_collective or dist.get_world_size(group) > 1)
+        self.peer = peer                          # peer-direct transport instead of the all-reduce (KMAP_DIST_EXCHANGE=direct)
         if self.coll and msg_t.is_cuda:
             assert_default_stream()
 
     def step(self, n_iter):
         d, s, m, mp, g = self.dist, self.s, self.m, self.mp, self.group
+        if self.peer is not None:
+            self.peer.step(n_iter)                # the whole segment is issued by ONE native call
+            self.peer.check()
+            return
         if not self.coll:
             for _ in range(n_iter):
                 s.forces_msg(mp)
@@ -233,6 +288,14 @@ class DistEmbedLoop:
         """n_iter iterations with device events around the three phases -> mean ms per iteration of each (events on torch's
         current stream = the library's stream).  The event records perturb the loop a little: use step() for the headline time."""
         import torch
+        if self.peer is not None:                 # three kernels issued by one native call: only the whole iteration can be timed
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.peer.step(n_iter)
+            e1.record()
+            self.peer.check()
+            torch.cuda.synchronize()
+            return {"iteration_ms": e0.elapsed_time(e1) / n_iter}
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_iter)]
         d = self.dist
         for e in ev:
@@ -254,12 +317,14 @@ class DistEmbedLoop:
 
 def kmap_from_kmers_distributed(samp_kh, samp_cnts, samp_label, conseq_list, kmer_len, n_neighbour=20, n_max_iter=2500,
                                 learning_rate=0.01, n_best_result=10, random_seed=None, mode=None, trace=None,
-                                neighbor_inds_mat=None, always_collective=False, profile_iters=0):
+                                neighbor_inds_mat=None, always_collective=False, profile_iters=0, exchange=None):
     """Multi-GPU version of visualization.kmap_from_kmers.  Call from every rank after
     torch.distributed.init_process_group("nccl") and torch.cuda.set_device(local_rank).
     neighbor_inds_mat: optional full (N, n_neighbour) table to use instead of the selection (tests inject it).
     always_collective / profile_iters: bench.py's instruments (all-reduce even on a one-rank group; that many leading
-    iterations with events around forces / collective / apply, reported in trace["phases"])."""
+    iterations with events around forces / collective / apply, reported in trace["phases"]).
+    exchange: "rccl" (one all-reduce per iteration, the default) or "direct" (PeerExchange: peer-to-peer stores + flags, no
+    library call between iterations); None = the KMAP_DIST_EXCHANGE environment variable."""
     import torch
     import torch.distributed as dist
     from . import _ffi
@@ -330,7 +395,9 @@ def kmap_from_kmers_distributed(samp_kh, samp_cnts, samp_label, conseq_list, kme
         sess.set_prob_lut(sums_d, lds, lut)
         sess.set_coords(ld_data, placeholders)
         msg_t = torch.zeros(2 * n + MSG_EXTRA, dtype=torch.float32, device="cuda")
-        loop = DistEmbedLoop(sess, msg_t, dist, always_collective=always_collective)
+        exchange = os.environ.get("KMAP_DIST_EXCHANGE", "rccl").lower() if exchange is None else exchange
+        peer = PeerExchange(sess, n, dist) if exchange == "direct" else None
+        loop = DistEmbedLoop(sess, msg_t, dist, always_collective=always_collective, peer=peer)
         prof = {}
 
         def step_fn(seg):              # the first profile_iters iterations run with events around their three phases
@@ -343,10 +410,13 @@ def kmap_from_kmers_distributed(samp_kh, samp_cnts, samp_label, conseq_list, kme
             trace["hbm"] = hbm
             trace["seed"] = random_seed
             trace["collectives"] = loop.n_collectives
+            trace["exchange"] = "direct" if peer is not None else "all_reduce"
             if profile_iters:
                 trace["phases"] = prof
         return sess.best(), lab
     finally:
+        if peer is not None:
+            peer.close()
         sess.close()
 
 

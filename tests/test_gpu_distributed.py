@@ -21,8 +21,8 @@ def _inputs():
     return kh, np.ones(N, np.int64), lab, ["ACGTACGT", "ACGTAC"]
 
 
-def _worker(rank, world, port, mode, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _worker(rank, world, port, mode, out_dir, exchange="rccl"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KMAP_DIST_EXCHANGE=exchange)
     import torch
     import torch.distributed as dist
     from kmap_amd.distributed import kmap_from_kmers_distributed
@@ -32,6 +32,7 @@ def _worker(rank, world, port, mode, out_dir):
         kh, cnts, lab, conseqs = _inputs()
         tr = {}
         best, _ = kmap_from_kmers_distributed(kh, cnts, lab, conseqs, K, n_max_iter=ITERS, random_seed=SEED, mode=mode, trace=tr)
+        assert tr["exchange"] == ("direct" if exchange == "direct" else "all_reduce")
         np.savez(Path(out_dir) / f"m{mode}_rank{rank}.npz", best=best, last=tr["last_coords"], losses=tr["losses"],
                  d_rows=tr["hbm"]["d_rows"])
     finally:
@@ -44,11 +45,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
+@pytest.mark.parametrize("exchange", ["rccl", "direct"])
 @pytest.mark.parametrize("mode", [1, 0])   # SEQ, FAST
-def test_two_ranks_one_gpu_equals_single(tmp_path, mode):
+def test_two_ranks_one_gpu_equals_single(tmp_path, mode, exchange):
+    """exchange = direct (KMAP_DIST_EXCHANGE): the iteration message travels by peer-to-peer stores into IPC-mapped receive areas +
+    flags instead of an all-reduce (PeerExchange; two processes on one GPU open each other's handles) -- the same bits."""
     import torch.multiprocessing as mp
     import kmap_amd.visualization as V
-    mp.spawn(_worker, args=(2, _free_port(), mode, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), mode, str(tmp_path), exchange), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / f"m{mode}_rank0.npz"), np.load(tmp_path / f"m{mode}_rank1.npz")
     np.testing.assert_array_equal(r0["last"], r1["last"])
     np.testing.assert_array_equal(r0["losses"], r1["losses"])
@@ -312,8 +316,8 @@ def test_visualize_kmers_cli_under_torchrun(tmp_path):
     assert outs[0] == outs[1] and outs[0].count("\n") == int(cnts.sum()) + 1
 
 
-def _cyclic_worker(rank, world, port, out_dir, n, iters):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _cyclic_worker(rank, world, port, out_dir, n, iters, exchange="rccl"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KMAP_DIST_EXCHANGE=exchange)
     import torch
     import torch.distributed as dist
     import kmap_amd.visualization as V
@@ -332,8 +336,8 @@ def _cyclic_worker(rank, world, port, out_dir, n, iters):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cyclic", ["1", "0"])
-def test_cyclic_symmetric_shards_match_single_gpu(tmp_path, monkeypatch, cyclic):
+@pytest.mark.parametrize("cyclic,exchange", [("1", "rccl"), ("0", "rccl"), ("1", "direct")])
+def test_cyclic_symmetric_shards_match_single_gpu(tmp_path, monkeypatch, cyclic, exchange):
     """FAST at N >= 16384 under torch.distributed: the ranks own cyclic 256-row blocks and evaluate each unordered pair once;
     the all-reduced gradient equals the single-GPU symmetric kernel's up to the order of the partial sums.  KMAP_DIST_CYCLIC=0:
     the same run on contiguous row blocks (the row-wise FAST kernel, every ordered pair) -- the layout below N = 16 384."""
@@ -341,7 +345,7 @@ def test_cyclic_symmetric_shards_match_single_gpu(tmp_path, monkeypatch, cyclic)
     import kmap_amd.visualization as V
     monkeypatch.setenv("KMAP_DIST_CYCLIC", cyclic)  # inherited by the spawned ranks
     n, iters = 16384 + 3 * 256 + 77, 6            # 68 row blocks, the last one ragged; odd split over 3 ranks
-    mp.spawn(_cyclic_worker, args=(3, _free_port(), str(tmp_path), n, iters), nprocs=3, join=True)
+    mp.spawn(_cyclic_worker, args=(3, _free_port(), str(tmp_path), n, iters, exchange), nprocs=3, join=True)
     r = [np.load(tmp_path / f"cyc_rank{i}.npz") for i in range(3)]
     for i in (1, 2):                              # identical state machines on every rank
         np.testing.assert_array_equal(r[0]["last"], r[i]["last"])
