@@ -123,6 +123,51 @@ def roof(bytes_per_launch, ms_list, what, note=None):
     return d
 
 
+# stage -> (workload of profiles/r*_pmc.json, [(kernel-name prefix, launches per stage pass)]): the kernels whose HBM bytes (rocprofv3
+# FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes) make up `moved_bytes` of a stage
+STAGE_KERNELS = {
+    "count_pass_k8": ("e2e", [("hist_packed_kernel<false, true>", 2), ("compact_count_kernel", 1), ("compact_write_kernel<unsigned int>", 1)]),
+    "count_pass_k8_dedupe": ("e2e", [("dedupe_bitmap_packed_kernel<true>", 1), ("max_read_len_kernel", 1), ("hist_packed_kernel<false, true>", 2),
+                                     ("compact_count_kernel", 1), ("compact_write_kernel<unsigned int>", 1)]),
+    "count_pass_k14": ("count14", [("fine_count_kernel", 1), ("fine_offsets_kernel", 1), ("fine_scatter_kernel", 1), ("fine_zero_heavy_kernel", 1),
+                                   ("fine_hist_kernel", 1), ("fine_spill_kernel", 1), ("rc_merge_tiles_kernel", 1), ("compact_write_kernel<unsigned int>", 1)]),
+    "mask_k8": ("e2e", [("hits_planes_kernel<8, false>", 1), ("mask_cover_packed_kernel", 1)]),
+    "scan_k8_r2": ("e2e", [("hits_planes_kernel<8, true>", 1), ("scan_hits_reads_fused_kernel", 1), ("scan_reorder_kernel", 1)]),
+    "knn_select": ("e2e", [("knn_select_kernel", 1)]),
+    "knn_sums": ("e2e", [("knn_profile_kernel", 1), ("knn_sums_mfma_kernel", 1)]),
+    "embed_iter_fast": ("e2e", [("forces_sym2_kernel", 1), ("sym_apply_kernel", 1), ("reduce_loss_kernel", 1)]),
+    "embed_iter_seq": ("seq", [("forces_seq_kernel", 1), ("apply_kernel<true>", 1)]),
+}
+
+
+def add_moved_bytes(stages):
+    """`frac` of a stage prices SURVEY 8(d)'s ALGORITHMIC bytes; `frac_moved` prices the bytes the stage's kernels actually moved
+    to and from HBM (PMC passes of the latest profiles/r*_pmc.json, collected offline by tools/profile_round.sh) over the same
+    measured time -- a stage whose kernels read no matrix, or each pair once, is not credited with bytes it never moved"""
+    pmc = sorted((ROOT / "profiles").glob("r*_pmc.json"))
+    if not pmc:
+        return
+    try:
+        wl = json.loads(pmc[-1].read_text())["workloads"]
+    except Exception:   # noqa: BLE001
+        return
+    for name, (w, kernels) in STAGE_KERNELS.items():
+        if name not in stages or w not in wl:
+            continue
+        total, missing = 0.0, []
+        for prefix, times in kernels:
+            hit = [v.get("hbm_bytes") for k, v in wl[w].items() if k.startswith(prefix) and v.get("hbm_bytes") is not None]
+            if hit:
+                total += times * sum(hit) / len(hit)
+            else:
+                missing.append(prefix)
+        st = stages[name]
+        if total > 0 and len(missing) < len(kernels):
+            st["moved_bytes"] = total
+            st["frac_moved"] = total / (st["ms_median"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            st["moved_source"] = f"profiles/{pmc[-1].name} [{w}]" + (f"; no counters for {missing}" if missing else "")
+
+
 def stage_rooflines(reads, kh, lab, conseq_lens):
     """Every stage of the C3 path besides the headline kernel, timed in isolation on resident inputs with HIP events; bytes are
     SURVEY 8(d)'s algorithmic figures (1 B per read position and pass for the read stages -- the uint8 contract; the kernels
@@ -191,6 +236,7 @@ def stage_rooflines(reads, kh, lab, conseq_lens):
         sess.close()
     for b in (sums_d, nb_d, kh_d, lab_d):
         b.free()
+    add_moved_bytes(out)
     return out
 
 
@@ -319,11 +365,36 @@ def embed_dist_leg(dist, torch, world, kh, lab, conseqs, iters=200):
     t = torch.tensor([loop_s], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     cyc = os.environ.get("KMAP_DIST_CYCLIC", "1") != "0" and n >= 16384 and world > 1
+    # the same loop with the peer-direct exchange (kmap_amd.distributed.PeerExchange: IPC-mapped receive areas, push + flag,
+    # no library call between iterations) next to the all-reduce form; its failure is reported, not raised
+    direct = {}
+    if _all_ok(dist, torch, flag):
+        d_err, d_loop = "", 0.0
+        for it in (24, iters):
+            if not _all_ok(dist, torch, flag):
+                break
+            dist.barrier()
+            tr = {}
+            try:
+                kmap_from_kmers_distributed(kh, ones, lab, conseqs, K, n_max_iter=it, random_seed=7, trace=tr, mode=V.EMBED_FAST, exchange="direct")
+                d_loop = tr["loop_s"]
+            except Exception as e:   # noqa: BLE001
+                d_err = f"{type(e).__name__}: {e}"[:300]
+                flag.fill_(1)
+        if _all_ok(dist, torch, flag):
+            td = torch.tensor([d_loop], dtype=torch.float64, device="cuda")
+            dist.all_reduce(td, op=dist.ReduceOp.MAX)
+            direct = {"loop_s": float(td.item()), "ms_per_iteration": float(td.item()) / iters * 1e3,
+                      "what": "forces -> push kernel (peer-to-peer stores into every rank's IPC-mapped receive area + flag) -> apply (bounded wait, "
+                              "sum of the slots in rank order); the whole segment issued by one native call"}
+        else:
+            direct = {"error": d_err or "another rank failed"}
+            flag.zero_()                                  # the all-reduce numbers above stand
     res = {"n_kmers": n, "scaling": "strong", "layout": "each unordered pair once, cyclic 256-row blocks per rank" if cyc else "contiguous row blocks",
            "mode": "FAST", "iterations": iters, "loop_s": float(t.item()), "ms_per_iteration": float(t.item()) / iters * 1e3,
            "collectives_per_iteration": 1, "message_bytes": (2 * n + 8) * 4, "phases_ms_rank0": phases,
            "phases_note": "device events around forces (force kernel + partial sums + loss limbs), the all-reduce, apply; 20 iterations of a separate run",
-           "d_rows_per_rank": hbm.get("d_rows"), "d_bytes_per_rank": hbm.get("d_bytes")}
+           "d_rows_per_rank": hbm.get("d_rows"), "d_bytes_per_rank": hbm.get("d_bytes"), "exchange_direct": direct}
     if world == 1:
         tr = {}
         V.kmap_from_kmers(kh, ones, lab, conseqs, K, n_max_iter=24, random_seed=7, mode=V.EMBED_FAST)
@@ -380,8 +451,10 @@ def count_dist_leg(dist, torch, world, k=15, n_reads=1_000_000, read_len=150, re
     tb = 4 ** k * 4
     res.update({"k": k, "reads": n_reads, "read_len": read_len, "table_bytes": tb,
                 "bytes_received_per_rank": {"all_reduce": 2 * tb * (world - 1) // world,
-                                            "key_range": (tb + 2 * (tb // 8) + 12 * res.get("n_uniq", 0)) * (world - 1) // world,
-                                            "note": "ring estimates; key_range = table slices + presence nibbles (all-reduced) + the all-gathered shards (12 B per distinct k-mer)"}})
+                                            "key_range": (tb + 2 * (tb // 8) + (12 * res.get("n_uniq", 0) if res.get("n_uniq", 0) <= 4_000_000 else 0)) * (world - 1) // world,
+                                            "note": "ring estimates; key_range = table slices + presence nibbles (all-reduced); above 4e6 distinct k-mers the "
+                                                    "(k-mer, count) shards are NOT exchanged: the table stays sharded and find_motif works on local partials "
+                                                    "(kmap_amd.distributed.CountShard); below, + the all-gathered shards (12 B per distinct k-mer)"}})
     return res
 
 

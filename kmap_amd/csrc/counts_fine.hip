@@ -47,6 +47,52 @@ __device__ __forceinline__ void tile_keys(const uint32_t *__restrict__ h, const 
     }
 }
 
+// ---- the packed source, two groups per thread, as RAW loads + a separate key computation --------------------------------------
+// A tile's keys come from four loads per thread (8 B of codes + 4 B, 8 B of invalid flags, 4 B of skip bits: the thread's groups g0,
+// g0 + 1 are an aligned pair).  Split from the arithmetic so that the loads of the block's NEXT tile can be issued at the top of the
+// current one -- unconditionally, on clamped addresses: a block's 16 waves all reach a tile's first use together (the barriers
+// keep them in step), and without the prefetch every tile began with one exposed memory round trip (r03: ~0.4 ms of the 3.0).
+struct RawPair {
+    uint32_t c0, c1, c2;            // codes of groups g0, g0 + 1, g0 + 2
+    uint32_t f01, f23;              // invalid flags of groups g0 .. g0 + 3 (little-endian pairs)
+    uint32_t sk;                    // skip bits of groups g0 (high half), g0 + 1 (low half)
+};
+__device__ __forceinline__ void raw_pair_load(RawPair &r, const uint32_t *__restrict__ codes, const uint16_t *__restrict__ inval,
+                                              const uint32_t *__restrict__ skip, int64_t n, int64_t g0) {
+    const int64_t glast = (((n + 15) >> 4) - 1) & ~(int64_t)1;            // last aligned pair that holds data (kmap_packed_groups: g + 3 stays inside)
+    const int64_t g = g0 < glast ? g0 : (glast > 0 ? glast : 0);
+    const uint2 c = *reinterpret_cast<const uint2 *>(codes + g);
+    r.c0 = c.x;
+    r.c1 = c.y;
+    r.c2 = codes[g + 2];
+    const uint2 f = *reinterpret_cast<const uint2 *>(inval + g);
+    r.f01 = f.x;
+    r.f23 = f.y;
+    r.sk = skip ? skip[g >> 1] : 0u;
+}
+__device__ __forceinline__ void group_keys_from(uint32_t hi, uint32_t lo, uint64_t bad, uint32_t skip16, int64_t left, int k, uint32_t (&keys)[16]) {
+    for (int have = 1; have < k;) {
+        const int step = (have <= k - have) ? have : k - have;
+        bad |= bad << step;
+        have += step;
+    }
+    uint32_t drop16 = ((uint32_t)(bad >> 32) & 0xFFFFu) | skip16;          // windows 0..15 in bits 15..0
+    if (left < 16) drop16 |= left <= 0 ? 0xFFFFu : ((1u << (16 - (int)left)) - 1u);   // windows that start inside the array
+    const int sh = 32 - 2 * k;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t top = (i == 0) ? hi : __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * i);
+        keys[i] = (top >> sh) | (uint32_t)__builtin_amdgcn_sbfe((int)drop16, 15 - i, 1);   // all ones when dropped (k <= 14: never a hash)
+    }
+}
+__device__ __forceinline__ void raw_pair_keys(const RawPair &r, int64_t n, int k, int64_t g0, uint32_t (&v)[32]) {
+    const uint32_t f0 = r.f01 & 0xFFFFu, f1 = r.f01 >> 16, f2 = r.f23 & 0xFFFFu, f3 = r.f23 >> 16;
+    group_keys_from(r.c0, r.c1, ((uint64_t)f0 << 32) | ((uint64_t)f1 << 16) | f2, r.sk >> 16, n - 16 * g0, k,
+                    *reinterpret_cast<uint32_t(*)[16]>(&v[0]));
+    group_keys_from(r.c1, r.c2, ((uint64_t)f1 << 32) | ((uint64_t)f2 << 16) | f3, r.sk & 0xFFFFu, n - 16 * (g0 + 1), k,
+                    *reinterpret_cast<uint32_t(*)[16]>(&v[16]));
+}
+
 // (1) valid keys per (class, bucket): gcount[class * NB + bucket].  (Measured: a bucket-only extraction -- five instead of eleven
 // vector instructions per window, byte offsets straight into the counters -- 0.48 against 0.43 ms: the pass sits at the LDS atomic rate.)  The grid is a multiple of 8, so all tiles of a block share
 // their class (tile = blockIdx + i * gridDim).
@@ -60,11 +106,25 @@ __global__ __launch_bounds__(FS_TPB) void fine_count_kernel(const uint32_t *__re
     __syncthreads();
     const int64_t n_tiles = (n + FS_TPB * KPT - 1) / (FS_TPB * KPT);
     const uint32_t dummy = (uint32_t)NB + (threadIdx.x & 63u);
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        uint32_t v[KPT];
-        tile_keys<PACKED, GPT>(h, inval, skip, k, n, tile, v);
+    if constexpr (PACKED && GPT == 2) {
+        auto g0_of = [&](int64_t tile) { return ((tile * (int64_t)(FS_TPB * KPT)) >> 4) + 2 * (int64_t)threadIdx.x; };
+        RawPair cur, nxt;
+        raw_pair_load(cur, h, inval, skip, n, g0_of(blockIdx.x));
+        for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+            raw_pair_load(nxt, h, inval, skip, n, g0_of(tile + gridDim.x));          // next tile's loads in flight (clamped behind the array)
+            uint32_t v[KPT];
+            raw_pair_keys(cur, n, k, g0_of(tile), v);
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) atomicAdd(&cnt[v[j] == INV32 ? dummy : v[j] >> low_bits], 1u);
+            for (int j = 0; j < KPT; ++j) atomicAdd(&cnt[v[j] == INV32 ? dummy : v[j] >> low_bits], 1u);
+            cur = nxt;
+        }
+    } else {
+        for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+            uint32_t v[KPT];
+            tile_keys<PACKED, GPT>(h, inval, skip, k, n, tile, v);
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) atomicAdd(&cnt[v[j] == INV32 ? dummy : v[j] >> low_bits], 1u);
+        }
     }
     __syncthreads();
     const int cls = (int)(blockIdx.x & (FC - 1));
@@ -188,14 +248,22 @@ __global__ __launch_bounds__(FS_TPB) void fine_scatter_kernel(const uint32_t *__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t low_mask = (1u << low_bits) - 1u;
     const int64_t n_tiles = (n + FT - 1) / FT;
+    constexpr bool PREF = PACKED && GPT == 2;
+    auto g0_of = [&](int64_t tile) { return ((tile * (int64_t)FT) >> 4) + 2 * (int64_t)threadIdx.x; };
+    RawPair raw_cur, raw_nxt;
+    if constexpr (PREF) raw_pair_load(raw_cur, h, inval, skip, n, g0_of(blockIdx.x));
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int cls = (int)(tile & (FC - 1));
+        if constexpr (PREF) raw_pair_load(raw_nxt, h, inval, skip, n, g0_of(tile + gridDim.x));   // next tile's loads in flight
 #pragma unroll
         for (int j = 0; j < BPT; ++j) cnt[threadIdx.x * BPT + j] = 0;
         for (int w = threadIdx.x; w < SW; w += FS_TPB) startbits[w] = 0;
         __syncthreads();
         uint32_t v[KPT];
-        tile_keys<PACKED, GPT>(h, inval, skip, k, n, tile, v);
+        if constexpr (PREF) raw_pair_keys(raw_cur, n, k, g0_of(tile), v);
+        else tile_keys<PACKED, GPT>(h, inval, skip, k, n, tile, v);
+        // (taking each key's rank from the returning form of this atomic, so that the placement below is a plain read instead of a
+        // second atomic, needs 16 more registers per thread at the 128 this block size allows: spills, 6.8 instead of 5.9 ms)
 #pragma unroll
         for (int j = 0; j < KPT; ++j)
             if (v[j] != INV32) atomicAdd(&cnt[v[j] >> low_bits], 1u);
@@ -266,6 +334,7 @@ __global__ __launch_bounds__(FS_TPB) void fine_scatter_kernel(const uint32_t *__
             if (p < n_valid) out[based[rank] + p] = sorted[p];
         }
         __syncthreads();
+        if constexpr (PREF) raw_cur = raw_nxt;
     }
 }
 

@@ -166,11 +166,52 @@ __device__ __forceinline__ void seq_terms(const SeqBatch &cur, const float *__re
     }
     if (LOSS) ce2 = __builtin_amdgcn_logf(prod) + (es2.x + es2.y);
 }
+// FAR batches: every pair of the wave's batch has d2 >= 1000, so every q = 1 / (1 + d2) <= 1 / 1001 is clipped to 0.001f
+// (visualization.py:254-255) and q, 1 - q, q / (1 - q), their logs and the product of the eight (1 - q) are the SAME floats for all
+// pairs: the two divisions, the clip and the logs are replaced by constants -- constants computed once per thread by the very
+// instruction sequences of the general path, on the hardware (seq_far_consts), so a batch evaluated here has bit for bit the terms
+// and the loss partial the general path gives it.  12 instead of 26 instructions per pair of terms.  Once an embedding has spread
+// out most batches are far (r04, N = 5000, two motif clusters + noise: 33 % of all pairs after 100 iterations, 74 % after 2500).
+struct SeqFar {
+    float q, u, lg, logprod8;
+};
+__device__ __forceinline__ SeqFar seq_far_consts() {
+    SeqFar f;
+    float q = 0.001f;
+    asm volatile("" : "+v"(q));                   // evaluated by the instructions below, not folded by the compiler
+    f.q = __builtin_amdgcn_fmed3f(q, 0.001f, 0.999f);
+    const float omq = 1.0f - f.q;
+    f.u = seq_quo<KMAP_SEQ_QUO_RSTEPS, KMAP_SEQ_QUO_STEPS>(f.q, omq);
+    f.lg = __builtin_amdgcn_logf(f.u);
+    float prod = 1.0f;
+#pragma unroll
+    for (int c = 0; c < SQ_CPL; ++c) prod = prod * omq;   // the general path's chain, column by column
+    f.logprod8 = __builtin_amdgcn_logf(prod);
+    return f;
+}
+template <bool LUTSRC, bool LOSS>
+__device__ __forceinline__ void seq_terms_far(const SeqBatch &cur, const float *__restrict__ lut_s, const f32x2 (&dx)[SQ_CPL / 2],
+                                              const f32x2 (&dy)[SQ_CPL / 2], const SeqFar &far, float (&tx)[SQ_CPL], float (&ty)[SQ_CPL],
+                                              float &ce2) {
+    const f32x2 q2 = {far.q, far.q}, u2 = {far.u, far.u}, lg2 = {far.lg, far.lg};
+    f32x2 es2 = {0.0f, 0.0f};
+#pragma unroll
+    for (int d = 0; d < SQ_CPL / 2; ++d) {
+        const f32x2 p = LUTSRC ? f32x2{lut_s[cur.w[d] & 0xFFFFu], lut_s[cur.w[d] >> 16]} : cur.pf[d];
+        const f32x2 t = u2 * (p - q2);
+        const f32x2 tx2 = t * dx[d], ty2 = t * dy[d];
+        tx[2 * d] = tx2.x; tx[2 * d + 1] = tx2.y;
+        ty[2 * d] = ty2.x; ty[2 * d + 1] = ty2.y;
+        if (LOSS) es2 = pk_fma(p, lg2, es2);
+    }
+    if (LOSS) ce2 = far.logprod8 + (es2.x + es2.y);
+}
+
 // wave-uniform dispatch over the variants.  rows_in_wave consecutive rows from wave_row_min; batch = columns [j0, j0 + batch_cols)
 template <bool LUTSRC>
 __device__ __forceinline__ void seq_terms_dispatch(const SeqBatch &cur, const float *__restrict__ lut_s, float xi, float yi, int i32,
                                                    int64_t n, int64_t j0, int batch_cols, int64_t wave_row_min, int rows_in_wave,
-                                                   int jl32, float (&tx)[SQ_CPL], float (&ty)[SQ_CPL], float &ce2) {
+                                                   int jl32, const SeqFar &far, float (&tx)[SQ_CPL], float (&ty)[SQ_CPL], float &ce2) {
     // (a) no column of the batch lies right of any of the wave's rows -> no loss terms (each unordered pair is charged to its
     // j > i side); (b) some squared distance is too large for the short divisions -> generic division
     const bool want_loss = (j0 + batch_cols - 1) > wave_row_min;
@@ -185,12 +226,18 @@ __device__ __forceinline__ void seq_terms_dispatch(const SeqBatch &cur, const fl
     const f32x2 m01 = __builtin_elementwise_max(d2[0], d2[1]), m23 = __builtin_elementwise_max(d2[2], d2[3]);
     const f32x2 m = __builtin_elementwise_max(m01, m23);
     const bool slow = __any(!(fmaxf(m.x, m.y) < 1e30f));
+    const f32x2 l01 = __builtin_elementwise_min(d2[0], d2[1]), l23 = __builtin_elementwise_min(d2[2], d2[3]);
+    const f32x2 l = __builtin_elementwise_min(l01, l23);
+    const bool all_far = !__any(!(fminf(l.x, l.y) >= 1000.0f));         // NaN-safe: a NaN distance is not far
     // (c) the batch neither reaches past column n-1 nor contains the diagonal of any of the wave's rows -> no per-term masks
     const bool plain = (j0 + batch_cols <= n) && (j0 + batch_cols - 1 < wave_row_min || j0 > wave_row_min + rows_in_wave - 1);
     const int n32 = (int)n;
     ce2 = 0.0f;
     if (slow) {   // rare (coordinates beyond 1e15): one generic instantiation
         seq_terms<LUTSRC, true, true, true>(cur, lut_s, dx, dy, d2, i32, n32, jl32, tx, ty, ce2);
+    } else if (plain && all_far) {
+        if (want_loss) seq_terms_far<LUTSRC, true>(cur, lut_s, dx, dy, far, tx, ty, ce2);
+        else seq_terms_far<LUTSRC, false>(cur, lut_s, dx, dy, far, tx, ty, ce2);
     } else if (plain) {
         if (want_loss) seq_terms<LUTSRC, false, true, false>(cur, lut_s, dx, dy, d2, i32, n32, jl32, tx, ty, ce2);
         else seq_terms<LUTSRC, false, false, false>(cur, lut_s, dx, dy, d2, i32, n32, jl32, tx, ty, ce2);
@@ -221,6 +268,7 @@ __device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *_
     const int64_t wave_row_min = row0 + lrow0 + (bid * SQ_WAVES + wave) * SQ_ROWS;   // smallest global row of the wave
     float gx = 0.0f, gy = 0.0f, ce_acc = 0.0f;
     double loss = 0.0;
+    const SeqFar far = seq_far_consts();
     auto run = [&](auto vec_tag) {
     constexpr bool VEC = decltype(vec_tag)::value;
     // two batch buffers in alternating roles (no register copies between batches): while `cur` is evaluated, `nxt` is in flight
@@ -231,7 +279,7 @@ __device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *_
         seq_load<LUTSRC, VEC>(nxt, src, X, Yy, lrc, (j0 + SQ_BATCH < n) ? jl + SQ_BATCH : jl, n);   // prefetch, always (see seq_load)
         float tx[SQ_CPL], ty[SQ_CPL];
         float ce2;                                                           // loss terms in log2 units (order-free)
-        seq_terms_dispatch<LUTSRC>(cur, lut_s, xi, yi, i32, n, j0, SQ_BATCH, wave_row_min, SQ_ROWS, (int)jl, tx, ty, ce2);
+        seq_terms_dispatch<LUTSRC>(cur, lut_s, xi, yi, i32, n, j0, SQ_BATCH, wave_row_min, SQ_ROWS, (int)jl, far, tx, ty, ce2);
         ce_acc += ce2;
         // ordered accumulation over the batch's 32 columns: column j0 + 8*s2 + c lives in sub-lane s2, slot c
         asm volatile("s_nop 1");
@@ -340,6 +388,7 @@ __device__ __forceinline__ void seq_row16_body(const ProbSrc &src, const float *
     const int64_t wave_row_min = row0 + wave_lr;
     float gx = 0.0f, gy = 0.0f, ce_acc = 0.0f;
     double loss = 0.0;
+    const SeqFar far = seq_far_consts();
     auto run = [&](auto vec_tag) {
     constexpr bool VEC = decltype(vec_tag)::value;
     // (computing the terms of batch b + 1 in the same loop body as the adds of batch b -- a software pipeline for the scheduler to
@@ -351,7 +400,7 @@ __device__ __forceinline__ void seq_row16_body(const ProbSrc &src, const float *
         seq_load<LUTSRC, VEC>(nxt, src, X, Yy, lrc, (j0 + SR_BATCH < n) ? jl + SR_BATCH : jl, n);   // prefetch, always (see seq_load)
         float tx[SQ_CPL], ty[SQ_CPL];
         float ce2;
-        seq_terms_dispatch<LUTSRC>(cur, lut_s, xi, yi, i32, n, j0, SR_BATCH, wave_row_min, SR_ROWS, (int)jl, tx, ty, ce2);
+        seq_terms_dispatch<LUTSRC>(cur, lut_s, xi, yi, i32, n, j0, SR_BATCH, wave_row_min, SR_ROWS, (int)jl, far, tx, ty, ce2);
         ce_acc += ce2;
         asm volatile("s_nop 1");
 #define SEQ_ADD16(K)                                                                                  \
@@ -417,6 +466,7 @@ __device__ __forceinline__ void seq_wide_body(const ProbSrc &src, const float *_
     f32x2 acc = {0.0f, 0.0f};
     float ce_acc = 0.0f;
     double loss = 0.0;
+    const SeqFar far = seq_far_consts();
     auto run = [&](auto vec_tag) {
     constexpr bool VEC = decltype(vec_tag)::value;
     SeqBatch bufA, bufB;
@@ -429,7 +479,7 @@ __device__ __forceinline__ void seq_wide_body(const ProbSrc &src, const float *_
         seq_load<LUTSRC, VEC>(nxt, src, X, Yy, lrc, (j0 + BC < n) ? jl + BC : jl, n);      // prefetch, always (see seq_load)
         float tx[SQ_CPL], ty[SQ_CPL];
         float ce2;
-        seq_terms_dispatch<LUTSRC>(cur, lut_s, xi, yi, i32, n, j0, BC, wave_row_min, RW, (int)jl, tx, ty, ce2);
+        seq_terms_dispatch<LUTSRC>(cur, lut_s, xi, yi, i32, n, j0, BC, wave_row_min, RW, (int)jl, far, tx, ty, ce2);
         ce_acc += ce2;
 #pragma unroll
         for (int c = 0; c < SQ_CPL; c += 2) {
