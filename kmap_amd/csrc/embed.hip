@@ -299,11 +299,13 @@ __global__ __launch_bounds__(BLK) void apply_peer_kernel(LoopState *__restrict__
                                                          float *__restrict__ loss_log, int64_t loss_log_cap) {
     if (threadIdx.x == 0) {
         const unsigned long long t0 = wall_clock64();
-        for (int q = 0; q < world; ++q) {
+        bool gave_up = __hip_atomic_load(timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // sticky: after one time-out the
+        for (int q = 0; q < world && !gave_up; ++q) {                        //  rest of the segment does not wait 2 s per iteration again
             const unsigned long long *f = flags + (size_t)parity * world + q;
             while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != iter_tag) {
                 if (wall_clock64() - t0 > 200000000ull) {                   // 2 s at 100 MHz: a peer is gone
                     atomicMax(timed_out, 1ull);
+                    gave_up = true;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(8);

@@ -173,6 +173,35 @@ def test_packed_scan_vs_oracle(env, k, r):
     ds.close()
 
 
+def test_packed_scan_more_hits_than_the_one_pass_buffer(env):
+    """The one-pass per-read form writes the positions into a temporary buffer of max(2 n_seq, 2^20) entries cut into 64 regions; a
+    scan with far more hits (a 3-mer at radius 1: most windows of most reads) must notice the overflow and fall back to the
+    count / scan / write form -- same lists as the oracle's, read by read."""
+    _ffi, _, DeviceSeq, O = env
+    rng = np.random.default_rng(99)
+    n_reads, L = 30_000, 150
+    seq = rng.integers(0, 4, size=n_reads * (L + 1)).astype(np.uint8)
+    seq = seq.reshape(n_reads, L + 1)
+    seq[::2, :] = 0                                           # every other read poly-A: all its windows tie at the minimum (only the
+    seq[1::4, :] = 3                                          #  hits at a read's minimum are kept), a quarter poly-T
+    seq[:, L] = 255
+    seq = np.ascontiguousarray(seq.reshape(-1))
+    borders = np.stack([np.arange(n_reads) * (L + 1), np.arange(n_reads) * (L + 1) + L], axis=1).astype(np.int64)
+    ds = DeviceSeq(seq, borders)
+    for k, cons, r in ((3, int(O.kmer2hash("AAA")), 1), (4, int(O.kmer2hash("TTTT")), 2)):
+        hits, pos = ds.scan(k, cons, r, True)
+        assert len(pos) > max(2 * n_reads, 1 << 20)           # beyond the buffer: the fallback ran
+        offs = np.concatenate([[0], np.cumsum(hits, dtype=np.int64)])
+        assert offs[-1] == len(pos)
+        buf, md = np.empty(L, np.int32), C.c_int(0)
+        for i in list(range(0, n_reads, 997)) + [n_reads - 1]:
+            a, b = borders[i]
+            m = O.lib().ko_scan_read(np.ascontiguousarray(seq[a:b]), b - a, k, cons, r, 1, buf, C.byref(md))
+            assert hits[i] == m
+            np.testing.assert_array_equal(pos[offs[i]:offs[i + 1]], buf[:m])
+    ds.close()
+
+
 def test_counting_full_size_properties(env):
     """3 M x 150 bp reads (4.5e8 positions; the C3 shape at 30 %): size-independent properties instead of a CPU recount:
     sum of counts == number of valid windows, the revcom merge conserves the total up to palindrome doubling, per-read
