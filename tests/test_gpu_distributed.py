@@ -39,6 +39,37 @@ def _worker(rank, world, port, mode, out_dir, exchange="rccl"):
         dist.destroy_process_group()
 
 
+def _timeout_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KMAP_DIST_EXCHANGE="direct")
+    import time
+    import torch
+    import torch.distributed as dist
+    from kmap_amd.distributed import kmap_from_kmers_distributed
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        kh, cnts, lab, conseqs = _inputs()
+        t0, msg = time.perf_counter(), ""
+        try:      # rank 1 runs no iteration, i.e. never pushes: rank 0's waits must run into their bound, not spin for ever
+            kmap_from_kmers_distributed(kh, cnts, lab, conseqs, K, n_max_iter=6 if rank == 0 else 0, random_seed=SEED, mode=0)
+        except RuntimeError as e:
+            msg = str(e)
+        (Path(out_dir) / f"timeout_rank{rank}.txt").write_text(f"{time.perf_counter() - t0:.2f}|{msg}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_exchange_wait_is_bounded(tmp_path):
+    """a rank whose peer never pushes: the apply kernel's wait gives up after its 2-second bound (once: the sticky flag lets the rest
+    of the segment through), the host raises -- no kernel spins for ever, the other rank ends normally"""
+    import torch.multiprocessing as mp
+    mp.spawn(_timeout_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    t0, m0 = (tmp_path / "timeout_rank0.txt").read_text().split("|", 1)
+    t1, m1 = (tmp_path / "timeout_rank1.txt").read_text().split("|", 1)
+    assert "did not arrive within the wait bound" in m0 and m1 == ""
+    assert 1.5 < float(t0) < 30.0
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
