@@ -1,5 +1,6 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence of a round on the GPU box (run through gpurun); summaries land in gpurun_out/ and are
+# Collects the rocprofv3 evidence of a round on the GPU box (run through gpurun; delete the LOCAL gpurun_out/round_prof and
+# gpurun_out/pmc_round first - gpurun merges into them and stale per-process CSVs would be averaged in); summaries land in gpurun_out/ and are
 # copied into profiles/ by tools/collect_profiles.py.  Kernel trace and PMC passes are separate runs.
 set -e
 cd /tmp && export TMPDIR=/tmp
