@@ -254,15 +254,34 @@ __global__ __launch_bounds__(LDSMODE ? HP_TPB : BLK) void hist_packed_kernel(con
 // 7.5 ms.  Both are gone; CHANGELOG.md has the numbers.)
 constexpr int DS_CAP = 512;             // longest read handled here (longer ones: the hash-array path of kmer_ops.hip)
 constexpr int DS_WAVES = 4;
-// Here: * the set is a BITMAP in LDS indexed by the k-mer itself (4^k bits, k <= 8: exact) or by 16 hashed bits (k >= 9),
+// Here: * the set is a BITMAP in LDS indexed by the k-mer itself (4^k bits, 3 <= k <= 8: exact) or by 15 hashed bits (other k),
 //         one returning ds_or per window: the lane that finds its bit clear keeps the k-mer, no probing, no loop;
-//       * hashed mode: a lane that finds its bit set is only a candidate (143 windows in 65 536 bits: ~0.15 false positives
-//         per read).  Candidates are confirmed exactly, one at a time, against all windows of the read up to this step
-//         (recomputed from the packed codes): duplicate iff another window with the same k-mer claimed a bit, or starts earlier;
+//       * hashed mode: a lane that finds its bit set is only a candidate (143 windows in 32 768 bits: ~0.3 false positives
+//         per read).  Candidates are confirmed exactly, one at a time, against all windows of the read up to this step:
+//         duplicate iff another window with the same k-mer claimed a bit, or starts earlier;
 //       * waves are persistent (a grid-stride loop over the reads), everything wave-uniform is scalar, positions are 32-bit
 //         offsets from the read's first skip word.
-constexpr int DB_HASH_WORDS = 1024;     // hashed bitmap: 32 768 bits per wave (143 windows: ~0.3 false positives per read)
+// Round 4: the kernel was bound by instruction issue (104 vector + ~80 scalar instructions per read, PMC issue utilisation 0.77),
+// so the common read (at most DB_NB = 3 steps of 64 windows, not at the very end of the arrays) now runs a form with ~9 vector
+// instructions per step:
+//       * the step's loads have NO per-lane address arithmetic: lane l's windows start at offsets 64c + l from a 32-aligned
+//         position, so its group index is 4c + (l >> 4) -- a loop-invariant lane offset + an immediate on a scalar base;
+//       * the window's bits leave the two code words by ONE 64-bit shift with a per-lane constant; in exact mode the bitmap's word
+//         comes from the k-mer's LOW bits and the bit from its high five, so address and bit are one and-or and two shifts of
+//         the shifted pair (the k-mer itself is never formed);
+//       * "window touches an invalid position" is one AND of the raw flag word with a per-lane constant mask (the window's k
+//         flags, rotated into the word's little-endian half order once, outside the loop);
+//       * "window starts inside the read" is a scalar 64-bit mask per step (from the read's [lo, hi)), ANDed with the ballot;
+//         invalid lanes OR a zero bit into the set (no exec masking, no result register to pre-clear);
+//       * the words touched are zeroed by all lanes, valid or not (every other word of the bitmap is zero already);
+//       * a read's geometry reaches the scalar registers as TWO v_readlane (its first skip word's index and one packed word), the
+//         three base addresses are scalar adds.
+//       Reads with more steps, or whose loads could run past the arrays' padding, take the general form below (one step at a
+//       time, clamped loads).
+constexpr int DB_HASH_WORDS = 1024;     // hashed bitmap: 32 768 bits per wave
 constexpr int DB_MAXSTEPS = (DS_CAP + 31 + 63) / 64;
+constexpr int DB_NB = 3;                // steps of the fast form
+constexpr int DB_TAIL_GROUPS = 4 * DB_NB;   // the fast form loads groups 0 .. 4 DB_NB of the read's frame
 struct DbRead {                         // a read as the dedupe kernel sees it (all wave-uniform)
     const uint32_t *crd;                // codes of the group holding the read's first skip word
     const uint16_t *ird;
@@ -270,53 +289,37 @@ struct DbRead {                         // a read as the dedupe kernel sees it (
     int lo, hi;                         // the read's positions as offsets from that word's first position: [lo, hi)
     int gmax;                           // last group (offset) a window of the read starts in
     int nsteps;                         // 64-position steps; 0 = nothing to do
+    bool fast;                          // nsteps <= DB_NB and the unclamped loads stay inside the arrays
 };
-__device__ __forceinline__ DbRead db_read(const uint32_t *codes, const uint16_t *inval, uint32_t *skip, int64_t n, int64_t st, int64_t en) {
-    if (st < 0) st = 0;
-    if (en > n) en = n;
-    const int64_t a0 = st & ~(int64_t)31;
-    DbRead g;
-    g.crd = codes + (a0 >> 4);
-    g.ird = inval + (a0 >> 4);
-    g.srd = skip + (a0 >> 5);
-    g.lo = (int)(st - a0);
-    g.hi = (int)(en - a0);
-    g.gmax = g.hi > 0 ? (g.hi - 1) >> 4 : 0;
-    g.nsteps = en - st <= 1 ? 0 : (g.hi + 63) >> 6;                       // a read of one window has no duplicate
-    return g;
-}
-// the two groups a window starting at offset o needs (lanes behind the read are clamped into the arrays and come out invalid).
-// Raw: nothing may be computed from the loaded registers before the window is used, or the prefetch of the next read turns into
-// a load-and-wait (s_waitcnt sits where the first use is).
 struct DbRaw {
     uint32_t c0, c1;                    // codes of groups g, g + 1
-    uint16_t f0, f1;                    // their invalid flags
+    uint32_t fw;                        // their invalid flags as loaded: f0 | f1 << 16
 };
-// The read's pointers reach the wave through v_readlane (Batch / pick below), so the compiler no longer knows them to be global and
-// emits FLAT loads -- which count in lgkmcnt as well as vmcnt: every wait for an LDS atomic's result then also waited for the window
-// loads prefetched for the NEXT read, the very stall the vector border loads were introduced to remove.  The address-space casts
-// make them global_load again.
+// The read's pointers reach the wave through v_readlane, so the compiler no longer knows them to be global and emits FLAT loads --
+// which count in lgkmcnt as well as vmcnt: every wait for an LDS atomic's result then also waited for the window loads prefetched
+// for the NEXT read.  The address-space casts make them global_load again.
 typedef const __attribute__((address_space(1))) uint32_t *db_g32;
 typedef const __attribute__((address_space(1))) uint16_t *db_g16;
-__device__ __forceinline__ void db_load(const DbRead &g, int o, DbRaw &w) {
-    const uint32_t gi = (uint32_t)min(o >> 4, g.gmax);                      // unsigned: scalar base + 32-bit lane offset addressing
+typedef uint32_t __attribute__((aligned(2))) db_u32a2;                   // two neighbouring 16-bit flag words as one (2-byte aligned) load
+typedef const __attribute__((address_space(1))) db_u32a2 *db_g32a2;
+typedef __attribute__((address_space(3))) uint32_t *db_l32;
+// general form: any offset, clamped into the read's groups (lanes behind the read come out invalid)
+__device__ __forceinline__ void db_load_clamped(const DbRead &g, int o, DbRaw &w) {
+    const uint32_t gi = (uint32_t)min(o >> 4, g.gmax);
     const db_g32 crd = (db_g32)g.crd;
     const db_g16 ird = (db_g16)g.ird;
     w.c0 = crd[gi];
     w.c1 = crd[gi + 1];
-    w.f0 = ird[gi];
-    w.f1 = ird[gi + 1];
+    w.fw = *(db_g32a2)(ird + gi);
 }
 __device__ __forceinline__ bool db_window(const DbRead &g, int o, const DbRaw &w, int k, uint32_t kbits, uint64_t kones, uint32_t &h) {
     const int i = o & 15;
     const uint64_t t0 = ((uint64_t)w.c0 << 32) | w.c1;
-    const uint32_t fl = ((uint32_t)w.f0 << 16) | w.f1;                    // 32 invalid flags, position 0 in bit 31
-    const uint32_t top = (uint32_t)(t0 >> (32 - 2 * i));                  // the 16 bases from position i on (one 64-bit shift, not two)
-    h = (top >> (32 - 2 * k)) & kbits;                                    // k <= 16: the window lies in groups g, g + 1
+    const uint32_t fl = (w.fw << 16) | (w.fw >> 16);                      // 32 invalid flags, position 0 in bit 31
+    h = (uint32_t)(t0 >> (64 - 2 * i - 2 * k)) & kbits;                   // k <= 16: the window lies in groups g, g + 1
     const bool bad = ((fl >> (32 - i - k)) & (uint32_t)kones) != 0;       // 1 <= 32 - i - k <= 31
     return o >= g.lo && o < g.hi && !bad;
 }
-
 template <bool EXACT>
 __global__ __launch_bounds__(KMAP_WAVE *DS_WAVES) void dedupe_bitmap_packed_kernel(const uint32_t *__restrict__ codes,
                                                                                    const uint16_t *__restrict__ inval, int64_t n,
@@ -325,190 +328,273 @@ __global__ __launch_bounds__(KMAP_WAVE *DS_WAVES) void dedupe_bitmap_packed_kern
     extern __shared__ uint4 db_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int per_wave = bw + (EXACT ? 0 : 2 * DB_MAXSTEPS + 2);         // words: bitmap (+ the steps' claim masks)
-    uint32_t *bm = reinterpret_cast<uint32_t *>(db_raw) + (size_t)wave * ((per_wave + 3) & ~3);
-    unsigned long long *claims = reinterpret_cast<unsigned long long *>(bm + bw);
+    // LDS: the waves' bitmaps first (bw words each, bw a power of two: a wave's bitmap is aligned to its size, so that a word's
+    // address is `offset | base`), then the hashed mode's claim masks
+    uint32_t *bm = reinterpret_cast<uint32_t *>(db_raw) + (size_t)wave * bw;
+    unsigned long long *claims = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint32_t *>(db_raw) + (size_t)DS_WAVES * bw) + (size_t)wave * (DB_MAXSTEPS + 1);
+    const uint32_t bm_base = (uint32_t)(uintptr_t)(db_l32)bm;            // LDS byte address of the wave's bitmap
+    if (bm_base & ((uint32_t)bw * 4u - 1u)) __builtin_trap();             // (dynamic LDS starts at 0 in this kernel: no static LDS)
     const uint32_t kbits = k < 16 ? (1u << (2 * k)) - 1u : ~0u;
     const uint64_t kones = (1ull << k) - 1ull;
     const int64_t n_waves = (int64_t)gridDim.x * DS_WAVES;
-    constexpr int NB = 3;
+    const int64_t last_group = ((n + 15) >> 4) + 1;                       // the arrays hold at least (n + 15) / 16 + 2 groups (kmap_packed_groups)
+    // per-lane constants of the fast form
+    const int li = lane & 15;
+    const uint32_t lane_g = (uint32_t)lane >> 4;
+    const uint32_t sh_h = (uint32_t)(64 - 2 * li - 2 * k);                // k-mer = low 2k bits of (c0:c1) >> sh_h
+    uint32_t lane_bad;                                                    // the window's k flags in the raw flag word
+    {
+        const uint32_t m = (uint32_t)kones << (32 - li - k);
+        lane_bad = (m << 16) | (m >> 16);
+    }
+    const int wbits = EXACT ? 2 * k - 5 : 10;                             // exact: word = low 2k - 5 bits of the k-mer, bit = its high 5
+    uint32_t amask = ((1u << wbits) - 1u) << 2;
+    asm volatile("v_mov_b32 %0, %0" : "+v"(amask));                       // a vector register: (x & amask) | base is then ONE v_and_or (one scalar operand per instruction)
+    uint32_t off[DB_NB];                                                  // the lane's window offset in each step of the frame
+#pragma unroll
+    for (int c = 0; c < DB_NB; ++c) off[c] = (uint32_t)(64 * c + lane);
     // a wave takes 64 CONSECUTIVE reads per batch -- reads (b n_waves + w) 64 .. + 63 in batch b -- so that the batch's border load
-    // is one coalesced KiB (lane-strided by n_waves reads it fetched a whole sector per 16 bytes: 1.0 GB of the kernel's 1.6 GB
-    // of HBM traffic at C3) and the window loads walk through one contiguous stretch of the packed array
+    // is one coalesced KiB and the window loads walk through one contiguous stretch of the packed array
     const int64_t wave_global = (int64_t)blockIdx.x * DS_WAVES + wave;
-    if (wave_global * 64 >= n_seq) return;
+    int64_t base = wave_global * 64;                                      // first read of the current batch
+    if (base >= n_seq) return;
     const int64_t batch_step = n_waves * 64;                              // first read of the wave's next batch - of this one
-    {   // the bitmap is zeroed once; after a read every lane zeroes the words it touched (3 scattered stores instead of bw / 256
-        // 16-byte stores per lane: the LDS pipe is the busiest unit of this kernel)
+    {   // the bitmap is zeroed once; after a read the words it touched are zeroed again
         uint4 *b4 = reinterpret_cast<uint4 *>(bm);
         const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
         for (int t = lane; t < bw / 4; t += 64) b4[t] = zero;
     }
     __builtin_amdgcn_wave_barrier();
-    // two-deep software pipeline over the wave's reads: while read i is hashed and inserted, the window loads of read i+1 and
-    // the border load of read i+2 are in flight (one read at a time left ~9000 clocks of exposed latency per read: scalar
-    // load -> window loads -> LDS atomics, with 20 waves per CU)
-    // Borders come through VECTOR loads, 64 reads at a time (lane l holds the borders of the read this wave handles l
-    // iterations into the batch) and reach the scalar registers by v_readlane.  As scalar loads they shared the lgkm counter
-    // with the LDS atomics: every wait for an atomic's result also waited for the border load of two reads ahead (~1 us).
-    // The geometry of a read (db_read: ~45 scalar instructions) is computed here too, by the lane that loaded the borders -- 64
-    // reads per vector instruction -- and travels as three addresses and one packed word: 7 v_readlane + 4 s_bfe per read.
+    // Borders come through VECTOR loads, 64 reads at a time (lane l holds the read this wave handles l iterations into the batch)
+    // and reach the scalar registers by v_readlane: as scalar loads they shared the lgkm counter with the LDS atomics.  The
+    // geometry of a read is computed by the lane that loaded the borders -- 64 reads per vector instruction.
     struct Batch {
-        uint64_t crd, ird, srd;
-        uint32_t pk;                    // lo | hi << 5 | gmax << 16 | nsteps << 24
+        uint32_t w5;                    // index of the read's first skip word (position >> 5): 2^37 positions
+        uint32_t pk;                    // lo | hi << 5 | gmax << 16 | nsteps << 24 | fast << 30 | work << 31
     };
-    auto batch = [&](int64_t b, Batch &B) {
-        const int64_t rr = (b * n_waves + wave_global) * 64 + lane;
+    auto batch = [&](int64_t first, Batch &B) {
+        const int64_t rr = first + lane;
         int64_t st = 0, en = 0;
         if (rr < n_seq) {
             st = borders[2 * rr];
             en = borders[2 * rr + 1];
         }
-        const DbRead g = db_read(codes, inval, skip, n, st, en);
-        B.crd = (uint64_t)g.crd;
-        B.ird = (uint64_t)g.ird;
-        B.srd = (uint64_t)g.srd;
-        B.pk = (uint32_t)g.lo | ((uint32_t)g.hi << 5) | ((uint32_t)g.gmax << 16) | ((uint32_t)g.nsteps << 24);
+        if (st < 0) st = 0;
+        if (en > n) en = n;
+        const int64_t a0 = st & ~(int64_t)31;
+        const int lo = (int)(st - a0), hi = (int)(en - a0);
+        const int gmax = hi > 0 ? (hi - 1) >> 4 : 0;
+        const int nsteps = en - st <= 1 ? 0 : (hi + 63) >> 6;             // a read of one window has no duplicate
+        const bool fast = nsteps <= DB_NB && (a0 >> 4) + DB_TAIL_GROUPS <= last_group;
+        B.w5 = (uint32_t)(a0 >> 5);
+        B.pk = (uint32_t)lo | ((uint32_t)hi << 5) | ((uint32_t)gmax << 16) | ((uint32_t)nsteps << 24) | (fast ? 0x40000000u : 0u) |
+               (nsteps ? 0x80000000u : 0u);
     };
-    auto lane64 = [](uint64_t v, int l) -> uint64_t {
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
-        return ((uint64_t)hi << 32) | lo;
+    // what the wave keeps of a read: two scalars and the prefetched windows of its (up to) DB_NB steps
+    struct Rd {
+        uint32_t w5, pk;
+        DbRaw W[DB_NB];
     };
-    auto pick = [&](const Batch &B, int l) -> DbRead {
+    auto pick = [&](const Batch &B, int l, Rd &R) {
+        R.w5 = (uint32_t)__builtin_amdgcn_readlane((int)B.w5, l);
+        R.pk = (uint32_t)__builtin_amdgcn_readlane((int)B.pk, l);
+    };
+    // the steps' loads, unclamped, on every path the same number (with a load count that depends on a branch the compiler waits
+    // with vmcnt(0) before the current read's windows are used, i.e. for the loads just issued); a read that takes the general form
+    // loads for itself: its prefetch reads the head of the arrays instead (never used)
+    auto prefetch = [&](Rd &R) {
+        const uint32_t w5p = (R.pk & 0x40000000u) ? R.w5 : 0u;
+        const db_g32 crd = (db_g32)codes + 2 * (size_t)w5p;
+        db_g32 crd1 = (db_g32)codes + 1 + 2 * (size_t)w5p;
+        asm volatile("" : "+s"(crd1));
+        const db_g16 ird = (db_g16)inval + 2 * (size_t)w5p;
+#pragma unroll
+        for (int c = 0; c < DB_NB; ++c) {
+            // two 4-byte code loads on purpose: merged into one 8-byte load the pair arrives as c1:c0 and has to be swapped (a
+            // v_pk_mov per step) before the 64-bit shift; `crd1` is `crd + 1` behind an empty asm, so that the compiler cannot
+            // see they are neighbours.  Group 4c + (lane >> 4): a loop-invariant lane offset + an immediate on a scalar base.
+            const uint32_t gi = lane_g + 4u * c;
+            R.W[c].c0 = crd[gi];
+            R.W[c].c1 = crd1[gi];
+            R.W[c].fw = *(db_g32a2)(ird + gi);
+        }
+    };
+    auto geometry = [&](const Rd &R) -> DbRead {                          // the full geometry: general form and skip-word writes only
         DbRead g;
-        g.crd = reinterpret_cast<const uint32_t *>(lane64(B.crd, l));
-        g.ird = reinterpret_cast<const uint16_t *>(lane64(B.ird, l));
-        g.srd = reinterpret_cast<uint32_t *>(lane64(B.srd, l));
-        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)B.pk, l);
-        g.lo = (int)(pk & 31u);
-        g.hi = (int)((pk >> 5) & 2047u);
-        g.gmax = (int)((pk >> 16) & 255u);
-        g.nsteps = (int)(pk >> 24);
+        g.crd = codes + 2 * (size_t)R.w5;
+        g.ird = inval + 2 * (size_t)R.w5;
+        g.srd = skip + (size_t)R.w5;
+        g.lo = (int)(R.pk & 31u);
+        g.hi = (int)((R.pk >> 5) & 2047u);
+        g.gmax = (int)((R.pk >> 16) & 255u);
+        g.nsteps = (int)((R.pk >> 24) & 63u);
+        g.fast = (R.pk & 0x40000000u) != 0;
         return g;
     };
-    Batch cur, nxt;                                                       // current and next batch of 64 reads
-    batch(0, cur);
-    batch(1, nxt);
-    int64_t it = 0;                                                       // iteration = index into the wave's reads
-    DbRead G = pick(cur, 0);
-    DbRaw W[NB];
-#pragma unroll
-    for (int c = 0; c < NB; ++c) db_load(G, c * 64 + lane, W[c]);
-    int64_t rn = wave_global * 64 + 1;                                        // read of iteration it + 1 (adds only: no 64-bit multiply per read)
-    for (;;) {
-        const bool has_next = rn < n_seq;                                 // wave-uniform
-        DbRead Gn = G;
-        DbRaw Wn[NB];
-        if (has_next) {
-            const int l = (int)((it + 1) & 63);
-            if (l == 0) {                                                 // the next read opens a new batch
-                cur = nxt;
-                batch((it + 1) / 64 + 1, nxt);
+    // duplicates of step cs (lane l -> window 64 cs + l) leave as two skip words; words that straddle a read border are shared with
+    // the neighbouring read's wave and are ORed atomically, the others are plain stores into the zeroed array
+    auto write_skip = [&](const DbRead &G, int cs, unsigned long long m) {
+        if (lane < 2) {
+            const uint32_t bits = __builtin_bitreverse32(lane ? (uint32_t)(m >> 32) : (uint32_t)m);   // lane l of the half -> bit 31-l
+            const int w0 = cs * 64 + 32 * lane;                           // first position (offset) of this word
+            if (bits) {
+                typedef __attribute__((address_space(1))) uint32_t *db_gw32;      // global, not flat (see above)
+                const db_gw32 sw = (db_gw32)G.srd + (w0 >> 5);
+                if (w0 < G.lo || w0 + 32 > G.hi) __hip_atomic_fetch_or(sw, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *sw = bits;
             }
-            Gn = pick(cur, l);
         }
-        // always NB loads, on every path (clamped into the read; for the last read they repeat the current one): with a load
-        // count that depends on a branch the compiler waits with vmcnt(0) before the current read's windows are used, i.e. for
-        // the loads just issued
+    };
+    auto process = [&](const Rd &R) {
+        if (!(R.pk & 0x80000000u)) return;                                // no step: nothing to do
+        if (R.pk & 0x40000000u) {
+            const uint32_t lo = R.pk & 31u, hi = (R.pk >> 5) & 2047u;
+            uint32_t addr[DB_NB], bit[DB_NB], old[DB_NB], h[DB_NB];
+            unsigned long long vm[DB_NB];                                 // valid windows of the step, as a lane mask
 #pragma unroll
-        for (int c = 0; c < NB; ++c) db_load(Gn, c * 64 + lane, Wn[c]);
-        const int64_t rnn = ((it + 2) & 63) ? rn + 1 : rn - 63 + batch_step;   // rn is the last read of its batch when it + 2 opens one
-        if (G.nsteps) {
-            int touched[NB];                                              // word index per prefetched step, -1 = none
-#pragma unroll
-            for (int c = 0; c < NB; ++c) touched[c] = -1;
-            for (int c0 = 0; c0 < G.nsteps; c0 += NB) {
-                if (c0) {                                                 // reads longer than the prefetched steps
-#pragma unroll
-                    for (int c = 0; c < NB; ++c)
-                        if (c0 + c < G.nsteps) db_load(G, (c0 + c) * 64 + lane, W[c]);
+            for (int c = 0; c < DB_NB; ++c) {
+                const DbRaw &w = R.W[c];
+                const uint64_t t0 = ((uint64_t)w.c0 << 32) | w.c1;
+                uint32_t x, s;
+                if (EXACT) {
+                    x = (uint32_t)(t0 >> (sh_h - 2));                     // k-mer << 2 (+ the bases before it above)
+                    s = x >> (2 + wbits);                                 // its high five bits (the shift below ignores the rest)
+                    h[c] = 0;
+                } else {
+                    h[c] = (uint32_t)(t0 >> sh_h) & kbits;
+                    const uint32_t y = h[c] * 0x9E3779B1u;
+                    x = y >> 15;                                          // 10 hashed bits << 2
+                    s = y >> 27;
                 }
-                // the batch's atomics go out back to back (steps behind the read: all lanes invalid, nothing issued), then
-                // their results are looked at: one LDS round trip per batch instead of one per step
-                uint32_t h[NB], old[NB], bit[NB];
-                bool valid[NB];
+                addr[c] = (x & amask) | bm_base;
+                // "starts inside the read" per lane (one compare per step, two in the first): as scalar masks built from lo / hi
+                // these were ~9 scalar instructions per step, and the CU's ONE scalar unit was the kernel's bound (94 scalar
+                // against 44 vector instructions per read, PMC)
+                unsigned long long ok = __ballot((w.fw & lane_bad) == 0) & __ballot(off[c] < hi);
+                if (c == 0) ok &= __ballot(off[0] >= lo);
+                vm[c] = ok;
+                bit[c] = __builtin_amdgcn_inverse_ballot_w64(ok) ? 1u << (s & 31u) : 0u;     // invalid lanes OR a zero into the set
+                old[c] = __hip_atomic_fetch_or((db_l32)(uintptr_t)addr[c], bit[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            unsigned long long m[DB_NB], any = 0;
 #pragma unroll
-                for (int c = 0; c < NB; ++c) {
-                    valid[c] = db_window(G, (c0 + c) * 64 + lane, W[c], k, kbits, kones, h[c]) && c0 + c < G.nsteps;
-                    const uint32_t idx = EXACT ? h[c] : (h[c] * 0x9E3779B1u) >> 17;
-                    bit[c] = 1u << (idx & 31);
-                    old[c] = 0;
-                    if (valid[c]) old[c] = atomicOr(&bm[idx >> 5], bit[c]);
-                    if (c0 == 0) touched[c] = valid[c] ? (int)(idx >> 5) : -1;
-                }
-                unsigned long long claim[NB];
+            for (int c = 0; c < DB_NB; ++c) {
+                m[c] = __ballot((old[c] & bit[c]) != 0);
+                any |= m[c];
+            }
+            if (any) {                                                    // wave-uniform; most reads have no repeated k-mer: one branch per read
+                const DbRead G = geometry(R);
+                unsigned long long claim[DB_NB];
 #pragma unroll
-                for (int c = 0; c < NB; ++c) {
-                    const int cs = c0 + c;
-                    if (cs >= G.nsteps) break;                            // wave-uniform
-                    const bool saw_set = valid[c] && (old[c] & bit[c]);
-                    unsigned long long m = __ballot(saw_set);
+                for (int c = 0; c < DB_NB; ++c) {
+                    unsigned long long mc = m[c];
                     if (!EXACT) {
-                        claim[c] = __ballot(valid[c] && !saw_set);
-                        if (G.nsteps > NB && lane == 0) claims[cs] = claim[c];   // long reads: later batches look the masks up in LDS
-                        unsigned long long cand = m;
-                        m = 0;
+                        claim[c] = vm[c] & ~mc;
+                        unsigned long long cand = mc;
+                        mc = 0;
                         while (cand) {                                    // scalar loop, rarely entered
                             const int y = __builtin_ctzll(cand);
                             cand &= cand - 1;
                             const uint32_t hc = (uint32_t)__builtin_amdgcn_readlane((int)h[c], y);
-                            const int py = cs * 64 + y;
-                            bool found = false;
-                            for (int c2 = 0; c2 <= cs && !found; ++c2) {
-                                const int o2 = c2 * 64 + lane;
-                                uint32_t h2;
-                                bool v2;
-                                unsigned long long cl2;
-                                if (c2 >= c0) {                           // a step of this batch: still in registers
-                                    const int j = c2 - c0;
-                                    h2 = j == 0 ? h[0] : j == 1 ? h[1] : h[2];
-                                    v2 = j == 0 ? valid[0] : j == 1 ? valid[1] : valid[2];
-                                    cl2 = j == 0 ? claim[0] : j == 1 ? claim[1] : claim[2];
-                                } else {
-                                    DbRaw w2;
-                                    db_load(G, o2, w2);
-                                    v2 = db_window(G, o2, w2, k, kbits, kones, h2);
-                                    cl2 = claims[c2];
-                                }
-                                const bool match = v2 && h2 == hc && o2 != py && (((cl2 >> lane) & 1ull) || o2 < py);
-                                found = __any(match);
+                            unsigned long long found = 0;
+#pragma unroll
+                            for (int c2 = 0; c2 <= c; ++c2) {             // an equal window that claimed its bit, or an earlier one
+                                const unsigned long long before = c2 < c ? ~0ull : ((1ull << y) - 1ull);
+                                const unsigned long long self = c2 == c ? (1ull << y) : 0ull;
+                                found |= __ballot(h[c2] == hc) & vm[c2] & (claim[c2] | before) & ~self;
                             }
-                            if (found) m |= 1ull << y;
+                            if (found) mc |= 1ull << y;
                         }
                     }
-                    if (m) {                                              // wave-uniform
-                        if (lane < 2) {
-                            const uint32_t bits = __builtin_bitreverse32(lane ? (uint32_t)(m >> 32) : (uint32_t)m);   // lane l of the half -> bit 31-l
-                            const int w0 = cs * 64 + 32 * lane;           // first position (offset) of this word
-                            if (bits) {
-                                typedef __attribute__((address_space(1))) uint32_t *db_gw32;      // global, not flat (see db_load)
-                                const db_gw32 sw = (db_gw32)G.srd + (w0 >> 5);
-                                if (w0 < G.lo || w0 + 32 > G.hi) __hip_atomic_fetch_or(sw, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // shared with a neighbouring read
-                                else *sw = bits;
-                            }
-                        }
-                    }
+                    if (mc) write_skip(G, c, mc);
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            if (G.nsteps <= NB) {
 #pragma unroll
-                for (int c = 0; c < NB; ++c)
-                    if (touched[c] >= 0) bm[touched[c]] = 0u;
-            } else {                                                      // long read: the whole bitmap
-                uint4 *b4 = reinterpret_cast<uint4 *>(bm);
-                const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
-                for (int t = lane; t < bw / 4; t += 64) b4[t] = zero;
-            }
+            for (int c = 0; c < DB_NB; ++c) *(db_l32)(uintptr_t)addr[c] = 0u;   // all lanes: the other words are zero anyway
             __builtin_amdgcn_wave_barrier();
+            return;
         }
-        if (!has_next) break;
-        G = Gn;
-#pragma unroll
-        for (int c = 0; c < NB; ++c) W[c] = Wn[c];
-        rn = rnn;
-        ++it;
+        // general form: one step at a time, clamped loads
+        const DbRead G = geometry(R);
+        for (int cs = 0; cs < G.nsteps; ++cs) {
+            DbRaw w;
+            db_load_clamped(G, cs * 64 + lane, w);
+            uint32_t hh;
+            const bool valid = db_window(G, cs * 64 + lane, w, k, kbits, kones, hh);
+            const uint32_t idx = EXACT ? hh : (hh * 0x9E3779B1u) >> 17;
+            const uint32_t b = 1u << (idx & 31);
+            uint32_t o = 0;
+            if (valid) o = atomicOr(&bm[idx >> 5], b);
+            const bool saw_set = valid && (o & b);
+            unsigned long long m = __ballot(saw_set);
+            if (!EXACT) {
+                const unsigned long long cl = __ballot(valid && !saw_set);
+                if (lane == 0) claims[cs] = cl;
+                __builtin_amdgcn_wave_barrier();
+                unsigned long long cand = m;
+                m = 0;
+                while (cand) {
+                    const int y = __builtin_ctzll(cand);
+                    cand &= cand - 1;
+                    const uint32_t hc = (uint32_t)__builtin_amdgcn_readlane((int)hh, y);
+                    const int py = cs * 64 + y;
+                    bool found = false;
+                    for (int c2 = 0; c2 <= cs && !found; ++c2) {
+                        const int o2 = c2 * 64 + lane;
+                        DbRaw w2;
+                        db_load_clamped(G, o2, w2);
+                        uint32_t h2;
+                        const bool v2 = db_window(G, o2, w2, k, kbits, kones, h2);
+                        const unsigned long long cl2 = claims[c2];
+                        found = __any(v2 && h2 == hc && o2 != py && (((cl2 >> lane) & 1ull) || o2 < py));
+                    }
+                    if (found) m |= 1ull << y;
+                }
+            }
+            if (m) write_skip(G, cs, m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint4 *b4 = reinterpret_cast<uint4 *>(bm);
+        const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+        for (int t = lane; t < bw / 4; t += 64) b4[t] = zero;
+        __builtin_amdgcn_wave_barrier();
+    };
+    // Two-deep software pipeline over the wave's reads, unrolled by two (reads alternate between A and B: no register copies from
+    // "next" to "current"): while a read is inserted, the window loads of the next one and the border load of the next BATCH are
+    // in flight.  A batch holds 64 reads (an even number) unless it is the wave's last one.
+    Batch cur, nxt;
+    batch(base, cur);
+    batch(base + batch_step, nxt);
+    int cnt = (int)(n_seq - base < 64 ? n_seq - base : 64);               // reads of the current batch
+    Rd A, B;
+    pick(cur, 0, A);
+    prefetch(A);
+    int l = 0;                                                            // A's index in the batch (even)
+    for (;;) {
+        const bool in_batch = l + 1 < cnt;                                // otherwise: an odd count, i.e. the wave's last batch ends with A
+        if (in_batch) pick(cur, l + 1, B);
+        else B = A;
+        prefetch(B);
+        process(A);
+        if (!in_batch) break;
+        l += 2;
+        bool more = true;
+        if (l >= cnt) {                                                   // the batch ends with B
+            base += batch_step;
+            if (base >= n_seq) more = false;
+            else {
+                cur = nxt;
+                batch(base + batch_step, nxt);
+                cnt = (int)(n_seq - base < 64 ? n_seq - base : 64);
+                l = 0;
+            }
+        }
+        if (more) pick(cur, l, A);
+        else A = B;
+        prefetch(A);
+        process(B);
+        if (!more) break;
     }
 }
 // (r03 built and measured a quarter-wave form -- 16 lanes per read, four reads per wave in lock-step, 143 / 160 lane utilisation,
@@ -954,10 +1040,9 @@ int dedupe_skip_bits(const uint32_t *codes_dev, const uint16_t *inval_dev, int64
     KMAP_CHECK_HIP(hipMemcpyAsync(&max_len, mx, 8, hipMemcpyDeviceToHost, st));
     KMAP_CHECK_HIP(hipStreamSynchronize(st));
     if (max_len > (unsigned long long)DS_CAP) return KMAP_OK;
-    const bool exact = k <= 8;                                            // 4^k bits fit the per-wave bitmap
-    const int bw = exact ? std::max(4, (int)((1u << (2 * k)) >> 5)) : DB_HASH_WORDS;
-    const int per_wave = (bw + (exact ? 0 : 2 * DB_MAXSTEPS + 2) + 3) & ~3;
-    const size_t lds = (size_t)DS_WAVES * per_wave * 4;
+    const bool exact = k >= 3 && k <= 8;                                  // 4^k bits fit the per-wave bitmap (and a k-mer has the 5 bits that pick the bit)
+    const int bw = exact ? std::max(4, (int)((1u << (2 * k)) >> 5)) : DB_HASH_WORDS;   // a power of two (the kernel ORs a word's offset into the bitmap's base)
+    const size_t lds = (size_t)DS_WAVES * bw * 4 + (exact ? 0 : (size_t)DS_WAVES * (DB_MAXSTEPS + 1) * 8);
     // persistent grid = exactly the blocks that are resident at once (one more would run as a second round)
     int dev = 0, cus = 0, per_cu = 0;
     KMAP_CHECK_HIP(hipGetDevice(&dev));

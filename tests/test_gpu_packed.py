@@ -331,6 +331,47 @@ def test_dedupe_long_reads_both_paths(env, max_len):
     ds.close()
 
 
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 7, 8, 9, 11, 16])
+def test_dedupe_fast_and_general_forms(env, k):
+    """The dedupe kernel's two forms side by side: ragged reads of 1 .. 230 positions (0 .. 4 steps of 64 windows: up to 3 steps run
+    the unclamped fast form, 4 the general one; reads of one window have no step at all), every start offset inside a skip word,
+    reads WITHOUT a separator between them (a window may run into the next read: it still belongs to the read it starts in), the
+    last reads right at the end of the arrays (their unclamped loads would pass the padding: general form), low-complexity reads
+    (most windows duplicates) and N bases.  k = 1, 2 take the hashed bitmap (a k-mer needs 5 bits to pick its bit in the exact
+    one), 3 .. 8 the exact one, above that the hashed one with its exact confirmation.  Counts == oracle."""
+    _ffi, DeviceCounts, DeviceSeq, O = env
+    rng = np.random.default_rng(4100 + k)
+    lens = rng.integers(1, 231, size=6000)
+    lens[-40:] = rng.integers(1, 60, size=40)                    # short reads at the very end: several frames inside the tail zone
+    parts, borders, pos = [], [], 0
+    for r, ln in enumerate(lens):
+        kind = r % 7
+        if kind == 0:
+            body = np.full(ln, rng.integers(0, 4), np.uint8)                                     # homopolymer
+        elif kind == 1:
+            body = np.resize(rng.integers(0, 4, size=rng.integers(2, 6)).astype(np.uint8), ln)   # tandem repeat
+        else:
+            body = rng.integers(0, 4, size=ln).astype(np.uint8)
+            if kind == 2:
+                body[rng.random(ln) < 0.03] = 255
+        parts.append(body)
+        borders.append((pos, pos + ln))
+        pos += ln
+        if r % 3:                                                # two reads in three end in a separator, the third touches the next read
+            parts.append(np.array([255], np.uint8))
+            pos += 1
+    seq = np.concatenate(parts)
+    borders = np.array(borders, np.int64)
+    ds, dc = DeviceSeq(seq, borders), DeviceCounts()
+    ds.count(dc, k, dedupe=True, merge_revcom=False)
+    u, c = dc.fetch()
+    ou, oc = O.count_kmers(seq, borders, k, rep_mode=False, revcom_mode=False)
+    np.testing.assert_array_equal(u, ou)
+    np.testing.assert_array_equal(c, oc)
+    dc.close()
+    ds.close()
+
+
 def test_bitsliced_scan_and_mask_fuzz_vs_oracle(env):
     """Seeded fuzz of the bit-sliced window test (k <= 16) against the oracle: random k, radius (0 .. beyond k), strand flag,
     consensus (random, poly-A, poly-T = the all-ones hash of invalid windows), N rate, read lengths 0 .. 1500 (short-read path,
