@@ -486,82 +486,97 @@ __global__ __launch_bounds__(HR_TPB) void scan_hits_reads_kernel(HrCtx c, const 
 // reads at 57 % issue utilisation -- instruction-bound as much as latency-bound: two chunks of six word loads, mask building and
 // the hit loop ran once for the counts and again for the positions.)
 constexpr int HF_WORDS = 12, HF_KEEP = 4, HF_CURSORS = 64;
+// (r04, second pass: 1010 vector + 490 scalar instructions per wave at C3, issue utilisation 0.85.  The hit loop popped "the earliest
+// hit of six 64-bit words" through a chain of compares and selects per iteration -- and the compiler turned that loop, divergent
+// through its `continue`s, into three nested ones glued together by dozens of mask operations.  Now: one plain loop per 64-bit
+// word (ascending order as before), the distance from a per-read code pointer + 32-bit offsets, and the wave takes the form with
+// NQ = 3 words (192 positions) when all its reads fit: half the loads, masks and loops for 150-bp reads.)
 typedef uint32_t hf_u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+template <int NQ>
 struct HfRead {
-    uint64_t q[HF_WORDS / 2];            // the read's hit bits, position p of the word stream in bit 63 - (p & 63) of q[p >> 6]
+    uint64_t q[NQ];                      // the read's hit bits, position p of the word stream in bit 63 - (p & 63) of q[p >> 6]
     int keep[HF_KEEP];                   // first positions (relative to the read) at the minimum, ascending
     int a_off;                           // bit offset of the read's first position in the word stream
-    int64_t word0;                       // absolute position of the stream's bit 0
+    const uint32_t *cb;                  // codes / invalid flags of the group holding the stream's bit 0
+    const uint16_t *ib;
 };
+__device__ __forceinline__ int hf_words(const HrRead &r) { return (int)(((r.st & 31) + r.stop + 31) >> 5); }
 __device__ __forceinline__ bool hf_applies(const HrRead &r) {
-    const int end = (int)(r.st & 31) + (int)r.stop;
-    return !r.quirk && r.stop > 0 && r.stop <= 32 * HF_WORDS && ((end + 31) >> 5) <= HF_WORDS;
+    return !r.quirk && r.stop > 0 && r.stop <= 32 * HF_WORDS && hf_words(r) <= HF_WORDS;
 }
-// pops the earliest hit of the six words (0 words: returns false); rel = its position in the word stream
-__device__ __forceinline__ bool hf_pop(uint64_t (&q)[HF_WORDS / 2], int &rel) {
-    int sel = -1;
-    uint64_t cur = 0;
-#pragma unroll
-    for (int t = HF_WORDS / 2 - 1; t >= 0; --t)
-        if (q[t]) { sel = t; cur = q[t]; }
-    if (sel < 0) return false;
-    const int tb = 63 - __builtin_clzll(cur);
-    const uint64_t clr = ~(1ull << tb);
-#pragma unroll
-    for (int t = 0; t < HF_WORDS / 2; ++t) q[t] &= (sel == t) ? clr : ~0ull;
-    rel = 64 * sel + 63 - tb;
-    return true;
-}
+// distance of the window `rel` positions into the word stream (hr_dist with 32-bit offsets from the read's pointers)
 template <bool CHECK_INVALID>
-__device__ __forceinline__ void hf_count(const HrCtx &c, HrRead &r, HfRead &f, bool active) {
+__device__ __forceinline__ int hf_dist(const HrCtx &c, const uint32_t *__restrict__ cb, const uint16_t *__restrict__ ib, int rel) {
+    const uint32_t g = (uint32_t)rel >> 4;
+    const int i = rel & 15;
+    const uint32_t hi = cb[g], lo = cb[g + 1];
+    const uint32_t top = i ? __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * i) : hi;
+    uint32_t h = (top >> (32 - 2 * c.k)) & c.km;
+    if (CHECK_INVALID) {
+        const uint64_t m = ((uint64_t)ib[g] << 32) | ((uint64_t)ib[g + 1] << 16) | ib[g + 2];
+        if (((m >> (48 - i - c.k)) & ((1ull << c.k) - 1ull)) != 0) h = c.km;
+    }
+    int d = popc2(h ^ c.cons);
+    if (c.revcom) {
+        const int d2 = popc2(h ^ c.rcc);
+        d = d2 < d ? d2 : d;
+    }
+    return d;
+}
+template <int NQ, bool CHECK_INVALID>
+__device__ __forceinline__ void hf_count(const HrCtx &c, HrRead &r, HfRead<NQ> &f, bool active) {
     f.a_off = (int)(r.st & 31);
-    f.word0 = (r.st >> 5) << 5;
+    f.cb = c.codes + ((r.st >> 5) << 1);
+    f.ib = c.inval + ((r.st >> 5) << 1);
     const int end = f.a_off + (int)r.stop;
     const int nw = active ? (end + 31) >> 5 : 0;
     const uint32_t *hw = c.hit32 + (r.st >> 5);
-    uint32_t x[HF_WORDS];
+    uint32_t x[2 * NQ];
 #pragma unroll
-    for (int t = 0; t < HF_WORDS / 2; ++t) {   // word pairs behind the read's last word repeat its last pair (inside the array)
+    for (int t = 0; t < NQ; ++t) {          // word pairs behind the read's last word repeat its last pair (inside the array)
         const int at = (2 * t < nw) ? 2 * t : (nw > 0 ? (nw - 1) & ~1 : 0);
         const hf_u32x2 v = *reinterpret_cast<const hf_u32x2 *>(hw + at);
         x[2 * t] = v.x;
         x[2 * t + 1] = v.y;
     }
 #pragma unroll
-    for (int j = 0; j < HF_WORDS; ++j) {
+    for (int j = 0; j < 2 * NQ; ++j) {
         uint32_t m = j < nw ? ~0u : 0u;
         if (j == 0) m &= ~0u >> f.a_off;
         if (j == nw - 1) m &= ~0u << (32 * nw - end);
         x[j] &= m;
     }
 #pragma unroll
-    for (int t = 0; t < HF_WORDS / 2; ++t) f.q[t] = ((uint64_t)x[2 * t] << 32) | x[2 * t + 1];
-    uint64_t w[HF_WORDS / 2];
-#pragma unroll
-    for (int t = 0; t < HF_WORDS / 2; ++t) w[t] = f.q[t];
+    for (int t = 0; t < NQ; ++t) f.q[t] = ((uint64_t)x[2 * t] << 32) | x[2 * t + 1];
 #pragma unroll
     for (int t = 0; t < HF_KEEP; ++t) f.keep[t] = 0;
-    int rel;
-    while (hf_pop(w, rel)) {                // a wave runs this as often as its busiest read has hits
-        const int d = hr_dist<CHECK_INVALID>(c.codes, c.inval, f.word0 + rel, c.k, c.km, c.cons, c.rcc, c.revcom);
-        const int p = rel - f.a_off;
-        if (d < r.best) {
-            r.mixed = r.mixed || r.count > 0;
-            r.best = d;
-            r.count = 1;
-            f.keep[0] = p;
-        } else if (d == r.best) {
 #pragma unroll
-            for (int t = 1; t < HF_KEEP; ++t)
-                if (r.count == t) f.keep[t] = p;
-            ++r.count;
-        } else {
-            r.mixed = true;
+    for (int t = 0; t < NQ; ++t) {
+        uint64_t w = f.q[t];
+        while (w) {                         // a wave runs this as often as its busiest read has hits in this word
+            const int lz = __builtin_clzll(w);
+            w &= ~(0x8000000000000000ull >> lz);
+            const int rel = 64 * t + lz;
+            const int d = hf_dist<CHECK_INVALID>(c, f.cb, f.ib, rel);
+            const int p = rel - f.a_off;
+            if (d < r.best) {
+                r.mixed = r.mixed || r.count > 0;
+                r.best = d;
+                r.count = 1;
+                f.keep[0] = p;
+            } else if (d == r.best) {
+#pragma unroll
+                for (int u = 1; u < HF_KEEP; ++u)
+                    if (r.count == u) f.keep[u] = p;
+                ++r.count;
+            } else {
+                r.mixed = true;
+            }
         }
     }
 }
-template <bool CHECK_INVALID>
-__device__ __forceinline__ void hf_write(const HrCtx &c, const HrRead &r, HfRead &f, uint64_t base, int32_t *__restrict__ pos_out, uint64_t cap) {
+template <int NQ, bool CHECK_INVALID>
+__device__ __forceinline__ void hf_write(const HrCtx &c, const HrRead &r, const HfRead<NQ> &f, uint64_t base, int32_t *__restrict__ pos_out, uint64_t cap) {
     if (r.count == 0) return;
     if (r.count <= HF_KEEP) {               // the positions are in registers
 #pragma unroll
@@ -569,11 +584,17 @@ __device__ __forceinline__ void hf_write(const HrCtx &c, const HrRead &r, HfRead
             if (t < r.count && base + t < cap) pos_out[base + t] = f.keep[t];
         return;
     }
-    int rel;
-    while (hf_pop(f.q, rel)) {              // many hits (or several distances): walk the saved words again
-        if (r.mixed && hr_dist<CHECK_INVALID>(c.codes, c.inval, f.word0 + rel, c.k, c.km, c.cons, c.rcc, c.revcom) != r.best) continue;
-        if (base < cap) pos_out[base] = rel - f.a_off;
-        ++base;
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {          // many hits (or several distances): walk the saved words again
+        uint64_t w = f.q[t];
+        while (w) {
+            const int lz = __builtin_clzll(w);
+            w &= ~(0x8000000000000000ull >> lz);
+            const int rel = 64 * t + lz;
+            if (r.mixed && hf_dist<CHECK_INVALID>(c, f.cb, f.ib, rel) != r.best) continue;
+            if (base < cap) pos_out[base] = rel - f.a_off;
+            ++base;
+        }
     }
 }
 
@@ -590,8 +611,11 @@ __global__ __launch_bounds__(HR_TPB) void scan_hits_reads_fused_kernel(HrCtx c, 
     hr_setup(c, borders, s, n_seq, r);
     const bool fast = hf_applies(r);
     const bool general = !fast && (r.stop > 0 || r.quirk);                  // long reads, the negative-slice quirk
-    HfRead f;
-    hf_count<CHECK_INVALID>(c, r, f, fast);
+    const bool narrow = __all(!fast || hf_words(r) <= 6);                   // wave-uniform: every short read of the wave fits three 64-bit words
+    HfRead<3> f3;
+    HfRead<HF_WORDS / 2> f6;
+    if (narrow) hf_count<3, CHECK_INVALID>(c, r, f3, fast);
+    else hf_count<HF_WORDS / 2, CHECK_INVALID>(c, r, f6, fast);
     if (__any(general)) {                                                   // wave-uniform: the general form for the lanes that need it
         HrRead g = r;
         if (!general) { g.stop = 0; g.quirk = false; }
@@ -621,7 +645,10 @@ __global__ __launch_bounds__(HR_TPB) void scan_hits_reads_fused_kernel(HrCtx c, 
     }
     __syncthreads();
     const uint64_t base = s_base + in_block;
-    if (fast) hf_write<CHECK_INVALID>(c, r, f, base, tmp_pos, cap);         // writes behind `cap` are dropped (the caller falls back)
+    if (fast) {                                                             // writes behind `cap` are dropped (the caller falls back)
+        if (narrow) hf_write<3, CHECK_INVALID>(c, r, f3, base, tmp_pos, cap);
+        else hf_write<HF_WORDS / 2, CHECK_INVALID>(c, r, f6, base, tmp_pos, cap);
+    }
     if (__any(general)) {
         HrRead g = r;
         if (!general) { g.count = 0; g.stop = 0; g.quirk = false; }
