@@ -228,6 +228,7 @@ struct HrCtx {
     const uint32_t *__restrict__ codes;
     const uint16_t *__restrict__ inval;
     int64_t n;
+    int64_t n_alloc;                     // groups the code / flag arrays hold (kmap_packed_groups(n))
     int k, revcom, d_inv, radius;
     uint32_t km, cons, rcc;
 };
@@ -497,19 +498,24 @@ struct HfRead {
     uint64_t q[NQ];                      // the read's hit bits, position p of the word stream in bit 63 - (p & 63) of q[p >> 6]
     int keep[HF_KEEP];                   // first positions (relative to the read) at the minimum, ascending
     int a_off;                           // bit offset of the read's first position in the word stream
-    const uint32_t *cb;                  // codes / invalid flags of the group holding the stream's bit 0
-    const uint16_t *ib;
+    uint32_t row;                        // index (dwords) into the block's code rows of the group holding the stream's bit 0
+    const uint16_t *ib;                  // invalid flags of that group
 };
+template <int NQ>
+constexpr int hf_row_words() { return 4 * NQ + 1; }   // code words of 64 NQ positions + the next group (a window runs into it)
 __device__ __forceinline__ int hf_words(const HrRead &r) { return (int)(((r.st & 31) + r.stop + 31) >> 5); }
 __device__ __forceinline__ bool hf_applies(const HrRead &r) {
     return !r.quirk && r.stop > 0 && r.stop <= 32 * HF_WORDS && hf_words(r) <= HF_WORDS;
 }
-// distance of the window `rel` positions into the word stream (hr_dist with 32-bit offsets from the read's pointers)
+// distance of the window `rel` positions into the word stream: hr_dist on the read's code words in LDS.  (From global memory every
+// iteration of the divergent hit loops began with a dependent load of two code words -- ~5 exposed round trips per wave, 75 % of
+// the wave-cycles waiting.  The read's 13 / 25 code words now arrive in the same round trip as its hit words and are parked in a
+// per-lane LDS row: odd row length, no bank conflicts between the lanes' rows.)
 template <bool CHECK_INVALID>
-__device__ __forceinline__ int hf_dist(const HrCtx &c, const uint32_t *__restrict__ cb, const uint16_t *__restrict__ ib, int rel) {
+__device__ __forceinline__ int hf_dist(const HrCtx &c, const uint32_t *code_rows, uint32_t row, const uint16_t *__restrict__ ib, int rel) {
     const uint32_t g = (uint32_t)rel >> 4;
     const int i = rel & 15;
-    const uint32_t hi = cb[g], lo = cb[g + 1];
+    const uint32_t hi = code_rows[row + g], lo = code_rows[row + g + 1];
     const uint32_t top = i ? __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * i) : hi;
     uint32_t h = (top >> (32 - 2 * c.k)) & c.km;
     if (CHECK_INVALID) {
@@ -524,9 +530,9 @@ __device__ __forceinline__ int hf_dist(const HrCtx &c, const uint32_t *__restric
     return d;
 }
 template <int NQ, bool CHECK_INVALID>
-__device__ __forceinline__ void hf_count(const HrCtx &c, HrRead &r, HfRead<NQ> &f, bool active) {
+__device__ __forceinline__ void hf_count(const HrCtx &c, HrRead &r, HfRead<NQ> &f, bool active, uint32_t *code_rows) {
+    constexpr int NG = hf_row_words<NQ>();
     f.a_off = (int)(r.st & 31);
-    f.cb = c.codes + ((r.st >> 5) << 1);
     f.ib = c.inval + ((r.st >> 5) << 1);
     const int end = f.a_off + (int)r.stop;
     const int nw = active ? (end + 31) >> 5 : 0;
@@ -538,6 +544,25 @@ __device__ __forceinline__ void hf_count(const HrCtx &c, HrRead &r, HfRead<NQ> &
         const hf_u32x2 v = *reinterpret_cast<const hf_u32x2 *>(hw + at);
         x[2 * t] = v.x;
         x[2 * t + 1] = v.y;
+    }
+    {   // the read's code words: NG consecutive groups from the one of the stream's bit 0, moved back where they would pass the end
+        // of the array (the caller guarantees n_alloc >= NG); same round trip as the hit words above
+        const int64_t g0 = active ? (r.st >> 5) << 1 : 0;
+        const int64_t gb = g0 + NG <= c.n_alloc ? g0 : c.n_alloc - NG;
+        typedef uint32_t hf_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+        // a wave's rows start at the wave's share of the block's array (the waves of a block may run different NQ)
+        const uint32_t row0 = (threadIdx.x >> 6) * (64u * hf_row_words<HF_WORDS / 2>()) + (threadIdx.x & 63u) * (uint32_t)NG;
+        uint32_t *my = code_rows + row0;
+        hf_u32x4 v[NQ];
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) v[t] = *reinterpret_cast<const hf_u32x4 *>(c.codes + gb + 4 * t);
+        const uint32_t last = c.codes[gb + 4 * NQ];
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) {
+            my[4 * t] = v[t].x; my[4 * t + 1] = v[t].y; my[4 * t + 2] = v[t].z; my[4 * t + 3] = v[t].w;
+        }
+        my[4 * NQ] = last;
+        f.row = row0 + (uint32_t)(g0 - gb);
     }
 #pragma unroll
     for (int j = 0; j < 2 * NQ; ++j) {
@@ -557,7 +582,7 @@ __device__ __forceinline__ void hf_count(const HrCtx &c, HrRead &r, HfRead<NQ> &
             const int lz = __builtin_clzll(w);
             w &= ~(0x8000000000000000ull >> lz);
             const int rel = 64 * t + lz;
-            const int d = hf_dist<CHECK_INVALID>(c, f.cb, f.ib, rel);
+            const int d = hf_dist<CHECK_INVALID>(c, code_rows, f.row, f.ib, rel);
             const int p = rel - f.a_off;
             if (d < r.best) {
                 r.mixed = r.mixed || r.count > 0;
@@ -576,7 +601,8 @@ __device__ __forceinline__ void hf_count(const HrCtx &c, HrRead &r, HfRead<NQ> &
     }
 }
 template <int NQ, bool CHECK_INVALID>
-__device__ __forceinline__ void hf_write(const HrCtx &c, const HrRead &r, const HfRead<NQ> &f, uint64_t base, int32_t *__restrict__ pos_out, uint64_t cap) {
+__device__ __forceinline__ void hf_write(const HrCtx &c, const HrRead &r, const HfRead<NQ> &f, uint64_t base, int32_t *__restrict__ pos_out, uint64_t cap,
+                                         const uint32_t *code_rows) {
     if (r.count == 0) return;
     if (r.count <= HF_KEEP) {               // the positions are in registers
 #pragma unroll
@@ -591,7 +617,7 @@ __device__ __forceinline__ void hf_write(const HrCtx &c, const HrRead &r, const 
             const int lz = __builtin_clzll(w);
             w &= ~(0x8000000000000000ull >> lz);
             const int rel = 64 * t + lz;
-            if (r.mixed && hf_dist<CHECK_INVALID>(c, f.cb, f.ib, rel) != r.best) continue;
+            if (r.mixed && hf_dist<CHECK_INVALID>(c, code_rows, f.row, f.ib, rel) != r.best) continue;
             if (base < cap) pos_out[base] = rel - f.a_off;
             ++base;
         }
@@ -606,6 +632,7 @@ __global__ __launch_bounds__(HR_TPB) void scan_hits_reads_fused_kernel(HrCtx c, 
                                                                        uint64_t cap) {
     __shared__ unsigned int s_wave[HR_TPB / 64];
     __shared__ unsigned long long s_base;
+    __shared__ uint32_t s_codes[HR_TPB * hf_row_words<HF_WORDS / 2>()];     // a row of code words per thread (25.6 KB)
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     HrRead r;
     hr_setup(c, borders, s, n_seq, r);
@@ -614,8 +641,8 @@ __global__ __launch_bounds__(HR_TPB) void scan_hits_reads_fused_kernel(HrCtx c, 
     const bool narrow = __all(!fast || hf_words(r) <= 6);                   // wave-uniform: every short read of the wave fits three 64-bit words
     HfRead<3> f3;
     HfRead<HF_WORDS / 2> f6;
-    if (narrow) hf_count<3, CHECK_INVALID>(c, r, f3, fast);
-    else hf_count<HF_WORDS / 2, CHECK_INVALID>(c, r, f6, fast);
+    if (narrow) hf_count<3, CHECK_INVALID>(c, r, f3, fast, s_codes);
+    else hf_count<HF_WORDS / 2, CHECK_INVALID>(c, r, f6, fast, s_codes);
     if (__any(general)) {                                                   // wave-uniform: the general form for the lanes that need it
         HrRead g = r;
         if (!general) { g.stop = 0; g.quirk = false; }
@@ -646,8 +673,8 @@ __global__ __launch_bounds__(HR_TPB) void scan_hits_reads_fused_kernel(HrCtx c, 
     __syncthreads();
     const uint64_t base = s_base + in_block;
     if (fast) {                                                             // writes behind `cap` are dropped (the caller falls back)
-        if (narrow) hf_write<3, CHECK_INVALID>(c, r, f3, base, tmp_pos, cap);
-        else hf_write<HF_WORDS / 2, CHECK_INVALID>(c, r, f6, base, tmp_pos, cap);
+        if (narrow) hf_write<3, CHECK_INVALID>(c, r, f3, base, tmp_pos, cap, s_codes);
+        else hf_write<HF_WORDS / 2, CHECK_INVALID>(c, r, f6, base, tmp_pos, cap, s_codes);
     }
     if (__any(general)) {
         HrRead g = r;
@@ -727,7 +754,7 @@ int kmap_bitslice_hits(const uint32_t *planes, const uint16_t *inval, int64_t n,
 static HrCtx make_ctx(const uint32_t *hit32, const uint32_t *codes, const uint16_t *inval, int64_t n, int k, uint64_t cons, int revcom,
                       int radius) {
     HrCtx c;
-    c.hit32 = hit32; c.codes = codes; c.inval = inval; c.n = n; c.k = k; c.revcom = revcom; c.radius = radius;
+    c.hit32 = hit32; c.codes = codes; c.inval = inval; c.n = n; c.n_alloc = kmap_packed_groups(n); c.k = k; c.revcom = revcom; c.radius = radius;
     c.km = low_mask<uint32_t>(k);
     c.cons = (uint32_t)cons & c.km;
     c.rcc = rc_host(c.cons, k);
@@ -765,6 +792,17 @@ int kmap_bitslice_scan_reads_all(const uint32_t *hit32, const uint32_t *codes, c
     const HrCtx c = make_ctx(hit32, codes, inval, n, k, cons, revcom, radius);
     const int64_t nblk = (n_seq + HR_TPB - 1) / HR_TPB;
     const bool chk = c.d_inv <= radius;
+    if (c.n_alloc < hf_row_words<HF_WORDS / 2>()) {                          // an input shorter than one row of code words: the two-pass form
+        KMAP_TRY(kmap_bitslice_scan_reads(false, hit32, codes, inval, n, borders, n_seq, k, cons, revcom, radius, s, st));
+        KMAP_TRY(exclusive_scan_u32(reinterpret_cast<uint32_t *>(s->offs + nblk + 1), nblk, s->offs, st));
+        uint64_t tot = 0;
+        KMAP_CHECK_HIP(hipMemcpyAsync(&tot, s->offs + nblk, 8, hipMemcpyDeviceToHost, st));
+        KMAP_CHECK_HIP(hipStreamSynchronize(st));
+        KMAP_TRY(kmap_scan_reserve_pos(s, tot));
+        *total_out = tot;
+        if (tot == 0) return KMAP_OK;
+        return kmap_bitslice_scan_reads(true, hit32, codes, inval, n, borders, n_seq, k, cons, revcom, radius, s, st);
+    }
     // s->offs ((n_seq + 1) uint64 + 128 B) holds: block offsets uint64[nblk + 1] | block sums uint32[nblk] (padded to 8 B) |
     // unordered block bases uint64[nblk] | cursor uint64
     uint64_t *boffs = s->offs;

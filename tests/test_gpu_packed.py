@@ -118,6 +118,37 @@ def test_packed_mask_negative_radius_matches_nothing(env):
         ds.close()
 
 
+def test_packed_scan_tiny_inputs(env):
+    """Inputs shorter than one row of code words of the one-pass scan kernel (25 groups = 400 positions): the two-pass form runs;
+    and inputs just above that size, whose reads all sit in the zone where the kernel moves its code-word row back from the end of
+    the arrays.  Hits, positions == oracle."""
+    _ffi, _, DeviceSeq, O = env
+    rng = np.random.default_rng(77)
+    for total, k, r in ((40, 4, 1), (200, 6, 2), (330, 8, 3), (420, 8, 3), (700, 12, 5), (1500, 14, 6)):
+        parts, borders, st = [], [], 0
+        while st < total:
+            L = int(rng.integers(1, 90))
+            parts += [rng.integers(0, 4, size=L).astype(np.uint8), np.array([255], np.uint8)]
+            borders.append((st, st + L))
+            st += L + 1
+        seq, borders = np.concatenate(parts), np.array(borders, np.int64)
+        ds = DeviceSeq(seq, borders)
+        a, b = borders[len(borders) // 2]
+        src = seq[a:b]
+        cons = int(O.comp_kmer_hash(src, k)[0]) if b - a >= k else 5          # the k-mer a middle read starts with: at least one exact hit
+        for cc in (cons, 0):
+            for revcom in (True, False):
+                hits, pos = ds.scan(k, cc, r, revcom)
+                buf, md, off = np.empty(4096, np.int32), C.c_int(0), 0
+                for i, (x, y) in enumerate(borders):
+                    m = O.lib().ko_scan_read(np.ascontiguousarray(seq[x:y]), y - x, k, cc, r, int(revcom), buf, C.byref(md))
+                    assert hits[i] == m, (total, k, i, hits[i], m)
+                    np.testing.assert_array_equal(pos[off:off + m], buf[:m])
+                    off += m
+                assert off == len(pos)
+        ds.close()
+
+
 def test_packed_mask_many_consensuses(env):
     _ffi, _, DeviceSeq, O = env
     rng = np.random.default_rng(13)
