@@ -81,6 +81,10 @@ int kmap_allow_lds(const void *kernel, int bytes) {
     std::lock_guard<std::mutex> lock(mu);
     int &have = done[std::make_pair(kernel, dev)];
     if (have < bytes) {
+        // the library is built for gfx950 (160 KiB of LDS per workgroup); say so instead of failing inside the launch elsewhere
+        int limit = 0;
+        KMAP_CHECK_HIP(hipDeviceGetAttribute(&limit, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+        KMAP_REQUIRE(bytes <= limit, "a kernel needs %d bytes of LDS per workgroup, device %d offers %d (this library targets MI355X / gfx950)", bytes, dev, limit);
         KMAP_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         have = bytes;
     }

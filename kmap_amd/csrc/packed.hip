@@ -211,7 +211,9 @@ __global__ __launch_bounds__(LDSMODE ? HP_TPB : BLK) void hist_packed_kernel(con
                 // no branch, no exec mask per window (a pass was bound by instruction issue: ~10 instructions per window, two of
                 // them scalar): a window that is invalid (sign-extended flag bit ORed in) or belongs to another pass's bin range
                 // lands, by one unsigned min, in the lane's private bin behind the table
-                uint32_t a = ((top >> sh) - b0) | (uint32_t)__builtin_amdgcn_sbfe((int)bad16, 15 - i, 1);
+                // (key ^ b0) | flag in one v_bitop3: b0 is a multiple of the 32 768 bins of a pass, so inside the pass's range the
+                // XOR is the subtraction, and outside it leaves a high bit set
+                uint32_t a = __builtin_amdgcn_bitop3_b32(top >> sh, b0, (uint32_t)__builtin_amdgcn_sbfe((int)bad16, 15 - i, 1), 0xBE);
                 a = a < dummy ? a : dummy;
                 atomicAdd(&lb[a], 1u);
             }
@@ -560,6 +562,10 @@ __global__ __launch_bounds__(KMAP_WAVE *DS_WAVES) void dedupe_bitmap_packed_kern
         for (int t = lane; t < bw / 4; t += 64) b4[t] = zero;
         __builtin_amdgcn_wave_barrier();
     };
+    // (Measured and dropped in r04: three register sets with the loads two reads ahead -- 1.30 against 1.27 ms, the waits are not
+    // on the window loads; and, on top of that, the next read's bitmap words / bits / masks computed between the issue of this
+    // read's LDS atomics and the use of their results -- 1.41 ms: the prepared state travels through 18 more registers and the
+    // compiler's copies of it cost more than the LDS round trip they hide.)
     // Two-deep software pipeline over the wave's reads, unrolled by two (reads alternate between A and B: no register copies from
     // "next" to "current"): while a read is inserted, the window loads of the next one and the border load of the next BATCH are
     // in flight.  A batch holds 64 reads (an even number) unless it is the wave's last one.
