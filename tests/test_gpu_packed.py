@@ -362,7 +362,7 @@ def test_dedupe_long_reads_both_paths(env, max_len):
     ds.close()
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 7, 8, 9, 11, 16])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 16])
 def test_dedupe_fast_and_general_forms(env, k):
     """The dedupe kernel's two forms side by side: ragged reads of 1 .. 230 positions (0 .. 4 steps of 64 windows: up to 3 steps run
     the unclamped fast form, 4 the general one; reads of one window have no step at all), every start offset inside a skip word,
