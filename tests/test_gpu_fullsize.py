@@ -139,14 +139,23 @@ def test_c3_scan_full_size(c3_reads, c3_dev):
         assert _check_scan(seq, borders, hits, pos, len(conseq), int(kmer2hash(conseq)), radius, sample) > 3000
 
 
-def test_c5_scan_full_size():
-    """BASELINE config C5: k = 14, max_ham_dist = 5 Hamming-ball scan over 50 M x 300 bp reads (1.505e10 positions)."""
+C5_MOTIF = "AGGACCTACGTACA"
+
+
+@pytest.fixture(scope="module")
+def c5_reads():
     from kmap_amd import synth
+    seq, borders = synth.synth_reads(50_000_000, 300, 3, motifs=(C5_MOTIF, "AATCGATAGC"))
+    assert len(seq) == 15_050_000_000
+    return seq, borders
+
+
+def test_c5_scan_full_size(c5_reads):
+    """BASELINE config C5: k = 14, max_ham_dist = 5 Hamming-ball scan over 50 M x 300 bp reads (1.505e10 positions)."""
     from kmap_amd.kmer_count import kmer2hash
     from kmap_amd.motif_discovery import DeviceSeq
-    motif = "AGGACCTACGTACA"
-    seq, borders = synth.synth_reads(50_000_000, 300, 3, motifs=(motif, "AATCGATAGC"))
-    assert len(seq) == 15_050_000_000
+    motif = C5_MOTIF
+    seq, borders = c5_reads
     ds = DeviceSeq(seq, borders)
     hits, pos = ds.scan(14, kmer2hash(motif), 5, True)
     ds.close()
@@ -155,6 +164,38 @@ def test_c5_scan_full_size():
     rng = np.random.default_rng(3)
     sample = np.concatenate([[0, len(borders) - 1], rng.integers(0, len(borders), size=12_000)])
     assert _check_scan(seq, borders, hits, pos, 14, int(kmer2hash(motif)), 5, sample) > 4000
+
+
+def test_c5_counting_beyond_2_32_positions(c5_reads):
+    """Counting with per-read dedupe on the C5 reads: 1.505e10 positions, i.e. position, group and skip-word indices beyond 2^32 /
+    2^28 in the dedupe kernel's batches, the histogram passes and the partitioned k = 14 count (64-bit stream cursors).  The count
+    tables are linear in the reads (dedupe works per read, the revcom merge is linear): whole == sum over three uneven read ranges,
+    each small enough for 32-bit positions; closed-form total without dedupe."""
+    from kmap_amd.kmer_count import DeviceCounts
+    from kmap_amd.motif_discovery import DeviceSeq
+    seq, borders = c5_reads
+    n_reads = len(borders)
+    dc = DeviceCounts()
+    ds = DeviceSeq(seq, borders)
+    full = {}
+    for k in (8, 14):
+        ds.count(dc, k, dedupe=True, merge_revcom=True)
+        full[k] = _dense(*dc.fetch(), k)
+    ds.count(dc, 8, dedupe=False, merge_revcom=False)
+    assert int(dc.fetch()[1].sum(dtype=np.int64)) == n_reads * (300 - 8 + 1)        # no N in the synthetic reads
+    ds.close()
+    cuts = [0, 13_000_001, 31_234_567, n_reads]
+    acc = {k: np.zeros(4 ** k, np.int64) for k in (8, 14)}
+    for a, b in zip(cuts, cuts[1:]):
+        s, bd = _slice_reads(seq, borders, a, b)
+        part = DeviceSeq(s, bd)
+        for k in (8, 14):
+            part.count(dc, k, dedupe=True, merge_revcom=True)
+            acc[k] += _dense(*dc.fetch(), k)
+        part.close()
+    dc.close()
+    for k in (8, 14):
+        np.testing.assert_array_equal(acc[k], full[k])
 
 
 def _pipeline_like_sample(n, seed):
