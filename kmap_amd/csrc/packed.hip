@@ -1036,6 +1036,8 @@ int dedupe_skip_bits(const uint32_t *codes_dev, const uint16_t *inval_dev, int64
                      hipStream_t st, uint32_t **skip_out) {
     *skip_out = nullptr;
     if (n_seq == 0 || n == 0) return KMAP_OK;
+    // arrays shorter than one read frame of the kernel's unclamped prefetch (13 groups = 208 positions): the hash-array path
+    if (((n + 15) >> 4) + 2 <= DB_TAIL_GROUPS) return KMAP_OK;
     const size_t words = (size_t)((n + 31) >> 5) + 4;
     uint32_t *skip = nullptr;
     KMAP_TRY(kmap_scratch((void **)&skip, words * 4 + 16, st, KMAP_SLOT_C));

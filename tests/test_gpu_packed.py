@@ -403,6 +403,33 @@ def test_dedupe_fast_and_general_forms(env, k):
     ds.close()
 
 
+def test_dedupe_tiny_arrays(env):
+    """Counting with per-read dedupe on arrays around the size of one read frame of the dedupe kernel's unclamped loads (13 groups =
+    208 positions): shorter arrays take the hash-array path, the first longer ones run the kernel with every read in its tail zone."""
+    _ffi, DeviceCounts, DeviceSeq, O = env
+    rng = np.random.default_rng(8)
+    for total in (3, 17, 40, 150, 175, 176, 177, 191, 192, 193, 207, 208, 209, 230, 400):
+        parts, borders, pos = [], [], 0
+        while pos < total:
+            ln = int(min(total - pos, rng.integers(1, 70)))
+            parts.append(np.resize(rng.integers(0, 4, size=rng.integers(1, 5)).astype(np.uint8), ln))   # short tandem repeats: duplicates
+            borders.append((pos, pos + ln))
+            pos += ln
+            if pos < total:
+                parts.append(np.array([255], np.uint8))
+                pos += 1
+        seq, bd = np.concatenate(parts), np.array(borders, np.int64)
+        ds, dc = DeviceSeq(seq, bd), DeviceCounts()
+        for k in (2, 4, 8, 9):
+            ds.count(dc, k, dedupe=True, merge_revcom=False)
+            u, c = dc.fetch()
+            ou, oc = O.count_kmers(seq, bd, k, rep_mode=False, revcom_mode=False)
+            np.testing.assert_array_equal(u, ou, err_msg=f"n={len(seq)} k={k}")
+            np.testing.assert_array_equal(c, oc, err_msg=f"n={len(seq)} k={k}")
+        dc.close()
+        ds.close()
+
+
 def test_bitsliced_scan_and_mask_fuzz_vs_oracle(env):
     """Seeded fuzz of the bit-sliced window test (k <= 16) against the oracle: random k, radius (0 .. beyond k), strand flag,
     consensus (random, poly-A, poly-T = the all-ones hash of invalid windows), N rate, read lengths 0 .. 1500 (short-read path,
