@@ -280,10 +280,18 @@ __global__ __launch_bounds__(KMAP_WAVE *SEL_WAVES) void knn_select_kernel(const 
     const int nsteps = (int)((n + 1023) >> 10);                             // 1024 bytes per wave and step
     const int nfull = (int)(n >> 10);
     const int lane_chunks = (int)(ldd >> 4);                                // 16-byte chunks inside the row's pitch
+    // Both passes keep the chunks of the next TWO steps in flight (unconditional loads on clamped chunk indices; r04: one
+    // dependent 16-byte load per step and wave, 49 exposed round trips per pass, was the whole kernel -- 71 % of the wave-cycles
+    // waiting at 35 % issue utilisation).
+    const int last_chunk = lane_chunks - 1;
+    auto chunk_at = [&](int s) { const int c = s * 64 + lane; return row4[c < last_chunk ? c : last_chunk]; };
+    uint4 pf0 = chunk_at(0), pf1 = chunk_at(1);
     for (int s = 0; s < nsteps; ++s) {
         const int chunk = s * 64 + lane;
-        uint4 w = make_uint4(~0u, ~0u, ~0u, ~0u);
-        if (chunk < lane_chunks) w = row4[chunk];
+        uint4 w = pf0;
+        pf0 = pf1;
+        pf1 = chunk_at(s + 2);
+        if (chunk >= lane_chunks) w = make_uint4(~0u, ~0u, ~0u, ~0u);
         const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
         if (s < nfull) {                                                    // wave-uniform: all 1024 entries exist
 #pragma unroll
@@ -333,10 +341,14 @@ __global__ __launch_bounds__(KMAP_WAVE *SEL_WAVES) void knn_select_kernel(const 
     uint32_t need_lt = below;                                               // entries < t still to find
     uint32_t written = 0;
     const uint32_t T = (uint32_t)t * 0x01010101u;
+    pf0 = chunk_at(0);
+    pf1 = chunk_at(1);
     for (int s = 0; s < nsteps && written < (uint32_t)n_nb; ++s) {
         const int chunk = s * 64 + lane;
-        uint4 w = make_uint4(~0u, ~0u, ~0u, ~0u);                           // 0xFF bytes: neither < t nor == t (t < 32)
-        if (chunk < lane_chunks) w = row4[chunk];
+        uint4 w = pf0;
+        pf0 = pf1;
+        pf1 = chunk_at(s + 2);
+        if (chunk >= lane_chunks) w = make_uint4(~0u, ~0u, ~0u, ~0u);       // 0xFF bytes: neither < t nor == t (t < 32)
         const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
         uint32_t lt[4], eq[4], any = 0;
 #pragma unroll
