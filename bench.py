@@ -335,7 +335,7 @@ def _all_ok(dist, torch, flag):
     return int(flag.item()) == 0
 
 
-def embed_dist_leg(dist, torch, world, kh, lab, conseqs, iters=200):
+def embed_dist_leg(dist, torch, world, kh, lab, conseqs, iters=200, mode=None):
     """STRONG scaling of the C3 embedding: the N = 50 000 hand-over sample FIXED, sharded over all ranks (kmap_amd.distributed):
     ms per iteration of the loop (device-synchronised on both sides, max over ranks) and, from a separate short run with device
     events around the phases, forces / collective / apply ms.  On one rank the all-reduce is issued anyway (one-rank RCCL
@@ -343,6 +343,7 @@ def embed_dist_leg(dist, torch, world, kh, lab, conseqs, iters=200):
     Errors are reported in the line, not raised: the headline above is already measured."""
     from kmap_amd import visualization as V
     from kmap_amd.distributed import kmap_from_kmers_distributed
+    mode = V.EMBED_FAST if mode is None else mode
     n = len(kh)
     ones = np.ones(n, np.int64)
     err, loop_s, hbm, phases = "", 0.0, {}, None
@@ -353,7 +354,7 @@ def embed_dist_leg(dist, torch, world, kh, lab, conseqs, iters=200):
         dist.barrier()
         tr = {}
         try:
-            kmap_from_kmers_distributed(kh, ones, lab, conseqs, K, n_max_iter=it, random_seed=7, trace=tr, mode=V.EMBED_FAST,
+            kmap_from_kmers_distributed(kh, ones, lab, conseqs, K, n_max_iter=it, random_seed=7, trace=tr, mode=mode,
                                         always_collective=True, profile_iters=prof)
             loop_s, hbm = tr["loop_s"], tr["hbm"]
             phases = tr.get("phases", phases)
@@ -364,7 +365,7 @@ def embed_dist_leg(dist, torch, world, kh, lab, conseqs, iters=200):
         return {"error": err or "another rank failed"}
     t = torch.tensor([loop_s], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    cyc = os.environ.get("KMAP_DIST_CYCLIC", "1") != "0" and n >= 16384 and world > 1
+    cyc = mode == V.EMBED_FAST and os.environ.get("KMAP_DIST_CYCLIC", "1") != "0" and n >= 16384 and world > 1
     # the same loop with the peer-direct exchange (kmap_amd.distributed.PeerExchange: IPC-mapped receive areas, push + flag,
     # no library call between iterations) next to the all-reduce form; its failure is reported, not raised
     direct = {}
@@ -376,7 +377,7 @@ def embed_dist_leg(dist, torch, world, kh, lab, conseqs, iters=200):
             dist.barrier()
             tr = {}
             try:
-                kmap_from_kmers_distributed(kh, ones, lab, conseqs, K, n_max_iter=it, random_seed=7, trace=tr, mode=V.EMBED_FAST, exchange="direct")
+                kmap_from_kmers_distributed(kh, ones, lab, conseqs, K, n_max_iter=it, random_seed=7, trace=tr, mode=mode, exchange="direct")
                 d_loop = tr["loop_s"]
             except Exception as e:   # noqa: BLE001
                 d_err = f"{type(e).__name__}: {e}"[:300]
@@ -391,14 +392,14 @@ def embed_dist_leg(dist, torch, world, kh, lab, conseqs, iters=200):
             direct = {"error": d_err or "another rank failed"}
             flag.zero_()                                  # the all-reduce numbers above stand
     res = {"n_kmers": n, "scaling": "strong", "layout": "each unordered pair once, cyclic 256-row blocks per rank" if cyc else "contiguous row blocks",
-           "mode": "FAST", "iterations": iters, "loop_s": float(t.item()), "ms_per_iteration": float(t.item()) / iters * 1e3,
+           "mode": "FAST" if mode == V.EMBED_FAST else "SEQ (the reference's summation order: the parity-grade loop)", "iterations": iters, "loop_s": float(t.item()), "ms_per_iteration": float(t.item()) / iters * 1e3,
            "collectives_per_iteration": 1, "message_bytes": (2 * n + 8) * 4, "phases_ms_rank0": phases,
            "phases_note": "device events around forces (force kernel + partial sums + loss limbs), the all-reduce, apply; 20 iterations of a separate run",
            "d_rows_per_rank": hbm.get("d_rows"), "d_bytes_per_rank": hbm.get("d_bytes"), "exchange_direct": direct}
     if world == 1:
         tr = {}
-        V.kmap_from_kmers(kh, ones, lab, conseqs, K, n_max_iter=24, random_seed=7, mode=V.EMBED_FAST)
-        V.kmap_from_kmers(kh, ones, lab, conseqs, K, n_max_iter=iters, random_seed=7, trace=tr, mode=V.EMBED_FAST)
+        V.kmap_from_kmers(kh, ones, lab, conseqs, K, n_max_iter=24, random_seed=7, mode=mode)
+        V.kmap_from_kmers(kh, ones, lab, conseqs, K, n_max_iter=iters, random_seed=7, trace=tr, mode=mode)
         res["resident_ms_per_iteration"] = tr["loop_s"] / iters * 1e3
         res["overhead_ms_per_iter"] = res["ms_per_iteration"] - res["resident_ms_per_iteration"]
         res["overhead_note"] = ("sharded loop on a one-rank RCCL group (forces_msg -> all_reduce -> apply_msg, issued from Python) minus the "
@@ -456,6 +457,186 @@ def count_dist_leg(dist, torch, world, k=15, n_reads=1_000_000, read_len=150, re
                                                     "(k-mer, count) shards are NOT exchanged: the table stays sharded and find_motif works on local partials "
                                                     "(kmap_amd.distributed.CountShard); below, + the all-gathered shards (12 B per distinct k-mer)"}})
     return res
+
+
+def reads_dist_leg(dist, torch, world, rank, res_dir, reps=3):
+    """STRONG scaling of the read stages on the C3 reads (10 M x 150 bp, FIXED): contiguous read ranges per rank
+    (kmap_amd.distributed.make_dist_device_seq; a rank maps the res_dir's pickles and uploads only its slice), one pass each of
+    count k = 8 with per-read dedupe, count k = 14, occurrence scan k = 8 r = 2 -- the collective of the pass included (all-reduce
+    of the 4^k table; device all-gather of the hit lists).  ms per pass = best of `reps`, max over ranks; `frac_per_gpu` prices a
+    rank's own positions (1 B each) over that time against ITS 8 TB/s.  Errors are reported in the line, not raised."""
+    from kmap_amd import _ffi
+    from kmap_amd.distributed import make_dist_device_seq
+    from kmap_amd.kmer_count import DeviceCounts, kmer2hash, load_array_pickle
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    res, err = {}, ""
+    try:
+        seq = load_array_pickle(Path(res_dir) / "input.bin.pkl", populate=False)
+        borders = load_array_pickle(Path(res_dir) / "input.seqboarder.bin.pkl", populate=False)
+        ds = make_dist_device_seq(seq, borders, dist)
+        dc = DeviceCounts()
+        cons = int(kmer2hash("CCTACGTA"))
+        scan = ds.scan_lazy if getattr(ds, "scan_lazy", None) is not None else ds.scan
+        passes = {"count_k8_dedupe": lambda: ds.count(dc, 8, dedupe=True, merge_revcom=True),
+                  "count_k14": lambda: ds.count(dc, 14, dedupe=False, merge_revcom=True),
+                  "scan_k8_r2": lambda: scan(8, cons, 2, True)}
+        local = float(ds.n)
+        for name, fn in passes.items():
+            best = None
+            for rep in range(reps + 1):                   # the first pass allocates tables / communicator buffers
+                dist.barrier()
+                torch.cuda.synchronize()
+                _ffi.sync()
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                _ffi.sync()
+                dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+                if rep > 0:
+                    best = float(dt.item()) if best is None else min(best, float(dt.item()))
+            res[name] = {"ms": best * 1e3, "positions_this_rank": local, "frac_per_gpu": local / best / 1e9 / HBM_PEAK_GBS}
+        res["n_uniq_k14"] = int(dc.n_uniq)
+        dc.close()
+        ds.close()
+    except Exception as e:   # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"[:300]
+        flag.fill_(1)
+    if not _all_ok(dist, torch, flag):
+        return {"error": err or "another rank failed"}
+    res.update({"scaling": "strong", "reads": int(len(borders)), "what": "C3 reads sharded by contiguous read ranges; wall time of one pass incl. "
+                "its collective (host-synchronised on both sides), best of %d, max over ranks" % reps})
+    return res
+
+
+def e2e_dist_leg(dist, rank, reads, modes=("default", "fast")):
+    """north_star's own metric under the process group: `scan_motif` (reads sharded) + `visualize_kmers` (rows sharded) on a clean C3
+    res_dir, wall time of the slowest rank (kmap_amd.e2e.run_e2e_dist); default = SEQ, the reference's arithmetic."""
+    from kmap_amd.e2e import run_e2e_dist
+    out = {}
+    for mode in modes:
+        try:
+            r = run_e2e_dist(dist, "C3", mode, reads=reads if rank == 0 else None)
+            if r is not None:
+                out[mode] = {"scan_motif_s": r["times"]["scan_motif_s"], "visualize_kmers_s": r["times"]["visualize_kmers_s"],
+                             "e2e_s": r["times"]["e2e_s"], "final_conseq": r["final_conseq"], "stages": r["stages"]}
+        except Exception as e:   # noqa: BLE001 -- a verb that raises on one rank ends the job at the launcher; what can be caught is reported
+            out[mode] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            break
+    out["workload"] = ("C3 (10 M x 150 bp synthetic reads, k = 6..9, N = 50 000, 2500 iterations), both verbs under the process group, clean res_dir, "
+                       "wall time = max over ranks; default = SEQ embedding (the reference's summation order), fast = visualization.embed_mode = \"fast\"")
+    return out
+
+
+def shard_proxy(G, reads, res_dir, c3s, overhead_ms):
+    """ONE GPU, N = 1 only: every rank's share of a G-GPU run, one after the other on this GPU, so that the shapes a G-GPU node will
+    run are measured before such a node exists.  Per stage: `shard_ms` (HIP-event median per shard), `max_shard_ms`,
+    `one_gpu_ms` (the unsharded stage, same code, same run), `work_inflation` = sum of the shards / one_gpu_ms, and
+    `predicted_ms` = max_shard_ms (+ the per-iteration exchange overhead measured on the one-rank group for the embedding
+    stages; the collectives of the read stages are NOT in it -- their bytes are stated instead).  Stages: Hamming rows, neighbour
+    selection, neighbour sums, SEQ forces of contiguous rows, FAST forces of cyclic blocks at N = 50 000 (C3) and N = 200 000 (C4);
+    count k = 8 with dedupe / count k = 14 / scan k = 8 r = 2 over reads / G."""
+    import ctypes as C
+    from kmap_amd import _ffi, visualization as V
+    from kmap_amd.distributed import row_partition
+    from kmap_amd.hamdist import hamdist_matrix_dev, pitch_for
+    from kmap_amd.kmer_count import DeviceCounts, kmer2hash
+    from kmap_amd.motif_discovery import DeviceSeq
+    lib = _ffi.lib()
+    out = {"G": G, "stages": {}}
+
+    def entry(shard, one, extra_ms=0.0, note=None):
+        d = {"shard_ms": shard, "max_shard_ms": max(shard), "one_gpu_ms": one, "work_inflation": sum(shard) / one,
+             "predicted_ms": max(shard) + extra_ms, "predicted_speedup": one / (max(shard) + extra_ms)}
+        if note:
+            d["note"] = note
+        return d
+
+    def med(fn, reps):
+        return statistics.median(timed_launches(fn, reps, warmup=1))
+
+    for tag, n in (("c3", N_BASE), ("c4", N_C4)):
+        if tag == "c3":
+            kh, lab, conseqs = c3s
+            lens = [len(c) for c in conseqs]
+        else:
+            kh, lab, lens, conseqs = pipeline_sample(res_dir, n)
+        n = len(kh)
+        ldd, lds = pitch_for(n), (n + 127) & ~127
+        kh_d, lab_d = _ffi.DeviceBuffer.from_numpy(kh), _ffi.DeviceBuffer.from_numpy(lab)
+        parts = [(0, n)] + [row_partition(n, G, r) for r in range(G)]            # the unsharded stage first, then the G shards
+        nb_all = _ffi.DeviceBuffer(n * 20 * 4)
+        ham, sel, sums_ms, seq_ms = [], [], [], []
+        lut = V.hd_prob_lut(K, 20, 400 * K)
+        ld0, ph = V._init_draws(n, 0, 7)
+        reps = 5 if n <= N_BASE else 3
+        # pass 1: Hamming rows + neighbour selection of every share (the shares' tables together = the all-gathered table)
+        for row0, nrows in parts:
+            D_d = _ffi.DeviceBuffer(nrows * ldd)
+            ham.append(med(lambda: hamdist_matrix_dev(kh_d.ptr, lab_d.ptr, n, K, lens, D_d.ptr, ldd, row0=row0, nrows=nrows), reps))
+            sel.append(med(lambda: _ffi.check(lib.kmap_knn_select_u8_dev(D_d.ptr, ldd, n, 20, 0, nrows, nb_all.ptr + row0 * 80, None)), reps))
+            D_d.free()
+        # pass 2: neighbour sums + SEQ forces of the share's rows
+        for row0, nrows in parts:
+            sums_d = _ffi.DeviceBuffer(nrows * lds * 2)
+            sums_ms.append(med(lambda: V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, K, lens, nb_all, 20, row0=row0, nrows=nrows, out=sums_d.ptr), reps))
+            sess = V.EmbedSession(n, 1, 0.01, V.EMBED_SEQ, row0=row0, nrows=nrows)
+            _ffi.check(lib.kmap_embed_set_prob_lut(sess._h, sums_d.ptr, lds, _ffi.ptr(lut), len(lut)))
+            sess.set_coords(ld0, None)
+            seq_ms.append(med(lambda: sess.forces(), reps))
+            sess.close()
+            sums_d.free()
+        # pass 3: FAST forces, cyclic 256-row blocks of the symmetric kernel (rank r owns blocks r, r + G, ...)
+        fast_ms = []
+        for world, ranks in ((1, [0]), (G, list(range(G)))):
+            for r in ranks:
+                blocks = V.cyclic_blocks(n, world, r) if world > 1 else [(0, n)]
+                blk_bytes = (V.CYCLIC_BLOCK_ROWS if world > 1 else n) * lds * 2
+                sums_d = _ffi.DeviceBuffer(max(len(blocks), 1) * blk_bytes)
+                for b, (r0, nr) in enumerate(blocks):
+                    V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, K, lens, nb_all, 20, row0=r0, nrows=nr, out=sums_d.ptr + b * blk_bytes)
+                sess = V.EmbedSession(n, 1, 0.01, V.EMBED_FAST, cyclic=(world, r)) if world > 1 else V.EmbedSession(n, 1, 0.01, V.EMBED_FAST)
+                _ffi.check(lib.kmap_embed_set_prob_lut(sess._h, sums_d.ptr, lds, _ffi.ptr(lut), len(lut)))
+                sess.set_coords(ld0, None)
+                fast_ms.append(med(lambda: sess.forces(), reps))
+                sess.close()
+                sums_d.free()
+        for b in (nb_all, kh_d, lab_d):
+            b.free()
+        st = out["stages"]
+        st[f"{tag}_hamming_rows"] = entry(ham[1:], ham[0])
+        st[f"{tag}_knn_select"] = entry(sel[1:], sel[0])
+        st[f"{tag}_knn_sums"] = entry(sums_ms[1:], sums_ms[0])
+        st[f"{tag}_embed_forces_seq"] = entry(seq_ms[1:], seq_ms[0], overhead_ms, f"rows [r N / {G}, (r + 1) N / {G}) x all {n} columns, the reference's summation order; "
+                                              "+ exchange overhead of the one-rank group per iteration")
+        st[f"{tag}_embed_forces_fast"] = entry(fast_ms[1:], fast_ms[0], overhead_ms, "cyclic 256-row blocks, each unordered pair once")
+    # ---- read stages on reads / G
+    seq, borders = reads
+    nreads = len(borders)
+    cons = int(kmer2hash("CCTACGTA"))
+    t = {"count_k8_dedupe": [], "count_k14": [], "scan_k8_r2": []}
+    h = _ffi.vp()
+    _ffi.check(lib.kmap_scan_create(C.byref(h)))
+    tot = _ffi.i64(0)
+    for r0, nr in [(0, nreads)] + [row_partition(nreads, G, r) for r in range(G)]:
+        lo, hi = int(borders[r0, 0]), int(borders[r0 + nr - 1, 1]) + 1
+        ds = DeviceSeq(np.ascontiguousarray(seq[lo:hi]), borders[r0:r0 + nr] - lo)
+        dc = DeviceCounts()
+        t["count_k8_dedupe"].append(med(lambda: ds.count(dc, 8, dedupe=True, merge_revcom=True), 4))
+        t["count_k14"].append(med(lambda: ds.count(dc, 14, dedupe=False, merge_revcom=True), 4))
+        t["scan_k8_r2"].append(med(lambda: _ffi.check(lib.kmap_scan_run_packed_dev(h.value, ds.codes.ptr, ds.inval_orig.ptr, ds.n, ds.borders.ptr, ds.n_seq, 8, cons, 2, 1,
+                                                                               C.byref(tot), ds.planes.ptr, None)), 4))
+        dc.close()
+        ds.close()
+    lib.kmap_scan_destroy(h.value)
+    coll = {"count_k8_dedupe": "all-reduce of 4^8 x 4 B = 256 KiB", "count_k14": "all-reduce of 4^14 x 4 B = 1 GiB (ring: 2 (G-1)/G x 1 GiB per link pair)",
+            "scan_k8_r2": "all-gather of the hit lists"}
+    for name, v in t.items():
+        out["stages"]["reads_" + name] = entry(v[1:], v[0], 0.0, "collective not included: " + coll[name])
+    out["exchange_overhead_ms_per_iteration"] = overhead_ms
+    out["what"] = (f"every rank's share of a {G}-GPU run timed on ONE GPU, shard after shard (HIP events, median); predicted_ms = slowest shard "
+                   f"(+ the measured one-rank exchange overhead for the embedding stages); not a measurement on {G} GPUs")
+    return out
 
 
 def c4_leg(dist, torch, res_dir, rank, world, barrier):
@@ -693,6 +874,11 @@ def main():
     ap.add_argument("--no-count-dist", action="store_true", help="skip the multi-GPU counting leg (k = 15: all-reduce vs key-range shards)")
     ap.add_argument("--no-c5", action="store_true", help="skip the full-size C5 scan leg (N=1 only)")
     ap.add_argument("--quick", action="store_true", help="smaller CPU-baseline samples (rehearsals)")
+    ap.add_argument("--shard-proxy", type=int, default=0, metavar="G",
+                    help="N=1 only: time every rank's share of a G-GPU run on this one GPU (Hamming / kNN / SEQ + FAST forces at N = 50 000 and 200 000, "
+                         "count / scan of reads / G) and print max-shard, work inflation and the predicted G-GPU time per stage")
+    ap.add_argument("--no-reads-dist", action="store_true", help="skip the read-sharded C3 count / scan leg (multi-rank)")
+    ap.add_argument("--no-e2e-dist", action="store_true", help="skip the end-to-end run of both verbs under the process group (multi-rank)")
     ap.add_argument("--no-stages", action="store_true", help="skip the per-stage roofline timings")
     ap.add_argument("--e2e", default="full", choices=["none", "k9", "full"],
                     help="end-to-end timings on C3 (rank 0, N=1 only): k9 = k 6..9 in both embedding modes; full = also the default k 6..16")
@@ -720,6 +906,8 @@ def main():
     # over gloo, every rank on GPU 0); the real runs use one GPU per rank and RCCL ("nccl").
     backend = os.environ.get("KMAP_BENCH_BACKEND", "nccl")
     dev = 0 if os.environ.get("KMAP_BENCH_SAME_GPU") else local_rank
+    if os.environ.get("KMAP_BENCH_SAME_GPU"):
+        os.environ["KMAP_DIST_SAME_GPU"] = "1"      # the verbs of the e2e leg pick their device the same way
     torch.cuda.set_device(dev)
     _ffi.check(_ffi.lib().kmap_set_device(dev))
     dist = None
@@ -853,10 +1041,15 @@ def main():
                 dist1.init_process_group("nccl" if backend == "nccl" else backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                                          **({"device_id": torch.device("cuda", dev)} if backend == "nccl" else {}))
                 own_group = True
+                from kmap_amd.visualization import EMBED_SEQ
                 embed_dist = embed_dist_leg(dist1, torch, 1, *c3s)
+                embed_dist["seq"] = embed_dist_leg(dist1, torch, 1, *c3s, iters=100, mode=EMBED_SEQ)
             else:
+                from kmap_amd.visualization import EMBED_SEQ
                 guard.leg("embed_dist")
                 embed_dist = embed_dist_leg(dist, torch, world, *c3s)
+                guard.leg("embed_dist.seq")
+                embed_dist["seq"] = embed_dist_leg(dist, torch, world, *c3s, iters=100, mode=EMBED_SEQ)
         except Exception as e:   # noqa: BLE001 -- reported, the headline is already measured
             embed_dist = {"error": f"{type(e).__name__}: {e}"[:300]}
         finally:
@@ -875,6 +1068,16 @@ def main():
         _ffi.check(_ffi.lib().kmap_scratch_release(1 << 30))
         if line is not None:
             line["count_dist"] = count_dist
+    if dist is not None and not args.no_reads_dist:
+        if dist is not None:
+            box = [res_dir]
+            dist.broadcast_object_list(box, 0)
+            res_dir_all = box[0]
+        guard.leg("reads_dist")
+        rd = reads_dist_leg(dist, torch, world, rank, res_dir_all)
+        _ffi.check(_ffi.lib().kmap_scratch_release(1 << 30))
+        if line is not None:
+            line["reads_dist"] = rd
     c4 = None
     if not args.no_c4:
         guard.leg("c4")
@@ -885,8 +1088,20 @@ def main():
         if line is not None:
             line["c4"] = c4
 
+    if dist is not None and not args.no_e2e_dist:
+        guard.limit = max(guard.limit, 600.0)        # two whole runs of both verbs
+        guard.leg("e2e")
+        ed = e2e_dist_leg(dist, rank, reads)
+        if line is not None:
+            line["e2e"] = ed
     guard.done()
     if rank == 0:
+        if world == 1 and args.shard_proxy > 1:
+            ov = (embed_dist or {}).get("seq", {}).get("overhead_ms_per_iter") or (embed_dist or {}).get("overhead_ms_per_iter") or 0.0
+            try:
+                line["shard_proxy"] = shard_proxy(args.shard_proxy, reads, res_dir, c3s, max(float(ov), 0.0))
+            except Exception as e:   # noqa: BLE001 -- reported, the headline is already measured
+                line["shard_proxy"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_stages:
             line["roofline"]["stages"] = stage_rooflines(reads, kh, lab, lens)
         kh_d.free()
@@ -897,19 +1112,22 @@ def main():
             def pack(r):
                 return {"scan_motif_s": r["times"]["scan_motif_s"], "visualize_kmers_s": r["times"]["visualize_kmers_s"],
                         "e2e_s": r["times"]["e2e_s"], "final_conseq": r["final_conseq"], "stages": r["stages"]}
-            e2e = {"k6_9": {"default": pack(first), "seq": pack(run_e2e("C3", "seq", reads=reads))}}
+            e2e = {"k6_9": {"default": pack(first), "fast": pack(run_e2e("C3", "fast", reads=reads)),
+                            "exact": pack(run_e2e("C3", "exact", reads=reads))}}
             if args.e2e == "full":
                 e2e["k6_16"] = {"default": pack(run_e2e("C3", "default", min_k=6, max_k=16, reads=reads))}
             e2e["workload"] = (f"C3: {first['n_reads']} x {first['read_len']} bp synthetic reads, N={first['n_total']} sampled k-mers, "
                                f"{first['iters']} iterations, 1 GPU, clean res_dir; k6_9: k = 6..9 (longest final = the configs' k = 8), k6_16: the "
-                               f"reference's default k range (default_config.toml:7-8); default = package default embedding mode (FAST "
-                               f"wavefront sums above N = 16384: per-step pinned, no digit-level reference exists at this N), seq = the "
-                               f"reference's summation order (the parity-grade number)")
+                               f"reference's default k range (default_config.toml:7-8); default = the package default = SEQ, the reference's "
+                               f"arithmetic and summation order at every N (the parity-grade number; neighbour ties / top-k / draws by the device "
+                               f"rules above the documented sizes), fast = config.toml visualization.embed_mode = \"fast\" (opt-in: wavefront-parallel "
+                               f"row sums, per-step pinned), exact = config.toml general.exact = true (SEQ + np.argpartition neighbours / top-k + "
+                               f"np.random.multinomial at every size: the strict drop-in run)")
             reads = None          # 1.5 GB of host memory back before the next legs
             c2 = run_e2e("C2", "default")
             e2e["c2"] = {"default": pack(c2), "workload": (f"C2: {c2['n_reads']} x {c2['read_len']} bp synthetic reads, N={c2['n_total']} sampled k-mers, "
                                                            f"{c2['iters']} iterations (the reference's default size, default_config.toml:24-32), k = 6..9, "
-                                                           f"package default embedding mode = SEQ (the reference's summation order) at this N, 1 GPU, clean res_dir")}
+                                                           f"package default embedding mode = SEQ (the reference's summation order), 1 GPU, clean res_dir")}
             line["e2e"] = e2e
         reads = None
         if world == 1 and not args.no_c5:

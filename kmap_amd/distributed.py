@@ -355,10 +355,7 @@ def kmap_from_kmers_distributed(samp_kh, samp_cnts, samp_label, conseq_list, kme
             nb_local = vz.knn_select_dev(D_d.ptr, ldd, n, n_neighbour, row0=0, nrows=nrows)     # D_d holds local rows from 0
         else:
             # drop-in neighbour choice for the local rows on the host (numpy argpartition on int64 rows)
-            rows = np.empty((max(nrows, 1), n), np.uint8)
-            if nrows:
-                check(_ffi.lib().kmap_memcpy2d_d2h(ptr(rows), n, D_d.ptr, ldd, n, nrows, None))
-            sel = np.argpartition(rows[:nrows].astype(np.int64), n_neighbour, axis=1)[:, :n_neighbour].astype(np.int32)
+            sel = vz.knn_select_numpy(D_d.ptr, ldd, n, n_neighbour, nrows=nrows).astype(np.int32)
             nb_local = _ffi.DeviceBuffer.from_numpy(sel) if nrows else _ffi.DeviceBuffer(16)
         nb = all_gather_rows_dev(dist, nb_local, n, world, rank, n_neighbour)
         nb_local.free()
@@ -570,7 +567,10 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None, shard_counts
             check(_ffi.lib().kmap_memcpy_h2d(self.inval_work.ptr, _ffi.ptr(flags), ng * 2, None))
             _ffi.sync()
 
-        def count(self, dc, k, dedupe, merge_revcom, use_work=True):
+        def count(self, dc, k, dedupe, merge_revcom, use_work=True, gather_full=False):
+            """gather_full: this call's table is the one k{k}.pkl is written from (find_motif's first round) -- if it stays
+            sharded, rank `full_table_rank` also receives the whole of it.  The masked re-counts of the later rounds never do:
+            12 B per unique k-mer over the links and a second multi-GB table on the writer rank, per round, for nothing."""
             if k > 16:
                 raise ValueError("sharded counting all-reduces the 4^k histogram and needs k <= 16")
             if on_dev:
@@ -584,14 +584,14 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None, shard_counts
             bins = torch.as_tensor(_DevArray(p.value, 4 ** k, "<i4"), device="cuda")   # int32 sum wraps like uint32
             by_range = (k >= 15 and 4 * n_all_positions < 4 ** k) if shard_counts is None else bool(shard_counts)
             if by_range and 11 <= k <= 16 and world <= 15 and (world > 1 or shard_counts):   # one rank: only when forced (tests)
-                return self._count_by_key_range(dc, k, merge_revcom, bins)
+                return self._count_by_key_range(dc, k, merge_revcom, bins, gather_full)
             dist.all_reduce(bins, op=dist.ReduceOp.SUM, group=group)      # stream-ordered after the histogram kernels
             nu = _ffi.i64(0)
             check(_ffi.lib().kmap_counts_finish(dc._h, k, int(merge_revcom), C.byref(nu), None))
             dc.k, dc.n_uniq = k, nu.value
             return dc.n_uniq
 
-        def _count_by_key_range(self, dc, k, merge_revcom, bins):
+        def _count_by_key_range(self, dc, k, merge_revcom, bins, gather_full=False):
             """bins: this rank's local 4^k table (device tensor view).  Every collective below works on device tensors (gloo
             stages them through the host itself)."""
             lib = _ffi.lib()
@@ -617,11 +617,13 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None, shard_counts
             sizes = [int(v) for v in sizes.cpu().numpy()]
             total = int(sum(sizes))
             dc._unshard()
-            keep = self.keep_sharded if self.keep_sharded is not None else total > TOPK_DEVICE_MIN
+            from . import _policy
+            # KMAP_EXACT / general.exact: find_motif calls np.argpartition on the whole fetched table -> every rank holds it
+            keep = self.keep_sharded if self.keep_sharded is not None else (total > TOPK_DEVICE_MIN and not _policy.exact())
             if keep:
                 # the table STAYS sharded: find_motif's top-k and Hamming-ball masses are local partials + tiny collectives
                 # (CountShard); only the rank that writes k{k}.pkl -- if any -- receives the other ranks' shards
-                if self.full_table_rank is not None:
+                if gather_full and self.full_table_rank is not None:
                     full = self._gather_table(dc, k, sizes, nu.value, dst=self.full_table_rank)
                     if full is not None:
                         dc._full = full
@@ -662,9 +664,9 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None, shard_counts
                         glist = [t.cuda() for t in hl]
                 if rank != dst:
                     return None, None
-                parts = torch.stack(glist)
-            all_u32 = torch.cat([parts[r, :kw * sizes[r]] for r in range(world)]).contiguous()
-            all_c = torch.cat([parts[r, kw * cap:kw * cap + sizes[r]] for r in range(world)]).contiguous()
+                parts = glist                                            # indexed per rank below: no stacked copy
+            all_u32 = torch.cat([parts[r][:kw * sizes[r]] for r in range(world)]).contiguous()
+            all_c = torch.cat([parts[r][kw * cap:kw * cap + sizes[r]] for r in range(world)]).contiguous()
             all_u = all_u32.view(kdt) if kw == 2 else all_u32
             return all_u, all_c
 

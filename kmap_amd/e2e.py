@@ -31,11 +31,9 @@ def run_e2e(config="C2", mode="default", min_k=6, max_k=9, iters=None, keep=Fals
     import io
     from . import motif_discovery as md, synth, visualization as vz
     c = CONFIGS[config]
+    assert mode in ("default", "seq", "fast", "exact"), mode
     prev_mode = os.environ.get("KMAP_EMBED_MODE")
-    if mode in ("seq", "fast"):
-        os.environ["KMAP_EMBED_MODE"] = mode
-    else:
-        os.environ.pop("KMAP_EMBED_MODE", None)   # package default: SEQ up to N = 16384, FAST above
+    os.environ.pop("KMAP_EMBED_MODE", None)       # the run is steered through config.toml's optional keys, like a user's
     md.STAGE_TIMES.clear()
     vz.STAGE_TIMES.clear()
     t = {}
@@ -47,6 +45,12 @@ def run_e2e(config="C2", mode="default", min_k=6, max_k=9, iters=None, keep=Fals
             "motif_discovery": {"motif_pos_density_flag": reports, "motif_co_occurence_flag": reports, "gen_hamball_flag": reports,
                                 "n_total_sample": c["n_total"], "n_motif_sample": c["n_motif"]},
             "visualization": {"gen_fig_flag": False, "random_seed": 7, "n_max_iter": iters or c["iters"]}}
+    # "default": the keys are absent (SEQ, the reference's arithmetic, at every N); "fast": opt-in FAST embedding; "exact": SEQ +
+    # the reference's numpy calls at every size (np.argpartition neighbours / top-k, np.random.multinomial)
+    if mode in ("seq", "fast"):
+        over["visualization"]["embed_mode"] = mode
+    if mode == "exact":
+        over["general"] = {"exact": True}
     t0 = time.perf_counter()
     synth.write_res_dir(res, seq, borders, over)
     t["write_inputs_s"] = time.perf_counter() - t0
@@ -74,4 +78,70 @@ def run_e2e(config="C2", mode="default", min_k=6, max_k=9, iters=None, keep=Fals
         else:
             os.environ["KMAP_EMBED_MODE"] = prev_mode
         if not keep:
+            shutil.rmtree(res, ignore_errors=True)
+
+
+def run_e2e_dist(dist, config="C3", mode="default", min_k=6, max_k=9, iters=None, reads=None, shared_dir=None):
+    """The two verbs on one clean res_dir under an initialised process group (every rank calls this): rank 0 writes the inputs
+    (reads: its (seq, borders), or generated), all ranks then run `_scan_motif` (reads sharded) and `_visualize_kmers` (rows sharded)
+    on it; the times are the slowest rank's.  shared_dir: where the res_dir is created (a path every rank sees; default: the system
+    temp directory -- one node).  Returns the same dictionary as run_e2e on rank 0, None elsewhere."""
+    import contextlib
+    import io
+    import torch
+    from . import motif_discovery as md, synth, visualization as vz
+    from .distributed import _coll_device
+    assert mode in ("default", "seq", "fast", "exact"), mode
+    c = CONFIGS[config]
+    rank = dist.get_rank()
+    prev_mode = os.environ.pop("KMAP_EMBED_MODE", None)
+    box = [None]
+    if rank == 0:
+        seq, borders = reads if reads is not None else synth.synth_reads(c["n_reads"], c["read_len"], c["seed"])
+        res = Path(tempfile.mkdtemp(prefix=f"kmap_{config}_dist_", dir=shared_dir))
+        over = {"kmer_count": {"min_k": min_k, "max_k": max_k},
+                "motif_discovery": {"motif_pos_density_flag": False, "motif_co_occurence_flag": False, "gen_hamball_flag": False,
+                                    "n_total_sample": c["n_total"], "n_motif_sample": c["n_motif"]},
+                "visualization": {"gen_fig_flag": False, "random_seed": 7, "n_max_iter": iters or c["iters"]}}
+        if mode in ("seq", "fast"):
+            over["visualization"]["embed_mode"] = mode
+        if mode == "exact":
+            over["general"] = {"exact": True}
+        synth.write_res_dir(res, seq, borders, over)
+        del seq, borders
+        box = [str(res)]
+    dist.broadcast_object_list(box, 0)
+    res = Path(box[0])
+    md.STAGE_TIMES.clear()
+    vz.STAGE_TIMES.clear()
+
+    def slowest(seconds):
+        t = torch.tensor([seconds], dtype=torch.float64, device=_coll_device(dist))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    t = {}
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            np.random.seed(123)
+            dist.barrier()
+            t0 = time.perf_counter()
+            md._scan_motif(str(res))              # ends with a barrier of its own
+            t["scan_motif_s"] = slowest(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            vz._visualize_kmers(str(res))
+            t["visualize_kmers_s"] = slowest(time.perf_counter() - t0)
+        t["e2e_s"] = t["scan_motif_s"] + t["visualize_kmers_s"]
+        if rank != 0:
+            return None
+        finals = (res / "final_conseq.txt").read_text().split()
+        rows = (res / "low_dim_data.tsv").read_text().splitlines()
+        stages = dict(md.STAGE_TIMES)
+        stages.update({"viz_" + k: v for k, v in vz.STAGE_TIMES.items()})
+        return {"config": config, "mode": mode, **c, "k_range": [min_k, max_k], "final_conseq": finals, "n_embedded": len(rows) - 1,
+                "times": t, "stages": stages, "world": dist.get_world_size(), "res_dir": None}
+    finally:
+        if prev_mode is not None:
+            os.environ["KMAP_EMBED_MODE"] = prev_mode
+        dist.barrier()
+        if rank == 0:
             shutil.rmtree(res, ignore_errors=True)

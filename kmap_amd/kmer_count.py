@@ -209,12 +209,15 @@ class DeviceCounts:
     def fetch(self, stream=None):
         """(unique hashes, counts) as the reference's numpy arrays.  stream: a non-default stream handle -> the copy runs there
         through pinned staging buffers (a background thread can then drain this table while the default stream keeps working).
-        Sharded table: every rank must call it (the shards are all-gathered on the host)."""
+        Sharded table: COLLECTIVE -- every rank must call it, and every rank takes the same path (the shards are all-gathered on
+        the host) whether or not it also holds a gathered copy; the rank that does reads that copy with fetch_full()."""
         if self._shard is not None:
-            if self._full is not None:
-                return self._full.fetch(stream)
             return self._shard.gather_host(*self._fetch_local(self._shard.n_local))
         return self._fetch_local(self.n_uniq, stream)
+
+    def fetch_full(self, stream=None):
+        """local, no collective: the gathered copy on the rank that holds one (the writer of k{k}.pkl), else None"""
+        return None if self._full is None else self._full.fetch(stream)
 
     def total(self):
         t = _ffi.i64(0)

@@ -37,6 +37,15 @@ TOPK_DEVICE_MIN = 4_000_000
 SAVE_ASYNC_MIN = 4_000_000   # tables above this many unique k-mers are fetched + pickled by a background TableSaver
 TOPK_DEVICE_MAX_K = 16       # kmap_counts_topk keeps 16 candidates per thread; a larger top_k takes the host path at any size
 
+
+
+def _device_topk(n_uniq, top_k):
+    """find_motif's candidates from kmap_counts_topk (largest count, then lowest index) instead of np.argpartition on the
+    fetched table (reference motif_discovery.py:661)?  Never under KMAP_EXACT=1 / config general.exact."""
+    from . import _policy
+    return n_uniq > TOPK_DEVICE_MIN and top_k <= TOPK_DEVICE_MAX_K and not _policy.exact()
+
+
 STAGE_TIMES = {}   # cumulative wall-clock per stage of the last runs (tools/e2e.py, bench.py report it)
 
 
@@ -109,7 +118,7 @@ class DeviceSeq:
         """restore the unmasked reads (reference motif_discovery.py:263): n/8 bytes"""
         check(_ffi.lib().kmap_memcpy_d2d(self.inval_work.ptr, self.inval_orig.ptr, self.groups * 2, None))
 
-    def count(self, dc: DeviceCounts, k, dedupe, merge_revcom, use_work=True):
+    def count(self, dc: DeviceCounts, k, dedupe, merge_revcom, use_work=True, gather_full=False):
         inval = self.inval_work if use_work else self.inval_orig
         nu = _ffi.i64(0)
         dc._unshard()
@@ -440,9 +449,9 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
             check(_ffi.lib().kmap_counts_load(dc._h, ptr(u), ptr(c), len(u), kmer_len))
             dc.k, dc.n_uniq = kmer_len, len(u)
         else:
-            dev_seq.count(dc, kmer_len, dedupe=not rep_mode, merge_revcom=merge_revcom_mode)   # first round
+            dev_seq.count(dc, kmer_len, dedupe=not rep_mode, merge_revcom=merge_revcom_mode, gather_full=True)   # first round: the table k{k}.pkl holds
             uniq_kh_arr, uniq_kh_cnt_arr = None, None
-        big = dc.n_uniq > TOPK_DEVICE_MIN and top_k <= TOPK_DEVICE_MAX_K
+        big = _device_topk(dc.n_uniq, top_k)
         n_total_kmer = _wrap_total(dc.total(), kmer_len)   # first round only (:648)
         first = dc                                          # the first-round table (trial 0 reads it)
         if save_kmer_cnt_flag and kmer_cnt_pkl_file and not Path(kmer_cnt_pkl_file).exists():
@@ -504,7 +513,7 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
             dev_seq.mask(kmer_len, np.array(cons), np.array([max_ham_dist] * len(cons)))
             dev_seq.count(dc, kmer_len, dedupe=False, merge_revcom=merge_revcom_mode)   # later rounds: no dedupe (:695)
             cur = dc
-            big = dc.n_uniq > TOPK_DEVICE_MIN and top_k <= TOPK_DEVICE_MAX_K
+            big = _device_topk(dc.n_uniq, top_k)
             uniq_kh_arr, uniq_kh_cnt_arr = None, None
         if saver is not None and table_savers is None:
             saver.join()
@@ -780,7 +789,9 @@ def sample_disp_kmer(conseq_list: List[str], kmer_len: int, motif_def_dict: dict
     from the same global np.random stream (one np.random.multinomial per label over the members' normalised counts), so the
     sample equals the reference's for a given seed.  Labels with more than TOPK_DEVICE_MIN members are drawn by inverse CDF
     instead (np.random.multinomial walks every category: minutes at 1e9 members) -- a documented deviation in the random
-    draws, not in the distribution, for tables the reference cannot process."""
+    draws, not in the distribution, for tables the reference cannot process; KMAP_EXACT=1 / config general.exact keeps
+    np.random.multinomial at every size."""
+    from . import _policy
     conseq_list = [s for s in conseq_list if 2 < len(s) <= kmer_len]
     assert len(conseq_list) > 0
     assert all(len(a) >= len(b) for a, b in zip(conseq_list, conseq_list[1:]))   # longest first, as merge_consensus_seqs emits
@@ -815,7 +826,7 @@ def sample_disp_kmer(conseq_list: List[str], kmer_len: int, motif_def_dict: dict
         picked, picked_cnt = [], []
         for c, n_draw in enumerate(quota):
             m = int(label_members[c])
-            if m > TOPK_DEVICE_MIN:
+            if m > TOPK_DEVICE_MIN and not _policy.exact():
                 where, times = np.unique(tab.cdf_pick(c, int(label_weight[c]), int(n_draw)), return_counts=True)
             else:
                 members = tab.member_indices(c, m)
@@ -897,6 +908,8 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
     assert proc_fasta_file_path.exists()
 
     config_dict = load_toml(config_file_path)
+    from . import _policy
+    _policy.apply_config(config_dict)          # optional keys general.exact / visualization.embed_mode
     motif_def_dict = gen_motif_def_dict(config_dict, debug=debug)
     md = config_dict["motif_discovery"]
     min_k, max_k = config_dict["kmer_count"]["min_k"], config_dict["kmer_count"]["max_k"]

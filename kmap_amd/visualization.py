@@ -20,21 +20,14 @@ EMBED_FAST, EMBED_SEQ = 0, 1
 
 
 def default_mode(n=None):
-    """Embedding arithmetic when the caller does not choose: KMAP_EMBED_MODE=seq|fast wins; otherwise
-    SEQ (the reference's f32 summation order; reproduces its trajectories digit for digit) up to the size at which
-    scan_motif still writes the int64 matrix (N <= 16384, the regime where the reference itself can run), and FAST above
-    it, where no digit-level reference exists anyway (neighbour ties are resolved by the device rule there, see knn_mode).
-    FAST sums each row wavefront-parallel: same per-pair values, different rounding of the row sums; gradient descent
-    amplifies that (measured: 1e-3 relative on the loss after 200 iterations at N=96) -- statistically equivalent
-    embeddings, not the same digits."""
-    import os
-    forced = os.environ.get("KMAP_EMBED_MODE", "").lower()
-    if forced in ("seq", "fast"):
-        return EMBED_FAST if forced == "fast" else EMBED_SEQ
-    if n is None:
-        return EMBED_SEQ
-    from .motif_discovery import DENSE_PKL_MAX_N
-    return EMBED_SEQ if n <= DENSE_PKL_MAX_N else EMBED_FAST
+    """Embedding arithmetic when the caller does not choose: SEQ -- the reference's own arithmetic (visualization.py:296-317,
+    taichi_core.py:305-326: IEEE f32, row sums in ascending j, no FMA; coordinates within 1e-5 of the reference's numpy-f32
+    execution) -- at EVERY N.  FAST (each unordered pair once, wavefront-parallel row sums: same per-pair values, different
+    rounding of the row sums, which gradient descent amplifies -- 1e-3 relative on the loss after 200 iterations at N = 96:
+    statistically equivalent embeddings, not the same digits) is opt-in: `visualization.embed_mode = "fast"` in config.toml
+    or KMAP_EMBED_MODE=fast (the environment wins).  n is accepted for the callers' convenience and plays no part."""
+    from . import _policy
+    return EMBED_FAST if _policy.embed_mode() == "fast" else EMBED_SEQ
 
 
 STAGE_TIMES = {}          # cumulative wall-clock per stage (tools/e2e.py, bench.py report it)
@@ -57,13 +50,44 @@ class _stage:
 def knn_mode(n):
     """'numpy' (the reference's np.argpartition on int64 rows: drop-in, tie order numpy/ISA specific) up to the size where
     scan_motif still writes the int64 matrix; 'device' (smallest distance, then lowest index) above it, where the
-    reference cannot run and 2.5e9+ int64 entries would have to be streamed through the host.  KMAP_KNN overrides."""
+    reference cannot run and 2.5e9+ int64 entries would have to be streamed through the host.  KMAP_KNN overrides;
+    KMAP_EXACT=1 / config general.exact selects 'numpy' at every size."""
     import os
+    from . import _policy
     from .motif_discovery import DENSE_PKL_MAX_N
     forced = os.environ.get("KMAP_KNN", "").lower()
     if forced in ("numpy", "device"):
         return forced
-    return "numpy" if n <= DENSE_PKL_MAX_N else "device"
+    return "numpy" if (n <= DENSE_PKL_MAX_N or _policy.exact()) else "device"
+
+
+def knn_select_numpy(D_dev_ptr, ldd, n, n_nb, nrows=None):
+    """The reference's neighbour choice (visualization.py:100: np.argpartition on int64 rows) for rows [0, nrows) of a uint8
+    device matrix, streamed back in row blocks: the copy of block b + 1 runs while worker threads partition block b (introselect
+    runs outside the GIL; rows are independent, so the result equals one call on the whole matrix)."""
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    nrows = n if nrows is None else nrows
+    if nrows == 0:
+        return np.zeros((0, n_nb), np.int64)
+    blk = max(1, min(nrows, (32 << 20) // max(n, 1)))
+    out = np.empty((nrows, n_nb), np.int64)
+
+    def part(r0, rows):
+        out[r0:r0 + len(rows)] = np.argpartition(rows.astype(np.int64), n_nb, axis=1)[:, :n_nb]
+
+    with ThreadPoolExecutor(max(1, min(16, (os.cpu_count() or 2) - 1))) as pool:
+        jobs = []
+        for r0 in range(0, nrows, blk):
+            r1 = min(nrows, r0 + blk)
+            rows = np.empty((r1 - r0, n), np.uint8)
+            check(_ffi.lib().kmap_memcpy2d_d2h(ptr(rows), n, D_dev_ptr + r0 * ldd, ldd, n, r1 - r0, None))
+            jobs.append(pool.submit(part, r0, rows))
+            while len(jobs) > 24:                 # bound the blocks in flight (32 MB each + their int64 copies)
+                jobs.pop(0).result()
+        for j in jobs:
+            j.result()
+    return out
 
 
 def knn_select_dev(D_dev_ptr, ldd, n, n_nb, row0=0, nrows=None, stream=None):
@@ -426,14 +450,7 @@ def kmap_from_kmers(samp_kh, samp_cnts, samp_label, conseq_list, kmer_len, n_nei
             neighbor_inds_mat = knn_select_dev(D_d.ptr, ldd, n, n_neighbour)
         elif neighbor_inds_mat is None:
             # drop-in neighbour choice: numpy argpartition on int64 rows, streamed back in row blocks
-            nbs = []
-            blk = max(1, min(n, (64 << 20) // max(n, 1)))
-            for r0 in range(0, n, blk):
-                r1 = min(n, r0 + blk)
-                rows = np.empty((r1 - r0, n), np.uint8)
-                check(_ffi.lib().kmap_memcpy2d_d2h(ptr(rows), n, D_d.ptr + r0 * ldd, ldd, n, r1 - r0, None))
-                nbs.append(np.argpartition(rows.astype(np.int64), n_neighbour, axis=1)[:, :n_neighbour])
-            neighbor_inds_mat = np.concatenate(nbs)
+            neighbor_inds_mat = knn_select_numpy(D_d.ptr, ldd, n, n_neighbour)
     if trace is not None and not isinstance(neighbor_inds_mat, _ffi.DeviceBuffer):
         trace["nb"] = np.asarray(neighbor_inds_mat)            # the host-chosen neighbours (numpy mode / injected)
     with _stage("knn_sums"):
@@ -502,6 +519,8 @@ def _visualize_kmers_impl(res_dir, debug, mode, dist, rank, neighbor_inds_mat=No
     cfg_path = Path(res_dir) / FileNameDict["config_file"]
     assert cfg_path.exists()
     cfg = load_toml(cfg_path)
+    from . import _policy
+    _policy.apply_config(cfg)          # optional keys general.exact / visualization.embed_mode
     if not debug:
         debug = cfg["general"]["debug"]
     vz = cfg["visualization"]

@@ -212,12 +212,16 @@ def _kept_worker(rank, world, port, out_dir):
         out = {}
         cands = {13: [0, 5, 0x1B1B1B1, 4 ** 13 - 1], 16: [0, 0x1B1B1B1B, 4 ** 16 - 1]}
         for k in (13, 16):                                   # 16: int64 keys, 16-GiB tables
-            ds.count(dc, k, dedupe=True, merge_revcom=True)
+            ds.count(dc, k, dedupe=True, merge_revcom=True)          # a masked re-count of find_motif: nobody gathers the table
+            assert dc._shard is not None and dc._full is None and dc.fetch_full() is None
+            ds.count(dc, k, dedupe=True, merge_revcom=True, gather_full=True)   # the table k{k}.pkl is written from
             assert dc._shard is not None and (dc._full is not None) == (rank == 0)
             out[k] = {"n_uniq": dc.n_uniq, "n_local": dc._shard.n_local, "total": dc.total(), "top": dc.topk(7),
                       "mass": dc.hamball_mass(np.array(cands[k], np.uint64), 3, True)}
+            out[k]["all"] = dc.fetch()                               # collective: EVERY rank calls it, with full_table_rank set
+            out[k]["total_after"] = dc.total()                       # ... and the next collective still pairs up
             if rank == 0:
-                out[k]["full"] = dc.fetch()
+                out[k]["full"] = dc.fetch_full()
         ds.reset()
         # the reads hold poly-A / poly-T stretches: a consensus within the radius of the all-T k-mer also matches the windows that touch a
         # separator (the reference's all-ones invalid hash, kmer_count.py:580-610) and masks k - 1 positions into the NEXT read --
@@ -261,6 +265,10 @@ def test_find_motif_on_counts_that_stay_sharded(tmp_path):
         np.testing.assert_array_equal(fu, ou)
         np.testing.assert_array_equal(fc, oc)
         assert fu.dtype == ou.dtype and fc.dtype == oc.dtype
+        for r in res:                                        # fetch() on a sharded table: collective, same answer on every rank
+            np.testing.assert_array_equal(r[k]["all"][0], ou)
+            np.testing.assert_array_equal(r[k]["all"][1], oc)
+            assert r[k]["total_after"] == int(oc.sum())
     old = md.TOPK_DEVICE_MIN
     md.TOPK_DEVICE_MIN = 1000
     try:

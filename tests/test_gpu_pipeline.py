@@ -124,6 +124,25 @@ def test_find_motif_device_topk_path(run_dir, golden, motif_defs, monkeypatch):
     assert list(outs[0].keys()) == list(outs[1].keys()) and len(outs[0]) >= 1
     for kh in outs[0]:
         assert outs[0][kh] == outs[1][kh]
+    # KMAP_EXACT=1 (or general.exact in config.toml): np.argpartition on the fetched table whatever the threshold says
+    from kmap_amd import _policy
+    from kmap_amd.kmer_count import DeviceCounts
+
+    def no_topk(self, top_k):
+        raise AssertionError("device top-k used in exact mode")
+    for how in ("env", "config"):
+        with monkeypatch.context() as mp:
+            mp.setattr(DeviceCounts, "topk", no_topk)
+            if how == "env":
+                mp.setenv("KMAP_EXACT", "1")
+            else:
+                _policy.apply_config({"general": {"exact": True}})
+            try:
+                r = MD.find_motif(s["seq"].copy(), 11, d.max_ham_dist, d.p_uniform, d.ratio_mu, d.ratio_std, d.ratio_cutoff,
+                                  save_kmer_cnt_flag=False, boarder_pkl_file=bpk)
+            finally:
+                _policy.reset()
+        assert list(r.keys()) == list(outs[0].keys()) and all(r[kh] == outs[0][kh] for kh in r)
     # the large-table path writes k{k}.pkl from a background thread (protocol 5) while the trials run: same content
     pkl = run_dir.parent / "bg_k11.pkl"
     if pkl.exists():
@@ -377,6 +396,16 @@ def test_sample_disp_kmer_vs_oracle(run_dir, golden, motif_defs, monkeypatch):
         np.testing.assert_array_equal(got[2], olab[inds])
         assert got[0].dtype == ou.dtype and got[2].dtype == np.int64
         assert got[2].max() == len(cons_list) and int(got[1].sum()) == 4000
+        # KMAP_EXACT=1: np.random.multinomial per label at every size (reference motif_discovery.py:912) == the oracle's restatement
+        monkeypatch.setenv("KMAP_EXACT", "1")
+        np.random.seed(5)
+        got = MD.sample_disp_kmer(ordered, kk, mdd, d / "kc", n_total_sample=4000, n_motif_kmer=2000)
+        np.random.seed(5)
+        want = O.sample_disp_kmer(ordered, kk, r_of, u, c, n_total_sample=4000, n_motif_kmer=2000)
+        for a, b in zip(got[:3], want[:3]):
+            np.testing.assert_array_equal(a, b)
+            assert a.dtype == b.dtype
+        monkeypatch.delenv("KMAP_EXACT")
 
 
 def test_genome_like_input_vs_oracle(motif_defs):
@@ -559,3 +588,43 @@ def test_second_dataset_repetitive_mode_and_noise_kmers(golden, tmp_path):
     assert klen == int(g["hamdist_kmer_len"]) and mat.dtype == np.int64
     np.testing.assert_array_equal(mat, g["hamdist_mat_u8"])
     np.testing.assert_array_equal(lab, g["hamdist_label"])
+
+
+def test_exact_run_above_the_thresholds(monkeypatch):
+    """config.toml `general.exact = true` (run_e2e mode "exact"): with every scale threshold pulled below the run's sizes -- compact
+    hand-off, device top-k, inverse-CDF draws, device neighbour rule would all apply -- both verbs still take the reference's numpy
+    calls (np.argpartition :661 / visualization.py:100, np.random.multinomial :912) and its arithmetic (SEQ), so every output file
+    equals the run below the thresholds (the regime that IS the reference's path); `visualization.embed_mode = "fast"` (the
+    opt-in key) runs to a file of the same shape."""
+    import pickle
+    import shutil
+    from pathlib import Path
+    from kmap_amd import motif_discovery as MD
+    from kmap_amd.e2e import run_e2e
+    monkeypatch.delenv("KMAP_EXACT", raising=False)
+    monkeypatch.delenv("KMAP_KNN", raising=False)
+    dirs = []
+    try:
+        base = run_e2e("C1s", "default", keep=True)
+        dirs.append(base["res_dir"])
+        monkeypatch.setattr(MD, "TOPK_DEVICE_MIN", 50)
+        monkeypatch.setattr(MD, "DENSE_PKL_MAX_N", 100)
+        exact = run_e2e("C1s", "exact", keep=True)
+        dirs.append(exact["res_dir"])
+        fast = run_e2e("C1s", "fast", keep=True)
+        dirs.append(fast["res_dir"])
+        b, e, f = (Path(d) for d in dirs)
+        assert base["final_conseq"] == exact["final_conseq"] and len(fast["final_conseq"]) >= 1   # fast: device rules apply (ties may differ)
+        for name in ("candidate_conseq.csv", "final_conseq.txt", "low_dim_data.tsv"):
+            assert (b / name).read_bytes() == (e / name).read_bytes(), name
+        sb, se = (pickle.load(open(d / "sample_kmers.pkl", "rb")) for d in (b, e))
+        for x, y in zip(sb[:3], se[:3]):
+            np.testing.assert_array_equal(x, y)
+        hb, he = (pickle.load(open(d / "sample_kmer_hamdist_mat.pkl", "rb")) for d in (b, e))
+        assert hb[1] is not None and he[1] is None                      # dense int64 matrix vs compact hand-off
+        np.testing.assert_array_equal(hb[2], he[2])
+        tb, tf = (np.loadtxt(d / "low_dim_data.tsv", skiprows=1) for d in (b, f))
+        assert tb.shape == tf.shape and np.isfinite(tf).all()
+    finally:
+        for d in dirs:
+            shutil.rmtree(d, ignore_errors=True)

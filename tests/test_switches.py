@@ -29,17 +29,56 @@ def test_every_switch_of_the_product_is_named_in_a_test():
 
 
 def test_embed_mode_switch(monkeypatch):
-    """KMAP_EMBED_MODE=seq|fast overrides the size rule (SEQ up to the dense hand-over limit, FAST above)"""
-    from kmap_amd import visualization as V
-    from kmap_amd.motif_discovery import DENSE_PKL_MAX_N
+    """SEQ -- the reference's arithmetic (visualization.py:296-317) -- is the default at EVERY N; FAST is opt-in through config.toml's
+    optional visualization.embed_mode key or KMAP_EMBED_MODE (the environment wins)"""
+    from kmap_amd import _policy, visualization as V
     monkeypatch.delenv("KMAP_EMBED_MODE", raising=False)
-    assert V.default_mode(DENSE_PKL_MAX_N) == V.EMBED_SEQ and V.default_mode(DENSE_PKL_MAX_N + 1) == V.EMBED_FAST
+    _policy.reset()
+    assert V.default_mode(50_000) == V.EMBED_SEQ and V.default_mode(200_000) == V.EMBED_SEQ and V.default_mode() == V.EMBED_SEQ
     monkeypatch.setenv("KMAP_EMBED_MODE", "seq")
     assert V.default_mode(10 ** 6) == V.EMBED_SEQ
     monkeypatch.setenv("KMAP_EMBED_MODE", "FAST")
     assert V.default_mode(10) == V.EMBED_FAST
     monkeypatch.setenv("KMAP_EMBED_MODE", "bogus")
     assert V.default_mode(10) == V.EMBED_SEQ
+    monkeypatch.delenv("KMAP_EMBED_MODE")
+    try:
+        _policy.apply_config({"visualization": {"embed_mode": "fast"}})
+        assert V.default_mode(10) == V.EMBED_FAST
+        monkeypatch.setenv("KMAP_EMBED_MODE", "seq")
+        assert V.default_mode(10) == V.EMBED_SEQ
+        monkeypatch.delenv("KMAP_EMBED_MODE")
+        _policy.apply_config({"general": {}, "visualization": {}})          # keys absent (the reference's config.toml)
+        assert V.default_mode(10 ** 6) == V.EMBED_SEQ
+        with pytest.raises(ValueError):
+            _policy.apply_config({"visualization": {"embed_mode": "quick"}})
+    finally:
+        _policy.reset()
+
+
+def test_exact_switch(monkeypatch):
+    """KMAP_EXACT=1 / config general.exact: the reference's numpy calls at every size -- np.argpartition neighbours
+    (visualization.py:100), np.argpartition top-k (motif_discovery.py:661), np.random.multinomial (:912); the GPU tests
+    test_find_motif_device_topk_path / test_sample_disp_kmer_vs_oracle / test_exact_run_above_the_thresholds run the paths"""
+    from kmap_amd import _policy, motif_discovery as MD, visualization as V
+    monkeypatch.delenv("KMAP_EXACT", raising=False)
+    monkeypatch.delenv("KMAP_KNN", raising=False)
+    _policy.reset()
+    big = MD.DENSE_PKL_MAX_N + 1
+    assert not _policy.exact() and V.knn_mode(big) == "device" and MD._device_topk(MD.TOPK_DEVICE_MIN + 1, 5)
+    monkeypatch.setenv("KMAP_EXACT", "1")
+    assert _policy.exact() and V.knn_mode(big) == "numpy" and not MD._device_topk(MD.TOPK_DEVICE_MIN + 1, 5)
+    monkeypatch.setenv("KMAP_KNN", "device")                       # the specific switch still wins over the general one
+    assert V.knn_mode(big) == "device"
+    monkeypatch.delenv("KMAP_KNN")
+    monkeypatch.delenv("KMAP_EXACT")
+    try:
+        _policy.apply_config({"general": {"exact": True}})
+        assert _policy.exact() and V.knn_mode(big) == "numpy"
+        monkeypatch.setenv("KMAP_EXACT", "0")
+        assert not _policy.exact()
+    finally:
+        _policy.reset()
 
 
 def _csv_case(n_seq=70_000, n_cons=2, seed=3):
@@ -120,3 +159,9 @@ def test_knn_numpy_mode_above_the_dense_limit(monkeypatch):
     assert V.knn_mode(10) == "device"
     monkeypatch.delenv("KMAP_KNN")
     assert V.knn_mode(n) == "device" and V.knn_mode(DENSE_PKL_MAX_N) == "numpy"
+    # KMAP_EXACT=1 selects the same neighbours (threaded row blocks == one argpartition call per row)
+    monkeypatch.setenv("KMAP_EXACT", "1")
+    assert V.knn_mode(n) == "numpy"
+    tr2 = {}
+    V.kmap_from_kmers(kh, np.ones(n, np.int64), lab, conseqs, k, n_max_iter=2, random_seed=5, mode=V.EMBED_FAST, trace=tr2)
+    np.testing.assert_array_equal(tr2["nb"], nb)
