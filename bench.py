@@ -17,7 +17,11 @@ C3 embedding, N = 50 000 fixed, sharded loop with its ONE all-reduce per iterati
 forces / collective / apply ms), `c4` (BASELINE config C4, N = 200 000 fixed: Hamming rows + the sharded embedding iteration) and,
 for G > 1, `count_dist` (one k = 15 count pass over read shards: all-reduce of the 4-GiB table vs bins owned by key range).
 At G = 1 `embed_dist` runs the sharded loop on a one-rank RCCL group next to the resident loop: `overhead_ms_per_iter` is what
-the multi-GPU plumbing (message kernels, collective launch, Python) costs before any link is involved.
+the multi-GPU plumbing (message kernels, collective launch, Python) costs before any link is involved.  `embed_dist.seq` is the same
+for the SEQ loop (the reference's summation order: the package default).  For G > 1 the line also carries `reads_dist` (the C3 reads
+sharded: count k = 8 with dedupe, count k = 14, scan k = 8 r = 2 -- ms per pass incl. the collective, max over ranks, per-GPU
+roofline fraction) and `e2e` (BOTH VERBS on a clean C3 res_dir under the process group, SEQ default and FAST: north_star's metric).
+`--shard-proxy G` (N = 1): every rank's share of a G-GPU run timed on the one GPU, shard after shard (`shard_proxy`).
 
 Extra objects on the JSON line:
   roofline      HIP-event kernel time of the headline kernel (mean / min / median per launch) vs the 8 TB/s HBM peak, algorithmic
