@@ -433,6 +433,7 @@ static int embed_create_impl(kmap_embed **out, int64_t n, int64_t row0, int64_t 
     }
     if (mode == KMAP_EMBED_SEQ) kmap_embed_seq_split(e);
     e->n_part = kmap_embed_force_blocks(e) > 0 ? kmap_embed_force_blocks(e) : 1;
+    if (mode == KMAP_EMBED_SEQ && kmap_embed_seq_blocks_max(e) > e->n_part) e->n_part = kmap_embed_seq_blocks_max(e);
     hipError_t err = hipSuccess;
     auto A = [&](void **p, size_t b) { if (err == hipSuccess) err = hipMalloc(p, b ? b : 16); };
     A((void **)&e->Y, ((size_t)2 * n + 64) * 4);            // + 64 floats: embed_seq.hip's 16-byte coordinate loads may run 7 floats past Yy

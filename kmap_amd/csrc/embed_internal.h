@@ -75,6 +75,8 @@ struct kmap_embed {
     int64_t seq_main_rows = 0;
     int seq_tail_g = 0;
     int64_t seq_pair_rows = 0;      // of the main rows, [0, seq_pair_rows) run in the pair form (32 rows per wave); multiple of 128
+    // SEQ producer / adder form (embed_seq.hip): blocks of seq_R <= seq_RP rows, one adder wave per block (0: the forms above)
+    int seq_R = 0, seq_RP = 0;
     // symmetric FAST path (all rows local): partial buffers
     float *rowpart = nullptr, *colpart = nullptr;
     int64_t symI = 0, symJ = 0;
@@ -100,6 +102,7 @@ int kmap_embed_launch_sym(kmap_embed *e, float *G, bool reduce_into_G, hipStream
 int kmap_embed_launch_seq(kmap_embed *e, float *G, hipStream_t st);                       // embed_seq.hip
 void kmap_embed_seq_split(kmap_embed *e);                                                 // embed_seq.hip: rows -> pair / quad / wide form
 int kmap_embed_seq_blocks(const kmap_embed *e);                                           // blocks (= loss partials) of the SEQ launch
+int kmap_embed_seq_blocks_max(const kmap_embed *e);                                       // ... of whichever form a later set_prob may select
 
 inline int kmap_embed_force_blocks(const kmap_embed *e) {
     if (e->sym) return (int)(e->n_lblocks * (((e->symJ + SY_WAVES - 1) / SY_WAVES) * SY_WAVES));

@@ -527,6 +527,236 @@ __device__ __forceinline__ void seq_wide_body(const ProbSrc &src, const float *_
     }
 }
 
+// =================================================================================================
+// SEQ forces, PRODUCER / ADDER form.  Same terms, same order of every row sum as the forms above; what differs is who adds.
+// In the quad / pair / row16 forms every wave both evaluates terms and walks the ordered add chain, and an ordered add serves only
+// the 16 / 32 / 4 rows of its wave: 8 / 4 / 30 add instructions per column and wave.  A session with few rows (a rank's share of a
+// row-sharded run: 6 250 x 50 000 at G = 8) cannot fill the SIMDs with such waves and runs at the latency of their chains and of
+// their one load in flight (r05 shard proxy: 0.68 ms per shard against 2.15 ms for all 50 000 rows -- 3.2x on 8 GPUs).  Here a
+// block owns R <= RP rows and splits the roles:
+//   * PRODUCER waves evaluate the terms of a chunk of CH columns for all R rows -- lanes along the columns, a step = RPS rows x CH
+//     columns = 512 terms -- into an LDS buffer.  Their only memory stream is the sums (one 16-byte load per lane and step, PF steps
+//     ahead: the steps of a producer are static, p, p + NP, p + 2 NP, ...); the chunk's coordinates and the block's row coordinates
+//     wait in LDS (loads return in order: a short-latency load issued behind a prefetch would wait for it);
+//   * ONE ADDER wave, a row per lane, reads the terms back -- (column pair, row) cells of 16 bytes, one ds_read_b128 per two
+//     columns -- and adds them in column order with one v_pk_add_f32 per column (x and y chains in one instruction): 1.5
+//     instructions per column for up to 64 rows, on a chain nothing else delays (s_setprio).  It also stages the coordinates of the
+//     chunk after next (its memory pipe is idle otherwise).
+// Two term buffers: while the adder consumes chunk u the producers fill chunk u + 1; one barrier per chunk.
+// LDS cell of (column pair cp = 4 g + d, row r) in units of 16 B: g * (4 RP + 1) + d * RP + r -- one cell of padding per column group g
+// (= producer lane): the producers' ds_write_b128 (8 lanes x 16 B per 128-B bank window: 8 consecutive column groups, odd pitch -> 8
+// different cells of the window) and the adder's ds_read_b128 (16 consecutive rows) are conflict-free, and the adder's address is
+// its row's 16 bytes + a compile-time offset: no address arithmetic inside its chain.
+// Waves w and w + 4 of a block share a SIMD (round-robin placement): wave 3 is the adder, waves 7 / 11 / 15 are producers only as far
+// as the launch says (SA_EA of them) and leave at once otherwise, so that the adder's SIMD carries the adder + SA_EA producers and the
+// other three SIMDs M producers each -- equal issue load (the adder issues about as much as three producers' steps).
+// =================================================================================================
+constexpr int SA_MAX_WAVES = 16;                 // 1 adder + up to 15 producers (the launch picks the number: a divisor-like match of the steps per chunk)
+constexpr int SA_ADDER = 3;                      // the adder's wave index
+constexpr int SA_PF = 4;                         // sums loads in flight per producer lane
+template <int RP, int CH>
+struct SaGeom {
+    static constexpr int LPR = CH / SQ_CPL;              // lanes per row in a producer step
+    static constexpr int RPS = KMAP_WAVE / LPR;          // rows per step
+    static constexpr int QP = 4 * RP + 1;                // cells (16 B) per column group: its four column pairs x RP rows + one of padding
+    static constexpr size_t BUF_BYTES = (size_t)(CH / 8) * QP * 16;
+    static constexpr size_t XY_FLOATS = 2 * (size_t)CH;  // one chunk's x | y
+    static constexpr size_t FIXED_BYTES = 2 * BUF_BYTES + 2 * XY_FLOATS * 4 + (size_t)RP * 8;   // term buffers, coordinate buffers, row coordinates
+    static_assert(LPR * RPS == KMAP_WAVE && (RP == 32 || RP == 64) && CH % 8 == 0 && CH <= 256, "geometry");
+};
+template <int RP, int CH>
+__global__ __launch_bounds__(KMAP_WAVE *SA_MAX_WAVES) void forces_seqa_kernel(ProbSrc src, const float *__restrict__ Y, int64_t n, int64_t row0,
+                                                                 int64_t nrows, int R, float *__restrict__ G,
+                                                                 double *__restrict__ loss_part) {
+    using GEO = SaGeom<RP, CH>;
+    constexpr int LPR = GEO::LPR, RPS = GEO::RPS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4 *buf0 = reinterpret_cast<f32x4 *>(smem);
+    f32x4 *buf1 = buf0 + GEO::BUF_BYTES / 16;
+    float *xy0 = reinterpret_cast<float *>(buf1 + GEO::BUF_BYTES / 16);      // x[CH] | y[CH] of the even chunks
+    float *xy1 = xy0 + GEO::XY_FLOATS;
+    f32x2 *rowxy = reinterpret_cast<f32x2 *>(xy1 + GEO::XY_FLOATS);          // (x, y) of the block's rows
+    float *lut_s = reinterpret_cast<float *>(rowxy + RP);
+    __shared__ double wl[SA_MAX_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // roles (see above): M producers on each of the three other SIMD classes, EA on the adder's
+    const int M = R >> 8 & 15, EA = R >> 12 & 3, SA_NP = 3 * M + EA;
+    R &= 255;
+    const int cls = wave & 3, idx = wave >> 2;
+    const float *X = Y, *Yy = Y + n;
+    const int64_t lr0 = (int64_t)blockIdx.x * R;                       // first local row of the block
+    const int Rb = (int)((nrows - lr0) < (int64_t)R ? (nrows - lr0) : (int64_t)R);   // rows of this block (>= 1)
+    const int S = (Rb + RPS - 1) / RPS;                                // producer steps per chunk
+    const int64_t nch = (n + CH - 1) / CH;                             // chunks
+    if (threadIdx.x < SA_MAX_WAVES) wl[threadIdx.x] = 0.0;
+    for (int t = threadIdx.x; t < src.lut_len && t < F_LUT_LDS; t += blockDim.x) lut_s[t] = src.lut[t];
+    for (int t = threadIdx.x; t < 2 * CH; t += blockDim.x) {           // coordinates of chunks 0 and 1 (columns past n - 1: the last point's)
+        const int64_t j = t < n ? t : n - 1;
+        (t < CH ? xy0 : xy1 - CH)[t] = X[j];
+        (t < CH ? xy0 : xy1 - CH)[CH + t] = Yy[j];
+    }
+    if (threadIdx.x < RP) {
+        const int64_t i = row0 + lr0 + (threadIdx.x < Rb ? threadIdx.x : Rb - 1);
+        rowxy[threadIdx.x] = f32x2{X[i], Yy[i]};
+    }
+    __syncthreads();
+    if (cls == 3 ? (idx > EA) : (idx >= M)) return;                    // a placeholder wave: it helped with the staging and leaves (an ended wave no longer counts at barriers)
+    if (wave == SA_ADDER) {
+        // ---------------- the adder: lane r = row lr0 + r; its u-th barrier = "chunk u is complete"
+        __builtin_amdgcn_s_setprio(3);
+        const int r = lane & (RP - 1);
+        f32x2 acc = {0.0f, 0.0f};
+        for (int64_t u = 0; u < nch; ++u) {
+            __syncthreads();
+            // coordinates of chunk u + 2 -> registers now, -> the buffer chunk u's producers have just finished with at the end
+            float sx[4], sy[4];
+            const int64_t jc = (u + 2) * CH + 4 * lane;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int64_t j = jc + c < n ? jc + c : n - 1;
+                sx[c] = X[j];
+                sy[c] = Yy[j];
+            }
+            const f32x4 *buf = (u & 1) ? buf1 : buf0;
+            const int ncols = (int)((n - u * CH) < (int64_t)CH ? (n - u * CH) : (int64_t)CH);
+            if (ncols == CH) {
+                // sixteen columns (two producer lanes' column groups = eight cells) per round, the next round's cells in flight
+                auto cells = [&](f32x4 (&v)[8], int g2) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 *cell = buf + (size_t)(2 * g2 + h) * GEO::QP + r;
+                        v[4 * h] = cell[0]; v[4 * h + 1] = cell[RP]; v[4 * h + 2] = cell[2 * RP]; v[4 * h + 3] = cell[3 * RP];
+                    }
+                };
+                auto adds = [&](const f32x4 (&v)[8]) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        acc += f32x2{v[c].x, v[c].y};
+                        acc += f32x2{v[c].z, v[c].w};
+                    }
+                };
+                f32x4 va[8], vb[8];
+                cells(va, 0);
+                static_assert(CH % 32 == 0, "two rounds per loop pass");
+#pragma unroll
+                for (int g2 = 0; g2 < CH / 16; g2 += 2) {                  // fully unrolled: every read is base + immediate offset
+                    cells(vb, g2 + 1);
+                    adds(va);
+                    cells(va, g2 + 2 < CH / 16 ? g2 + 2 : g2);              // behind the last round: a harmless re-read
+                    adds(vb);
+                }
+            } else {                                                   // the last chunk: only the columns that exist
+                for (int c = 0; c < ncols; ++c) {
+                    const int cp = c >> 1;
+                    const f32x4 v = buf[(size_t)(cp >> 2) * GEO::QP + (size_t)(cp & 3) * RP + r];
+                    acc += (c & 1) ? f32x2{v.z, v.w} : f32x2{v.x, v.y};
+                }
+            }
+            if (4 * lane < CH) {
+                float *xy = (u & 1) ? xy1 : xy0;
+                *reinterpret_cast<f32x4 *>(xy + 4 * lane) = f32x4{sx[0], sx[1], sx[2], sx[3]};
+                *reinterpret_cast<f32x4 *>(xy + CH + 4 * lane) = f32x4{sy[0], sy[1], sy[2], sy[3]};
+            }
+        }
+        if (lane < RP && lane < Rb) {
+            const int64_t i = row0 + lr0 + lane;
+            G[i] = acc.x;
+            G[n + i] = acc.y;
+        }
+        wl[wave] = 0.0;
+    } else {
+        // ---------------- a producer: steps p, p + NP, ... of the sequence (chunk 0: S steps), (chunk 1: S steps), ...
+        // Everything that says WHICH step is wave-uniform and lives in scalar registers (readfirstlane tells the compiler); a lane adds
+        // constants it computed once: its row inside the step, its eight columns, and their clamped forms for the block's last step
+        // (rows past the block -> its last row) and the last chunk (columns past n - 1 -> the last aligned group).
+        const int p = __builtin_amdgcn_readfirstlane(cls == 3 ? 3 * M + idx - 1 : 3 * idx + cls);
+        const int NP = __builtin_amdgcn_readfirstlane(SA_NP), nch32 = (int)nch;
+        const int sub = lane & (LPR - 1), rin = lane / LPR;
+        const int rows_last = Rb - (S - 1) * RPS;                          // rows of the block's last step (1 .. RPS)
+        const int rin_last = rin < rows_last ? rin : rows_last - 1;
+        const uint32_t ld2 = (uint32_t)src.ld * 2u;                        // bytes per sums row
+        const uint32_t off_row = (uint32_t)rin * ld2, off_row_last = (uint32_t)rin_last * ld2;
+        const int64_t jl_last = (int64_t)(nch32 - 1) * CH + sub * SQ_CPL;
+        const uint32_t off_col = (uint32_t)sub * SQ_CPL * 2u,
+                       off_col_last = (uint32_t)((jl_last < n ? jl_last : ((n - 1) & ~(int64_t)7)) - (int64_t)(nch32 - 1) * CH) * 2u;
+        const SeqFar far = seq_far_consts();
+        double loss = 0.0;
+        int pu = 0, pw = p;                                                // (chunk, step in chunk) of the next step to prefetch
+        auto norm = [&](int &u, int &w) {
+            while (w >= S) {
+                w -= S;
+                ++u;
+            }
+        };
+        norm(pu, pw);
+        const char *sums_base = reinterpret_cast<const char *>(src.ps + lr0 * src.ld);
+        auto issue = [&](u32x4 &q) {                                   // always a load: behind the last step the last step's again
+            const int u = pu < nch32 ? pu : nch32 - 1;
+            const char *row = sums_base + ((int64_t)pw * RPS * src.ld + (int64_t)u * CH) * 2;          // scalar
+            const uint32_t off = (pw == S - 1 ? off_row_last : off_row) + (u == nch32 - 1 ? off_col_last : off_col);
+            q = *reinterpret_cast<const u32x4 *>(row + off);
+            pw += NP;
+            norm(pu, pw);
+        };
+        u32x4 q[SA_PF];
+#pragma unroll
+        for (int i = 0; i < SA_PF; ++i) issue(q[i]);
+        int cu = 0, cw = p, passed = 0;
+        norm(cu, cw);
+        const float *xy_lane = xy0 + SQ_CPL * sub;
+        f32x4 *cell_lane = buf0 + (size_t)sub * GEO::QP + rin;
+        const int i_lane = (int)(row0 + lr0) + rin, i_lane_last = (int)(row0 + lr0) + rin_last;
+        auto step = [&](const u32x4 &sums) {
+            SeqBatch cur;
+            cur.w[0] = sums.x; cur.w[1] = sums.y; cur.w[2] = sums.z; cur.w[3] = sums.w;
+            while (passed < cu) {                                      // chunk cu's buffers are free once barrier cu - 1 has been passed
+                __syncthreads();
+                ++passed;
+            }
+            const bool last = cw == S - 1;                             // scalar
+            const float *xy = xy_lane + (cu & 1) * (int)GEO::XY_FLOATS;
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(xy), a1 = *reinterpret_cast<const f32x4 *>(xy + 4);
+            const f32x4 c0 = *reinterpret_cast<const f32x4 *>(xy + CH), c1 = *reinterpret_cast<const f32x4 *>(xy + CH + 4);
+            cur.x[0] = f32x2{a0.x, a0.y}; cur.x[1] = f32x2{a0.z, a0.w}; cur.x[2] = f32x2{a1.x, a1.y}; cur.x[3] = f32x2{a1.z, a1.w};
+            cur.y[0] = f32x2{c0.x, c0.y}; cur.y[1] = f32x2{c0.z, c0.w}; cur.y[2] = f32x2{c1.x, c1.y}; cur.y[3] = f32x2{c1.z, c1.w};
+            const int r_step = cw * RPS;                               // the step's first row inside the block (scalar)
+            const f32x2 rxy = rowxy[r_step + (last ? rin_last : rin)];
+            const int j0 = cu * CH;
+            float tx[SQ_CPL], ty[SQ_CPL];
+            float ce2;
+            seq_terms_dispatch<true>(cur, lut_s, rxy.x, rxy.y, r_step + (last ? i_lane_last : i_lane), n, (int64_t)j0, CH,
+                                     row0 + lr0 + r_step, RPS, j0 + sub * SQ_CPL, far, tx, ty, ce2);
+            if (!last || rin < rows_last) loss += (double)ce2;         // a clamped duplicate of the block's last row does not count
+            f32x4 *cell = cell_lane + (size_t)r_step + (cu & 1) * (GEO::BUF_BYTES / 16);   // row r_step + rin < S RPS <= RP
+#pragma unroll
+            for (int d = 0; d < SQ_CPL / 2; ++d) cell[(size_t)d * RP] = f32x4{tx[2 * d], ty[2 * d], tx[2 * d + 1], ty[2 * d + 1]};
+            cw += NP;
+            norm(cu, cw);
+        };
+        while (cu < nch32) {
+#pragma unroll
+            for (int i = 0; i < SA_PF; ++i) {
+                const u32x4 sums = q[i];
+                issue(q[i]);                                           // refill at once, on every path (see seq_load): SA_PF loads in flight
+                if (cu < nch32) step(sums);
+            }
+        }
+        while (passed < nch32) {                                       // the barriers the adder still waits at
+            __syncthreads();
+            ++passed;
+        }
+        loss *= -0.6931471805599453;   // log2 units -> -ln
+        for (int o = 32; o > 0; o >>= 1) loss += __shfl_down(loss, o);
+        if (lane == 0) wl[wave] = loss;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tsum = 0.0;
+        for (int w = 0; w < SA_MAX_WAVES; ++w) tsum += wl[w];
+        loss_part[blockIdx.x] = tsum;
+    }
+}
+
 // One launch for both forms: blocks [0, nb_tail) take the left-over rows in the wide form (GW lanes per row; GW = 0: none), the
 // blocks behind them the whole rounds in the quad form.  Launched together the wide waves share their SIMDs with three quad
 // waves each, which hides the latency of their N-step dependent add chain (alone on the machine -- as a second launch -- the
@@ -573,7 +803,21 @@ static int seq_tail_blocks(const kmap_embed *e) {
     const int64_t rows_per_block = (int64_t)SQ_WAVES * (KMAP_WAVE / e->seq_tail_g);
     return (int)((e->nrows - e->seq_main_rows + rows_per_block - 1) / rows_per_block);
 }
-int kmap_embed_seq_blocks(const kmap_embed *e) { return seq_main_blocks(e) + seq_tail_blocks(e); }
+// the producer / adder form needs its two 64-KiB term buffers + the LUT in the CU's 160 KiB of LDS
+constexpr size_t SA_LDS_MAX = 160 * 1024 - 512;
+static bool seq_adder_form(const kmap_embed *e) {
+    if (!e->seq_R) return false;
+    if (e->src.pf) return false;                          // f32 probability rows (the drop-in float operators): classic forms
+    const size_t lut = ((size_t)e->src.lut_len * 4 + 15) & ~(size_t)15;
+    // 16-byte loads of the sums: rows 16-byte aligned (the product's pitch is a multiple of 128 entries)
+    return SaGeom<32, 256>::FIXED_BYTES + lut <= SA_LDS_MAX && (e->src.ps == nullptr || e->src.ld % 8 == 0);
+}
+static int seq_adder_blocks(const kmap_embed *e) { return e->seq_R ? (int)((e->nrows + e->seq_R - 1) / e->seq_R) : 0; }
+int kmap_embed_seq_blocks(const kmap_embed *e) { return seq_adder_form(e) ? seq_adder_blocks(e) : seq_main_blocks(e) + seq_tail_blocks(e); }
+int kmap_embed_seq_blocks_max(const kmap_embed *e) {
+    const int a = seq_adder_blocks(e), c = seq_main_blocks(e) + seq_tail_blocks(e);
+    return a > c ? a : c;
+}
 
 // How the SEQ rows are split between the quad kernel and the wide kernel.  The kernels are VALU-issue bound and every wave of a
 // SIMD shares its issue slots, so the cost of a set of waves is (waves on the fullest SIMD) x (instructions per wave); per
@@ -584,6 +828,28 @@ void kmap_embed_seq_split(kmap_embed *e) {
     e->seq_main_rows = e->nrows;
     e->seq_tail_g = 0;
     e->seq_pair_rows = 0;
+    e->seq_R = e->seq_RP = 0;
+    {   // producer / adder form: KMAP_SEQ_FORM=adder|classic forces it on / off (A/B switch + the bit-identity tests of the forms)
+        const char *v = getenv("KMAP_SEQ_FORM");
+        const bool force_on = v && v[0] == 'a', force_off = v && v[0] == 'c';
+        int dev0 = 0, cus0 = 256;
+        if (hipGetDevice(&dev0) != hipSuccess || hipDeviceGetAttribute(&cus0, hipDeviceAttributeMultiprocessorCount, dev0) != hipSuccess || cus0 <= 0) cus0 = 256;
+        // r05 measurements (tools/seqa_check.py, ms per force evaluation, classic / this form): 650 x 1000: .023 / .028; 5000 x 5000: .083 / .054;
+        // 6250 x 50 000 (an eighth of C3): .69 / .38; 16 461 x 17 413: .80 / .40; 25 000 x 200 000 (an eighth of C4): 9.4 / 5.5;
+        // 50 000 x 50 000: 2.14 / 2.71 -- the quad / pair forms win once three or more whole rounds of their waves fill the machine
+        const bool want = force_on || (!force_off && e->nrows > 0 && e->n >= 3072 && 2 * e->nrows < 5 * (int64_t)(4 * cus0) * SQ_ROWS);
+        if (want && e->nrows > 0) {
+            // one block per CU and round; the fewest rounds the row slots allow, then the smallest R that still fits them (a block's
+            // producer time grows with R, its adder time does not)
+            const int rp = e->nrows > (int64_t)32 * cus0 ? 64 : 32;
+            const int64_t rounds = (e->nrows + (int64_t)rp * cus0 - 1) / ((int64_t)rp * cus0);
+            int R = (int)((e->nrows + rounds * cus0 - 1) / (rounds * cus0));
+            if (R < 1) R = 1;
+            if (R > rp) R = rp;
+            e->seq_R = R;
+            e->seq_RP = rp;
+        }
+    }
     static const int off = [] { const char *v = getenv("KMAP_SEQ_TAIL"); return v && v[0] == '0'; }();   // A/B switch
     if (off || e->nrows <= 0) return;
     int dev = 0, cus = 256;
@@ -625,6 +891,25 @@ void kmap_embed_seq_split(kmap_embed *e) {
 int kmap_embed_launch_seq(kmap_embed *e, float *G, hipStream_t st) {
     const bool lut = e->src.ps != nullptr;
     const size_t lds = lut ? (((size_t)e->src.lut_len * 4 + 15) & ~(size_t)15) : 16;
+    if (seq_adder_form(e)) {
+        const int nb = seq_adder_blocks(e);
+#define KMAP_SEQA(RP, CH)                                                                                                          \
+    do {                                                                                                                           \
+        const size_t lds_a = SaGeom<RP, CH>::FIXED_BYTES + lds;                                                                    \
+        KMAP_TRY(kmap_allow_lds((const void *)forces_seqa_kernel<RP, CH>, (int)lds_a));                                            \
+        const int steps = (e->seq_R + SaGeom<RP, CH>::RPS - 1) / SaGeom<RP, CH>::RPS;     /* producer steps per chunk */                   \
+        /* producers: one step each per chunk where 3 M + EA can equal the steps (7 .. 13 of them), else as many as fit */          \
+        int M = 4, EA = 1;                                                                                                         \
+        if (steps <= 13) { M = steps >= 12 ? 4 : steps >= 9 ? 3 : 2; EA = steps - 3 * M; if (EA < 0) { EA = 0; } if (EA > 3) { EA = 3; } }          \
+        const int waves = 4 * (M > EA + 1 ? M : EA + 1);                                                                           \
+        const int geo = e->seq_R | (M << 8) | (EA << 12);                                                                          \
+        forces_seqa_kernel<RP, CH><<<nb, KMAP_WAVE * waves, lds_a, st>>>(e->src, e->Y, e->n, e->row0, e->nrows, geo, G, e->loss_part); \
+    } while (0)
+        if (e->seq_RP == 64) KMAP_SEQA(64, 128); else KMAP_SEQA(32, 256);
+#undef KMAP_SEQA
+        KMAP_CHECK_HIP(hipGetLastError());
+        return KMAP_OK;
+    }
     const int nb_main = seq_main_blocks(e), nb_tail = seq_tail_blocks(e);
     const size_t lds_w = (nb_tail ? (size_t)SQ_WAVES * KMAP_WAVE * SQ_CPL * 8 : 0) + lds;
 #define KMAP_SEQ(LUT, GW)                                                                                                          \

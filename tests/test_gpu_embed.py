@@ -483,11 +483,14 @@ def test_seq_divisions_exhaustive():
     assert L.kmap_selftest_seq_div(2, 0, 0, 0, 1, C.byref(nb), None) == -1
 
 
-@pytest.mark.parametrize("n,row0,nrows", [(16384 + 1029, 0, None), (16384 + 1029, 300, 16384 + 77), (5000, 0, None), (1000, 100, 650)])
+@pytest.mark.parametrize("n,row0,nrows", [(16384 + 1029, 0, None), (16384 + 1029, 300, 16384 + 77), (5000, 0, None), (1000, 100, 650),
+                                          (5003, 0, None), (4136, 7, 31), (300, 0, None), (9001, 8000, 1001)])
 def test_seq_wide_tail_kernel_is_bit_identical(V, n, row0, nrows, tmp_path):
     """Rows that do not fill a round of quad waves go to the wide SEQ kernel (8 .. 64 lanes per row, terms exchanged through
     LDS, same j-ascending f32 sum): the gradient must equal the all-quad kernel's (KMAP_SEQ_TAIL=0) bit for bit, whatever the
-    split -- a full round + 1029 left-over rows (one-row waves), a row-sharded session, N = 5000 (all rows wide), a small N."""
+    split -- a full round + 1029 left-over rows (one-row waves), a row-sharded session, N = 5000 (all rows wide), a small N.
+    The producer / adder form (KMAP_SEQ_FORM=adder; blocks of <= 32 or 64 rows, one adder wave each) must give the same bits too:
+    odd N (columns past n - 1 in the last chunk), a 31-row session, N below one chunk, a shard at the end of the rows."""
     import os
     import subprocess
     import sys
@@ -509,12 +512,16 @@ def test_seq_wide_tail_kernel_is_bit_identical(V, n, row0, nrows, tmp_path):
             "np.savez(sys.argv[3], g=g.to_numpy(np.float32, (2, n)), l=l.to_numpy(np.float64, (1,)))")
     root = str(Path(__file__).resolve().parent.parent)
     outs = {}
-    for tag, env in (("split", {}), ("quad", {"KMAP_SEQ_TAIL": "0"})):
+    # "adder": the producer / adder form (the default of some of these shapes, forced for all of them here)
+    for tag, env in (("split", {"KMAP_SEQ_FORM": "classic"}), ("quad", {"KMAP_SEQ_FORM": "classic", "KMAP_SEQ_TAIL": "0"}),
+                     ("adder", {"KMAP_SEQ_FORM": "adder"})):
         r = subprocess.run([sys.executable, "-c", code, root, str(tmp_path / "in.npz"), str(tmp_path / f"{tag}.npz")],
                            env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[tag] = np.load(tmp_path / f"{tag}.npz")
     np.testing.assert_array_equal(outs["split"]["g"].view(np.uint32), outs["quad"]["g"].view(np.uint32))
+    np.testing.assert_array_equal(outs["adder"]["g"].view(np.uint32), outs["quad"]["g"].view(np.uint32))
+    assert abs(float(outs["adder"]["l"][0]) - float(outs["quad"]["l"][0])) <= 1e-7 * abs(float(outs["quad"]["l"][0]))
     assert outs["split"]["g"][:, row0:row0 + nrows].any() and not outs["split"]["g"][:, :row0].any()
     ls, lq = float(outs["split"]["l"][0]), float(outs["quad"]["l"][0])
     assert abs(ls - lq) <= 1e-8 * abs(lq)        # the loss is not bit-pinned: f32 partial sums over batches of different width

@@ -314,6 +314,31 @@ def test_c3_embedding_force_evaluation_full_size():
             # the SEQ kernel's large-N forms against the ORACLE's arithmetic, bit for bit, on sampled rows of every form: at
             # N = 50 000 rows [0, 32 768) run in the pair form, [32 768, 49 152) in the quad form, the last 848 in the wide form
             _assert_seq_rows_equal_oracle(outs[tag][0], sums_d, lds, lut, coords, _seq_form_rows(n))
+            # the producer / adder form (embed_seq.hip: the form of a rank's share of a row-sharded run, where the forms above cannot fill
+            # the machine): rank 5 of 8 (rows 31 250 .. 37 499: blocks of 25 rows, the last one short) and, forced, all 50 000 rows (the
+            # 64-row-slot geometry) -- bit for bit the other forms' gradient, hence the oracle's arithmetic
+            import os
+            for row0, nrows, force in ((31_250, 6_250, None), (0, n, "adder")):
+                if force:
+                    os.environ["KMAP_SEQ_FORM"] = force
+                try:
+                    sh = V.EmbedSession(n, 1, 0.01, V.EMBED_SEQ, row0=row0, nrows=nrows)
+                finally:
+                    os.environ.pop("KMAP_SEQ_FORM", None)
+                _ffi.check(_ffi.lib().kmap_embed_set_prob_lut(sh._h, sums_d.ptr + row0 * lds * 2, lds, _ffi.ptr(lut), len(lut)))
+                sh.set_coords(coords)
+                g2, l2 = _ffi.DeviceBuffer(2 * n * 4), _ffi.DeviceBuffer(8)
+                g2.zero()
+                sh.forces(g2.ptr, l2.ptr)
+                _ffi.sync()
+                part = g2.to_numpy(np.float32, (2, n))
+                np.testing.assert_array_equal(part[:, row0:row0 + nrows].view(np.uint32), outs[tag][0][:, row0:row0 + nrows].view(np.uint32))
+                assert not part[:, :row0].any() and not part[:, row0 + nrows:].any()
+                if nrows == n:
+                    assert abs(float(l2.to_numpy(np.float64, (1,))[0]) - outs[tag][1]) <= 1e-7 * abs(outs[tag][1])
+                sh.close()
+                g2.free()
+                l2.free()
         if tag == "fast":
             sess.set_jitter(np.random.default_rng(8).normal(0, 0.01, 4096))
             sess.step(20)

@@ -52,6 +52,9 @@ __global__ __launch_bounds__(256) void kdep(float *out, float seed) {
             if (OP == 2) asm volatile("v_rcp_f32 %0, %0" : "+v"(a));
             if (OP == 7) asm volatile("v_add_f32_dpp %0, %1, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(c));
             if (OP == 8) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a) : "v"(c));
+            if (OP == 6) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p) : "v"(c2));
+            if (OP == 12) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a) : "v"(c));
+            if (OP == 13) asm volatile("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %2" : "+v"(a), "+v"(p.x) : "v"(c));   // two chains, alternating
         }
     }
     if (a + p.x + p.y == 12345.678f) out[0] = a;
@@ -80,7 +83,7 @@ int main() {
     CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
     printf("clock %d kHz, %d CUs\n", clk_khz, cus);
     const char *names[] = {"v_fma_f32", "v_pk_fma_f32", "v_rcp_f32", "v_log_f32", "v_med3_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_add_f32_dpp", "v_mul_f32",
-                           "v_bitop3_b32", "v_alignbit_b32", "v_xor_b32"};
+                           "v_bitop3_b32", "v_alignbit_b32", "v_xor_b32", "v_add_f32", "2x v_add_f32 (two chains)"};
     // warm the clocks
     for (int r = 0; r < 20; ++r) k<0><<<cus * 4, 256>>>(out, 1.0f);
     CK(hipDeviceSynchronize());
@@ -97,6 +100,6 @@ int main() {
     ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7) ROW(8) ROW(9) ROW(10) ROW(11)
     printf("dependent chain (latency), one wave per SIMD: cycles per instruction\n");
 #define DROW(OP) { const double ms = run([&](int W) { kdep<OP><<<cus * W, 256>>>(out, 1.0f); }, 1); printf("%-16s %5.2f\n", names[OP], ms * 1e-3 * clk_khz * 1e3 / ((double)ITER * UNR)); }
-    DROW(0) DROW(1) DROW(2) DROW(7) DROW(8)
+    DROW(0) DROW(1) DROW(2) DROW(7) DROW(8) DROW(6) DROW(12) DROW(13)
     return 0;
 }
