@@ -183,7 +183,11 @@ int kmap_counts_adopt_dev(kmap_counts *c, const void *uniq_dev, const void *cnt_
 /* planes_dev (optional, from kmap_pack_planes_dev): with it and k <= 16 the Hamming-ball test of all windows runs bit-sliced
  * over positions (csrc/bitslice.hip) instead of window by window; NULL keeps the per-window kernels.  Results are identical. */
 int kmap_mask_hamball_packed_dev(const uint32_t *codes_dev, uint16_t *inval_dev, int64_t n, int k, const uint64_t *cons,
-                                 const int32_t *radius, int n_cons, const uint32_t *planes_dev, void *stream);  /* cons/radius: host */
+                                 const int32_t *radius, int n_cons, const uint32_t *planes_dev, void *stream);
+/* positions [0, m) of the packed reads become invalid (bit 15 - i of group word g = position 16 g + i): what a consensus within its
+ * radius of the all-T k-mer does to the k - 1 positions behind a separator (kmer_count.py:580-610) when that separator belongs to
+ * the previous rank's shard of the reads (kmap_amd/distributed.py DistDeviceSeq.mask); stream-ordered like every other call. */
+int kmap_inval_set_prefix_dev(uint16_t *inval_dev, int64_t m, void *stream);  /* cons/radius: host */
 /* bit planes of the packed reads, built once per upload: planes[g] = (H16 << 16) | L16, the high / low bits of the 16 base
  * codes of group g, first position most significant; planes_dev: uint32[kmap_packed_groups(n)] */
 int kmap_pack_planes_dev(const uint32_t *codes_dev, int64_t n, uint32_t *planes_dev, void *stream);
@@ -378,13 +382,23 @@ int64_t kmap_embed_msg_floats(int64_t n);
  * forces_msg into a local buffer -> push kernel (the message is copied into slot [parity][rank] of EVERY rank's area, then a
  * system-scope release store of the iteration number into the slot's flag) -> apply kernel (waits -- bounded -- for the world
  * flags of the iteration, adds the world slots in rank order, decodes the loss limbs, applies).  Sums in rank order are the
- * same on every rank, so all ranks take identical decisions.  A wait that exceeds its bound sets a sticky flag
- * (kmap_peer_status) and the iteration proceeds with whatever it has: the host raises, no kernel spins for ever. */
+ * same on every rank, so all ranks take identical decisions.  A wait that exceeds its bound (kmap_peer_set_timeout_ms, default
+ * 10 s) sets a sticky flag (kmap_peer_status); the blocks that gave up do not apply the iteration, the host raises after the
+ * segment and the coordinates are to be discarded: no kernel spins for ever.
+ * Before the first iteration a binding validates the mapping: kmap_peer_bus_id of every rank -> kmap_peer_can_access (same device,
+ * or hipDeviceCanAccessPeer), then kmap_peer_hello_push (a tagged word into every rank's area) -> barrier -> kmap_peer_hello_check
+ * (this rank's area holds every rank's word): a wrong handle or a link that does not carry stores is found here, not in iteration 1. */
 typedef struct kmap_peer kmap_peer;
 #define KMAP_PEER_HANDLE_BYTES 64
+#define KMAP_PEER_BUS_ID_BYTES 32
 int kmap_peer_create(kmap_peer **p, int world, int rank, int64_t msg_floats);
 int kmap_peer_handle(kmap_peer *p, void *handle_out /* KMAP_PEER_HANDLE_BYTES */);
+int kmap_peer_bus_id(char *bus_id_out /* KMAP_PEER_BUS_ID_BYTES, NUL-terminated PCI bus id of the current device */);
+int kmap_peer_can_access(const char *bus_id /* a rank's kmap_peer_bus_id */, int *can_access);
 int kmap_peer_connect(kmap_peer *p, const void *handles /* world x KMAP_PEER_HANDLE_BYTES, rank order */);
+int kmap_peer_hello_push(kmap_peer *p, uint64_t token);                  /* token + rank + 1 -> word [rank] of every rank's area */
+int kmap_peer_hello_check(kmap_peer *p, uint64_t token, int *n_missing); /* words of the own area that are not token + q + 1 */
+int kmap_peer_set_timeout_ms(kmap_peer *p, int64_t ms);                  /* bound of the apply kernel's wait (> 0) */
 int kmap_peer_status(kmap_peer *p, int *timed_out, int64_t *iterations);
 int kmap_peer_destroy(kmap_peer *p);
 int kmap_embed_step_peer(kmap_embed *e, kmap_peer *p, int n_iter, void *stream);

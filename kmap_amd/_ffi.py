@@ -93,6 +93,7 @@ _SIGS = {
     "kmap_counts_finish_range": (i32, [vp, i32, i32, u64, u64, P(i64), vp]),
     "kmap_counts_adopt_dev": (i32, [vp, vp, vp, i64, i32]),
     "kmap_mask_hamball_packed_dev": (i32, [vp, vp, i64, i32, vp, vp, i32, vp, vp]),
+    "kmap_inval_set_prefix_dev": (i32, [vp, i64, vp]),
     "kmap_pack_planes_dev": (i32, [vp, i64, vp, vp]),
     "kmap_scan_run_packed_dev": (i32, [vp, vp, vp, i64, vp, i64, i32, u64, i32, i32, P(i64), vp, vp]),
     "kmap_scan_create": (i32, [P(vp)]),
@@ -134,6 +135,11 @@ _SIGS = {
     "kmap_peer_create": (i32, [C.POINTER(vp), i32, i32, i64]),
     "kmap_peer_handle": (i32, [vp, vp]),
     "kmap_peer_connect": (i32, [vp, vp]),
+    "kmap_peer_bus_id": (i32, [vp]),
+    "kmap_peer_can_access": (i32, [vp, C.POINTER(i32)]),
+    "kmap_peer_hello_push": (i32, [vp, u64]),
+    "kmap_peer_hello_check": (i32, [vp, u64, C.POINTER(i32)]),
+    "kmap_peer_set_timeout_ms": (i32, [vp, i64]),
     "kmap_peer_status": (i32, [vp, C.POINTER(i32), C.POINTER(i64)]),
     "kmap_peer_destroy": (i32, [vp]),
     "kmap_embed_step_peer": (i32, [vp, vp, i32, vp]),
@@ -169,6 +175,11 @@ def lib():
             f.restype, f.argtypes = res, args
         _lib = L
     return _lib
+
+
+def last_error():
+    """message of the calling thread's last failed library call"""
+    return lib().kmap_last_error().decode(errors="replace")
 
 
 def check(rc):

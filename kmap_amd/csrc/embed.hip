@@ -288,22 +288,27 @@ __global__ __launch_bounds__(BLK) void peer_push_kernel(PeerTab tab, const float
         }
     }
 }
-// apply for the peer protocol: wait for the iteration's world flags in the own area (bounded: ~2 s of the 100 MHz wall clock,
-// then the sticky time-out word is set and the iteration goes on with what is there), add the world slots in rank order,
-// decode the loss limbs of the sum, apply.
+// apply for the peer protocol: wait for the iteration's world flags in the own area (bounded: `timeout_ticks` of the 100 MHz wall
+// clock; then the sticky time-out word is set and this block leaves the iteration unapplied -- the host raises after the segment
+// and discards the coordinates), add the world slots in rank order, decode the loss limbs of the sum, apply.
+// slots / flags are written by OTHER GPUs while this kernel runs: no const / __restrict__ on them (that would license scalar or
+// non-coherent loads of "memory that does not change during the dispatch"), and every thread fences (system-scope acquire) behind
+// the barrier before it reads a slot.
 __global__ __launch_bounds__(BLK) void apply_peer_kernel(LoopState *__restrict__ states, int cur, float *__restrict__ Y,
-                                                         const float *__restrict__ slots, const unsigned long long *__restrict__ flags,
+                                                         float *slots, unsigned long long *flags,
                                                          int world, int parity, unsigned long long iter_tag, int64_t msg_floats,
-                                                         unsigned long long *__restrict__ timed_out, float *__restrict__ snaps, int64_t n,
+                                                         unsigned long long *timed_out, unsigned long long timeout_ticks,
+                                                         float *__restrict__ snaps, int64_t n,
                                                          float lr, const double *__restrict__ normals, const int *__restrict__ n_normals_dev,
                                                          float *__restrict__ loss_log, int64_t loss_log_cap) {
+    __shared__ int gave_up_s;
     if (threadIdx.x == 0) {
         const unsigned long long t0 = wall_clock64();
         bool gave_up = __hip_atomic_load(timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // sticky: after one time-out the
-        for (int q = 0; q < world && !gave_up; ++q) {                        //  rest of the segment does not wait 2 s per iteration again
-            const unsigned long long *f = flags + (size_t)parity * world + q;
+        for (int q = 0; q < world && !gave_up; ++q) {                        //  rest of the segment does not wait per iteration again
+            unsigned long long *f = flags + (size_t)parity * world + q;
             while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != iter_tag) {
-                if (wall_clock64() - t0 > 200000000ull) {                   // 2 s at 100 MHz: a peer is gone
+                if (wall_clock64() - t0 > timeout_ticks) {                   // a peer is gone (or a host stalled beyond the bound)
                     atomicMax(timed_out, 1ull);
                     gave_up = true;
                     break;
@@ -311,13 +316,15 @@ __global__ __launch_bounds__(BLK) void apply_peer_kernel(LoopState *__restrict__
                 __builtin_amdgcn_s_sleep(8);
             }
         }
-        __threadfence_system();
+        gave_up_s = gave_up;
     }
     __syncthreads();
-    const float *base = slots + (size_t)parity * world * (size_t)msg_floats;
+    if (gave_up_s) return;                                                   // block-uniform: nothing of a partial sum is applied
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                            // system scope, every thread: the peers' slot stores
+    float *base = slots + (size_t)parity * world * (size_t)msg_floats;
     auto summed = [&](int64_t i) {
-        float s = base[i];
-        for (int q = 1; q < world; ++q) s += base[(size_t)q * msg_floats + i];   // rank order: the same float sum on every rank
+        float s = __builtin_nontemporal_load(base + i);
+        for (int q = 1; q < world; ++q) s += __builtin_nontemporal_load(base + (size_t)q * msg_floats + i);   // rank order: the same float sum on every rank
         return s;
     };
     float tail[MSG_EXTRA];
@@ -685,10 +692,10 @@ int kmap_embed_step_peer(kmap_embed *e, kmap_peer *p, int n_iter, void *stream) 
         const unsigned long long tag = p->iter + 1;
         KMAP_TRY(kmap_embed_forces_msg(e, p->msg_local, stream));
         peer_push_kernel<<<pgrid, BLK, 0, st>>>(tab, p->msg_local, p->slot_floats, p->world, p->rank, parity, tag, p->done);
-        apply_peer_kernel<<<agrid, BLK, 0, st>>>(e->states, e->cur, e->Y, (const float *)p->area,
-                                                 (const unsigned long long *)((char *)p->area + kmap_peer_slots_bytes(p)), p->world, parity, tag,
-                                                 p->slot_floats, p->done + 1, e->snaps, e->n, e->lr, e->normals, e->n_normals_dev, e->loss_log,
-                                                 e->loss_log_cap);
+        apply_peer_kernel<<<agrid, BLK, 0, st>>>(e->states, e->cur, e->Y, (float *)p->area,
+                                                 (unsigned long long *)((char *)p->area + kmap_peer_slots_bytes(p)), p->world, parity, tag,
+                                                 p->slot_floats, p->done + 1, p->timeout_ticks, e->snaps, e->n, e->lr, e->normals, e->n_normals_dev,
+                                                 e->loss_log, e->loss_log_cap);
         KMAP_CHECK_HIP(hipGetLastError());
         e->cur ^= 1;
         p->iter += 1;

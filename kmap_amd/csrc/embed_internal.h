@@ -123,9 +123,12 @@ struct kmap_peer {
     float *msg_local = nullptr;                // the message forces_msg writes (entries of other ranks' rows stay zero)
     unsigned long long *done = nullptr;        // push kernel's finished-blocks counter | sticky time-out flag
     uint64_t iter = 0;                         // iterations issued so far
+    unsigned long long timeout_ticks = 1000000000ull;   // bound of the apply kernel's wait in 100 MHz wall-clock ticks (10 s)
 };
 struct PeerTab {                               // kernel argument
     float *slots[KMAP_PEER_MAX];               // base of rank q's slots
     unsigned long long *flags[KMAP_PEER_MAX];  // base of rank q's flags
 };
+// area layout: slots float[2][world][slot_floats] | flags u64[2][world] | hello u64[world]
 inline size_t kmap_peer_slots_bytes(const kmap_peer *p) { return (size_t)2 * p->world * p->slot_floats * 4; }
+inline size_t kmap_peer_hello_offset(const kmap_peer *p) { return kmap_peer_slots_bytes(p) + (size_t)2 * p->world * 8; }

@@ -1150,6 +1150,24 @@ int kmap_counts_run_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const 
 // k <= 16: the bit-sliced formulation (bitslice.hip) on the reads' bit planes; the per-window kernels of this file serve k > 16
 static bool bitslice_on(int k) { return k <= 16; }
 
+namespace {
+__global__ void inval_prefix_kernel(uint16_t *__restrict__ inval, int64_t m) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t left = m - 16 * g;                           // positions of this group inside the prefix
+    if (left <= 0) return;
+    inval[g] |= left >= 16 ? (uint16_t)0xFFFFu : (uint16_t)(0xFFFFu << (16 - (int)left));
+}
+}  // namespace
+
+int kmap_inval_set_prefix_dev(uint16_t *inval_dev, int64_t m, void *stream) {
+    if (m <= 0) return KMAP_OK;
+    KMAP_REQUIRE(inval_dev, "inval_set_prefix: null pointer");
+    const int64_t ng = (m + 15) >> 4;
+    inval_prefix_kernel<<<(unsigned)((ng + 63) / 64), 64, 0, as_stream(stream)>>>(inval_dev, m);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+
 int kmap_mask_hamball_packed_dev(const uint32_t *codes_dev, uint16_t *inval_dev, int64_t n, int k, const uint64_t *cons,
                                  const int32_t *radius, int n_cons, const uint32_t *planes_dev, void *stream) {
     KMAP_REQUIRE(k > 0 && k < 32, "mask_hamball_packed: k=%d out of range", k);

@@ -199,6 +199,17 @@ def assert_default_stream():
 
 
 PEER_HANDLE_BYTES = 64
+PEER_BUS_ID_BYTES = 32
+
+
+class PeerTimeout(RuntimeError):
+    """a wait of the peer-direct apply kernel ran into its bound: the segment's iterations were not applied consistently"""
+
+
+class PeerExchangeError(RuntimeError):
+    """the peer-direct exchange cannot be set up on this node (no peer access, an area that cannot be mapped, a store that did not
+    arrive): raised on EVERY rank of the group together, before any iteration has run -- KMAP_DIST_EXCHANGE=auto falls back to the
+    all-reduce on it, =direct lets it through"""
 
 
 class PeerExchange:
@@ -206,26 +217,81 @@ class PeerExchange:
     through a HIP IPC handle, the handles are all-gathered once, and from then on an iteration is three kernels and no library
     call: forces into a local message -> push (the message into slot [rank] of every rank's area over the xGMI links + a release
     store of the iteration number) -> apply (waits for the world flags, adds the slots in rank order).  Works between the GPUs of
-    a node and between processes that share one GPU (the rehearsal on a one-GPU box)."""
+    a node and between processes that share one GPU (the rehearsal on a one-GPU box).
+    Set-up is validated before it is trusted: (1) every rank's device must be this rank's own or one hipDeviceCanAccessPeer allows;
+    (2) every area must map; (3) a handshake -- each rank stores a tagged word into every area, all verify their own area.  After
+    each of the three steps the ranks all-reduce a success flag, so a failure anywhere raises PeerExchangeError everywhere (no rank
+    is left waiting in a collective) with the handle destroyed.  KMAP_PEER_TIMEOUT_MS: bound of the apply kernel's wait (10 000)."""
 
-    def __init__(self, session, n, dist, group=None):
+    def __init__(self, session, n, dist, group=None, _corrupt_handle_of=None):
         import ctypes as C
         import torch
         from . import _ffi
         self.s, self.dist, self.group = session, dist, group
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         lib = _ffi.lib()
-        h = _ffi.vp()
-        _ffi.check(lib.kmap_peer_create(C.byref(h), world, rank, int(lib.kmap_embed_msg_floats(n))))
-        self._p = h.value
-        mine = np.zeros(PEER_HANDLE_BYTES, np.uint8)
-        _ffi.check(lib.kmap_peer_handle(self._p, _ffi.ptr(mine)))
         dev = _coll_device(dist, group)
-        allh = torch.empty(world * PEER_HANDLE_BYTES, dtype=torch.uint8, device=dev)
+        self._p = None
+        why = []
+
+        def agree(ok, what):
+            """all-reduce(MIN) of this rank's success: every rank learns whether ANY rank failed the step"""
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            if int(t.item()) == 0:
+                self._destroy_now()
+                raise PeerExchangeError(f"peer exchange: {what} failed on " + ("this rank: " + "; ".join(why) if not ok else "another rank"))
+
+        def attempt(fn, *args):
+            rc = fn(*args)
+            if rc != 0:
+                why.append(_ffi.last_error())
+            return rc == 0
+
+        h = _ffi.vp()
+        ok = attempt(lib.kmap_peer_create, C.byref(h), world, rank, int(lib.kmap_embed_msg_floats(n)))
+        self._p = h.value if ok else None
+        mine = np.zeros(PEER_HANDLE_BYTES + PEER_BUS_ID_BYTES, np.uint8)       # [IPC handle | PCI bus id]
+        if ok:
+            ok = attempt(lib.kmap_peer_handle, self._p, _ffi.ptr(mine)) and attempt(lib.kmap_peer_bus_id, mine[PEER_HANDLE_BYTES:].ctypes.data)
+        agree(ok, "creating / exporting a receive area")
+        rec = PEER_HANDLE_BYTES + PEER_BUS_ID_BYTES
+        allh = torch.empty(world * rec, dtype=torch.uint8, device=dev)
         dist.all_gather_into_tensor(allh, torch.from_numpy(mine).to(dev), group=group)
-        self._handles = np.ascontiguousarray(allh.cpu().numpy())
-        _ffi.check(lib.kmap_peer_connect(self._p, _ffi.ptr(self._handles)))
+        allh = np.ascontiguousarray(allh.cpu().numpy()).reshape(world, rec)
+        self._handles = np.ascontiguousarray(allh[:, :PEER_HANDLE_BYTES])
+        if _corrupt_handle_of is not None:                                     # fault injection (tests): a handle that maps nothing
+            self._handles[_corrupt_handle_of] = 0xA5
+        # (1) can this device store into every rank's device at all?
+        for q in range(world):
+            can = _ffi.i32(0)
+            bus = np.ascontiguousarray(allh[q, PEER_HANDLE_BYTES:])
+            if not attempt(lib.kmap_peer_can_access, bus.ctypes.data, C.byref(can)) or not can.value:
+                ok = False
+                why.append(f"no peer access to rank {q}'s device {bytes(bus).split(bytes(1))[0].decode(errors='replace')}")
+        agree(ok, "the peer-access check (hipDeviceCanAccessPeer)")
+        # (2) map every area
+        ok = attempt(lib.kmap_peer_connect, self._p, _ffi.ptr(self._handles))
+        agree(ok, "mapping the receive areas (hipIpcOpenMemHandle)")
+        # (3) handshake: a tagged word from every rank into every area, then every rank reads its own area back
+        token = 0x6B6D6170 << 16                                               # same on every rank
+        ok = attempt(lib.kmap_peer_hello_push, self._p, token)
+        agree(ok, "the handshake stores")          # doubles as the barrier between "everybody has stored" and "everybody checks"
+        miss = _ffi.i32(0)
+        ok = attempt(lib.kmap_peer_hello_check, self._p, token, C.byref(miss)) and miss.value == 0
+        if miss.value:
+            why.append(f"{miss.value} of {world} handshake words did not arrive in this rank's area")
+        agree(ok, "the handshake check")
+        ms = os.environ.get("KMAP_PEER_TIMEOUT_MS")
+        if ms:
+            _ffi.check(lib.kmap_peer_set_timeout_ms(self._p, int(ms)))
         dist.barrier(group=group)                 # nobody pushes before everybody's area is mapped everywhere
+
+    def _destroy_now(self):
+        from . import _ffi
+        if self._p:
+            _ffi.lib().kmap_peer_destroy(self._p)
+            self._p = None
 
     def step(self, n_iter):
         from . import _ffi
@@ -238,7 +304,8 @@ class PeerExchange:
         t, it = _ffi.i32(0), _ffi.i64(0)
         _ffi.check(_ffi.lib().kmap_peer_status(self._p, C.byref(t), C.byref(it)))
         if t.value:
-            raise RuntimeError(f"peer exchange: a rank's message did not arrive within the wait bound (after {it.value} iterations issued)")
+            raise PeerTimeout(f"peer exchange: a rank's message did not arrive within the wait bound (after {it.value} iterations issued); "
+                              "the coordinates of this run are not to be used")
 
     def close(self):
         from . import _ffi
@@ -323,8 +390,9 @@ def kmap_from_kmers_distributed(samp_kh, samp_cnts, samp_label, conseq_list, kme
     neighbor_inds_mat: optional full (N, n_neighbour) table to use instead of the selection (tests inject it).
     always_collective / profile_iters: bench.py's instruments (all-reduce even on a one-rank group; that many leading
     iterations with events around forces / collective / apply, reported in trace["phases"]).
-    exchange: "rccl" (one all-reduce per iteration, the default) or "direct" (PeerExchange: peer-to-peer stores + flags, no
-    library call between iterations); None = the KMAP_DIST_EXCHANGE environment variable."""
+    exchange: "rccl" (one all-reduce per iteration, the default), "direct" (PeerExchange: peer-to-peer stores + flags, no
+    library call between iterations; a set-up that fails its validation raises PeerExchangeError on every rank) or "auto" (direct
+    where the validation passes, otherwise the all-reduce + one warning); None = the KMAP_DIST_EXCHANGE environment variable."""
     import torch
     import torch.distributed as dist
     from . import _ffi
@@ -393,7 +461,15 @@ def kmap_from_kmers_distributed(samp_kh, samp_cnts, samp_label, conseq_list, kme
         sess.set_coords(ld_data, placeholders)
         msg_t = torch.zeros(2 * n + MSG_EXTRA, dtype=torch.float32, device="cuda")
         exchange = os.environ.get("KMAP_DIST_EXCHANGE", "rccl").lower() if exchange is None else exchange
-        peer = PeerExchange(sess, n, dist) if exchange == "direct" else None
+        peer = None
+        if exchange in ("direct", "auto"):
+            try:
+                peer = PeerExchange(sess, n, dist)
+            except PeerExchangeError as e:     # raised on every rank together
+                if exchange == "direct":
+                    raise
+                import warnings
+                warnings.warn(f"{e} -- falling back to one all-reduce per iteration (KMAP_DIST_EXCHANGE=auto)")
         loop = DistEmbedLoop(sess, msg_t, dist, always_collective=always_collective, peer=peer)
         prof = {}
 
@@ -558,14 +634,9 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None, shard_counts
                 hit = hit or bin((x | (x >> 1)) & 0x5555555555555555).count("1") <= int(r)
             if not hit:
                 return
-            m = min(k - 1, self.n)                                       # positions [0, m) become invalid
-            ng = (m + 15) // 16
-            flags = np.zeros(ng, np.uint16)
-            check(_ffi.lib().kmap_memcpy_d2h(_ffi.ptr(flags), self.inval_work.ptr, ng * 2, None))
-            for p in range(m):
-                flags[p >> 4] |= np.uint16(1 << (15 - (p & 15)))         # position i of a group in bit 15 - i
-            check(_ffi.lib().kmap_memcpy_h2d(self.inval_work.ptr, _ffi.ptr(flags), ng * 2, None))
-            _ffi.sync()
+            # positions [0, min(k - 1, n)) become invalid: a tiny kernel on the stream DeviceSeq.mask's kernels were queued on
+            # (the library's null stream), so it is ordered behind them without a host round trip
+            check(_ffi.lib().kmap_inval_set_prefix_dev(self.inval_work.ptr, min(k - 1, self.n), None))
 
         def count(self, dc, k, dedupe, merge_revcom, use_work=True, gather_full=False):
             """gather_full: this call's table is the one k{k}.pkl is written from (find_motif's first round) -- if it stays

@@ -40,7 +40,7 @@ def _worker(rank, world, port, mode, out_dir, exchange="rccl"):
 
 
 def _timeout_worker(rank, world, port, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KMAP_DIST_EXCHANGE="direct")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KMAP_DIST_EXCHANGE="direct", KMAP_PEER_TIMEOUT_MS="2000")
     import time
     import torch
     import torch.distributed as dist
@@ -68,6 +68,104 @@ def test_peer_exchange_wait_is_bounded(tmp_path):
     t1, m1 = (tmp_path / "timeout_rank1.txt").read_text().split("|", 1)
     assert "did not arrive within the wait bound" in m0 and m1 == ""
     assert 1.5 < float(t0) < 30.0
+
+
+def _verb_timeout_worker(rank, world, port, res_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KMAP_DIST_EXCHANGE="direct", KMAP_PEER_TIMEOUT_MS="1500",
+                      WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), KMAP_DIST_BACKEND="gloo", KMAP_DIST_SAME_GPU="1")
+    import torch
+    import torch.distributed as dist
+    import kmap_amd.distributed as D
+    import kmap_amd.visualization as V
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if rank == 1:                       # this rank's loop runs no iteration: it never pushes
+            real = D.kmap_from_kmers_distributed
+
+            def lazy(*a, **kw):
+                kw["n_max_iter"] = 0
+                return real(*a, **kw)
+            D.kmap_from_kmers_distributed = lazy
+        what = "returned"
+        try:
+            V._visualize_kmers_impl(res_dir, False, None, dist, rank)
+        except D.PeerTimeout:
+            what = "PeerTimeout"
+        (Path(res_dir) / f"verb_rank{rank}.txt").write_text(what)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_timeout_raises_out_of_the_verb_and_writes_no_file(tmp_path):
+    """a time-out of the peer-direct exchange inside `visualize_kmers`: the loop driver raises PeerTimeout after the segment (the
+    blocks that gave up applied nothing; whatever the others applied is discarded with the exception), and low_dim_data.tsv is never
+    written from such coordinates (reference visualization.py:36-87 writes it last)"""
+    import pickle
+    import torch.multiprocessing as mp
+    from kmap_amd._toml import dump_toml
+    from kmap_amd.kmer_count import read_default_config_file
+    kh, cnts, lab, conseqs = _inputs()
+    kh = np.unique(kh).astype(np.uint32)
+    lab, cnts = lab[:len(kh)], np.ones(len(kh), np.int64)
+    cfg = read_default_config_file()
+    cfg["visualization"].update(n_max_iter=8, random_seed=11, gen_fig_flag=False)
+    dump_toml(cfg, tmp_path / "config.toml")
+    with open(tmp_path / "sample_kmers.pkl", "wb") as fh:
+        pickle.dump([kh, cnts, lab, conseqs], fh)
+    with open(tmp_path / "sample_kmer_hamdist_mat.pkl", "wb") as fh:
+        pickle.dump([K, None, np.repeat(lab, cnts)], fh)
+    mp.spawn(_verb_timeout_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "verb_rank0.txt").read_text() == "PeerTimeout"
+    assert (tmp_path / "verb_rank1.txt").read_text() == "returned"
+    assert not (tmp_path / "low_dim_data.tsv").exists()
+
+
+def _bad_handle_worker(rank, world, port, out_dir, exchange):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import warnings
+    import torch
+    import torch.distributed as dist
+    import kmap_amd.distributed as D
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        real = D.PeerExchange
+
+        class Broken(real):                 # rank 0 receives a handle of rank 1 that maps nothing
+            def __init__(self, session, n, dist_, group=None):
+                super().__init__(session, n, dist_, group, _corrupt_handle_of=1 if dist_.get_rank() == 0 else None)
+        D.PeerExchange = Broken
+        kh, cnts, lab, conseqs = _inputs()
+        tr, what = {}, ""
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            try:
+                D.kmap_from_kmers_distributed(kh, cnts, lab, conseqs, K, n_max_iter=ITERS, random_seed=SEED, mode=1, trace=tr, exchange=exchange)
+                what = "ran:" + tr["exchange"] + ":" + ("warned" if any("falling back" in str(w.message) for w in caught) else "silent")
+            except D.PeerExchangeError as e:
+                what = "PeerExchangeError:" + str(e)
+        np.savez(Path(out_dir) / f"bad_{exchange}_rank{rank}.npz", what=what, losses=tr.get("losses", np.zeros(0)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_exchange_setup_failure_is_seen_by_every_rank_and_auto_falls_back(tmp_path):
+    """fault injection: one rank's copy of a peer's IPC handle is corrupt.  KMAP_DIST_EXCHANGE=direct: BOTH ranks raise
+    PeerExchangeError before any iteration (the rank that could map everything learns of the failure through the all-reduced success
+    flag instead of waiting for a peer that has left); =auto: both fall back to one all-reduce per iteration, warn once, and
+    produce the all-reduce run's losses."""
+    import torch.multiprocessing as mp
+    for exchange in ("direct", "auto"):
+        mp.spawn(_bad_handle_worker, args=(2, _free_port(), str(tmp_path), exchange), nprocs=2, join=True)
+    d0, d1 = (str(np.load(tmp_path / f"bad_direct_rank{r}.npz")["what"]) for r in range(2))
+    assert d0.startswith("PeerExchangeError:") and "this rank" in d0 and "cannot be mapped" in d0
+    assert d1.startswith("PeerExchangeError:") and "another rank" in d1
+    a = [np.load(tmp_path / f"bad_auto_rank{r}.npz") for r in range(2)]
+    assert all(str(x["what"]) == "ran:all_reduce:warned" for x in a)
+    np.testing.assert_array_equal(a[0]["losses"], a[1]["losses"])
+    assert len(a[0]["losses"]) == ITERS
 
 
 def _free_port():
