@@ -34,6 +34,7 @@ extern "C" {
 #define KMAP_E_NOMEM (-3)   /* device allocation failed */
 #define KMAP_E_UNSUP (-4)   /* valid request this build cannot serve */
 #define KMAP_E_STATE (-5)   /* handle used out of order */
+#define KMAP_E_IO (-6)      /* a file operation of the host-side writers failed (message has strerror) */
 
 /* ---- library / device -------------------------------------------------------------------- */
 int kmap_version(void);                       /* 1000*major + minor */
@@ -129,6 +130,10 @@ int kmap_counts_fetch(kmap_counts *c, void *uniq_out, void *cnt_out);
 int kmap_counts_fetch_stream(kmap_counts *c, void *uniq_out, void *cnt_out, void *stream);
 /* elements [first, first + count) of one array of the table in the reference's dtype: which = 0 unique hashes, 1 counts */
 int kmap_counts_fetch_range(kmap_counts *c, int which, int64_t first, int64_t count, void *out, void *stream);
+/* the same range written into an open file instead (pwrite at file_offset; the descriptor's own position is untouched): pinned
+ * staging, the next chunk crossing PCIe while the current one is written, counts widened on the device -- the k{k}.pkl writers of
+ * multi-GB tables (reference motif_discovery.py:642-645 pickles [k, uniq, cnt]) */
+int kmap_counts_write_range(kmap_counts *c, int which, int64_t first, int64_t count, int fd, int64_t file_offset, void *stream);
 /* device addresses of the resident table (uniq uint32 for k < 16 else uint64; cnt uint32 whatever k; counts > 2^32 wrap like the
  * histogram bins); valid until the next count / load / destroy on the handle.  Lets sample_disp_kmer (motif_discovery.py:812-921)
  * label a multi-GB table where it lies instead of re-reading k{k}.pkl */

@@ -66,6 +66,7 @@ _SIGS = {
     "kmap_counts_fetch_stream": (i32, [vp, vp, vp, vp]),
     "kmap_counts_table_dev": (i32, [vp, P(vp), P(vp), P(i64)]),
     "kmap_counts_fetch_range": (i32, [vp, i32, i64, i64, vp, vp]),
+    "kmap_counts_write_range": (i32, [vp, i32, i64, i64, i32, i64, vp]),
     "kmap_counts_total": (i32, [vp, P(i64)]),
     "kmap_hamball_extract": (i32, [vp, vp, i64, i32, u64, i32, i32, vp, vp, P(i64), vp]),
     "kmap_pos_density": (i32, [vp, vp, vp, vp, i64, i32, vp, i32, f64, vp]),
@@ -190,6 +191,8 @@ def check(rc):
         raise ValueError(msg)
     if rc == -3:
         raise MemoryError(msg)
+    if rc == -6:
+        raise OSError(msg)
     raise KmapError(f"libkmap_hip error {rc}: {msg}")
 
 

@@ -7,6 +7,11 @@
 // 288 GB: even the 16 GiB table of k = 16 is resident), followed by an order-preserving
 // compaction that applies the reverse-complement merge on the fly.  A uint32 bin wraps exactly
 // like the reference's int64 -> int32 cast of np.unique counts.
+#include <errno.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <type_traits>
 #include <algorithm>
 #include <mutex>
 #include <thread>
@@ -800,6 +805,76 @@ int staged_fetch(DST *dst, const SRC *src_dev, size_t n, hipStream_t st) {
     return KMAP_OK;
 }
 
+// counts widened to the reference's int64 on the device (k >= 16): the bytes that cross PCIe are the bytes of the file
+__global__ __launch_bounds__(256) void widen_counts_kernel(const uint32_t *__restrict__ in, int64_t n, int64_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (int64_t)in[i];
+}
+
+// write() in full (short writes, EINTR); false + errno on failure
+static bool pwrite_all(int fd, const char *buf, size_t len, int64_t off) {
+    while (len) {
+        const ssize_t w = pwrite(fd, buf, len, (off_t)off);
+        if (w < 0) {
+            if (errno == EINTR) continue;
+            return false;
+        }
+        buf += w;
+        off += w;
+        len -= (size_t)w;
+    }
+    return true;
+}
+
+// `n` elements of a device array -> file bytes at `file_off`, in the file's dtype DST: chunk i + 1 crosses PCIe into one pinned
+// staging buffer while chunk i is written from the other -- no pageable copy, no conversion pass on the host (WIDEN: the uint32
+// counts become int64 on the device, in a scratch buffer the size of a chunk)
+template <typename SRC, typename DST>
+int staged_write(int fd, int64_t file_off, const SRC *src_dev, size_t n, hipStream_t st) {
+    if (n == 0) return KMAP_OK;
+    constexpr bool WIDEN = !std::is_same<SRC, DST>::value;
+    StagePair sp;
+    if (!sp.ok()) {
+        kmap_set_error("counts_write: pinned staging allocation failed");
+        return KMAP_E_NOMEM;
+    }
+    const size_t chunk = STAGE_BYTES / sizeof(DST);
+    DevBuf wide[2];
+    if (WIDEN) {
+        KMAP_TRY(wide[0].alloc(std::min(chunk, n) * sizeof(DST)));
+        KMAP_TRY(wide[1].alloc(std::min(chunk, n) * sizeof(DST)));
+    }
+    auto issue = [&](int b, size_t off, size_t len) -> hipError_t {
+        const void *from = src_dev + off;
+        if (WIDEN) {
+            widen_counts_kernel<<<(unsigned)((len + 255) / 256), 256, 0, st>>>((const uint32_t *)(src_dev + off), (int64_t)len, wide[b].as<int64_t>());
+            from = wide[b].p;
+        }
+        return hipMemcpyAsync(sp.buf[b], from, len * sizeof(DST), hipMemcpyDeviceToHost, st);
+    };
+    size_t off = 0, len = std::min(chunk, n);
+    int b = 0;
+    hipError_t err = issue(0, 0, len);
+    while (err == hipSuccess && off < n) {
+        err = hipStreamSynchronize(st);                           // chunk `b` has landed
+        if (err != hipSuccess) break;
+        const size_t next_off = off + len, next_len = next_off < n ? std::min(chunk, n - next_off) : 0;
+        if (next_len) err = issue(b ^ 1, next_off, next_len);
+        if (!pwrite_all(fd, (const char *)sp.buf[b], len * sizeof(DST), file_off + (int64_t)(off * sizeof(DST)))) {
+            const int en = errno;
+            (void)hipStreamSynchronize(st);
+            kmap_set_error("counts_write: pwrite failed: %s", strerror(en));
+            return KMAP_E_IO;
+        }
+        off = next_off;
+        len = next_len;
+        b ^= 1;
+    }
+    if (err != hipSuccess) (void)hipStreamSynchronize(st);
+    KMAP_CHECK_HIP(err);
+    return KMAP_OK;
+}
+
 // uint64 keys that fit 32 bits (k = 16): narrowed on the device so that half the bytes cross PCIe
 __global__ __launch_bounds__(256) void narrow_keys_kernel(const uint64_t *__restrict__ in, int64_t n, uint32_t *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -861,6 +936,24 @@ int kmap_counts_fetch_range(kmap_counts *c, int which, int64_t first, int64_t co
     }
     if (c->narrow) return staged_fetch<uint32_t, uint32_t>((uint32_t *)out, c->cnt + first, n, st);   // uint32 bits == int32 wrap
     return staged_fetch<uint32_t, int64_t>((int64_t *)out, c->cnt + first, n, st);
+}
+
+/* kmap_counts_fetch_range straight into a file: the range's bytes, in the reference's dtype, are written at `file_offset` of the open
+ * descriptor `fd` (pwrite: the descriptor's position is not used) from pinned staging buffers, the next chunk in flight while the
+ * current one is written.  The k{k}.pkl writers place the array payloads of a pickle whose layout they know this way. */
+int kmap_counts_write_range(kmap_counts *c, int which, int64_t first, int64_t count, int fd, int64_t file_offset, void *stream) {
+    KMAP_REQUIRE(c && c->k > 0 && (which == 0 || which == 1), "counts_write_range: nothing counted yet / bad selector");
+    KMAP_REQUIRE(first >= 0 && count >= 0 && first + count <= c->n_uniq, "counts_write_range: range outside the table");
+    KMAP_REQUIRE(fd >= 0 && file_offset >= 0, "counts_write_range: bad file descriptor / offset");
+    if (count == 0) return KMAP_OK;
+    hipStream_t st = as_stream(stream);
+    const size_t n = (size_t)count;
+    if (which == 0) {
+        if (c->narrow) return staged_write<uint32_t, uint32_t>(fd, file_offset, (const uint32_t *)c->uniq + first, n, st);
+        return staged_write<uint64_t, uint64_t>(fd, file_offset, (const uint64_t *)c->uniq + first, n, st);
+    }
+    if (c->narrow) return staged_write<uint32_t, uint32_t>(fd, file_offset, c->cnt + first, n, st);   // uint32 bits == int32 wrap
+    return staged_write<uint32_t, int64_t>(fd, file_offset, c->cnt + first, n, st);
 }
 
 int kmap_counts_total(kmap_counts *c, int64_t *total) {

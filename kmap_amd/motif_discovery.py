@@ -314,10 +314,12 @@ class TableSaver:
     another handle.  The table is streamed from a DeviceCounts handle that nobody writes any more: a dry run of the real
     pickler over untouched np.empty arrays of the right shape gives the byte layout (where the two array payloads go, and the
     small pieces around them); the payloads are then fetched chunk by chunk -- own stream, pinned staging, conversion to the
-    reference's dtypes on host threads, the next chunk in flight while the current one is written -- and written in place.
+    small pieces around them); the file is preallocated, and the payloads then go device -> pinned staging -> pwrite inside ONE native
+    call each (kmap_counts_write_range: own stream, the next chunk crossing PCIe while the current one is written, counts widened
+    to the reference's int64 on the device) -- no pageable copy and no conversion pass on the host.
     The file is byte for byte what pickle.dump writes, without ever holding the 15 GB of a k = 16 table (C3) in host memory
-    (fetching it whole, pickling and freeing it cost 2.5 s; measured alternatives: os.pwrite from several threads -- no gain,
-    one inode lock; filling a memory-mapped file -- 4x slower, page faults through overlayfs).
+    (fetching it whole, pickling and freeing it cost 2.5 s; measured alternatives: pwrite from several threads -- no gain, one
+    inode lock: tools/probes/file_write_rate.py; filling a memory-mapped file -- 4x slower, page faults through overlayfs).
     join() re-raises a failure on the caller's thread; the handle (the table resident in HBM) stays usable until close()."""
     CHUNK_BYTES = 128 << 20
 
@@ -330,7 +332,6 @@ class TableSaver:
 
     def _run(self):
         import time
-        from concurrent.futures import ThreadPoolExecutor
         try:
             t0 = time.perf_counter()
             lib = _ffi.lib()
@@ -350,34 +351,25 @@ class TableSaver:
                 return
             st = _ffi.vp()
             check(lib.kmap_stream_create(C.byref(st)))
-            pool = ThreadPoolExecutor(1)
-
-            def fetch(which, first, count, buf):
-                if self._dev is not None:
-                    check(lib.kmap_set_device(self._dev))
-                check(lib.kmap_counts_fetch_range(self.dc._h, which, first, count, buf.ctypes.data, st.value))
-                return buf[:count]
+            fd = os.open(tmp, os.O_CREAT | os.O_WRONLY | os.O_TRUNC, 0o644)
             try:
-                pieces = sorted([(pos, None, b) for pos, b in lay.small] + [(pos, i, None) for i, (pos, _) in enumerate(lay.big)])
-                with open(tmp, "wb") as fh:
-                    for pos, which, small in pieces:
-                        assert fh.tell() == pos
-                        if which is None:
-                            fh.write(small)
-                            continue
-                        step = self.CHUNK_BYTES // np.dtype(dts[which]).itemsize
-                        bufs = [np.empty(min(step, n), dts[which]) for _ in range(2)]
-                        nxt = pool.submit(fetch, which, 0, min(step, n), bufs[0])
-                        for i, first in enumerate(range(0, n, step)):
-                            cur = nxt.result()
-                            if first + step < n:
-                                nxt = pool.submit(fetch, which, first + step, min(step, n - first - step), bufs[(i + 1) & 1])
-                            fh.write(memoryview(cur))
-                    assert fh.tell() == lay.pos
-                os.replace(tmp, self.path)
+                # the size is known: reserve the extents first (one file takes ~10.5 GB/s of buffered writes on the test boxes however
+                # many threads write it -- the inode lock --, 12.5 GB/s into preallocated extents: tools/probes/file_write_rate.py)
+                try:
+                    os.posix_fallocate(fd, 0, lay.pos)
+                except OSError:      # a file system without fallocate: plain extending writes
+                    pass
+                for pos, small in lay.small:
+                    os.pwrite(fd, small, pos)
+                # the two array payloads: device -> pinned staging -> pwrite, natively (no pageable copy, no conversion pass on the
+                # host: the counts are widened on the device), the next chunk crossing PCIe while the current one is written
+                for which, (pos, _) in enumerate(lay.big):
+                    check(lib.kmap_counts_write_range(self.dc._h, which, 0, n, fd, pos, st.value))
+                os.ftruncate(fd, lay.pos)
             finally:
-                pool.shutdown()
+                os.close(fd)
                 lib.kmap_stream_destroy(st.value)
+            os.replace(tmp, self.path)
             STAGE_TIMES[f"bg_save_k{self.k}"] = time.perf_counter() - t0    # background: overlaps the main thread's stages
         except BaseException as e:   # noqa: BLE001 -- re-raised by join()
             self.err = e
@@ -982,15 +974,15 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
             head += ",n_motif_reads,n_all_reads,motif_reads_prop,motif_occurrence,motif_occurrence_per_motif_read"
         lines = [head]
         # find_motif of one k depends on nothing but the reads, so the k values go in the order that hides the background work
-        # best -- the largest k first: its count table (15 GB of k16.pkl at C3) is then fetched and pickled while every other k is
-        # counted -- and the per-k files, candidate rows and np.random draws (occurrence subsampling) follow in ascending k
-        # exactly as the reference emits them
+        # best -- the two largest k first: their count tables (15 GB of k16.pkl, 4 GB of k15.pkl at C3) are then written, to their two
+        # files in parallel, while every other k is counted -- and the per-k files, candidate rows and np.random draws (occurrence
+        # subsampling) follow in ascending k exactly as the reference emits them
         found, hit_lists, occ_written = {}, {}, set()
         occ_writers = savers.setdefault("occurrence", [])
         n_out, out_read_len = scan_seq.out_n_seq, scan_seq.out_read_len
         if dist is not None:      # tables that stay sharded (distributed.CountShard): only the writer of k{k}.pkl receives all shards
             count_seq.full_table_rank = 0 if save_kmer_cnt_flag else None
-        for kmer_len in sorted(range(min_k, max_k + 1), key=lambda k: (k != max_k, k)):
+        for kmer_len in sorted(range(min_k, max_k + 1), key=lambda k: (k < max_k - 1, k if k < max_k - 1 else -k)):   # max_k, max_k - 1, then ascending
             count_seq.reset()
             d = motif_def_dict[kmer_len]
             kmer_cnt_file = res / FileNameDict["kmer_count_dir"] / f"k{kmer_len}.pkl"
