@@ -396,6 +396,172 @@ __global__ __launch_bounds__(KMAP_WAVE *SEL_WAVES) void knn_select_kernel(const 
     }
 }
 
+// ---- one pass over the row (n_nb <= SEL1_CAP, 16-byte aligned pitch, values < 32: every Hamming row of the product) -------------
+// The two-pass kernel above reads the row once for the value histogram and again, up to the last selected entry, for the indices
+// (r04: 1.54 x N^2 bytes, 16 lane-private LDS atomics per 16 bytes in pass 1).  Here the wave keeps the selection of the entries
+// SEEN SO FAR while it reads the row once:
+//   * state: a bound T (an upper bound of the value of the row's n_nb-th smallest entry), per value v <= T a list of the indices
+//     taken (LDS, <= n_nb each, in index order) and its length cnt[v] (lane v of a vector register; cnt[T] in a scalar),
+//     below = sum of cnt[v < T].  Always below < n_nb and below + cnt[T] <= n_nb, with equality once n_nb entries <= T were seen;
+//   * an entry == T enters while below + cnt[T] < n_nb (a later one never does: the ones held have lower indices); an entry < T
+//     enters, and if the selection was full the last entry of T's list leaves; when that list is empty and below == n_nb the bound
+//     drops to the largest value that has entries;
+//   * so once the selection is full only entries BELOW the bound matter: per 1024 entries four SWAR compares and a ballot;
+//   * the first bound comes from the value counters of the row's first SEL1_BOOT steps (8192 entries, re-read from L2 right
+//     after): a sample of the row that holds n_nb entries <= T0 proves the row does.  The tighter the first bound, the fewer
+//     entries ever take the scalar insertion path (N = 50 000, k = 8: T0 = 2 against a final 1 or 2).
+// A sample without n_nb entries below 32 (never a Hamming row of k < 32) sends the row to the generic two-pass path; larger bytes
+// elsewhere in the row are just never candidates.
+constexpr int SEL1_CAP = 32;
+constexpr int SEL1_BOOT = 8;
+constexpr int SEL1_WAVES = 4;
+__global__ __launch_bounds__(KMAP_WAVE *SEL1_WAVES) void knn_select1_kernel(const uint8_t *__restrict__ D, int64_t ldd, int64_t n, int n_nb,
+                                                                             int64_t row0, int64_t nrows, int32_t *__restrict__ nb) {
+    __shared__ uint32_t bins[SEL1_WAVES][SEL_VALS * 64];     // the lists (32 x SEL1_CAP words) re-use a wave's counters after the bound is known
+    static_assert(32 * SEL1_CAP <= SEL_VALS * 64, "lists alias the counters");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t lr = (int64_t)blockIdx.x * SEL1_WAVES + wave;
+    if (lr >= nrows) return;
+    uint32_t *h = bins[wave];
+    int32_t *lists = reinterpret_cast<int32_t *>(bins[wave]);
+    const uint8_t *row = D + (row0 + lr) * ldd;
+    int32_t *out = nb + lr * n_nb;
+    const uint4 *row4 = reinterpret_cast<const uint4 *>(row);
+    const int nsteps = (int)((n + 1023) >> 10), nfull = (int)(n >> 10);
+    const int lane_chunks = (int)(ldd >> 4), last_chunk = lane_chunks - 1;
+    auto chunk_at = [&](int s) { const int c = s * 64 + lane; return row4[c < last_chunk ? c : last_chunk]; };
+    auto valid16 = [&](int s, int chunk) -> uint32_t {                       // bytes of the lane's chunk that lie inside the row
+        if (s < nfull) return 0xFFFFu;
+        const int64_t left = n - (int64_t)chunk * 16;
+        return left >= 16 ? 0xFFFFu : left <= 0 ? 0u : (1u << (int)left) - 1u;
+    };
+    // ---- the first bound: value counters of the first steps
+#pragma unroll
+    for (int v = 0; v < SEL_VALS; ++v) h[v * 64 + lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const int nboot = nsteps < SEL1_BOOT ? nsteps : SEL1_BOOT;
+    for (int s = 0; s < nboot; ++s) {
+        const int chunk = s * 64 + lane;
+        uint4 w = chunk_at(s);
+        if (chunk >= lane_chunks) w = make_uint4(~0u, ~0u, ~0u, ~0u);
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+        const uint32_t ok = valid16(s, chunk);
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            uint32_t v = (ws[b >> 2] >> (8 * (b & 3))) & 0xFFu;
+            v = v < 32u ? v : 32u;
+            if ((ok >> b) & 1u) atomicAdd(&h[v * 64 + lane], 1u);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    uint32_t tot = 0;
+    if (lane < SEL_VALS) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(h + lane * 64);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint4 c = p[q];
+            tot += (c.x + c.y) + (c.z + c.w);
+        }
+    }
+    uint32_t bigflag = (uint32_t)__builtin_amdgcn_readlane((int)tot, 32);   // some byte >= 32
+    uint32_t cum = lane < 32 ? tot : 0u;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        const uint32_t up = __shfl_up(cum, o);
+        if (lane >= o) cum += up;
+    }
+    const unsigned long long reach = __ballot(lane < 32 && cum >= (uint32_t)n_nb);
+    if (reach == 0ull) bigflag = 1u;             // fewer than n_nb entries below 32 in the sample
+    __builtin_amdgcn_wave_barrier();             // the counters are dead: their words become the lists
+    // ---- state
+    int T = bigflag ? 0 : __builtin_ctzll(reach);
+    uint32_t below = 0, cntT = 0;                // entries held with value < T / == T
+    uint32_t cntv = 0;                           // lane v < T: entries held with value v
+    // one candidate entry (index j, value v), in index order
+    auto take = [&](int v, int32_t j) {
+        if (v > T) return;                                                   // the bound dropped inside this step
+        if (v == T) {
+            if (below + cntT < (uint32_t)n_nb) {
+                if (lane == 0) lists[T * SEL1_CAP + (int)cntT] = j;
+                ++cntT;
+            }
+            return;
+        }
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cntv, v);
+        if (lane == 0) lists[v * SEL1_CAP + (int)c] = j;                     // c <= below < n_nb <= SEL1_CAP
+        cntv = lane == v ? c + 1u : cntv;
+        ++below;
+        if (below + cntT > (uint32_t)n_nb) --cntT;                           // the selection was full: the last entry == T leaves (cntT > 0 here)
+        if (cntT == 0 && below == (uint32_t)n_nb) {                          // all n_nb below the bound: it drops to the largest value held
+            const unsigned long long held = __ballot(cntv != 0u && lane < T);
+            const int Tn = 63 - __builtin_clzll(held);
+            cntT = (uint32_t)__builtin_amdgcn_readlane((int)cntv, Tn);
+            cntv = lane == Tn ? 0u : cntv;
+            below -= cntT;
+            T = Tn;
+        }
+    };
+    uint4 pf0 = chunk_at(0), pf1 = chunk_at(1), pf2 = chunk_at(2);
+    for (int s = 0; s < nsteps && bigflag == 0u; ++s) {
+        const int chunk = s * 64 + lane;
+        uint4 w = pf0;
+        pf0 = pf1; pf1 = pf2; pf2 = chunk_at(s + 3);
+        if (chunk >= lane_chunks) w = make_uint4(~0u, ~0u, ~0u, ~0u);       // 0xFF bytes: never candidates
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+        // candidates: bytes <= T while the selection is not full, bytes < T afterwards
+        const uint32_t TT = (uint32_t)(T + (below + cntT < (uint32_t)n_nb ? 1 : 0)) * 0x01010101u;
+        // (bytes >= 32 behind the sample are simply never candidates: the bound is below 32; `& ~x` keeps bytes >= 128, whose
+        // borrow would read as "below", out -- one v_bitop3 with the complement and the mask)
+        uint32_t lt[4], any = 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            lt[d] = ~((ws[d] | 0x80808080u) - TT) & ~ws[d] & 0x80808080u;
+            any |= lt[d];
+        }
+        const uint32_t ok = s < nfull ? 0xFFFFu : valid16(s, chunk);         // the row's last step: bytes behind the row do not count
+        if (__ballot(any != 0u) == 0ull) continue;                           // wave-uniform: no candidate in these 1024 entries
+        uint32_t m16 = 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) m16 |= swar_pack4(lt[d]) << (4 * d);
+        m16 &= ok;
+        unsigned long long cand = __ballot(m16 != 0u);
+        while (cand) {                                                       // scalar: lanes in order, bytes in order = index order
+            const int L = __builtin_ctzll(cand);
+            cand &= cand - 1;
+            uint32_t mL = (uint32_t)__builtin_amdgcn_readlane((int)m16, L);
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)ws[0], L), w1 = (uint32_t)__builtin_amdgcn_readlane((int)ws[1], L);
+            const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)ws[2], L), w3 = (uint32_t)__builtin_amdgcn_readlane((int)ws[3], L);
+            const int32_t base = (int32_t)(((int64_t)s * 64 + L) * 16);
+            while (mL) {
+                const int b = __builtin_ctz(mL);
+                mL &= mL - 1;
+                const uint32_t word = (b < 8) ? (b < 4 ? w0 : w1) : (b < 12 ? w2 : w3);
+                take((int)((word >> (8 * (b & 3))) & 0xFFu), base + b);
+            }
+        }
+    }
+    if (bigflag) {
+        __builtin_amdgcn_wave_barrier();
+        knn_select_row_generic(row, n, n_nb, h, lane, out);
+        return;
+    }
+    // ---- write the lists: lane v copies the entries of value v (lane T: cntT of them) behind those of the smaller values
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    const uint32_t mine = lane < T ? cntv : (lane == T ? cntT : 0u);
+    uint32_t inc = mine;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        const uint32_t up = __shfl_up(inc, o);
+        if (lane >= o) inc += up;
+    }
+    const uint32_t at = inc - mine;
+    for (uint32_t i = 0; i < (uint32_t)n_nb; ++i)
+        if (i < mine && lane < 32) out[at + i] = lists[lane * SEL1_CAP + (int)i];
+}
+
 // generic float smoothing in the reference's summation order (taichi_core.py:227-249):
 // thread per (i,j), i<j: 400 gathers ii-outer/jj-inner, /n_nb twice; mirrored; diagonal 0
 __global__ __launch_bounds__(BLK) void knn_smooth_f32_kernel(const float *__restrict__ D, const int32_t *__restrict__ nb,
@@ -476,6 +642,16 @@ int kmap_knn_select_u8_dev(const uint8_t *D_dev, int64_t ldd, int64_t n, int n_n
     if (nrows == 0) return KMAP_OK;
     KMAP_REQUIRE(D_dev && nb_out_dev, "knn_select: null pointer");
     const int aligned = (ldd % 16 == 0) && ((uintptr_t)D_dev % 16 == 0);   // 16-byte row loads (always true for kmap_hamdist_pitch)
+    static const bool two_pass = [] { const char *v = getenv("KMAP_KNN_SELECT"); return v && v[0] == '2'; }();   // A/B switch: the two-pass kernel
+    static const bool one_pass = [] { const char *v = getenv("KMAP_KNN_SELECT"); return v && v[0] == '1'; }();
+    // r05, N = 50 000: 0.66 ms (one pass, 1.16 x N^2 bytes with the sample) against 0.68 - 0.73 (two passes, 1.54 x); N = 17 000: 0.149
+    // against 0.112 -- the single pass pays ~45 scalar insertions per row for not knowing the final bound, which long rows amortise
+    if (aligned && n_nb <= SEL1_CAP && !two_pass && (one_pass || n >= 32768)) {
+        knn_select1_kernel<<<(unsigned)((nrows + SEL1_WAVES - 1) / SEL1_WAVES), KMAP_WAVE * SEL1_WAVES, 0, as_stream(stream)>>>(
+            D_dev, ldd, n, n_nb, row0, nrows, nb_out_dev);
+        KMAP_CHECK_HIP(hipGetLastError());
+        return KMAP_OK;
+    }
     knn_select_kernel<<<(unsigned)((nrows + SEL_WAVES - 1) / SEL_WAVES), KMAP_WAVE * SEL_WAVES, 0, as_stream(stream)>>>(
         D_dev, ldd, n, n_nb, row0, nrows, nb_out_dev, aligned);
     KMAP_CHECK_HIP(hipGetLastError());

@@ -60,8 +60,24 @@ def test_knn_sums_chunked_rows_vs_oracle(V):
     np.testing.assert_array_equal(got, want)
 
 
-def test_device_knn_selection_vs_oracle_rule(V):
-    """Device k-NN selection (smallest distance, then lowest index) == stable argsort, as sets per row."""
+@pytest.mark.parametrize("kernel", ["1", "2"])
+def test_device_knn_selection_vs_oracle_rule(kernel):
+    """Device k-NN selection (smallest distance, then lowest index) == stable argsort, as sets per row -- for the one-pass kernel
+    (KMAP_KNN_SELECT=1: running selection under a bound from a sample of the row; the default of long rows) and the two-pass one
+    (=2: histogram, then indices).  The switch is read once per process: the cases run in a child process."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = str(Path(__file__).resolve().parent.parent)
+    code = "import sys; sys.path.insert(0, sys.argv[1]); import tests.test_gpu_embed as T; T._knn_select_cases(); print('cases ok')"
+    r = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, KMAP_KNN_SELECT=kernel), cwd=root, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "cases ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def _knn_select_cases():
+    from kmap_amd import visualization as V
     from oracle import oracle as O
     from kmap_amd import _ffi
     from kmap_amd.hamdist import pitch_for

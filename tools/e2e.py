@@ -16,7 +16,7 @@ def main():
     from kmap_amd.e2e import CONFIGS, run_e2e
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
-    ap.add_argument("--mode", default="default", choices=["default", "seq", "fast"])
+    ap.add_argument("--mode", default="default", choices=["default", "seq", "fast", "exact"])
     ap.add_argument("--min_k", type=int, default=6)
     ap.add_argument("--max_k", type=int, default=9)
     ap.add_argument("--iters", type=int, default=None)
