@@ -502,6 +502,44 @@ def test_cyclic_symmetric_shards_match_single_gpu(tmp_path, monkeypatch, cyclic,
     assert diff.max() <= 5e-4 * scale and np.quantile(diff, 0.99) <= 2e-5 * scale
 
 
+def _seq_shard_worker(rank, world, port, out_dir, n, iters):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from kmap_amd.distributed import kmap_from_kmers_distributed
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(5)
+        kh = rng.integers(0, 4 ** K, size=n, dtype=np.uint64)
+        lab = np.sort(rng.integers(0, 3, size=n)).astype(np.int64)
+        tr = {}
+        best, _ = kmap_from_kmers_distributed(kh, np.ones(n, np.int64), lab, ["ACGTACGT", "ACGTAC"], K, n_max_iter=iters, random_seed=SEED, mode=1, trace=tr)
+        np.savez(Path(out_dir) / f"seqsh_rank{rank}.npz", best=best, last=tr["last_coords"], losses=tr["losses"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_seq_row_shards_in_the_producer_adder_form_equal_single_gpu(tmp_path):
+    """SEQ (the package default) at an N where a rank's share runs in the producer / adder form of the force kernel (N >= 3072,
+    fewer rows than 2.5 rounds of quad waves; embed_seq.hip): three ranks with contiguous row blocks -- a row is summed by one adder
+    lane in column order whatever the sharding, so coordinates and losses equal the single-GPU run's, bit for bit, on every rank."""
+    import torch.multiprocessing as mp
+    import kmap_amd.visualization as V
+    n, iters = 4099, 9                            # odd N (last chunk ragged), rows 1367 / 1366 / 1366
+    mp.spawn(_seq_shard_worker, args=(3, _free_port(), str(tmp_path), n, iters), nprocs=3, join=True)
+    r = [np.load(tmp_path / f"seqsh_rank{i}.npz") for i in range(3)]
+    rng = np.random.default_rng(5)
+    kh = rng.integers(0, 4 ** K, size=n, dtype=np.uint64)
+    lab = np.sort(rng.integers(0, 3, size=n)).astype(np.int64)
+    tr = {}
+    best, _ = V.kmap_from_kmers(kh, np.ones(n, np.int64), lab, ["ACGTACGT", "ACGTAC"], K, n_max_iter=iters, random_seed=SEED, mode=V.EMBED_SEQ, trace=tr)
+    for x in r:
+        np.testing.assert_array_equal(x["last"], tr["last_coords"])
+        np.testing.assert_array_equal(x["best"], best)
+        np.testing.assert_allclose(x["losses"], tr["losses"], rtol=1e-6)
+
+
 def _seed_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
