@@ -242,6 +242,93 @@ __global__ __launch_bounds__(LDSMODE ? HP_TPB : BLK) void hist_packed_kernel(con
     }
 }
 
+// ---- the same with 16-bit LDS counters: 65 536 bins per pass (k = 8 in ONE pass instead of two, k = 9 in four instead of eight) ----
+// Two counters per LDS word, plain (non-returning) adds of 1 or 1 << 16.  A block adds at most 1024 x 16 = 16 384 windows per round of its
+// loop; every HP16_ROUNDS = 3 rounds the block meets at a barrier and sweeps the table (32 words per thread): a word with a half at or
+// above 0x4000 is emptied (atomic exchange) into the global bins.  Between two looks at a word at most 49 152 adds can land on it, so a
+// half stays below 0x4000 + 49 152 = 65 536: no carry ever reaches the neighbour.  (The returning form of the add with a check of the
+// returned word was measured first: 0.97 against 0.94 ms for the two 32-bit passes -- the returned data costs what the second pass did.)
+constexpr int HP16_BINS = 65536;
+constexpr int HP16_ROUNDS = 3;
+__global__ __launch_bounds__(HP_TPB) void hist_packed16_kernel(const uint32_t *__restrict__ codes, const uint16_t *__restrict__ inval,
+                                                               int64_t n, int k, uint32_t bin0, uint32_t *__restrict__ bins,
+                                                               const uint32_t *__restrict__ skip) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lb[];      // HP16_BINS / 2 words + 64 lane-private words for dropped windows
+    for (int b = threadIdx.x; b < HP16_BINS / 2 + 64; b += blockDim.x) lb[b] = 0;
+    __syncthreads();
+    const int64_t n_groups = (n + 15) >> 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t g_first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t g_last = n_groups - 1;
+    uint32_t nc0 = 0, nc1 = 0, nsk = 0;
+    uint16_t nf0 = 0, nf1 = 0, nf2 = 0;
+    const uint32_t *skp = skip ? skip : codes;
+    if (n_groups > 0) {
+        const int64_t gl = g_first < n_groups ? g_first : g_last;
+        nc0 = codes[gl]; nc1 = codes[gl + 1];
+        nf0 = inval[gl]; nf1 = inval[gl + 1]; nf2 = inval[gl + 2];
+        nsk = skp[gl >> 1];
+    }
+    const uint32_t dummy = (uint32_t)HP16_BINS + 2u * (threadIdx.x & 63u);   // bin index of the lane's private word (low half)
+    const int sh = 32 - 2 * k;
+    // every thread of the block runs the same number of rounds (the barriers): a thread behind the last group counts nothing
+    const int64_t rounds = (n_groups - (int64_t)blockIdx.x * blockDim.x + stride - 1) / stride;      // of thread 0 = the block's maximum
+    auto sweep = [&]() {
+        typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+        for (int q = threadIdx.x; q < HP16_BINS / 8; q += HP_TPB) {        // 4 words = 8 bins per step
+            const u32x4v v = *reinterpret_cast<const u32x4v *>(lb + 4 * q);
+            if (((v.x | v.y | v.z | v.w) & 0xC000C000u) == 0u) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t w0 = j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w;
+                if ((w0 & 0xC000C000u) == 0u) continue;
+                const uint32_t w = atomicExch(&lb[4 * q + j], 0u);
+                const uint32_t b = (uint32_t)(8 * q + 2 * j);
+                if (w & 0xFFFFu) atomicAdd(&bins[bin0 + b], w & 0xFFFFu);
+                if (w >> 16) atomicAdd(&bins[bin0 + b + 1], w >> 16);
+            }
+        }
+        if (threadIdx.x < 64) lb[HP16_BINS / 2 + threadIdx.x] = 0;          // the private words only absorb: nobody reads them
+    };
+    int64_t g = g_first;
+    for (int64_t r = 0; r < rounds; ++r, g += stride) {
+        if (r && r % HP16_ROUNDS == 0) {
+            __syncthreads();
+            sweep();
+        }
+        const uint32_t hi = nc0, lo = nc1;
+        uint64_t bad = ((uint64_t)nf0 << 32) | ((uint64_t)nf1 << 16) | nf2;
+        const uint32_t sk16 = skip ? ((nsk >> ((g & 1) ? 0 : 16)) & 0xFFFFu) : 0u;
+        {
+            const int64_t gn = g + stride < n_groups ? g + stride : g_last;      // clamped: the last round re-reads a valid group
+            nc0 = codes[gn]; nc1 = codes[gn + 1];
+            nf0 = inval[gn]; nf1 = inval[gn + 1]; nf2 = inval[gn + 2];
+            nsk = skp[gn >> 1];
+        }
+        if (g >= n_groups || (bad >> 32) == 0xFFFFull) continue;   // behind the array / group entirely invalid
+        for (int have = 1; have < k;) {
+            const int step = (have <= k - have) ? have : k - have;
+            bad |= bad << step;
+            have += step;
+        }
+        const uint32_t bad16 = (uint32_t)(bad >> 32) | sk16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t top = (i == 0) ? hi : __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * i);
+            // (key ^ bin0) | flag: inside the pass's range the XOR is the subtraction, outside it (or dropped) a high bit is set
+            uint32_t a = __builtin_amdgcn_bitop3_b32(top >> sh, bin0, (uint32_t)__builtin_amdgcn_sbfe((int)bad16, 15 - i, 1), 0xBE);
+            a = a < dummy ? a : dummy;
+            atomicAdd(lb + (a >> 1), 1u << ((a & 1u) << 4));
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < HP16_BINS / 2; b += blockDim.x) {
+        const uint32_t w = lb[b];
+        if (w & 0xFFFFu) atomicAdd(&bins[bin0 + 2 * b], w & 0xFFFFu);
+        if (w >> 16) atomicAdd(&bins[bin0 + 2 * b + 1], w >> 16);
+    }
+}
+
 // ---- per-read de-duplication as skip bits (remove_duplicate_hash_per_seq, kmer_count.py:743-760, fused with counting) -----------
 // The reference invalidates every repeated hash of a read before counting; only the COUNTS are used afterwards, so which of the
 // equal windows survives does not matter.  One wave per read: the windows are hashed straight from the packed codes, 64 at a
@@ -1097,7 +1184,13 @@ int kmap_counts_hist_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const
     if (n > 0) {
         const size_t n_bins = (size_t)1 << (2 * k);
         const size_t passes = (n_bins + HP_BINS - 1) / HP_BINS;
-        if (passes <= 32 && n >= (1 << 16)) {   // k <= 10: 32 passes x 0.375 B/position still beat scattered device atomics
+        static const bool wide_counters = [] { const char *v = getenv("KMAP_HIST16"); return v && v[0] == '0'; }();   // A/B switch: 32-bit LDS counters
+        if (n_bins >= (size_t)HP16_BINS && n_bins / HP16_BINS <= 16 && n >= (1 << 16) && !wide_counters) {
+            // k = 8, 9: 16-bit LDS counters, 65 536 bins per pass
+            KMAP_TRY(kmap_allow_lds((const void *)hist_packed16_kernel, (HP16_BINS / 2 + 64) * 4));
+            for (size_t p = 0; p < n_bins / HP16_BINS; ++p)
+                hist_packed16_kernel<<<256, HP_TPB, (HP16_BINS / 2 + 64) * 4, st>>>(codes_dev, inval_dev, n, k, (uint32_t)(p * HP16_BINS), c->bins, skip);
+        } else if (passes <= 32 && n >= (1 << 16)) {   // k <= 10: 32 passes x 0.375 B/position still beat scattered device atomics
             KMAP_TRY(kmap_allow_lds((const void *)hist_packed_kernel<false, true>, (HP_BINS + 64) * 4));
             for (size_t p = 0; p < passes; ++p)
                 hist_packed_kernel<false, true><<<256, HP_TPB, (HP_BINS + 64) * 4, st>>>(codes_dev, inval_dev, n, k,
