@@ -312,7 +312,15 @@ def test_lds_histogram_hot_bins(env, k):
     ~85 % of the keys and is cut into ~130 slices that add their bins to the table with device atomics; at k = 13 / 14 (two 16-bit
     counters per LDS word) the poly-A bin also spills its 16 384-count chunks to the global list.  Counts must equal the oracle's,
     with and without per-read dedupe."""
-    _ffi, DeviceCounts, DeviceSeq, O = env
+    _hot_bins_case(k, *env)
+
+
+def _hot_bins_case(k, _ffi=None, DeviceCounts=None, DeviceSeq=None, O=None):
+    if _ffi is None:
+        from kmap_amd import _ffi
+        from kmap_amd.kmer_count import DeviceCounts
+        from kmap_amd.motif_discovery import DeviceSeq
+        from oracle import oracle as O
     rng = np.random.default_rng(500 + k)
     seq, borders = synth(rng, 60_000, 190, 210, p_n=0.001)
     for r in range(len(borders)):
@@ -332,6 +340,21 @@ def test_lds_histogram_hot_bins(env, k):
             assert c.max() > 8_000_000
     dc.close()
     ds.close()
+
+
+@pytest.mark.parametrize("k", [8, 9])
+def test_hist_counter_width_switch(k):
+    """KMAP_HIST16=0: the k = 8 / 9 histogram with 32-bit LDS counters (32 768 bins per pass, two / eight passes) instead of the default
+    16-bit ones (65 536 bins per pass + the sweep that keeps the halves from carrying): the same counts under the same skew (the
+    switch is read once per process: a child runs the case)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = str(Path(__file__).resolve().parent.parent)
+    code = f"import sys; sys.path.insert(0, sys.argv[1]); import tests.test_gpu_packed as T; T._hot_bins_case({k}); print('case ok')"
+    r = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, KMAP_HIST16="0"), cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "case ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 @pytest.mark.parametrize("max_len", [512, 513])
