@@ -130,14 +130,14 @@ def roof(bytes_per_launch, ms_list, what, note=None):
 # stage -> (workload of profiles/r*_pmc.json, [(kernel-name prefix, launches per stage pass)]): the kernels whose HBM bytes (rocprofv3
 # FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes) make up `moved_bytes` of a stage
 STAGE_KERNELS = {
-    "count_pass_k8": ("e2e", [("hist_packed_kernel<false, true>", 2), ("compact_count_kernel", 1), ("compact_write_kernel<unsigned int>", 1)]),
-    "count_pass_k8_dedupe": ("e2e", [("dedupe_bitmap_packed_kernel<true>", 1), ("max_read_len_kernel", 1), ("hist_packed_kernel<false, true>", 2),
+    "count_pass_k8": ("e2e", [("hist_packed16_kernel", 1), ("compact_count_kernel", 1), ("compact_write_kernel<unsigned int>", 1)]),
+    "count_pass_k8_dedupe": ("e2e", [("dedupe_bitmap_packed_kernel<true>", 1), ("max_read_len_kernel", 1), ("hist_packed16_kernel", 1),
                                      ("compact_count_kernel", 1), ("compact_write_kernel<unsigned int>", 1)]),
     "count_pass_k14": ("count14", [("fine_count_kernel", 1), ("fine_offsets_kernel", 1), ("fine_scatter_kernel", 1), ("fine_zero_heavy_kernel", 1),
                                    ("fine_hist_kernel", 1), ("fine_spill_kernel", 1), ("rc_merge_tiles_kernel", 1), ("compact_write_kernel<unsigned int>", 1)]),
     "mask_k8": ("e2e", [("hits_planes_kernel<8, false>", 1), ("mask_cover_packed_kernel", 1)]),
     "scan_k8_r2": ("e2e", [("hits_planes_kernel<8, true>", 1), ("scan_hits_reads_fused_kernel", 1), ("scan_reorder_kernel", 1)]),
-    "knn_select": ("e2e", [("knn_select_kernel", 1)]),
+    "knn_select": ("e2e", [("knn_select1_kernel", 1)]),
     "knn_sums": ("e2e", [("knn_profile_kernel", 1), ("knn_sums_mfma_kernel", 1)]),
     "embed_iter_fast": ("e2e", [("forces_sym2_kernel", 1), ("sym_apply_kernel", 1), ("reduce_loss_kernel", 1)]),
     "embed_iter_seq": ("seq", [("forces_seq_kernel", 1), ("apply_kernel<true>", 1)]),
@@ -878,9 +878,9 @@ def main():
     ap.add_argument("--no-count-dist", action="store_true", help="skip the multi-GPU counting leg (k = 15: all-reduce vs key-range shards)")
     ap.add_argument("--no-c5", action="store_true", help="skip the full-size C5 scan leg (N=1 only)")
     ap.add_argument("--quick", action="store_true", help="smaller CPU-baseline samples (rehearsals)")
-    ap.add_argument("--shard-proxy", type=int, default=0, metavar="G",
+    ap.add_argument("--shard-proxy", type=int, default=8, metavar="G",
                     help="N=1 only: time every rank's share of a G-GPU run on this one GPU (Hamming / kNN / SEQ + FAST forces at N = 50 000 and 200 000, "
-                         "count / scan of reads / G) and print max-shard, work inflation and the predicted G-GPU time per stage")
+                         "count / scan of reads / G) and print max-shard, work inflation and the predicted G-GPU time per stage; 0 = skip")
     ap.add_argument("--no-reads-dist", action="store_true", help="skip the read-sharded C3 count / scan leg (multi-rank)")
     ap.add_argument("--no-e2e-dist", action="store_true", help="skip the end-to-end run of both verbs under the process group (multi-rank)")
     ap.add_argument("--no-stages", action="store_true", help="skip the per-stage roofline timings")

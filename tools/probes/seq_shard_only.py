@@ -1,7 +1,10 @@
+#!/usr/bin/env python3
+"""Only SEQ force evaluations of a row-sharded session (default: rank 0 of 8 at C3, 6 250 x 50 000, producer / adder form): workload
+for kernel-time / PMC passes.  `seq_shard_only.py [adder|classic] [n row0 nrows]`"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tools"))
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tools"))   # seqa_check.forces
 from kmap_amd import _ffi, visualization as V
 import seqa_check as sc
 form = sys.argv[1] if len(sys.argv) > 1 else "adder"

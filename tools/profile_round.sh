@@ -12,6 +12,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/bench_pmc_write -- python
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/bench_pmc_fetch -- python3 $R/bench.py --no-cpu-baseline --no-c4 --no-c5 --no-stages --no-embed-dist --e2e none --steps 5 --warmup 1 > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e2e_trace -- python3 $R/tools/e2e.py --config C3 --mode fast --iters 100 > $OUT/e2e_trace.json 2> $OUT/e2e_trace.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/embed_trace -- python3 $R/tools/bench_embed.py --n 50000 --iters 20 > $OUT/embed_trace.txt 2> $OUT/embed_trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/seqshard_trace -- python3 $R/tools/probes/seq_shard_only.py adder > $OUT/seqshard_trace.txt 2> $OUT/seqshard_trace.err
 # (the full-size C5 scan is part of bench_trace: bench.py's c5 leg generates its 50 M x 300 bp reads in HBM)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scan_trace -- python3 $R/tools/bench_scan.py --reads 10000000 --read_len 150 --k 8 --radius 2 --reps 5 > $OUT/scan_trace.json 2> $OUT/scan_trace.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/count_trace -- python3 $R/tools/probes/count_only.py 14 5 0 > $OUT/count_trace.txt 2> $OUT/count_trace.err
