@@ -137,7 +137,7 @@ STAGE_KERNELS = {
                                    ("fine_hist_kernel", 1), ("fine_spill_kernel", 1), ("rc_merge_tiles_kernel", 1), ("compact_write_kernel<unsigned int>", 1)]),
     "mask_k8": ("e2e", [("hits_planes_kernel<8, false>", 1), ("mask_cover_packed_kernel", 1)]),
     "scan_k8_r2": ("e2e", [("hits_planes_kernel<8, true>", 1), ("scan_hits_reads_fused_kernel", 1), ("scan_reorder_kernel", 1)]),
-    "knn_select": ("e2e", [("knn_select1_kernel", 1)]),
+    "knn_select": ("e2e", [("knn_select_kernel", 1)]),
     "knn_sums": ("e2e", [("knn_profile_kernel", 1), ("knn_sums_mfma_kernel", 1)]),
     "embed_iter_fast": ("e2e", [("forces_sym2_kernel", 1), ("sym_apply_kernel", 1), ("reduce_loss_kernel", 1)]),
     "embed_iter_seq": ("seq", [("forces_seq_kernel", 1), ("apply_kernel<true>", 1)]),

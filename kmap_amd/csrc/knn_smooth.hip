@@ -407,8 +407,8 @@ __global__ __launch_bounds__(KMAP_WAVE *SEL_WAVES) void knn_select_kernel(const 
 //     enters, and if the selection was full the last entry of T's list leaves; when that list is empty and below == n_nb the bound
 //     drops to the largest value that has entries;
 //   * so once the selection is full only entries BELOW the bound matter: per 1024 entries four SWAR compares and a ballot;
-//   * the first bound comes from the value counters of the row's first SEL1_BOOT steps (8192 entries, re-read from L2 right
-//     after): a sample of the row that holds n_nb entries <= T0 proves the row does.  The tighter the first bound, the fewer
+//   * the first bound comes from the value counters of SEL1_BOOT steps of the row (8192 entries around the diagonal, re-read from
+//     L2 later): a sample of the row that holds n_nb entries <= T0 proves the row does.  The tighter the first bound, the fewer
 //     entries ever take the scalar insertion path (N = 50 000, k = 8: T0 = 2 against a final 1 or 2).
 // A sample without n_nb entries below 32 (never a Hamming row of k < 32) sends the row to the generic two-pass path; larger bytes
 // elsewhere in the row are just never candidates.
@@ -440,8 +440,13 @@ __global__ __launch_bounds__(KMAP_WAVE *SEL1_WAVES) void knn_select1_kernel(cons
 #pragma unroll
     for (int v = 0; v < SEL_VALS; ++v) h[v * 64 + lane] = 0;
     __builtin_amdgcn_wave_barrier();
+    // the sample: SEL1_BOOT steps around the row's own column -- in the pipeline's matrices (k-mers grouped by label, copies of a
+    // sampled k-mer adjacent) a row's nearest entries sit around its diagonal, so the first bound is close to the final one; any
+    // window of the row would be valid
     const int nboot = nsteps < SEL1_BOOT ? nsteps : SEL1_BOOT;
-    for (int s = 0; s < nboot; ++s) {
+    int s_first = (int)((row0 + lr) >> 10) - SEL1_BOOT / 2;
+    s_first = s_first < 0 ? 0 : (s_first + nboot > nsteps ? nsteps - nboot : s_first);
+    for (int s = s_first; s < s_first + nboot; ++s) {
         const int chunk = s * 64 + lane;
         uint4 w = chunk_at(s);
         if (chunk >= lane_chunks) w = make_uint4(~0u, ~0u, ~0u, ~0u);
@@ -644,9 +649,11 @@ int kmap_knn_select_u8_dev(const uint8_t *D_dev, int64_t ldd, int64_t n, int n_n
     const int aligned = (ldd % 16 == 0) && ((uintptr_t)D_dev % 16 == 0);   // 16-byte row loads (always true for kmap_hamdist_pitch)
     static const bool two_pass = [] { const char *v = getenv("KMAP_KNN_SELECT"); return v && v[0] == '2'; }();   // A/B switch: the two-pass kernel
     static const bool one_pass = [] { const char *v = getenv("KMAP_KNN_SELECT"); return v && v[0] == '1'; }();
-    // r05, N = 50 000: 0.66 ms (one pass, 1.16 x N^2 bytes with the sample) against 0.68 - 0.73 (two passes, 1.54 x); N = 17 000: 0.149
-    // against 0.112 -- the single pass pays ~45 scalar insertions per row for not knowing the final bound, which long rows amortise
-    if (aligned && n_nb <= SEL1_CAP && !two_pass && (one_pass || n >= 32768)) {
+    // r05, N = 50 000, ms per launch (tools/probes/knn_select_only.py), one pass / two passes: unique sorted k-mers 0.60 / 0.74, a
+    // synthetic count-expanded sample 0.61 / 0.68, the C3 hand-over itself 0.74 / 0.66 -- half of its rows are motif k-mers whose 20
+    // neighbours are label mates at the start of the row, where the two-pass kernel's second pass ends after a few steps.  The
+    // product's matrices are hand-overs: the two-pass kernel stays the default, the one-pass kernel is KMAP_KNN_SELECT=1.
+    if (aligned && n_nb <= SEL1_CAP && !two_pass && one_pass) {
         knn_select1_kernel<<<(unsigned)((nrows + SEL1_WAVES - 1) / SEL1_WAVES), KMAP_WAVE * SEL1_WAVES, 0, as_stream(stream)>>>(
             D_dev, ldd, n, n_nb, row0, nrows, nb_out_dev);
         KMAP_CHECK_HIP(hipGetLastError());
