@@ -262,7 +262,7 @@ def test_early_stop_golden(V, golden, tag):
 
 
 def test_fast_vs_seq_at_default_size(V):
-    """N = 5000 (the reference's default n_total_sample), k = 8: FAST tracks SEQ's loss curve (see default_mode() for why trajectories are not compared digit by digit); the loss decreases; best snapshot has the lowest logged loss."""
+    """N = 5000 (the reference's default n_total_sample), k = 8: FAST (opt-in) tracks SEQ's loss curve (see default_mode() for why trajectories are not compared digit by digit); the loss decreases; best snapshot has the lowest logged loss."""
     from oracle import oracle as O
     rng = np.random.default_rng(12)
     n, k = 5000, 8

@@ -281,7 +281,7 @@ def _assert_seq_rows_equal_oracle(g, sums_d, lds, lut, coords, rows):
 
 
 def test_c3_embedding_force_evaluation_full_size():
-    """N = 50 000 with the hand-over's label structure: the symmetric FAST kernel (the C3 default) against the SEQ kernel (the
+    """N = 50 000 with the hand-over's label structure: the symmetric FAST kernel (the opt-in mode) against the SEQ kernel (the default: the
     reference's summation order) on one force evaluation -- loss to 2e-6, gradient to 2e-5 of its scale -- and 20 FAST
     iterations that keep lowering the loss."""
     from kmap_amd import _ffi, visualization as V
