@@ -98,6 +98,21 @@ __device__ __forceinline__ void seq_load(SeqBatch &b, const ProbSrc &src, const 
 }
 
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// The LUT is the first object of every SEQ kernel's LDS and the kernels have no static LDS: it starts at LDS address 0 (checked on
+// entry, seq_lut_at_zero), so the byte offset of an entry IS its address and one SDWA shift per entry (pick the 16-bit half, scale by
+// 4) replaces and / shift + shift-add (embed_fast.hip uses the same gather).
+__device__ __forceinline__ f32x2 seq_lut_pair(uint32_t w) {
+    uint32_t a, b;
+    const uint32_t two = 2u;
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a) : "s"(two), "v"(w));
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(b) : "s"(two), "v"(w));
+    typedef const __attribute__((address_space(3))) float *lds_f32;
+    return f32x2{*reinterpret_cast<lds_f32>(a), *reinterpret_cast<lds_f32>(b)};
+}
+__device__ __forceinline__ void seq_lut_at_zero(const float *lut_s) {
+    typedef __attribute__((address_space(3))) const float *lds_f32;
+    if ((uint32_t)(uintptr_t)(lds_f32)lut_s != 0u) __builtin_trap();
+}
 
 // The 8 terms of one lane's batch: t * dx, t * dy of columns jl32 .. jl32 + 7 against point (xi, yi) = row i32, and the batch's
 // cross-entropy contribution in log2 units.  SLOW: generic IEEE divisions (some squared distance beyond 1e30); LOSS: the batch has
@@ -116,7 +131,7 @@ __device__ __forceinline__ void seq_terms(const SeqBatch &cur, const float *__re
     float prod = 1.0f;
 #pragma unroll
     for (int d = 0; d < SQ_CPL / 2; ++d) {                               // 4 independent pairs of terms
-        const f32x2 p = LUTSRC ? f32x2{lut_s[cur.w[d] & 0xFFFFu], lut_s[cur.w[d] >> 16]} : cur.pf[d];
+        const f32x2 p = LUTSRC ? seq_lut_pair(cur.w[d]) : cur.pf[d];
         const f32x2 s1 = one2 + d2[d];                                   // d2 = (dx*dx) + (dy*dy), no FMA (taichi_core.py:254)
         f32x2 q;                                                         // 1 / (1 + d2)   :255
         if (SLOW) {
@@ -197,7 +212,7 @@ __device__ __forceinline__ void seq_terms_far(const SeqBatch &cur, const float *
     f32x2 es2 = {0.0f, 0.0f};
 #pragma unroll
     for (int d = 0; d < SQ_CPL / 2; ++d) {
-        const f32x2 p = LUTSRC ? f32x2{lut_s[cur.w[d] & 0xFFFFu], lut_s[cur.w[d] >> 16]} : cur.pf[d];
+        const f32x2 p = LUTSRC ? seq_lut_pair(cur.w[d]) : cur.pf[d];
         const f32x2 t = u2 * (p - q2);
         const f32x2 tx2 = t * dx[d], ty2 = t * dy[d];
         tx[2 * d] = tx2.x; tx[2 * d + 1] = tx2.y;
@@ -561,7 +576,7 @@ struct SaGeom {
     static constexpr int QP = 4 * RP + 1;                // cells (16 B) per column group: its four column pairs x RP rows + one of padding
     static constexpr size_t BUF_BYTES = (size_t)(CH / 8) * QP * 16;
     static constexpr size_t XY_FLOATS = 2 * (size_t)CH;  // one chunk's x | y
-    static constexpr size_t FIXED_BYTES = 2 * BUF_BYTES + 2 * XY_FLOATS * 4 + (size_t)RP * 8;   // term buffers, coordinate buffers, row coordinates
+    static constexpr size_t FIXED_BYTES = 2 * BUF_BYTES + 2 * XY_FLOATS * 4 + (size_t)RP * 8 + 16 * 8;   // term buffers, coordinate buffers, row coordinates, loss partials
     static_assert(LPR * RPS == KMAP_WAVE && (RP == 32 || RP == 64) && CH % 8 == 0 && CH <= 256, "geometry");
 };
 template <int RP, int CH>
@@ -570,14 +585,15 @@ __global__ __launch_bounds__(KMAP_WAVE *SA_MAX_WAVES) void forces_seqa_kernel(Pr
                                                                  double *__restrict__ loss_part) {
     using GEO = SaGeom<RP, CH>;
     constexpr int LPR = GEO::LPR, RPS = GEO::RPS;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    f32x4 *buf0 = reinterpret_cast<f32x4 *>(smem);
+    extern __shared__ __attribute__((aligned(16))) float smem[];             // LUT (at LDS address 0) | term buffers | coordinates | loss partials
+    float *lut_s = smem;
+    seq_lut_at_zero(lut_s);
+    f32x4 *buf0 = reinterpret_cast<f32x4 *>(smem + (((size_t)src.lut_len + 3) & ~(size_t)3));
     f32x4 *buf1 = buf0 + GEO::BUF_BYTES / 16;
     float *xy0 = reinterpret_cast<float *>(buf1 + GEO::BUF_BYTES / 16);      // x[CH] | y[CH] of the even chunks
     float *xy1 = xy0 + GEO::XY_FLOATS;
     f32x2 *rowxy = reinterpret_cast<f32x2 *>(xy1 + GEO::XY_FLOATS);          // (x, y) of the block's rows
-    float *lut_s = reinterpret_cast<float *>(rowxy + RP);
-    __shared__ double wl[SA_MAX_WAVES];
+    double *wl = reinterpret_cast<double *>(rowxy + RP);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // roles (see above): M producers on each of the three other SIMD classes, EA on the adder's
     const int M = R >> 8 & 15, EA = R >> 12 & 3, SA_NP = 3 * M + EA;
@@ -767,21 +783,24 @@ __global__ __launch_bounds__(KMAP_WAVE *SQ_WAVES) void forces_seq_kernel(ProbSrc
                                                                int64_t row0, int64_t pair_rows, int64_t main_rows, int64_t nrows,
                                                                int nb_tail, int nb_pair, int nb_main, float *__restrict__ G,
                                                                double *__restrict__ loss_part) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr size_t XCH_FLOATS = GW ? (size_t)SQ_WAVES * KMAP_WAVE * SQ_CPL * 2 : 0;   // exchange strips first, the LUT behind them
-    float *lut_s = smem + XCH_FLOATS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // LUT (at LDS address 0) | exchange strips of the wide form | SQ_WAVES loss partials
+    constexpr size_t XCH_FLOATS = GW ? (size_t)SQ_WAVES * KMAP_WAVE * SQ_CPL * 2 : 0;
+    float *lut_s = smem;
+    const size_t lut_floats = LUTSRC ? (((size_t)src.lut_len + 3) & ~(size_t)3) : 4;
+    float *xch_s = smem + lut_floats;
+    double *wl = reinterpret_cast<double *>(xch_s + XCH_FLOATS);
     if (LUTSRC) {
+        seq_lut_at_zero(lut_s);
         for (int t = threadIdx.x; t < src.lut_len && t < F_LUT_LDS; t += blockDim.x) lut_s[t] = src.lut[t];
         __syncthreads();
     }
-    __shared__ double wl[SQ_WAVES];
     if constexpr (GW != 0) {
         if ((int)blockIdx.x < nb_tail) {   // block-uniform
             if constexpr (GW == 16)   // one DPP row per matrix row: no exchange through LDS
                 seq_row16_body<LUTSRC>(src, Y, n, row0, main_rows, nrows, G, loss_part + nb_main, (int64_t)blockIdx.x, lut_s, wl);
             else
                 seq_wide_body<LUTSRC, GW>(src, Y, n, row0, main_rows, nrows, G, loss_part + nb_main, (int64_t)blockIdx.x, lut_s, wl,
-                                          reinterpret_cast<f32x2 *>(smem));
+                                          reinterpret_cast<f32x2 *>(xch_s));
             return;
         }
     }
@@ -834,10 +853,12 @@ void kmap_embed_seq_split(kmap_embed *e) {
         const bool force_on = v && v[0] == 'a', force_off = v && v[0] == 'c';
         int dev0 = 0, cus0 = 256;
         if (hipGetDevice(&dev0) != hipSuccess || hipDeviceGetAttribute(&cus0, hipDeviceAttributeMultiprocessorCount, dev0) != hipSuccess || cus0 <= 0) cus0 = 256;
-        // r05 measurements (tools/seqa_check.py, ms per force evaluation, classic / this form): 650 x 1000: .023 / .028; 5000 x 5000: .083 / .054;
-        // 6250 x 50 000 (an eighth of C3): .69 / .38; 16 461 x 17 413: .80 / .40; 25 000 x 200 000 (an eighth of C4): 9.4 / 5.5;
-        // 50 000 x 50 000: 2.14 / 2.71 -- the quad / pair forms win once three or more whole rounds of their waves fill the machine
-        const bool want = force_on || (!force_off && e->nrows > 0 && e->n >= 3072 && 2 * e->nrows < 5 * (int64_t)(4 * cus0) * SQ_ROWS);
+        // r05 measurements (tools/seqa_check.py, ms per force evaluation, classic / this form): 300 x 300: .019 / .013; 1000 x 1000: .023 / .016;
+        // 5000 x 5000: .082 / .045; 12 000 x 12 000: .26 / .17; 6250 x 50 000 (an eighth of C3): .67 / .35; 16 461 x 17 413: .79 / .38;
+        // 25 000 x 200 000 (an eighth of C4): 9.3 / 5.3; 30 000 x 30 000: .93 / .99; 40 000 x 40 000: 1.53 / 1.89; 50 000 x 50 000: 2.1 / 2.6
+        // -- the quad / pair forms win once their whole rounds (16 384 rows each) carry most of the rows.  Below n = 3072 the difference is
+        // microseconds and the small golden traces keep the form they were recorded against.
+        const bool want = force_on || (!force_off && e->nrows > 0 && e->n >= 3072 && 4 * e->nrows < 7 * (int64_t)(4 * cus0) * SQ_ROWS);
         if (want && e->nrows > 0) {
             // one block per CU and round; the fewest rounds the row slots allow, then the smallest R that still fits them (a block's
             // producer time grows with R, its adder time does not)
@@ -911,7 +932,7 @@ int kmap_embed_launch_seq(kmap_embed *e, float *G, hipStream_t st) {
         return KMAP_OK;
     }
     const int nb_main = seq_main_blocks(e), nb_tail = seq_tail_blocks(e);
-    const size_t lds_w = (nb_tail ? (size_t)SQ_WAVES * KMAP_WAVE * SQ_CPL * 8 : 0) + lds;
+    const size_t lds_w = (nb_tail ? (size_t)SQ_WAVES * KMAP_WAVE * SQ_CPL * 8 : 0) + lds + SQ_WAVES * 8;   // LUT | strips | loss partials
 #define KMAP_SEQ(LUT, GW)                                                                                                          \
     do {                                                                                                                           \
         KMAP_TRY(kmap_allow_lds((const void *)forces_seq_kernel<LUT, GW>, (int)lds_w));                                            \
