@@ -430,7 +430,7 @@ def test_visualize_kmers_cli_under_torchrun(tmp_path):
     lab, cnts = lab[:len(kh)], np.ones(len(kh), np.int64)
     cnts[::7] = 3                                               # expanded N > number of unique k-mers
     outs = []
-    for tag in ("single", "dist"):
+    for tag in ("single", "dist", "dist_auto"):       # dist_auto: KMAP_DIST_EXCHANGE=auto -- the validated peer-direct exchange inside the verb
         res = tmp_path / tag
         res.mkdir()
         cfg = read_default_config_file()
@@ -445,12 +445,14 @@ def test_visualize_kmers_cli_under_torchrun(tmp_path):
             cmd = [sys.executable, "-m", "kmap_amd", "visualize_kmers", "--res_dir", str(res)]
         else:
             env.update(KMAP_DIST_BACKEND="gloo", KMAP_DIST_SAME_GPU="1")
+            if tag == "dist_auto":
+                env.update(KMAP_DIST_EXCHANGE="auto")
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                    "--master-port", str(_free_port()), "-m", "kmap_amd", "visualize_kmers", "--res_dir", str(res)]
         r = subprocess.run(cmd, env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append((res / "low_dim_data.tsv").read_text())
-    assert outs[0] == outs[1] and outs[0].count("\n") == int(cnts.sum()) + 1
+    assert outs[0] == outs[1] == outs[2] and outs[0].count("\n") == int(cnts.sum()) + 1
 
 
 def _cyclic_worker(rank, world, port, out_dir, n, iters, exchange="rccl"):
@@ -618,7 +620,7 @@ def test_scan_motif_cli_under_torchrun(tmp_path):
     from kmap_amd import synth
     seq, borders = synth.synth_reads(40_001, 60, 12)
     outs = {}
-    for tag in ("single", "dist"):
+    for tag in ("single", "dist", "dist_auto"):       # dist_auto: KMAP_DIST_EXCHANGE=auto -- the validated peer-direct exchange inside the verb
         res = tmp_path / tag
         res.mkdir()
         over = {"kmer_count": {"min_k": 6, "max_k": 9},
