@@ -541,3 +541,14 @@ def test_seq_wide_tail_kernel_is_bit_identical(V, n, row0, nrows, tmp_path):
     assert outs["split"]["g"][:, row0:row0 + nrows].any() and not outs["split"]["g"][:, :row0].any()
     ls, lq = float(outs["split"]["l"][0]), float(outs["quad"]["l"][0])
     assert abs(ls - lq) <= 1e-8 * abs(lq)        # the loss is not bit-pinned: f32 partial sums over batches of different width
+
+
+def test_seq_adder_form_fuzz():
+    """the producer / adder form of the SEQ force kernel against the classic forms on 60 random shapes (rows: all / a few / a tail shard
+    / any range; N 40 .. 20 000 incl. values that are no multiple of 4 or 8; LUT lengths of k = 3 .. 20; coordinate scales from
+    coincident points to squared distances beyond 1e30): the same gradient bits, the same loss (tools/seqa_check.py)"""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    import seqa_check
+    assert seqa_check.fuzz(60, seed=7) == 0

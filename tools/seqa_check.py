@@ -40,7 +40,52 @@ def forces(form, n, row0, nrows, sums_d, lds, lut, ld, reps):
     return out, (statistics.median(ms) if ms else 0.0)
 
 
+def fuzz(count, seed=1):
+    """random shapes: n, row0, nrows (incl. 1 row, a tail shard, all rows), k (LUT length), coordinate scale (coincident points, far
+    points, squared distances beyond 1e30); producer / adder form against the classic forms, bit for bit"""
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for t in range(count):
+        n = int(rng.choice([rng.integers(40, 600), rng.integers(600, 5000), rng.integers(5000, 20000)]))
+        mode = int(rng.integers(0, 4))
+        if mode == 0:
+            row0, nrows = 0, n
+        elif mode == 1:
+            nrows = int(rng.integers(1, min(n, 70) + 1))
+            row0 = int(rng.integers(0, n - nrows + 1))
+        elif mode == 2:
+            nrows = int(rng.integers(1, n + 1))
+            row0 = n - nrows
+        else:
+            row0 = int(rng.integers(0, n))
+            nrows = int(rng.integers(1, n - row0 + 1))
+        k = int(rng.choice([3, 6, 8, 12, 16, 20]))
+        lut = V.hd_prob_lut(k, 20, 400 * k)
+        lds = (n + 127) & ~127
+        sums = rng.integers(0, len(lut), size=(nrows, lds), dtype=np.uint16)
+        sums_d = _ffi.DeviceBuffer.from_numpy(sums)
+        scale = float(rng.choice([0.01, 1.0, 5.0, 40.0, 1e3, 1e16]))
+        ld = (rng.standard_normal((2, n)) * scale).astype(np.float32)
+        if n > 6:
+            ld[:, 5] = ld[:, 4]
+        (gc, lc), _ = forces("classic", n, row0, nrows, sums_d, lds, lut, ld, 0)
+        (ga, la), _ = forces("adder", n, row0, nrows, sums_d, lds, lut, ld, 0)
+        same = np.array_equal(gc.view(np.uint32), ga.view(np.uint32))
+        lok = (not np.isfinite(lc) and not np.isfinite(la)) or abs(la - lc) <= 1e-6 * abs(lc) + 1e-30
+        if not (same and lok):
+            bad += 1
+            print(f"FAIL n={n} row0={row0} nrows={nrows} k={k} scale={scale}: bits {'same' if same else 'differ'} loss {lc!r} {la!r}", flush=True)
+        sums_d.free()
+        if (t + 1) % 25 == 0:
+            print(f"fuzz {t + 1}/{count}: {bad} failures", flush=True)
+    return bad
+
+
 def main():
+    if "--fuzz" in sys.argv:
+        bad = fuzz(int(sys.argv[sys.argv.index("--fuzz") + 1]))
+        print("FAILED" if bad else "fuzz ok")
+        return 1 if bad else 0
     big = "--big" in sys.argv
     cases = [(1000, 100, 650), (5003, 0, 5003), (5000, 0, 5000), (4096 + 40, 7, 31), (16384 + 1029, 300, 16384 + 77)]
     if big:
