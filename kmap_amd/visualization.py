@@ -71,10 +71,13 @@ def knn_select_numpy(D_dev_ptr, ldd, n, n_nb, nrows=None):
     if nrows == 0:
         return np.zeros((0, n_nb), np.int64)
     blk = max(1, min(nrows, (32 << 20) // max(n, 1)))
+    sub = max(1, (2 << 20) // max(n, 1))          # rows per argpartition call: their int64 copy (16 MB) stays in the last-level cache
     out = np.empty((nrows, n_nb), np.int64)
 
     def part(r0, rows):
-        out[r0:r0 + len(rows)] = np.argpartition(rows.astype(np.int64), n_nb, axis=1)[:, :n_nb]
+        for a in range(0, len(rows), sub):
+            piece = rows[a:a + sub]
+            out[r0 + a:r0 + a + len(piece)] = np.argpartition(piece.astype(np.int64), n_nb, axis=1)[:, :n_nb]
 
     with ThreadPoolExecutor(max(1, min(16, (os.cpu_count() or 2) - 1))) as pool:
         jobs = []
