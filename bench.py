@@ -1123,8 +1123,8 @@ def main():
             e2e["workload"] = (f"C3: {first['n_reads']} x {first['read_len']} bp synthetic reads, N={first['n_total']} sampled k-mers, "
                                f"{first['iters']} iterations, 1 GPU, clean res_dir; k6_9: k = 6..9 (longest final = the configs' k = 8), k6_16: the "
                                f"reference's default k range (default_config.toml:7-8); default = the package default = SEQ, the reference's "
-                               f"arithmetic and summation order at every N (the parity-grade number; neighbour ties / top-k / draws by the device "
-                               f"rules above the documented sizes), fast = config.toml visualization.embed_mode = \"fast\" (opt-in: wavefront-parallel "
+                               f"arithmetic and summation order at every N, neighbours by np.argpartition up to N = 65536 (the parity-grade number; "
+                               f"top-k / draws by the device rules above 4e6 unique k-mers), fast = config.toml visualization.embed_mode = \"fast\" (opt-in: wavefront-parallel "
                                f"row sums, per-step pinned), exact = config.toml general.exact = true (SEQ + np.argpartition neighbours / top-k + "
                                f"np.random.multinomial at every size: the strict drop-in run)")
             reads = None          # 1.5 GB of host memory back before the next legs

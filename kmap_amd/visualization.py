@@ -47,18 +47,20 @@ class _stage:
         STAGE_TIMES[self.name] = STAGE_TIMES.get(self.name, 0.0) + time.perf_counter() - self.t0
 
 
+KNN_NUMPY_MAX_N = 65536   # up to here the neighbours are the reference's own np.argpartition call (0.4 s of host time at N = 50 000)
+
+
 def knn_mode(n):
-    """'numpy' (the reference's np.argpartition on int64 rows: drop-in, tie order numpy/ISA specific) up to the size where
-    scan_motif still writes the int64 matrix; 'device' (smallest distance, then lowest index) above it, where the
-    reference cannot run and 2.5e9+ int64 entries would have to be streamed through the host.  KMAP_KNN overrides;
-    KMAP_EXACT=1 / config general.exact selects 'numpy' at every size."""
+    """'numpy' (the reference's np.argpartition on int64 rows, visualization.py:100: drop-in, tie order numpy / ISA specific; the rows
+    are streamed back from the device matrix and partitioned on host threads) up to N = 65 536 -- every BASELINE config a single GPU
+    embeds -- and 'device' (smallest distance, then lowest index) above, where 40+ GB of int64 rows would pass through the host.
+    KMAP_KNN overrides; KMAP_EXACT=1 / config general.exact selects 'numpy' at every size."""
     import os
     from . import _policy
-    from .motif_discovery import DENSE_PKL_MAX_N
     forced = os.environ.get("KMAP_KNN", "").lower()
     if forced in ("numpy", "device"):
         return forced
-    return "numpy" if (n <= DENSE_PKL_MAX_N or _policy.exact()) else "device"
+    return "numpy" if (n <= KNN_NUMPY_MAX_N or _policy.exact()) else "device"
 
 
 def knn_select_numpy(D_dev_ptr, ldd, n, n_nb, nrows=None):

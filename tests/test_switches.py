@@ -64,7 +64,7 @@ def test_exact_switch(monkeypatch):
     monkeypatch.delenv("KMAP_EXACT", raising=False)
     monkeypatch.delenv("KMAP_KNN", raising=False)
     _policy.reset()
-    big = MD.DENSE_PKL_MAX_N + 1
+    big = V.KNN_NUMPY_MAX_N + 1
     assert not _policy.exact() and V.knn_mode(big) == "device" and MD._device_topk(MD.TOPK_DEVICE_MIN + 1, 5)
     monkeypatch.setenv("KMAP_EXACT", "1")
     assert _policy.exact() and V.knn_mode(big) == "numpy" and not MD._device_topk(MD.TOPK_DEVICE_MIN + 1, 5)
@@ -133,8 +133,8 @@ def test_io_threads_switch(tmp_path):
 
 @pytest.mark.gpu
 def test_knn_numpy_mode_above_the_dense_limit(monkeypatch):
-    """KMAP_KNN=numpy above N = 16 384: the neighbours are the reference's np.argpartition on int64 rows (visualization.py:100),
-    taken from the device matrix streamed back in row blocks.  Checked on sampled rows against argpartition of the ORACLE's rows."""
+    """the neighbours above the dense hand-over limit (N > 16 384; numpy is the default up to N = 65 536, KMAP_KNN=numpy beyond) are
+    the reference's np.argpartition on int64 rows (visualization.py:100), taken from the device matrix streamed back in row blocks.  Checked on sampled rows against argpartition of the ORACLE's rows."""
     from kmap_amd import visualization as V
     from kmap_amd.motif_discovery import DENSE_PKL_MAX_N
     from oracle import oracle as O
@@ -158,10 +158,11 @@ def test_knn_numpy_mode_above_the_dense_limit(monkeypatch):
     monkeypatch.setenv("KMAP_KNN", "device")
     assert V.knn_mode(10) == "device"
     monkeypatch.delenv("KMAP_KNN")
-    assert V.knn_mode(n) == "device" and V.knn_mode(DENSE_PKL_MAX_N) == "numpy"
-    # KMAP_EXACT=1 selects the same neighbours (threaded row blocks == one argpartition call per row)
+    assert V.knn_mode(n) == "numpy" and V.knn_mode(V.KNN_NUMPY_MAX_N) == "numpy" and V.knn_mode(V.KNN_NUMPY_MAX_N + 1) == "device"
+    # the default at this N (numpy up to N = 65 536) and KMAP_EXACT=1 select the same neighbours (threaded row blocks == one
+    # argpartition call per row)
     monkeypatch.setenv("KMAP_EXACT", "1")
-    assert V.knn_mode(n) == "numpy"
+    assert V.knn_mode(n) == "numpy" and V.knn_mode(V.KNN_NUMPY_MAX_N + 1) == "numpy"
     tr2 = {}
     V.kmap_from_kmers(kh, np.ones(n, np.int64), lab, conseqs, k, n_max_iter=2, random_seed=5, mode=V.EMBED_FAST, trace=tr2)
     np.testing.assert_array_equal(tr2["nb"], nb)
