@@ -50,6 +50,11 @@ __device__ __forceinline__ void add_quad_block(float &gx, float &gy, const float
     KMAP_QP8(4, "[0,0,2,2]") KMAP_QP8(5, "[1,1,3,3]")        // two sub-lanes per row (pair form): lane 0 / 1 of each lane pair
 #undef KMAP_QP8
 }
+// a wave-uniform 64-bit value, moved to scalar registers (the compiler cannot see that `threadIdx.x >> 6` is uniform)
+__device__ __forceinline__ int64_t seq_uniform(int64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
 constexpr int SQ_CPL = 8;                       // consecutive columns per lane per batch (one 16-byte load of u16 sums)
 
 struct SeqBatch {                                // raw operands of one batch of one lane, as column pairs (c, c + 1)
@@ -222,14 +227,27 @@ __device__ __forceinline__ void seq_terms_far(const SeqBatch &cur, const float *
     if (LOSS) ce2 = far.logprod8 + (es2.x + es2.y);
 }
 
-// wave-uniform dispatch over the variants.  rows_in_wave consecutive rows from wave_row_min; batch = columns [j0, j0 + batch_cols)
+// min / max of three as ONE instruction (the d2 are results of arithmetic: nothing to canonicalise first, which the compiler's
+// own min / max lowering does with a v_max x, x per operand)
+__device__ __forceinline__ float seq_min3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float seq_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// wave-uniform dispatch over the variants of one batch.  `plain`: the batch neither reaches past column n - 1 nor contains the diagonal
+// of any of the wave's rows (no per-term masks); `want_loss`: some column of the batch lies right of some row of the wave (each
+// unordered pair is charged to its j > i side).  Both are the caller's, who knows them as scalars.  The far test comes first and needs
+// only the smallest d2 of the batch; the largest (some squared distance too large for the short divisions -> generic division) is
+// looked at by the batches that do divide: a far batch has no division, its q is the clip constant whatever the distance.
 template <bool LUTSRC>
-__device__ __forceinline__ void seq_terms_dispatch(const SeqBatch &cur, const float *__restrict__ lut_s, float xi, float yi, int i32,
-                                                   int64_t n, int64_t j0, int batch_cols, int64_t wave_row_min, int rows_in_wave,
-                                                   int jl32, const SeqFar &far, float (&tx)[SQ_CPL], float (&ty)[SQ_CPL], float &ce2) {
-    // (a) no column of the batch lies right of any of the wave's rows -> no loss terms (each unordered pair is charged to its
-    // j > i side); (b) some squared distance is too large for the short divisions -> generic division
-    const bool want_loss = (j0 + batch_cols - 1) > wave_row_min;
+__device__ __forceinline__ void seq_terms_select(const SeqBatch &cur, const float *__restrict__ lut_s, float xi, float yi, int i32, int n32,
+                                                 int jl32, bool plain, bool want_loss, const SeqFar &far, float (&tx)[SQ_CPL],
+                                                 float (&ty)[SQ_CPL], float &ce2) {
     const f32x2 xi2 = {xi, xi}, yi2 = {yi, yi};
     f32x2 dx[SQ_CPL / 2], dy[SQ_CPL / 2], d2[SQ_CPL / 2];
 #pragma unroll
@@ -238,27 +256,33 @@ __device__ __forceinline__ void seq_terms_dispatch(const SeqBatch &cur, const fl
         dy[d] = yi2 - cur.y[d];
         d2[d] = dx[d] * dx[d] + dy[d] * dy[d];
     }
-    const f32x2 m01 = __builtin_elementwise_max(d2[0], d2[1]), m23 = __builtin_elementwise_max(d2[2], d2[3]);
-    const f32x2 m = __builtin_elementwise_max(m01, m23);
-    const bool slow = __any(!(fmaxf(m.x, m.y) < 1e30f));
-    const f32x2 l01 = __builtin_elementwise_min(d2[0], d2[1]), l23 = __builtin_elementwise_min(d2[2], d2[3]);
-    const f32x2 l = __builtin_elementwise_min(l01, l23);
-    const bool all_far = !__any(!(fminf(l.x, l.y) >= 1000.0f));         // NaN-safe: a NaN distance is not far
-    // (c) the batch neither reaches past column n-1 nor contains the diagonal of any of the wave's rows -> no per-term masks
-    const bool plain = (j0 + batch_cols <= n) && (j0 + batch_cols - 1 < wave_row_min || j0 > wave_row_min + rows_in_wave - 1);
-    const int n32 = (int)n;
     ce2 = 0.0f;
-    if (slow) {   // rare (coordinates beyond 1e15): one generic instantiation
+    if (plain) {
+        const float l = seq_min3(seq_min3(seq_min3(d2[0].x, d2[0].y, d2[1].x), d2[1].y, d2[2].x), d2[2].y, fminf(d2[3].x, d2[3].y));
+        if (!__any(!(l >= 1000.0f))) {                                   // a NaN distance gives NaN terms on either path
+            if (want_loss) seq_terms_far<LUTSRC, true>(cur, lut_s, dx, dy, far, tx, ty, ce2);
+            else seq_terms_far<LUTSRC, false>(cur, lut_s, dx, dy, far, tx, ty, ce2);
+            return;
+        }
+    }
+    const float m = seq_max3(seq_max3(seq_max3(d2[0].x, d2[0].y, d2[1].x), d2[1].y, d2[2].x), d2[2].y, fmaxf(d2[3].x, d2[3].y));
+    if (__any(!(m < 1e30f))) {   // rare (coordinates beyond 1e15): one generic instantiation
         seq_terms<LUTSRC, true, true, true>(cur, lut_s, dx, dy, d2, i32, n32, jl32, tx, ty, ce2);
-    } else if (plain && all_far) {
-        if (want_loss) seq_terms_far<LUTSRC, true>(cur, lut_s, dx, dy, far, tx, ty, ce2);
-        else seq_terms_far<LUTSRC, false>(cur, lut_s, dx, dy, far, tx, ty, ce2);
     } else if (plain) {
         if (want_loss) seq_terms<LUTSRC, false, true, false>(cur, lut_s, dx, dy, d2, i32, n32, jl32, tx, ty, ce2);
         else seq_terms<LUTSRC, false, false, false>(cur, lut_s, dx, dy, d2, i32, n32, jl32, tx, ty, ce2);
     } else {
         seq_terms<LUTSRC, false, true, true>(cur, lut_s, dx, dy, d2, i32, n32, jl32, tx, ty, ce2);
     }
+}
+// rows_in_wave consecutive rows from wave_row_min; batch = columns [j0, j0 + batch_cols)
+template <bool LUTSRC>
+__device__ __forceinline__ void seq_terms_dispatch(const SeqBatch &cur, const float *__restrict__ lut_s, float xi, float yi, int i32,
+                                                   int64_t n, int64_t j0, int batch_cols, int64_t wave_row_min, int rows_in_wave,
+                                                   int jl32, const SeqFar &far, float (&tx)[SQ_CPL], float (&ty)[SQ_CPL], float &ce2) {
+    const bool want_loss = (j0 + batch_cols - 1) > wave_row_min;
+    const bool plain = (j0 + batch_cols <= n) && (j0 + batch_cols - 1 < wave_row_min || j0 > wave_row_min + rows_in_wave - 1);
+    seq_terms_select<LUTSRC>(cur, lut_s, xi, yi, i32, (int)n, jl32, plain, want_loss, far, tx, ty, ce2);
 }
 
 // quad form, block `bid` of the rows [0, nrows) (lut_s: the block's LUT copy in LDS, already filled; wl: SQ_WAVES doubles of LDS)
@@ -317,7 +341,91 @@ __device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *_
         if (j0 + SQ_BATCH < n) step(bufB, bufA, j0 + SQ_BATCH);
     }
     };
-    if (vec) run(std::true_type{});
+    // The product's shape (u16 sums + LUT, n % 4 == 0, pitch % 8 == 0): everything that says WHICH batch lives in scalar registers.
+    // The wave's rows and the batch's columns are wave-uniform, so the load addresses are a scalar base (advanced by scalar adds) + a
+    // per-lane byte offset computed once, and "left of the rows / on their diagonal / right of them / past column n - 1" are scalar
+    // compares: no vector instruction of a step goes into bookkeeping (r05: 113 of the 265 instructions of a far step did).
+    auto run_scalar = [&]() {
+        const int64_t wave_lr0 = seq_uniform(lrow0 + (bid * SQ_WAVES + wave) * SQ_ROWS);
+        const int64_t base_lr = wave_lr0 < nrows ? wave_lr0 : nrows - 1;           // a wave entirely behind the rows reads the last one
+        const char *sb = reinterpret_cast<const char *>(src.ps + base_lr * src.ld);
+        const char *xb = reinterpret_cast<const char *>(X), *yb = reinterpret_cast<const char *>(Yy);
+        // 32-bit scalars (n < 2^24 here): the scalar unit compares 32-bit integers, 64-bit compares would be vector instructions
+        const int n32 = (int)n, wrow_min = (int)(row0 + wave_lr0), wrow_max = wrow_min + SQ_ROWS - 1;
+        const int j0_last = ((n32 - 1) / SQ_BATCH) * SQ_BATCH;                     // the batch that may reach past column n - 1
+        const uint32_t row_off = (uint32_t)((lrc - base_lr) * src.ld * 2);         // < 64 rows x pitch x 2 bytes
+        const int jl_last = j0_last + sub * SQ_CPL;
+        const uint32_t col_last = (uint32_t)((jl_last < n32 ? jl_last : ((n32 - 1) & ~7)) - j0_last);
+        const uint32_t so = row_off + (uint32_t)sub * SQ_CPL * 2u, co = (uint32_t)sub * SQ_CPL * 4u;
+        const uint32_t so_last = row_off + col_last * 2u, co_last = col_last * 4u;
+        auto load = [&](SeqBatch &b, int j0) {                                     // j0: scalar; always 5 loads (see seq_load)
+            const bool lastb = j0 >= j0_last;
+            const uint32_t s_off = lastb ? so_last : so, c_off = lastb ? co_last : co;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(sb + (uint32_t)j0 * 2u + s_off);
+            b.w[0] = v.x; b.w[1] = v.y; b.w[2] = v.z; b.w[3] = v.w;
+            const char *xa = xb + (uint32_t)j0 * 4u, *ya = yb + (uint32_t)j0 * 4u;
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(xa + c_off), a1 = *reinterpret_cast<const f32x4 *>(xa + c_off + 16);
+            const f32x4 c0 = *reinterpret_cast<const f32x4 *>(ya + c_off), c1 = *reinterpret_cast<const f32x4 *>(ya + c_off + 16);
+            b.x[0] = f32x2{a0.x, a0.y}; b.x[1] = f32x2{a0.z, a0.w}; b.x[2] = f32x2{a1.x, a1.y}; b.x[3] = f32x2{a1.z, a1.w};
+            b.y[0] = f32x2{c0.x, c0.y}; b.y[1] = f32x2{c0.z, c0.w}; b.y[2] = f32x2{c1.x, c1.y}; b.y[3] = f32x2{c1.z, c1.w};
+        };
+        SeqBatch bufA, bufB;
+        load(bufA, 0);
+        const int jsub = sub * SQ_CPL;
+        // REGION 0: batches left of the wave's rows (no masks, no loss); 1: right of them and inside column n - 1 (no masks, loss);
+        // 2: anything (the batches on the diagonal and the one that reaches past column n - 1)
+        auto step = [&](auto region_tag, const SeqBatch &cur, SeqBatch &nxt, int j0) {
+            constexpr int REGION = decltype(region_tag)::value;
+            load(nxt, (j0 + SQ_BATCH < n32) ? j0 + SQ_BATCH : j0);
+            float tx[SQ_CPL], ty[SQ_CPL];
+            float ce2;
+            if constexpr (REGION == 2) {
+                const bool want_loss = (j0 + SQ_BATCH - 1) > wrow_min;
+                const bool plain = (j0 + SQ_BATCH <= n32) && (j0 + SQ_BATCH - 1 < wrow_min || j0 > wrow_max);
+                seq_terms_select<LUTSRC>(cur, lut_s, xi, yi, i32, n32, j0 + jsub, plain, want_loss, far, tx, ty, ce2);
+            } else {
+                seq_terms_select<LUTSRC>(cur, lut_s, xi, yi, i32, n32, j0 + jsub, true, REGION == 1, far, tx, ty, ce2);
+            }
+            asm volatile("s_nop 1");
+            if constexpr (SUB == 4) {
+                add_quad_block<0>(gx, gy, tx, ty);
+                add_quad_block<1>(gx, gy, tx, ty);
+                add_quad_block<2>(gx, gy, tx, ty);
+                add_quad_block<3>(gx, gy, tx, ty);
+            } else {
+                add_quad_block<4>(gx, gy, tx, ty);
+                add_quad_block<5>(gx, gy, tx, ty);
+            }
+            if constexpr (REGION != 0) {                                         // left of the rows ce2 is 0 and ce_acc still is
+                ce_acc += ce2;
+                if (((j0 / SQ_BATCH) & 7) == 7) {
+                    loss += (double)ce_acc;
+                    ce_acc = 0.0f;
+                }
+            }
+        };
+        auto span = [&](auto region_tag, int ja, int jb) {                       // ja: a multiple of two batches, so bufA holds batch ja
+            for (int j0 = ja; j0 < jb; j0 += 2 * SQ_BATCH) {
+                step(region_tag, bufA, bufB, j0);
+                if (j0 + SQ_BATCH < jb) step(region_tag, bufB, bufA, j0 + SQ_BATCH);
+            }
+        };
+        // the three regions as three loops, their borders rounded to pairs of batches towards the diagonal region (which can do any
+        // batch): what a batch needs is then known where the code is written, not compared in every step
+        constexpr int B2 = 2 * SQ_BATCH;
+        const int jn = (n32 / B2) * B2;                                          // whole pairs of batches inside column n - 1
+        int ja = (wrow_min / B2) * B2, jb = ((wrow_max + B2) / B2) * B2;
+        if (ja > jn) ja = jn;
+        if (jb > jn) jb = n32;                                                   // no room right of the rows: the diagonal region runs to the end
+        span(std::integral_constant<int, 0>{}, 0, ja);
+        span(std::integral_constant<int, 2>{}, ja, jb);
+        if (jb < n32) {
+            span(std::integral_constant<int, 1>{}, jb, jn);
+            span(std::integral_constant<int, 2>{}, jn, n32);
+        }
+    };
+    if (LUTSRC && vec && src.ld < ((int64_t)1 << 24)) run_scalar();
+    else if (vec) run(std::true_type{});
     else run(std::false_type{});
     loss += (double)ce_acc;
     loss *= -0.6931471805599453;   // log2 units -> -ln
