@@ -348,43 +348,84 @@ __device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *_
     auto run_scalar = [&]() {
         const int64_t wave_lr0 = seq_uniform(lrow0 + (bid * SQ_WAVES + wave) * SQ_ROWS);
         const int64_t base_lr = wave_lr0 < nrows ? wave_lr0 : nrows - 1;           // a wave entirely behind the rows reads the last one
-        const char *sb = reinterpret_cast<const char *>(src.ps + base_lr * src.ld);
-        const char *xb = reinterpret_cast<const char *>(X), *yb = reinterpret_cast<const char *>(Yy);
         // 32-bit scalars (n < 2^24 here): the scalar unit compares 32-bit integers, 64-bit compares would be vector instructions
         const int n32 = (int)n, wrow_min = (int)(row0 + wave_lr0), wrow_max = wrow_min + SQ_ROWS - 1;
         const int j0_last = ((n32 - 1) / SQ_BATCH) * SQ_BATCH;                     // the batch that may reach past column n - 1
+        // Buffer loads: address = descriptor base + per-lane offset (computed once) + scalar offset (the batch: one scalar add per
+        // stream and step instead of a 64-bit pointer per load).  The batch that reaches past column n - 1 reads what lies there -- the
+        // rest of the sums row's pitch or the next row, Yy behind X, the session's 64 floats of padding behind Yy -- or, past the end of
+        // the descriptor, zeros: those columns are masked out of the terms by selects, never multiplied away.
         const uint32_t row_off = (uint32_t)((lrc - base_lr) * src.ld * 2);         // < 64 rows x pitch x 2 bytes
-        const int jl_last = j0_last + sub * SQ_CPL;
-        const uint32_t col_last = (uint32_t)((jl_last < n32 ? jl_last : ((n32 - 1) & ~7)) - j0_last);
         const uint32_t so = row_off + (uint32_t)sub * SQ_CPL * 2u, co = (uint32_t)sub * SQ_CPL * 4u;
-        const uint32_t so_last = row_off + col_last * 2u, co_last = col_last * 4u;
-        auto load = [&](SeqBatch &b, int j0) {                                     // j0: scalar; always 5 loads (see seq_load)
-            const bool lastb = j0 >= j0_last;
-            const uint32_t s_off = lastb ? so_last : so, c_off = lastb ? co_last : co;
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(sb + (uint32_t)j0 * 2u + s_off);
+        const uint64_t sums_bytes = (uint64_t)(nrows - base_lr) * (uint64_t)src.ld * 2u;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(src.ps + base_lr * src.ld), 0,
+                                                                          sums_bytes < 0xffffffffull ? (int)(uint32_t)sums_bytes : -1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, (int)((2 * n32 + 64) * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Yy), 0, (int)((n32 + 64) * 4), 0x00020000);
+        // j0: scalar.  The sums come from HBM, two steps ahead; the coordinates from L2, one step ahead and issued BEFORE the sums
+        // load of the same step: loads return in order, so whatever is issued ahead of a load that is awaited one step later has one
+        // step to arrive as well
+        auto load_w = [&](SeqBatch &b, int j0) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)so, j0 * 2, 0);
             b.w[0] = v.x; b.w[1] = v.y; b.w[2] = v.z; b.w[3] = v.w;
-            const char *xa = xb + (uint32_t)j0 * 4u, *ya = yb + (uint32_t)j0 * 4u;
-            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(xa + c_off), a1 = *reinterpret_cast<const f32x4 *>(xa + c_off + 16);
-            const f32x4 c0 = *reinterpret_cast<const f32x4 *>(ya + c_off), c1 = *reinterpret_cast<const f32x4 *>(ya + c_off + 16);
-            b.x[0] = f32x2{a0.x, a0.y}; b.x[1] = f32x2{a0.z, a0.w}; b.x[2] = f32x2{a1.x, a1.y}; b.x[3] = f32x2{a1.z, a1.w};
-            b.y[0] = f32x2{c0.x, c0.y}; b.y[1] = f32x2{c0.z, c0.w}; b.y[2] = f32x2{c1.x, c1.y}; b.y[3] = f32x2{c1.z, c1.w};
         };
-        SeqBatch bufA, bufB;
-        load(bufA, 0);
+        auto load_xy = [&](SeqBatch &b, int j0) {
+            const u32x4 a0 = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)co, j0 * 4, 0), a1 = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)co + 16, j0 * 4, 0);
+            const u32x4 c0 = __builtin_amdgcn_raw_buffer_load_b128(ry, (int)co, j0 * 4, 0), c1 = __builtin_amdgcn_raw_buffer_load_b128(ry, (int)co + 16, j0 * 4, 0);
+            auto f2 = [](uint32_t lo, uint32_t hi) { return f32x2{__uint_as_float(lo), __uint_as_float(hi)}; };
+            b.x[0] = f2(a0.x, a0.y); b.x[1] = f2(a0.z, a0.w); b.x[2] = f2(a1.x, a1.y); b.x[3] = f2(a1.z, a1.w);
+            b.y[0] = f2(c0.x, c0.y); b.y[1] = f2(c0.z, c0.w); b.y[2] = f2(c1.x, c1.y); b.y[3] = f2(c1.z, c1.w);
+        };
+        // Two stages, one batch apart, in one loop pass: stage A of batch s + 1 (differences, squared distances, the far test, the LUT
+        // gathers issued) and stage B of batch s (its terms from what stage A left, the ordered adds).  A wave is a chain of latencies
+        // -- the min tree feeding a scalar branch, the gathers' LDS round trip, the add chain -- and a SIMD has two or three of these
+        // waves: in one pass the latencies of a batch now lie beside the other batch's instructions instead of in front of its own
+        // (r05 what-ifs at N = 50 000, all batches far: without the adds 1.50 instead of 1.53 ms, without the gathers 1.49 -- nothing
+        // was busy, everything waited).
+        struct Staged {
+            f32x2 dx[SQ_CPL / 2], dy[SQ_CPL / 2], d2[SQ_CPL / 2];
+            SeqBatch g;                                                            // g.pf: the gathered probabilities
+        };
+        auto stage_a = [&](const SeqBatch &raw, Staged &st) -> bool {              // -> every pair of the batch is far (scalar)
+            const f32x2 xi2 = {xi, xi}, yi2 = {yi, yi};
+#pragma unroll
+            for (int d = 0; d < SQ_CPL / 2; ++d) {
+                st.g.pf[d] = seq_lut_pair(raw.w[d]);
+                st.dx[d] = xi2 - raw.x[d];
+                st.dy[d] = yi2 - raw.y[d];
+                st.d2[d] = st.dx[d] * st.dx[d] + st.dy[d] * st.dy[d];
+            }
+            const float l = seq_min3(seq_min3(seq_min3(st.d2[0].x, st.d2[0].y, st.d2[1].x), st.d2[1].y, st.d2[2].x), st.d2[2].y,
+                                     fminf(st.d2[3].x, st.d2[3].y));
+            return !__any(!(l >= 1000.0f));
+        };
         const int jsub = sub * SQ_CPL;
         // REGION 0: batches left of the wave's rows (no masks, no loss); 1: right of them and inside column n - 1 (no masks, loss);
         // 2: anything (the batches on the diagonal and the one that reaches past column n - 1)
-        auto step = [&](auto region_tag, const SeqBatch &cur, SeqBatch &nxt, int j0) {
+        auto stage_b = [&](auto region_tag, const Staged &st, bool all_far, int j0) {
             constexpr int REGION = decltype(region_tag)::value;
-            load(nxt, (j0 + SQ_BATCH < n32) ? j0 + SQ_BATCH : j0);
             float tx[SQ_CPL], ty[SQ_CPL];
-            float ce2;
+            float ce2 = 0.0f;
+            bool want_loss = REGION == 1, plain = REGION != 2;
             if constexpr (REGION == 2) {
-                const bool want_loss = (j0 + SQ_BATCH - 1) > wrow_min;
-                const bool plain = (j0 + SQ_BATCH <= n32) && (j0 + SQ_BATCH - 1 < wrow_min || j0 > wrow_max);
-                seq_terms_select<LUTSRC>(cur, lut_s, xi, yi, i32, n32, j0 + jsub, plain, want_loss, far, tx, ty, ce2);
+                want_loss = (j0 + SQ_BATCH - 1) > wrow_min;
+                plain = (j0 + SQ_BATCH <= n32) && (j0 + SQ_BATCH - 1 < wrow_min || j0 > wrow_max);
+            }
+            const int jl32 = j0 + jsub;
+            if (plain && all_far) {
+                if (want_loss) seq_terms_far<false, true>(st.g, lut_s, st.dx, st.dy, far, tx, ty, ce2);
+                else seq_terms_far<false, false>(st.g, lut_s, st.dx, st.dy, far, tx, ty, ce2);
             } else {
-                seq_terms_select<LUTSRC>(cur, lut_s, xi, yi, i32, n32, j0 + jsub, true, REGION == 1, far, tx, ty, ce2);
+                const float m = seq_max3(seq_max3(seq_max3(st.d2[0].x, st.d2[0].y, st.d2[1].x), st.d2[1].y, st.d2[2].x), st.d2[2].y,
+                                         fmaxf(st.d2[3].x, st.d2[3].y));
+                if (__any(!(m < 1e30f))) {
+                    seq_terms<false, true, true, true>(st.g, lut_s, st.dx, st.dy, st.d2, i32, n32, jl32, tx, ty, ce2);
+                } else if (plain) {
+                    if (want_loss) seq_terms<false, false, true, false>(st.g, lut_s, st.dx, st.dy, st.d2, i32, n32, jl32, tx, ty, ce2);
+                    else seq_terms<false, false, false, false>(st.g, lut_s, st.dx, st.dy, st.d2, i32, n32, jl32, tx, ty, ce2);
+                } else {
+                    seq_terms<false, false, true, true>(st.g, lut_s, st.dx, st.dy, st.d2, i32, n32, jl32, tx, ty, ce2);
+                }
             }
             asm volatile("s_nop 1");
             if constexpr (SUB == 4) {
@@ -404,10 +445,27 @@ __device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *_
                 }
             }
         };
-        auto span = [&](auto region_tag, int ja, int jb) {                       // ja: a multiple of two batches, so bufA holds batch ja
+        // raw batches (past the last one: the last one again).  At the top of a pass for batch j0: stA = stage A of batch j0; rawB =
+        // batch j0 + 1, both parts issued; rawA.w = the sums of batch j0 + 2, issued; rawA's coordinates free
+        SeqBatch rawA, rawB;
+        Staged stA, stB;
+        auto at = [&](int j0) { return j0 < j0_last ? j0 : j0_last; };
+        load_xy(rawA, 0);
+        load_w(rawA, 0);
+        load_xy(rawB, at(SQ_BATCH));
+        load_w(rawB, at(SQ_BATCH));
+        bool farA = stage_a(rawA, stA), farB = false;
+        load_w(rawA, at(2 * SQ_BATCH));
+        auto span = [&](auto region_tag, int ja, int jb) {                       // ja: a multiple of two batches
             for (int j0 = ja; j0 < jb; j0 += 2 * SQ_BATCH) {
-                step(region_tag, bufA, bufB, j0);
-                if (j0 + SQ_BATCH < jb) step(region_tag, bufB, bufA, j0 + SQ_BATCH);
+                load_xy(rawA, at(j0 + 2 * SQ_BATCH));
+                farB = stage_a(rawB, stB);
+                load_w(rawB, at(j0 + 3 * SQ_BATCH));
+                stage_b(region_tag, stA, farA, j0);
+                load_xy(rawB, at(j0 + 3 * SQ_BATCH));
+                farA = stage_a(rawA, stA);
+                load_w(rawA, at(j0 + 4 * SQ_BATCH));
+                if (j0 + SQ_BATCH < jb) stage_b(region_tag, stB, farB, j0 + SQ_BATCH);
             }
         };
         // the three regions as three loops, their borders rounded to pairs of batches towards the diagonal region (which can do any
