@@ -50,6 +50,56 @@ __device__ __forceinline__ void add_quad_block(float &gx, float &gy, const float
     KMAP_QP8(4, "[0,0,2,2]") KMAP_QP8(5, "[1,1,3,3]")        // two sub-lanes per row (pair form): lane 0 / 1 of each lane pair
 #undef KMAP_QP8
 }
+// Ordered adds with the x chain and the y chain on DIFFERENT lanes of a row, in ONE accumulator register.  Merged operands:
+// U[c] (even lanes: own t dx, odd lanes: the left neighbour's t dy) and W[c] (odd lanes: own t dx, even lanes: the right neighbour's
+// t dy).  Every row sum gets the same operands in the same order as with one register per chain.
+__device__ __forceinline__ void seq_merge_xy(float (&u)[8], float (&w)[8], const float (&tx)[8], const float (&ty)[8]) {
+    const uint64_t even = 0x5555555555555555ull, odd = 0xaaaaaaaaaaaaaaaaull;
+    // D = vcc ? src1 (own t dx) : dpp(src0 = the neighbour's t dy)
+#define KMAP_MERGE8(OUT, MASK, P)                                                                                                         \
+    asm volatile("s_mov_b64 vcc, %24\n\t"                                                                                                 \
+                 "v_cndmask_b32_dpp %0, %16, %8, vcc quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"                                       \
+                 "v_cndmask_b32_dpp %1, %17, %9, vcc quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"                                       \
+                 "v_cndmask_b32_dpp %2, %18, %10, vcc quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"                                      \
+                 "v_cndmask_b32_dpp %3, %19, %11, vcc quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"                                      \
+                 "v_cndmask_b32_dpp %4, %20, %12, vcc quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"                                      \
+                 "v_cndmask_b32_dpp %5, %21, %13, vcc quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"                                      \
+                 "v_cndmask_b32_dpp %6, %22, %14, vcc quad_perm:" P " row_mask:0xf bank_mask:0xf\n\t"                                      \
+                 "v_cndmask_b32_dpp %7, %23, %15, vcc quad_perm:" P " row_mask:0xf bank_mask:0xf"                                          \
+                 : "=&v"(OUT[0]), "=&v"(OUT[1]), "=&v"(OUT[2]), "=&v"(OUT[3]), "=&v"(OUT[4]), "=&v"(OUT[5]), "=&v"(OUT[6]), "=&v"(OUT[7])   \
+                 : "v"(tx[0]), "v"(tx[1]), "v"(tx[2]), "v"(tx[3]), "v"(tx[4]), "v"(tx[5]), "v"(tx[6]), "v"(tx[7]), "v"(ty[0]), "v"(ty[1]),    \
+                   "v"(ty[2]), "v"(ty[3]), "v"(ty[4]), "v"(ty[5]), "v"(ty[6]), "v"(ty[7]), "s"(MASK)                                       \
+                 : "vcc")
+    KMAP_MERGE8(u, even, "[0,0,2,2]");
+    KMAP_MERGE8(w, odd, "[1,1,3,3]");
+#undef KMAP_MERGE8
+}
+// quad form (four lanes per row): the x chain on lanes 0 / 1 of the quad, the y chain on lanes 2 / 3 -- U[c] serves the owners 0 and 2,
+// W[c] the owners 1 and 3: 16 merges + 32 adds instead of 64 adds
+__device__ __forceinline__ void add_quad_split(float &g, const float (&tx)[8], const float (&ty)[8]) {
+    float u[8], w[8];
+    seq_merge_xy(u, w, tx, ty);
+    asm volatile(
+        "v_add_f32_dpp %0, %1, %0 quad_perm:[0,0,1,1] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %2, %0 quad_perm:[0,0,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %3, %0 quad_perm:[0,0,1,1] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %4, %0 quad_perm:[0,0,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %5, %0 quad_perm:[0,0,1,1] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %6, %0 quad_perm:[0,0,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %7, %0 quad_perm:[0,0,1,1] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %8, %0 quad_perm:[0,0,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %9, %0 quad_perm:[1,1,0,0] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %10, %0 quad_perm:[1,1,0,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %11, %0 quad_perm:[1,1,0,0] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %12, %0 quad_perm:[1,1,0,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %13, %0 quad_perm:[1,1,0,0] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %14, %0 quad_perm:[1,1,0,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %15, %0 quad_perm:[1,1,0,0] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %16, %0 quad_perm:[1,1,0,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 quad_perm:[2,2,3,3] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %2, %0 quad_perm:[2,2,3,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %3, %0 quad_perm:[2,2,3,3] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %4, %0 quad_perm:[2,2,3,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %5, %0 quad_perm:[2,2,3,3] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %6, %0 quad_perm:[2,2,3,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %7, %0 quad_perm:[2,2,3,3] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %8, %0 quad_perm:[2,2,3,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %9, %0 quad_perm:[3,3,2,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %10, %0 quad_perm:[3,3,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %11, %0 quad_perm:[3,3,2,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %12, %0 quad_perm:[3,3,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %13, %0 quad_perm:[3,3,2,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %14, %0 quad_perm:[3,3,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %15, %0 quad_perm:[3,3,2,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %16, %0 quad_perm:[3,3,2,2] row_mask:0xf bank_mask:0xf"
+        : "+v"(g)
+        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(u[4]), "v"(u[5]), "v"(u[6]), "v"(u[7]), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]),
+          "v"(w[5]), "v"(w[6]), "v"(w[7]));
+}
 // a wave-uniform 64-bit value, moved to scalar registers (the compiler cannot see that `threadIdx.x >> 6` is uniform)
 __device__ __forceinline__ int64_t seq_uniform(int64_t v) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
@@ -427,22 +477,19 @@ __device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *_
                     seq_terms<false, false, true, true>(st.g, lut_s, st.dx, st.dy, st.d2, i32, n32, jl32, tx, ty, ce2);
                 }
             }
-            asm volatile("s_nop 1");
-            if constexpr (SUB == 4) {
-                add_quad_block<0>(gx, gy, tx, ty);
-                add_quad_block<1>(gx, gy, tx, ty);
-                add_quad_block<2>(gx, gy, tx, ty);
-                add_quad_block<3>(gx, gy, tx, ty);
-            } else {
-                add_quad_block<4>(gx, gy, tx, ty);
-                add_quad_block<5>(gx, gy, tx, ty);
-            }
             if constexpr (REGION != 0) {                                         // left of the rows ce2 is 0 and ce_acc still is
                 ce_acc += ce2;
                 if (((j0 / SQ_BATCH) & 7) == 7) {
                     loss += (double)ce_acc;
                     ce_acc = 0.0f;
                 }
+            }
+            asm volatile("s_nop 1");
+            if constexpr (SUB == 4) {
+                add_quad_split(gx, tx, ty);                                      // gx: the x sum in lanes 0 / 1 of the quad, the y sum in lanes 2 / 3
+            } else {
+                add_quad_block<4>(gx, gy, tx, ty);
+                add_quad_block<5>(gx, gy, tx, ty);
             }
         };
         // raw batches (past the last one: the last one again).  At the top of a pass for batch j0: stA = stage A of batch j0; rawB =
@@ -481,6 +528,7 @@ __device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *_
             span(std::integral_constant<int, 1>{}, jb, jn);
             span(std::integral_constant<int, 2>{}, jn, n32);
         }
+        if constexpr (SUB == 4) gy = __shfl(gx, (lane & ~3) | 2);                // the y chain lives in lanes 2 / 3 (add_quad_split)
     };
     if (LUTSRC && vec && src.ld < ((int64_t)1 << 24)) run_scalar();
     else if (vec) run(std::true_type{});
