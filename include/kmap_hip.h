@@ -329,6 +329,13 @@ int kmap_knn_sums_kmers_u64_dev(const uint64_t *kh_dev, const int32_t *label_dev
  * rule is used where the int64 matrix is never materialised on the host (N > 16384).  nb_out: int32 [nrows, n_nb]. */
 int kmap_knn_select_u8_dev(const uint8_t *D_dev, int64_t ldd, int64_t n, int n_nb, int64_t row0, int64_t nrows,
                            int32_t *nb_out_dev, void *stream);
+/* Helpers of the host-side neighbour choice (the reference's np.argpartition call, visualization.py:100, run on rows streamed back
+ * from the device matrix): the matrix expands every sampled k-mer to its count (motif_discovery.py:759-772, "each uniq kmer is
+ * expanded uniq_kmer_cnt times"), the row of a repeated k-mer equals the row above it, and equal rows partition alike -- fresh_dev[lr] (uint8) = row row0 + lr differs from the row above
+ * (lr = 0: 1); out row o = row idx_dev[o] of D (n bytes, pitch ldo): the rows that need a partition, compacted for the copy. */
+int kmap_rows_fresh_u8_dev(const uint8_t *D_dev, int64_t ldd, int64_t n, int64_t row0, int64_t nrows, uint8_t *fresh_dev, void *stream);
+int kmap_gather_rows_u8_dev(const uint8_t *D_dev, int64_t ldd, int64_t n, const int32_t *idx_dev, int64_t n_idx, uint8_t *out_dev,
+                            int64_t ldo, void *stream);
 /* generic float form in the reference's summation order (any distance matrix) */
 int kmap_knn_smooth_f32(const float *D, const int32_t *nb, int64_t n, int n_nb, float *S_out);
 

@@ -116,6 +116,8 @@ _SIGS = {
     "kmap_hamdist_matrix_u8": (i32, [vp, vp, i64, i32, vp, i32, vp]),
     "kmap_knn_sums_u8_dev": (i32, [vp, i64, vp, i64, i32, i64, i64, vp, i64, vp]),
     "kmap_knn_select_u8_dev": (i32, [vp, i64, i64, i32, i64, i64, vp, vp]),
+    "kmap_rows_fresh_u8_dev": (i32, [vp, i64, i64, i64, i64, vp, vp]),
+    "kmap_gather_rows_u8_dev": (i32, [vp, i64, i64, vp, i64, vp, i64, vp]),
     "kmap_knn_smooth_f32": (i32, [vp, vp, i64, i32, vp]),
     "kmap_ld_prob_mat_f32": (i32, [vp, i64, vp]),
     "kmap_cross_entropy_f32": (i32, [vp, vp, i64, vp]),

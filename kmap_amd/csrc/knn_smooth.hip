@@ -587,6 +587,43 @@ __global__ __launch_bounds__(BLK) void knn_smooth_f32_kernel(const float *__rest
     S[j * n + i] = s;
 }
 
+// ---- repeated rows: the host-side neighbour choice (np.argpartition) partitions a repeated row once -------------------------------
+// fresh[lr] = 1 if row row0 + lr differs from the row above it somewhere in its n bytes (lr = 0: always 1); one block per row
+__global__ __launch_bounds__(256) void rows_fresh_kernel(const uint8_t *__restrict__ D, int64_t ldd, int64_t n, int64_t row0,
+                                                         uint8_t *__restrict__ fresh) {
+    const int64_t lr = blockIdx.x;
+    int diff = lr == 0;
+    if (lr > 0) {
+        const uint8_t *a = D + (row0 + lr) * ldd, *b = a - ldd;
+        int64_t done = 0;
+        if ((((uintptr_t)a | (uintptr_t)b) & 15) == 0) {
+            const int64_t nv = n / 16;
+            const u32x4 *av = reinterpret_cast<const u32x4 *>(a), *bv = reinterpret_cast<const u32x4 *>(b);
+            for (int64_t t = threadIdx.x; t < nv; t += blockDim.x) {
+                const u32x4 x = av[t] ^ bv[t];
+                diff |= (x.x | x.y | x.z | x.w) != 0u;
+            }
+            done = nv * 16;
+        }
+        for (int64_t t = done + threadIdx.x; t < n; t += blockDim.x) diff |= a[t] != b[t];
+    }
+    const int any = __syncthreads_or(diff);
+    if (threadIdx.x == 0) fresh[lr] = any ? 1 : 0;
+}
+// out row o = row idx[o] of D (n bytes each); one block per output row
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t *__restrict__ D, int64_t ldd, int64_t n, const int32_t *__restrict__ idx,
+                                                          uint8_t *__restrict__ out, int64_t ldo) {
+    const int64_t o = blockIdx.x;
+    const uint8_t *a = D + (int64_t)idx[o] * ldd;
+    uint8_t *b = out + o * ldo;
+    int64_t done = 0;
+    if ((((uintptr_t)a | (uintptr_t)b) & 15) == 0) {
+        const int64_t nv = n / 16;
+        for (int64_t t = threadIdx.x; t < nv; t += blockDim.x) reinterpret_cast<u32x4 *>(b)[t] = reinterpret_cast<const u32x4 *>(a)[t];
+        done = nv * 16;
+    }
+    for (int64_t t = done + threadIdx.x; t < n; t += blockDim.x) b[t] = a[t];
+}
 }  // namespace
 
 extern "C" {
@@ -661,6 +698,26 @@ int kmap_knn_select_u8_dev(const uint8_t *D_dev, int64_t ldd, int64_t n, int n_n
     }
     knn_select_kernel<<<(unsigned)((nrows + SEL_WAVES - 1) / SEL_WAVES), KMAP_WAVE * SEL_WAVES, 0, as_stream(stream)>>>(
         D_dev, ldd, n, n_nb, row0, nrows, nb_out_dev, aligned);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+
+int kmap_rows_fresh_u8_dev(const uint8_t *D_dev, int64_t ldd, int64_t n, int64_t row0, int64_t nrows, uint8_t *fresh_dev, void *stream) {
+    KMAP_REQUIRE(n >= 0 && nrows >= 0 && row0 >= 0 && ldd >= n, "rows_fresh: bad sizes");
+    if (nrows == 0) return KMAP_OK;
+    KMAP_REQUIRE(D_dev && fresh_dev, "rows_fresh: null pointer");
+    KMAP_REQUIRE(nrows < ((int64_t)1 << 31), "rows_fresh: too many rows for one launch");
+    rows_fresh_kernel<<<(unsigned)nrows, 256, 0, as_stream(stream)>>>(D_dev, ldd, n, row0, fresh_dev);
+    KMAP_CHECK_HIP(hipGetLastError());
+    return KMAP_OK;
+}
+int kmap_gather_rows_u8_dev(const uint8_t *D_dev, int64_t ldd, int64_t n, const int32_t *idx_dev, int64_t n_idx, uint8_t *out_dev,
+                            int64_t ldo, void *stream) {
+    KMAP_REQUIRE(n >= 0 && n_idx >= 0 && ldd >= n && ldo >= n, "gather_rows: bad sizes");
+    if (n_idx == 0) return KMAP_OK;
+    KMAP_REQUIRE(D_dev && idx_dev && out_dev, "gather_rows: null pointer");
+    KMAP_REQUIRE(n_idx < ((int64_t)1 << 31), "gather_rows: too many rows for one launch");
+    gather_rows_kernel<<<(unsigned)n_idx, 256, 0, as_stream(stream)>>>(D_dev, ldd, n, idx_dev, out_dev, ldo);
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;
 }

@@ -66,33 +66,61 @@ def knn_mode(n):
 def knn_select_numpy(D_dev_ptr, ldd, n, n_nb, nrows=None):
     """The reference's neighbour choice (visualization.py:100: np.argpartition on int64 rows) for rows [0, nrows) of a uint8
     device matrix, streamed back in row blocks: the copy of block b + 1 runs while worker threads partition block b (introselect
-    runs outside the GIL; rows are independent, so the result equals one call on the whole matrix)."""
+    runs outside the GIL; rows are independent, so the result equals one call on the whole matrix).
+    The matrix repeats every sampled k-mer count times (motif_discovery.py:759-772), the row of a repeated k-mer is the row above
+    it byte for byte (C3: 17 554 distinct rows among 50 000), and np.argpartition of equal arrays is the same array: the device
+    flags the rows that differ from the row above (a comparison of the bytes, nothing is assumed about the sample), compacts
+    them, and only they are copied and partitioned; a repeated row takes its predecessor's result."""
     from concurrent.futures import ThreadPoolExecutor
     import os
     nrows = n if nrows is None else nrows
     if nrows == 0:
         return np.zeros((0, n_nb), np.int64)
-    blk = max(1, min(nrows, (32 << 20) // max(n, 1)))
+    lib = _ffi.lib()
+    fresh_d = _ffi.DeviceBuffer(nrows)
+    try:
+        check(lib.kmap_rows_fresh_u8_dev(D_dev_ptr, ldd, n, 0, nrows, fresh_d.ptr, None))
+        fresh = fresh_d.to_numpy(np.uint8, (nrows,)).astype(bool)
+    finally:
+        fresh_d.free()
+    idx = np.flatnonzero(fresh).astype(np.int32)
+    n_part = len(idx)
+    src, pitch, comp_d = D_dev_ptr, ldd, None
+    if n_part < nrows:                             # repeated rows: partition the compacted distinct ones
+        pitch = (n + 15) & ~15
+        idx_d = _ffi.DeviceBuffer.from_numpy(idx)
+        comp_d = _ffi.DeviceBuffer(n_part * pitch)
+        try:
+            check(lib.kmap_gather_rows_u8_dev(D_dev_ptr, ldd, n, idx_d.ptr, n_part, comp_d.ptr, pitch, None))
+            _ffi.sync()
+        finally:
+            idx_d.free()
+        src = comp_d.ptr
+    blk = max(1, min(n_part, (32 << 20) // max(n, 1)))
     sub = max(1, (2 << 20) // max(n, 1))          # rows per argpartition call: their int64 copy (16 MB) stays in the last-level cache
-    out = np.empty((nrows, n_nb), np.int64)
+    res = np.empty((n_part, n_nb), np.int64)
 
     def part(r0, rows):
         for a in range(0, len(rows), sub):
             piece = rows[a:a + sub]
-            out[r0 + a:r0 + a + len(piece)] = np.argpartition(piece.astype(np.int64), n_nb, axis=1)[:, :n_nb]
+            res[r0 + a:r0 + a + len(piece)] = np.argpartition(piece.astype(np.int64), n_nb, axis=1)[:, :n_nb]
 
-    with ThreadPoolExecutor(max(1, min(16, (os.cpu_count() or 2) - 1))) as pool:
-        jobs = []
-        for r0 in range(0, nrows, blk):
-            r1 = min(nrows, r0 + blk)
-            rows = np.empty((r1 - r0, n), np.uint8)
-            check(_ffi.lib().kmap_memcpy2d_d2h(ptr(rows), n, D_dev_ptr + r0 * ldd, ldd, n, r1 - r0, None))
-            jobs.append(pool.submit(part, r0, rows))
-            while len(jobs) > 24:                 # bound the blocks in flight (32 MB each + their int64 copies)
-                jobs.pop(0).result()
-        for j in jobs:
-            j.result()
-    return out
+    try:
+        with ThreadPoolExecutor(max(1, min(16, (os.cpu_count() or 2) - 1))) as pool:
+            jobs = []
+            for r0 in range(0, n_part, blk):
+                r1 = min(n_part, r0 + blk)
+                rows = np.empty((r1 - r0, n), np.uint8)
+                check(lib.kmap_memcpy2d_d2h(ptr(rows), n, src + r0 * pitch, pitch, n, r1 - r0, None))
+                jobs.append(pool.submit(part, r0, rows))
+                while len(jobs) > 24:                 # bound the blocks in flight (32 MB each + their int64 copies)
+                    jobs.pop(0).result()
+            for j in jobs:
+                j.result()
+    finally:
+        if comp_d is not None:
+            comp_d.free()
+    return res if n_part == nrows else res[np.cumsum(fresh) - 1]
 
 
 def knn_select_dev(D_dev_ptr, ldd, n, n_nb, row0=0, nrows=None, stream=None):

@@ -166,3 +166,40 @@ def test_knn_numpy_mode_above_the_dense_limit(monkeypatch):
     tr2 = {}
     V.kmap_from_kmers(kh, np.ones(n, np.int64), lab, conseqs, k, n_max_iter=2, random_seed=5, mode=V.EMBED_FAST, trace=tr2)
     np.testing.assert_array_equal(tr2["nb"], nb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,reps", [(1000, "counts"), (1003, "counts"), (777, "none"), (64, "all")])
+def test_knn_numpy_repeated_rows(n, reps):
+    """a sample repeats its k-mers count times (reference motif_discovery.py:759-772) and the row of a repeated k-mer equals the row
+    above it: knn_select_numpy partitions the distinct rows only (kmap_rows_fresh_u8_dev / kmap_gather_rows_u8_dev) and must return
+    exactly np.argpartition of every row -- with runs of repeats, without any, with one row repeated throughout, n % 16 != 0."""
+    from kmap_amd import _ffi, visualization as V
+    rng = np.random.default_rng(n)
+    if reps == "counts":
+        base = rng.integers(0, 9, size=(n // 3, n), dtype=np.uint8)
+        cnt = rng.integers(1, 6, size=len(base))
+        rows = np.repeat(base, cnt, axis=0)[:n]
+        rows = np.concatenate([rows, rng.integers(0, 9, size=(n - len(rows), n), dtype=np.uint8)])
+        rows[n // 2] = rows[n // 2 - 1]
+        rows[n // 2, n - 1] ^= 1                                   # differs from the row above in its last byte only
+    elif reps == "none":
+        rows = rng.integers(0, 9, size=(n, n), dtype=np.uint8)
+    else:
+        rows = np.repeat(rng.integers(0, 9, size=(1, n), dtype=np.uint8), n, axis=0)
+    ldd = (n + 127) & ~127
+    D = np.zeros((n, ldd), np.uint8)
+    D[:, :n] = rows
+    D_d = _ffi.DeviceBuffer.from_numpy(D)
+    fresh_d = _ffi.DeviceBuffer(n)
+    try:
+        _ffi.check(_ffi.lib().kmap_rows_fresh_u8_dev(D_d.ptr, ldd, n, 0, n, fresh_d.ptr, None))
+        fresh = fresh_d.to_numpy(np.uint8, (n,))
+        want_fresh = np.concatenate([[1], (rows[1:] != rows[:-1]).any(axis=1)]).astype(np.uint8)
+        np.testing.assert_array_equal(fresh, want_fresh)
+        for nrows in (n, n // 2 + 1):
+            nb = V.knn_select_numpy(D_d.ptr, ldd, n, 20, nrows)
+            np.testing.assert_array_equal(nb, np.argpartition(rows[:nrows].astype(np.int64), 20, axis=1)[:, :20])
+    finally:
+        D_d.free()
+        fresh_d.free()
