@@ -230,7 +230,15 @@ def stage_rooflines(reads, kh, lab, conseq_lens):
     ld0, ph = V._init_draws(n, 10, 7)
     for tag, mode, iters in (("embed_iter_fast", V.EMBED_FAST, 40), ("embed_iter_seq", V.EMBED_SEQ, 10)):
         sess = V.EmbedSession(n, 10, 0.01, mode)
-        _ffi.check(lib.kmap_embed_set_prob_lut(sess._h, sums_d.ptr, lds, _ffi.ptr(lut), len(lut)))    # sums stay ours (not in _keep)
+        own = []
+        if mode == V.EMBED_SEQ:    # as the product does: the repeated rows of the sample stored once, read through a row map
+            comp_d, rowmap_d, stored = V.dedupe_sums_rows(sums_d, n, lds, free_input=False)
+            _ffi.check(lib.kmap_embed_set_prob_lut(sess._h, comp_d.ptr, lds, _ffi.ptr(lut), len(lut)))
+            if rowmap_d is not None:
+                _ffi.check(lib.kmap_embed_set_row_map(sess._h, rowmap_d.ptr, stored))
+                own = [comp_d, rowmap_d]
+        else:
+            _ffi.check(lib.kmap_embed_set_prob_lut(sess._h, sums_d.ptr, lds, _ffi.ptr(lut), len(lut)))    # sums stay ours (not in _keep)
         sess.set_coords(ld0, ph)
         sess.set_jitter(np.random.normal(0, 0.01, 4096))
         ms = [t / 5 for t in timed_launches(lambda: sess.step(5), iters // 5)]
@@ -238,6 +246,8 @@ def stage_rooflines(reads, kh, lab, conseq_lens):
                         ("FAST: symmetric kernel, each unordered pair once -> N^2 bytes of sums actually read" if mode == V.EMBED_FAST
                          else "SEQ: the reference's summation order, bit-pinned path") + ")")
         sess.close()
+        for b in own:
+            b.free()
     for b in (sums_d, nb_d, kh_d, lab_d):
         b.free()
     add_moved_bytes(out)
@@ -585,11 +595,16 @@ def shard_proxy(G, reads, res_dir, c3s, overhead_ms):
             sums_d = _ffi.DeviceBuffer(nrows * lds * 2)
             sums_ms.append(med(lambda: V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, K, lens, nb_all, 20, row0=row0, nrows=nrows, out=sums_d.ptr), reps))
             sess = V.EmbedSession(n, 1, 0.01, V.EMBED_SEQ, row0=row0, nrows=nrows)
+            sums_d, rowmap_d, stored = V.dedupe_sums_rows(sums_d, nrows, lds)       # as the product does (repeated rows stored once)
             _ffi.check(lib.kmap_embed_set_prob_lut(sess._h, sums_d.ptr, lds, _ffi.ptr(lut), len(lut)))
+            if rowmap_d is not None:
+                _ffi.check(lib.kmap_embed_set_row_map(sess._h, rowmap_d.ptr, stored))
             sess.set_coords(ld0, None)
             seq_ms.append(med(lambda: sess.forces(), reps))
             sess.close()
             sums_d.free()
+            if rowmap_d is not None:
+                rowmap_d.free()
         # pass 3: FAST forces, cyclic 256-row blocks of the symmetric kernel (rank r owns blocks r, r + G, ...)
         fast_ms = []
         for world, ranks in ((1, [0]), (G, list(range(G)))):

@@ -367,6 +367,11 @@ int kmap_embed_destroy(kmap_embed *e);
 int kmap_embed_set_prob_f32(kmap_embed *e, const float *p_rows_dev, int64_t ld);       /* device rows */
 int kmap_embed_set_prob_lut(kmap_embed *e, const uint16_t *sums_rows_dev, int64_t ld, const float *lut,
                             int lut_len);                                               /* lut: host */
+/* SEQ sessions, after kmap_embed_set_prob_lut: the sums of session row r are row rowmap_dev[r] (int32, device, kept by the caller
+ * like the sums) of a matrix of src_rows rows -- for samples that repeat their k-mers in runs (motif_discovery.py:759-772), whose
+ * repeated rows are stored once.  The map starts at 0, ends at src_rows - 1 and steps by 0 or 1 (checked).  NULL: one stored row per
+ * session row again.  Results are those of the expanded matrix, bit for bit (same values through another address). */
+int kmap_embed_set_row_map(kmap_embed *e, const int32_t *rowmap_dev, int64_t src_rows);
 /* init: 2 x N coordinates, n_best placeholder snapshots (n_best x 2 x N), host arrays */
 int kmap_embed_set_coords(kmap_embed *e, const float *coords_2xn, const float *placeholders);
 /* jitter normals N(0, 0.01) pre-drawn (float64, as numpy draws them) from the host RNG stream,

@@ -128,6 +128,7 @@ _SIGS = {
     "kmap_embed_destroy": (i32, [vp]),
     "kmap_embed_set_prob_f32": (i32, [vp, vp, i64]),
     "kmap_embed_set_prob_lut": (i32, [vp, vp, i64, vp, i32]),
+    "kmap_embed_set_row_map": (i32, [vp, vp, i64]),
     "kmap_embed_set_coords": (i32, [vp, vp, vp]),
     "kmap_embed_set_jitter": (i32, [vp, vp, i32]),
     "kmap_embed_forces": (i32, [vp, vp, vp, vp]),

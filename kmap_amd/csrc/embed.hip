@@ -509,7 +509,7 @@ int kmap_embed_set_prob_f32(kmap_embed *e, const float *p_rows_dev, int64_t ld) 
         }
         e->n_part = n_part;
     }
-    e->src = ProbSrc{p_rows_dev, nullptr, nullptr, ld, 0};
+    e->src = ProbSrc{p_rows_dev, nullptr, nullptr, ld, 0, nullptr, e->nrows};
     e->have_prob = true;
     drop_graph(e);
     return KMAP_OK;
@@ -519,8 +519,29 @@ int kmap_embed_set_prob_lut(kmap_embed *e, const uint16_t *sums_rows_dev, int64_
     KMAP_REQUIRE(e && sums_rows_dev && lut && ld >= e->n, "embed_set_prob_lut: bad arguments");
     KMAP_REQUIRE(lut_len > 0 && lut_len <= F_LUT_LDS, "embed_set_prob_lut: lut_len=%d exceeds %d", lut_len, F_LUT_LDS);
     KMAP_CHECK_HIP(hipMemcpy(e->lut_dev, lut, (size_t)lut_len * 4, hipMemcpyHostToDevice));
-    e->src = ProbSrc{nullptr, sums_rows_dev, e->lut_dev, ld, lut_len};
+    e->src = ProbSrc{nullptr, sums_rows_dev, e->lut_dev, ld, lut_len, nullptr, e->nrows};
     e->have_prob = true;
+    drop_graph(e);
+    return KMAP_OK;
+}
+
+int kmap_embed_set_row_map(kmap_embed *e, const int32_t *rowmap_dev, int64_t src_rows) {
+    KMAP_REQUIRE(e && e->have_prob && e->src.ps, "embed_set_row_map: set the neighbour-sum + LUT source first");
+    if (!rowmap_dev) {
+        e->src.rowmap = nullptr;
+        e->src.src_rows = e->nrows;
+        drop_graph(e);
+        return KMAP_OK;
+    }
+    KMAP_REQUIRE(e->mode == KMAP_EMBED_SEQ && !e->sym, "embed_set_row_map: SEQ sessions only (the FAST kernels read one stored row per session row)");
+    KMAP_REQUIRE(src_rows >= 1 && src_rows <= e->nrows, "embed_set_row_map: src_rows must be in [1, rows of the session]");
+    std::vector<int32_t> m((size_t)e->nrows);
+    KMAP_CHECK_HIP(hipMemcpy(m.data(), rowmap_dev, (size_t)e->nrows * 4, hipMemcpyDeviceToHost));
+    bool ok = e->nrows > 0 && m[0] == 0 && (int64_t)m[(size_t)e->nrows - 1] == src_rows - 1;
+    for (int64_t r = 1; ok && r < e->nrows; ++r) ok = m[(size_t)r] == m[(size_t)r - 1] || m[(size_t)r] == m[(size_t)r - 1] + 1;
+    KMAP_REQUIRE(ok, "embed_set_row_map: the map must start at 0, end at src_rows - 1 and step by 0 or 1");
+    e->src.rowmap = rowmap_dev;
+    e->src.src_rows = src_rows;
     drop_graph(e);
     return KMAP_OK;
 }

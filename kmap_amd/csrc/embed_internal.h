@@ -20,7 +20,14 @@ struct ProbSrc {
     const float *lut;       // device LUT
     int64_t ld;
     int lut_len;
+    // SEQ sessions: the sums of local row r are row rowmap[r] of ps (null: row r).  The map never steps back and never skips
+    // (rowmap[0] = 0, rowmap[r + 1] - rowmap[r] is 0 or 1): a sample repeats its k-mers in runs, and the rows of a run share ONE
+    // stored row -- fewer distinct cache lines under a wave's loads (r05: the force evaluation of C3 1.56 -> 1.3x ms).
+    const int32_t *rowmap;
+    int64_t src_rows;       // rows of ps (= the session's rows without a map)
 };
+// stored row of local row r
+__device__ __forceinline__ int64_t prob_src_row(const ProbSrc &src, int64_t r) { return src.rowmap ? (int64_t)src.rowmap[r] : r; }
 
 constexpr int F_RPW = 2;          // FAST row-wise kernel: rows per wave
 constexpr int F_WAVES = 8;        //   waves per block

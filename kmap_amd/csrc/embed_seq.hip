@@ -349,6 +349,7 @@ __device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *_
     const int64_t lr = lrow0 + (bid * SQ_WAVES + wave) * SQ_ROWS + (lane / SQ_SUB);
     const bool valid = lr < nrows;
     const int64_t lrc = valid ? lr : nrows - 1;
+    const int64_t srow = prob_src_row(src, lrc);             // the stored row of its sums (ProbSrc::rowmap)
     const int64_t i = row0 + lrc;
     const float *X = Y, *Yy = Y + n;
     const float xi = X[i], yi = Yy[i];
@@ -362,10 +363,10 @@ __device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *_
     constexpr bool VEC = decltype(vec_tag)::value;
     // two batch buffers in alternating roles (no register copies between batches): while `cur` is evaluated, `nxt` is in flight
     SeqBatch bufA, bufB;
-    seq_load<LUTSRC, VEC>(bufA, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n);
+    seq_load<LUTSRC, VEC>(bufA, src, X, Yy, srow, (int64_t)sub * SQ_CPL, n);
     auto step = [&](const SeqBatch &cur, SeqBatch &nxt, int64_t j0) {
         const int64_t jl = j0 + (int64_t)sub * SQ_CPL;                       // this lane's first column of the batch
-        seq_load<LUTSRC, VEC>(nxt, src, X, Yy, lrc, (j0 + SQ_BATCH < n) ? jl + SQ_BATCH : jl, n);   // prefetch, always (see seq_load)
+        seq_load<LUTSRC, VEC>(nxt, src, X, Yy, srow, (j0 + SQ_BATCH < n) ? jl + SQ_BATCH : jl, n);   // prefetch, always (see seq_load)
         float tx[SQ_CPL], ty[SQ_CPL];
         float ce2;                                                           // loss terms in log2 units (order-free)
         seq_terms_dispatch<LUTSRC>(cur, lut_s, xi, yi, i32, n, j0, SQ_BATCH, wave_row_min, SQ_ROWS, (int)jl, far, tx, ty, ce2);
@@ -405,10 +406,11 @@ __device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *_
         // stream and step instead of a 64-bit pointer per load).  The batch that reaches past column n - 1 reads what lies there -- the
         // rest of the sums row's pitch or the next row, Yy behind X, the session's 64 floats of padding behind Yy -- or, past the end of
         // the descriptor, zeros: those columns are masked out of the terms by selects, never multiplied away.
-        const uint32_t row_off = (uint32_t)((lrc - base_lr) * src.ld * 2);         // < 64 rows x pitch x 2 bytes
+        const int64_t base_s = seq_uniform(prob_src_row(src, base_lr));            // stored rows never step back: srow >= base_s
+        const uint32_t row_off = (uint32_t)((srow - base_s) * src.ld * 2);         // < 64 rows x pitch x 2 bytes
         const uint32_t so = row_off + (uint32_t)sub * SQ_CPL * 2u, co = (uint32_t)sub * SQ_CPL * 4u;
-        const uint64_t sums_bytes = (uint64_t)(nrows - base_lr) * (uint64_t)src.ld * 2u;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(src.ps + base_lr * src.ld), 0,
+        const uint64_t sums_bytes = (uint64_t)(src.src_rows - base_s) * (uint64_t)src.ld * 2u;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(src.ps + base_s * src.ld), 0,
                                                                           sums_bytes < 0xffffffffull ? (int)(uint32_t)sums_bytes : -1, 0x00020000);
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, (int)((2 * n32 + 64) * 4), 0x00020000);
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Yy), 0, (int)((n32 + 64) * 4), 0x00020000);
@@ -609,6 +611,7 @@ __device__ __forceinline__ void seq_row16_body(const ProbSrc &src, const float *
     const int64_t lr = wave_lr + (lane / SR_SUB);
     const bool valid = lr < nrows;
     const int64_t lrc = valid ? lr : nrows - 1;
+    const int64_t srow = prob_src_row(src, lrc);             // the stored row of its sums (ProbSrc::rowmap)
     const int64_t i = row0 + lrc;
     const float *X = Y, *Yy = Y + n;
     const float xi = X[i], yi = Yy[i];
@@ -623,10 +626,10 @@ __device__ __forceinline__ void seq_row16_body(const ProbSrc &src, const float *
     // (computing the terms of batch b + 1 in the same loop body as the adds of batch b -- a software pipeline for the scheduler to
     // interleave -- measured slower: 0.066 vs 0.058 ms at N = 4000)
     SeqBatch bufA, bufB;
-    seq_load<LUTSRC, VEC>(bufA, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n);
+    seq_load<LUTSRC, VEC>(bufA, src, X, Yy, srow, (int64_t)sub * SQ_CPL, n);
     auto step = [&](const SeqBatch &cur, SeqBatch &nxt, int64_t j0) {
         const int64_t jl = j0 + (int64_t)sub * SQ_CPL;
-        seq_load<LUTSRC, VEC>(nxt, src, X, Yy, lrc, (j0 + SR_BATCH < n) ? jl + SR_BATCH : jl, n);   // prefetch, always (see seq_load)
+        seq_load<LUTSRC, VEC>(nxt, src, X, Yy, srow, (j0 + SR_BATCH < n) ? jl + SR_BATCH : jl, n);   // prefetch, always (see seq_load)
         float tx[SQ_CPL], ty[SQ_CPL];
         float ce2;
         seq_terms_dispatch<LUTSRC>(cur, lut_s, xi, yi, i32, n, j0, SR_BATCH, wave_row_min, SR_ROWS, (int)jl, far, tx, ty, ce2);
@@ -686,6 +689,7 @@ __device__ __forceinline__ void seq_wide_body(const ProbSrc &src, const float *_
     const int64_t lr = wave_lr + grp;
     const bool valid = lr < nrows;
     const int64_t lrc = valid ? lr : nrows - 1;
+    const int64_t srow = prob_src_row(src, lrc);             // the stored row of its sums (ProbSrc::rowmap)
     const int64_t i = row0 + lrc;
     const float *X = Y, *Yy = Y + n;
     const float xi = X[i], yi = Yy[i];
@@ -699,13 +703,13 @@ __device__ __forceinline__ void seq_wide_body(const ProbSrc &src, const float *_
     auto run = [&](auto vec_tag) {
     constexpr bool VEC = decltype(vec_tag)::value;
     SeqBatch bufA, bufB;
-    seq_load<LUTSRC, VEC>(bufA, src, X, Yy, lrc, (int64_t)sub * SQ_CPL, n);
+    seq_load<LUTSRC, VEC>(bufA, src, X, Yy, srow, (int64_t)sub * SQ_CPL, n);
     f32x2 *mine = xch + (size_t)lane * SQ_CPL;                         // = strip of row grp, columns sub * 8 .. + 7
     const f32x4 *strip = reinterpret_cast<const f32x4 *>(xch + (size_t)grp * BC);
     int batch = 0;
     auto step = [&](const SeqBatch &cur, SeqBatch &nxt, int64_t j0) {
         const int64_t jl = j0 + (int64_t)sub * SQ_CPL;
-        seq_load<LUTSRC, VEC>(nxt, src, X, Yy, lrc, (j0 + BC < n) ? jl + BC : jl, n);      // prefetch, always (see seq_load)
+        seq_load<LUTSRC, VEC>(nxt, src, X, Yy, srow, (j0 + BC < n) ? jl + BC : jl, n);      // prefetch, always (see seq_load)
         float tx[SQ_CPL], ty[SQ_CPL];
         float ce2;
         seq_terms_dispatch<LUTSRC>(cur, lut_s, xi, yi, i32, n, j0, BC, wave_row_min, RW, (int)jl, far, tx, ty, ce2);
@@ -790,7 +794,7 @@ struct SaGeom {
     static constexpr int QP = 4 * RP + 1;                // cells (16 B) per column group: its four column pairs x RP rows + one of padding
     static constexpr size_t BUF_BYTES = (size_t)(CH / 8) * QP * 16;
     static constexpr size_t XY_FLOATS = 2 * (size_t)CH;  // one chunk's x | y
-    static constexpr size_t FIXED_BYTES = 2 * BUF_BYTES + 2 * XY_FLOATS * 4 + (size_t)RP * 8 + 16 * 8;   // term buffers, coordinate buffers, row coordinates, loss partials
+    static constexpr size_t FIXED_BYTES = 2 * BUF_BYTES + 2 * XY_FLOATS * 4 + (size_t)RP * 8 + 16 * 8 + (size_t)RP * 4;   // term buffers, coordinate buffers, row coordinates, loss partials, sums-row offsets
     static_assert(LPR * RPS == KMAP_WAVE && (RP == 32 || RP == 64) && CH % 8 == 0 && CH <= 256, "geometry");
 };
 template <int RP, int CH>
@@ -808,6 +812,7 @@ __global__ __launch_bounds__(KMAP_WAVE *SA_MAX_WAVES) void forces_seqa_kernel(Pr
     float *xy1 = xy0 + GEO::XY_FLOATS;
     f32x2 *rowxy = reinterpret_cast<f32x2 *>(xy1 + GEO::XY_FLOATS);          // (x, y) of the block's rows
     double *wl = reinterpret_cast<double *>(rowxy + RP);
+    uint32_t *rowoff = reinterpret_cast<uint32_t *>(wl + 16);                // byte offset of block row r's sums row from the block's first (ProbSrc::rowmap)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // roles (see above): M producers on each of the three other SIMD classes, EA on the adder's
     const int M = R >> 8 & 15, EA = R >> 12 & 3, SA_NP = 3 * M + EA;
@@ -825,9 +830,11 @@ __global__ __launch_bounds__(KMAP_WAVE *SA_MAX_WAVES) void forces_seqa_kernel(Pr
         (t < CH ? xy0 : xy1 - CH)[t] = X[j];
         (t < CH ? xy0 : xy1 - CH)[CH + t] = Yy[j];
     }
+    const int64_t srow0 = prob_src_row(src, lr0);                           // block-uniform
     if (threadIdx.x < RP) {
-        const int64_t i = row0 + lr0 + (threadIdx.x < Rb ? threadIdx.x : Rb - 1);
-        rowxy[threadIdx.x] = f32x2{X[i], Yy[i]};
+        const int64_t lr = lr0 + (threadIdx.x < Rb ? threadIdx.x : Rb - 1);
+        rowxy[threadIdx.x] = f32x2{X[row0 + lr], Yy[row0 + lr]};
+        rowoff[threadIdx.x] = (uint32_t)((prob_src_row(src, lr) - srow0) * src.ld * 2);
     }
     __syncthreads();
     if (cls == 3 ? (idx > EA) : (idx >= M)) return;                    // a placeholder wave: it helped with the staging and leaves (an ended wave no longer counts at barriers)
@@ -904,8 +911,6 @@ __global__ __launch_bounds__(KMAP_WAVE *SA_MAX_WAVES) void forces_seqa_kernel(Pr
         const int sub = lane & (LPR - 1), rin = lane / LPR;
         const int rows_last = Rb - (S - 1) * RPS;                          // rows of the block's last step (1 .. RPS)
         const int rin_last = rin < rows_last ? rin : rows_last - 1;
-        const uint32_t ld2 = (uint32_t)src.ld * 2u;                        // bytes per sums row
-        const uint32_t off_row = (uint32_t)rin * ld2, off_row_last = (uint32_t)rin_last * ld2;
         const int64_t jl_last = (int64_t)(nch32 - 1) * CH + sub * SQ_CPL;
         const uint32_t off_col = (uint32_t)sub * SQ_CPL * 2u,
                        off_col_last = (uint32_t)((jl_last < n ? jl_last : ((n - 1) & ~(int64_t)7)) - (int64_t)(nch32 - 1) * CH) * 2u;
@@ -919,12 +924,12 @@ __global__ __launch_bounds__(KMAP_WAVE *SA_MAX_WAVES) void forces_seqa_kernel(Pr
             }
         };
         norm(pu, pw);
-        const char *sums_base = reinterpret_cast<const char *>(src.ps + lr0 * src.ld);
+        const char *sums_base = reinterpret_cast<const char *>(src.ps + srow0 * src.ld);
         auto issue = [&](u32x4 &q) {                                   // always a load: behind the last step the last step's again
             const int u = pu < nch32 ? pu : nch32 - 1;
-            const char *row = sums_base + ((int64_t)pw * RPS * src.ld + (int64_t)u * CH) * 2;          // scalar
-            const uint32_t off = (pw == S - 1 ? off_row_last : off_row) + (u == nch32 - 1 ? off_col_last : off_col);
-            q = *reinterpret_cast<const u32x4 *>(row + off);
+            const char *col = sums_base + (int64_t)u * CH * 2;                                        // scalar
+            const uint32_t off = rowoff[pw * RPS + (pw == S - 1 ? rin_last : rin)] + (u == nch32 - 1 ? off_col_last : off_col);
+            q = *reinterpret_cast<const u32x4 *>(col + off);
             pw += NP;
             norm(pu, pw);
         };

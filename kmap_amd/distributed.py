@@ -456,8 +456,11 @@ def kmap_from_kmers_distributed(samp_kh, samp_cnts, samp_label, conseq_list, kme
         sess = vz.EmbedSession(n, n_best_result, learning_rate, vz.EMBED_FAST, cyclic=(world, rank))
     else:
         sess = vz.EmbedSession(n, n_best_result, learning_rate, mode, row0=row0, nrows=nrows)
+    rowmap_d, stored = None, nrows
+    if not cyclic and mode == vz.EMBED_SEQ and nrows:
+        sums_d, rowmap_d, stored = vz.dedupe_sums_rows(sums_d, nrows, lds)     # the repeated rows of this rank's block, stored once
     try:
-        sess.set_prob_lut(sums_d, lds, lut)
+        sess.set_prob_lut(sums_d, lds, lut, rowmap_d, stored)
         sess.set_coords(ld_data, placeholders)
         msg_t = torch.zeros(2 * n + MSG_EXTRA, dtype=torch.float32, device="cuda")
         exchange = os.environ.get("KMAP_DIST_EXCHANGE", "rccl").lower() if exchange is None else exchange

@@ -552,3 +552,84 @@ def test_seq_adder_form_fuzz():
     sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
     import seqa_check
     assert seqa_check.fuzz(60, seed=7) == 0
+
+
+@pytest.mark.parametrize("n,row0,nrows", [(16384 + 1029, 0, None), (5003, 0, None), (1000, 100, 650), (4136, 7, 31), (9001, 8000, 1001),
+                                          (33000, 0, None)])
+def test_seq_row_map_is_bit_identical(V, n, row0, nrows, tmp_path):
+    """SEQ sessions read the sums of repeated rows through a row map (kmap_embed_set_row_map; dedupe_sums_rows stores a run of equal
+    rows once): the gradient and the loss must be those of the expanded matrix bit for bit, in the classic forms (pair / quad / wide,
+    scalar and generic loads: n % 4 != 0 takes the generic ones) and in the producer / adder form; runs of 1 .. 40 rows, a run across
+    every wave / block border, a session whose rows are all one run at the end."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    nrows = n - row0 if nrows is None else nrows
+    rng = np.random.default_rng(n + row0 + 1)
+    lds = (n + 127) & ~127
+    runs = rng.choice([1, 1, 1, 2, 3, 5, 17, 40], size=nrows)
+    runs = runs[:np.searchsorted(np.cumsum(runs), nrows) + 1]
+    stored = len(runs)
+    rowmap = np.repeat(np.arange(stored), runs)[:nrows].astype(np.int32)
+    rowmap[-min(nrows, 70):] = rowmap[-min(nrows, 70)]          # the last rows: one run
+    rowmap = (np.cumsum(np.concatenate([[0], np.diff(rowmap) != 0])) ).astype(np.int32)
+    stored = int(rowmap[-1]) + 1
+    comp = rng.integers(0, 3201, size=(stored, lds), dtype=np.uint16)
+    lut = V.hd_prob_lut(8, 20, 3200)
+    ld = (rng.standard_normal((2, n)) * rng.choice([5.0, 60.0])).astype(np.float32)
+    np.savez(tmp_path / "in.npz", comp=comp, rowmap=rowmap, ld=ld, lut=lut, meta=np.array([n, row0, nrows, lds, stored]))
+    code = ("import numpy as np, sys; sys.path.insert(0, sys.argv[1]); from kmap_amd import _ffi, visualization as V; d = np.load(sys.argv[2]);"
+            "n, row0, nrows, lds, stored = [int(v) for v in d['meta']]; use_map = sys.argv[4] == 'map';"
+            "sd = _ffi.DeviceBuffer.from_numpy(d['comp'] if use_map else d['comp'][d['rowmap']]);"
+            "md = _ffi.DeviceBuffer.from_numpy(d['rowmap']) if use_map else None;"
+            "s = V.EmbedSession(n, 10, 0.01, V.EMBED_SEQ, row0=row0, nrows=nrows);"
+            "s.set_prob_lut(sd, lds, d['lut'], md, stored); s.set_coords(d['ld']);"
+            "g = _ffi.DeviceBuffer(2 * n * 4); l = _ffi.DeviceBuffer(8); g.zero(); s.forces(g.ptr, l.ptr); _ffi.sync();"
+            "np.savez(sys.argv[3], g=g.to_numpy(np.float32, (2, n)), l=l.to_numpy(np.float64, (1,)))")
+    root = str(Path(__file__).resolve().parent.parent)
+    outs = {}
+    for form in ("classic", "adder"):
+        for how in ("full", "map"):
+            r = subprocess.run([sys.executable, "-c", code, root, str(tmp_path / "in.npz"), str(tmp_path / f"{form}_{how}.npz"), how],
+                               env=dict(os.environ, KMAP_SEQ_FORM=form), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs[form, how] = np.load(tmp_path / f"{form}_{how}.npz")
+    ref = outs["classic", "full"]
+    assert ref["g"][:, row0:row0 + nrows].any()
+    for key, o in outs.items():
+        np.testing.assert_array_equal(o["g"].view(np.uint32), ref["g"].view(np.uint32), err_msg=str(key))
+        assert float(o["l"][0]) == float(outs[key[0], "full"]["l"][0]), key      # same form, same partial sums: the same loss bits
+
+
+def test_seq_row_map_is_validated(V):
+    """kmap_embed_set_row_map: SEQ sessions only; the map starts at 0, ends at src_rows - 1, steps by 0 or 1; NULL removes it"""
+    from kmap_amd import _ffi
+    n = 300
+    lds = (n + 127) & ~127
+    lut = V.hd_prob_lut(8, 20, 3200)
+    sums_d = _ffi.DeviceBuffer.from_numpy(np.zeros((n, lds), np.uint16))
+    good = np.repeat(np.arange(100), 3).astype(np.int32)
+    lib = _ffi.lib()
+    s = V.EmbedSession(n, 2, 0.01, V.EMBED_SEQ)
+    try:
+        s.set_prob_lut(sums_d, lds, lut)
+        for bad, rows in ((good[::-1].copy(), 100), (good + 1, 101), (good * 2, 199), (good, 101), (good, 0)):
+            md = _ffi.DeviceBuffer.from_numpy(np.ascontiguousarray(bad))
+            assert lib.kmap_embed_set_row_map(s._h, md.ptr, rows) != 0
+            md.free()
+        md = _ffi.DeviceBuffer.from_numpy(good)
+        _ffi.check(lib.kmap_embed_set_row_map(s._h, md.ptr, 100))
+        _ffi.check(lib.kmap_embed_set_row_map(s._h, None, 0))
+        md.free()
+    finally:
+        s.close()
+    f = V.EmbedSession(n, 2, 0.01, V.EMBED_FAST)
+    try:
+        sums2_d = _ffi.DeviceBuffer.from_numpy(np.zeros((n, lds), np.uint16))
+        f.set_prob_lut(sums2_d, lds, lut)
+        md = _ffi.DeviceBuffer.from_numpy(good)
+        assert lib.kmap_embed_set_row_map(f._h, md.ptr, 100) != 0
+        md.free()
+    finally:
+        f.close()
