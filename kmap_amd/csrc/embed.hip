@@ -443,7 +443,7 @@ static int embed_create_impl(kmap_embed **out, int64_t n, int64_t row0, int64_t 
     if (mode == KMAP_EMBED_SEQ && kmap_embed_seq_blocks_max(e) > e->n_part) e->n_part = kmap_embed_seq_blocks_max(e);
     hipError_t err = hipSuccess;
     auto A = [&](void **p, size_t b) { if (err == hipSuccess) err = hipMalloc(p, b ? b : 16); };
-    A((void **)&e->Y, ((size_t)2 * n + 64) * 4);            // + 64 floats: embed_seq.hip's 16-byte coordinate loads may run 7 floats past Yy
+    A((void **)&e->Y, ((size_t)2 * n + 64) * 4);            // + 64 floats: embed_seq.hip's coordinate loads of the batch that reaches past column n - 1 run up to 31 floats past Yy
     A((void **)&e->G, (size_t)2 * n * 4);
     A((void **)&e->snaps, (size_t)n_best * 2 * n * 4);
     A((void **)&e->loss_log, (size_t)e->loss_log_cap * 4);
