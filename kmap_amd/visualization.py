@@ -47,7 +47,7 @@ class _stage:
         STAGE_TIMES[self.name] = STAGE_TIMES.get(self.name, 0.0) + time.perf_counter() - self.t0
 
 
-KNN_NUMPY_MAX_N = 65536   # up to here the neighbours are the reference's own np.argpartition call (0.4 s of host time at N = 50 000)
+KNN_NUMPY_MAX_N = 65536   # up to here the neighbours are the reference's own np.argpartition call (0.17 s of host time at C3's N = 50 000)
 
 
 def knn_mode(n):
