@@ -79,26 +79,18 @@ __device__ __forceinline__ void seq_merge_xy(float (&u)[8], float (&w)[8], const
 __device__ __forceinline__ void add_quad_split(float &g, const float (&tx)[8], const float (&ty)[8]) {
     float u[8], w[8];
     seq_merge_xy(u, w, tx, ty);
-    asm volatile(
-        "v_add_f32_dpp %0, %1, %0 quad_perm:[0,0,1,1] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %2, %0 quad_perm:[0,0,1,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %3, %0 quad_perm:[0,0,1,1] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %4, %0 quad_perm:[0,0,1,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %5, %0 quad_perm:[0,0,1,1] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %6, %0 quad_perm:[0,0,1,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %7, %0 quad_perm:[0,0,1,1] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %8, %0 quad_perm:[0,0,1,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %9, %0 quad_perm:[1,1,0,0] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %10, %0 quad_perm:[1,1,0,0] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %11, %0 quad_perm:[1,1,0,0] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %12, %0 quad_perm:[1,1,0,0] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %13, %0 quad_perm:[1,1,0,0] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %14, %0 quad_perm:[1,1,0,0] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %15, %0 quad_perm:[1,1,0,0] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %16, %0 quad_perm:[1,1,0,0] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %1, %0 quad_perm:[2,2,3,3] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %2, %0 quad_perm:[2,2,3,3] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %3, %0 quad_perm:[2,2,3,3] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %4, %0 quad_perm:[2,2,3,3] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %5, %0 quad_perm:[2,2,3,3] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %6, %0 quad_perm:[2,2,3,3] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %7, %0 quad_perm:[2,2,3,3] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %8, %0 quad_perm:[2,2,3,3] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %9, %0 quad_perm:[3,3,2,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %10, %0 quad_perm:[3,3,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %11, %0 quad_perm:[3,3,2,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %12, %0 quad_perm:[3,3,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %13, %0 quad_perm:[3,3,2,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %14, %0 quad_perm:[3,3,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %15, %0 quad_perm:[3,3,2,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %16, %0 quad_perm:[3,3,2,2] row_mask:0xf bank_mask:0xf"
-        : "+v"(g)
-        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(u[4]), "v"(u[5]), "v"(u[6]), "v"(u[7]), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]),
-          "v"(w[5]), "v"(w[6]), "v"(w[7]));
+    // one statement per add, not volatile: the compiler may place the next batch's instructions between them (the chain waits 8.7
+    // cycles per add; r05: no-far 1.95 -> 1.89 ms with the pair form's adds written this way)
+#define KMAP_ADDQ(SRC, P) asm("v_add_f32_dpp %0, %1, %0 quad_perm:" P " row_mask:0xf bank_mask:0xf" : "+v"(g) : "v"(SRC))
+#pragma unroll
+    for (int c = 0; c < 8; ++c) KMAP_ADDQ(u[c], "[0,0,1,1]");
+#pragma unroll
+    for (int c = 0; c < 8; ++c) KMAP_ADDQ(w[c], "[1,1,0,0]");
+#pragma unroll
+    for (int c = 0; c < 8; ++c) KMAP_ADDQ(u[c], "[2,2,3,3]");
+#pragma unroll
+    for (int c = 0; c < 8; ++c) KMAP_ADDQ(w[c], "[3,3,2,2]");
+#undef KMAP_ADDQ
 }
 // a wave-uniform 64-bit value, moved to scalar registers (the compiler cannot see that `threadIdx.x >> 6` is uniform)
 __device__ __forceinline__ int64_t seq_uniform(int64_t v) {
@@ -490,8 +482,14 @@ __device__ __forceinline__ void seq_quad_body(const ProbSrc &src, const float *_
             if constexpr (SUB == 4) {
                 add_quad_split(gx, tx, ty);                                      // gx: the x sum in lanes 0 / 1 of the quad, the y sum in lanes 2 / 3
             } else {
-                add_quad_block<4>(gx, gy, tx, ty);
-                add_quad_block<5>(gx, gy, tx, ty);
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    asm("v_add_f32_dpp %0, %2, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %3, %1 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf"
+                        : "+v"(gx), "+v"(gy) : "v"(tx[c]), "v"(ty[c]));
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    asm("v_add_f32_dpp %0, %2, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %3, %1 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf"
+                        : "+v"(gx), "+v"(gy) : "v"(tx[c]), "v"(ty[c]));
             }
         };
         // raw batches (past the last one: the last one again).  At the top of a pass for batch j0: stA = stage A of batch j0; rawB =
