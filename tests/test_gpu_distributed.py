@@ -18,6 +18,8 @@ def _inputs():
     rng = np.random.default_rng(31)
     kh = rng.integers(0, 4 ** K, size=N, dtype=np.uint64)
     lab = np.sort(rng.integers(0, 3, size=N)).astype(np.int64)
+    if os.environ.get("KMAP_TEST_REPEATS"):      # counts of 1 .. 6: runs of equal rows (the row map of the SEQ sessions)
+        return kh, rng.integers(1, 7, size=N).astype(np.int64), lab, ["ACGTACGT", "ACGTAC"]
     return kh, np.ones(N, np.int64), lab, ["ACGTACGT", "ACGTAC"]
 
 
@@ -193,6 +195,31 @@ def test_two_ranks_one_gpu_equals_single(tmp_path, mode, exchange):
     # per-row sums do not depend on the sharding (a row is always summed by one lane / one wave)
     np.testing.assert_array_equal(r0["last"], tr["last_coords"])
     np.testing.assert_array_equal(r0["best"], best)
+
+
+def test_two_ranks_with_repeated_kmers_equal_single(tmp_path, monkeypatch):
+    """a sample with counts of 1 .. 6: every rank stores the runs of equal sums rows of its block once and reads them through the
+    row map (dedupe_sums_rows in kmap_from_kmers_distributed) -- the same coordinates as the single-GPU run, which does the same on
+    all rows, and the same as the single-GPU run on the expanded matrix."""
+    import torch.multiprocessing as mp
+    import kmap_amd.visualization as V
+    monkeypatch.setenv("KMAP_TEST_REPEATS", "1")
+    mp.spawn(_worker, args=(2, _free_port(), 1, str(tmp_path), "rccl"), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "m1_rank0.npz"), np.load(tmp_path / "m1_rank1.npz")
+    np.testing.assert_array_equal(r0["last"], r1["last"])
+    kh, cnts, lab, conseqs = _inputs()
+    assert int(cnts.sum()) > 2 * N
+    tr = {}
+    best, _ = V.kmap_from_kmers(kh, cnts, lab, conseqs, K, n_max_iter=ITERS, random_seed=SEED, mode=1, trace=tr)
+    np.testing.assert_array_equal(r0["last"], tr["last_coords"])
+    np.testing.assert_array_equal(r0["best"], best)
+    real = V.dedupe_sums_rows
+    monkeypatch.setattr(V, "dedupe_sums_rows", lambda sums_d, nrows, lds, **kw: (sums_d, None, nrows))     # the expanded matrix
+    tr2 = {}
+    best2, _ = V.kmap_from_kmers(kh, cnts, lab, conseqs, K, n_max_iter=ITERS, random_seed=SEED, mode=1, trace=tr2)
+    monkeypatch.setattr(V, "dedupe_sums_rows", real)
+    np.testing.assert_array_equal(tr2["last_coords"], tr["last_coords"])
+    np.testing.assert_array_equal(best2, best)
 
 
 def _count_worker(rank, world, port, out_dir):

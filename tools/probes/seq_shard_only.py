@@ -15,6 +15,7 @@ lds = (n + 127) & ~127
 blk = rng.integers(0, 3201, size=(1024, lds), dtype=np.uint16)
 sums = np.concatenate([np.roll(blk, 17 * i, axis=1) for i in range((nrows + 1023) // 1024)])[:nrows]
 sums_d = _ffi.DeviceBuffer.from_numpy(sums)
-ld = (rng.standard_normal((2, n)) * 5).astype(np.float32)
+scale = float(os.environ.get("SEQ_SCALE", "5"))          # 5: no far step; 1e5: every step far
+ld = (rng.standard_normal((2, n)) * scale).astype(np.float32)
 _, t = sc.forces(form, n, row0, nrows, sums_d, lds, lut, ld, 5)
 print(form, n, nrows, "ms", round(t, 4))
