@@ -1,4 +1,4 @@
-"""World-size-2 `gloo` test (CPU) of the multi-GPU protocol of the embedding loop: row partition ->
+"""World-size-2 / 3 / 8 `gloo` tests (CPU) of the multi-GPU protocol of the embedding loop: row partition ->
 local forces -> ONE all-reduce of the message [gradient | loss limbs] -> identical apply on every rank.  The HIP session is replaced by a
 test double that computes with the CPU oracle (tests may use the oracle; the product never does)."""
 import os
@@ -140,7 +140,7 @@ class CyclicOracleSession:
         self.ld += (-(4.0 * self.msg[:2 * n].reshape(2, n)) * self.lr)     # apply_msg_kernel<no CLEAR>: nothing zeroed
 
 
-def _cyclic_worker(rank, world, port, n_iter, out_dir):
+def _cyclic_worker(rank, world, port, n_iter, out_dir, n=600):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
     import torch.distributed as dist
@@ -148,8 +148,7 @@ def _cyclic_worker(rank, world, port, n_iter, out_dir):
     from kmap_amd.visualization import cyclic_blocks
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        n = 600                                                 # three 256-row blocks: 256, 256, 88
-        rng = np.random.default_rng(4)
+        rng = np.random.default_rng(4)                          # n = 600: three 256-row blocks: 256, 256, 88
         p = rng.random((n, n)) * 0.9 + 0.05
         p = np.triu(p, 1)
         p = (p + p.T).astype(np.float32)
@@ -159,7 +158,7 @@ def _cyclic_worker(rank, world, port, n_iter, out_dir):
         sess = CyclicOracleSession(p, ld, blocks, 0.0005, msg_t.numpy())   # small steps: no chaotic amplification
         loop = DistEmbedLoop(sess, msg_t, dist if world > 1 else None)
         loop.step(n_iter)
-        np.savez(Path(out_dir) / f"cyc{rank}_of{world}.npz", ld=sess.ld, losses=np.array(sess.losses, np.float32),
+        np.savez(Path(out_dir) / f"cyc{rank}_of{world}_n{n}.npz", ld=sess.ld, losses=np.array(sess.losses, np.float32),
                  blocks=np.array(blocks).reshape(-1, 2))
     finally:
         dist.destroy_process_group()
@@ -173,12 +172,12 @@ def test_cyclic_block_protocol_matches_single_process(tmp_path):
     n_iter = 6
     for world in (1, 2, 3):
         mp.spawn(_cyclic_worker, args=(world, _free_port(), n_iter, str(tmp_path)), nprocs=world, join=True)
-    single = np.load(tmp_path / "cyc0_of1.npz")
+    single = np.load(tmp_path / "cyc0_of1_n600.npz")
     assert single["blocks"].tolist() == [[0, 256], [256, 256], [512, 88]]
-    two = [np.load(tmp_path / f"cyc{r}_of2.npz") for r in range(2)]
+    two = [np.load(tmp_path / f"cyc{r}_of2_n600.npz") for r in range(2)]
     assert two[0]["blocks"].tolist() == [[0, 256], [512, 88]] and two[1]["blocks"].tolist() == [[256, 256]]
     for world in (2, 3):
-        rs = [np.load(tmp_path / f"cyc{r}_of{world}.npz") for r in range(world)]
+        rs = [np.load(tmp_path / f"cyc{r}_of{world}_n600.npz") for r in range(world)]
         for r in rs[1:]:
             np.testing.assert_array_equal(rs[0]["ld"], r["ld"])        # every rank holds the same iterate
             np.testing.assert_array_equal(rs[0]["losses"], r["losses"])
@@ -186,7 +185,49 @@ def test_cyclic_block_protocol_matches_single_process(tmp_path):
         np.testing.assert_allclose(rs[0]["ld"], single["ld"], rtol=0, atol=1e-4 * np.abs(single["ld"]).max())
 
 
-def _gather_worker(rank, world, port, out_dir):
+@pytest.mark.timeout(900)
+def test_eight_rank_protocols_match_single_process(tmp_path):
+    """the node the path is built for has EIGHT ranks: contiguous rows (SEQ; 96 rows = 12 per rank) bit for bit against one process
+    and against the golden trace; the cyclic symmetric layout with 9 blocks (rank 0 owns the first and the ragged last one, every
+    other rank one) against one process; ragged all-gathers in which three of the eight ranks bring nothing"""
+    import torch.multiprocessing as mp
+    n_iter = 12
+    mp.spawn(_worker, args=(8, _free_port(), n_iter, str(tmp_path)), nprocs=8, join=True)
+    mp.spawn(_worker, args=(1, _free_port(), n_iter, str(tmp_path)), nprocs=1, join=True)
+    rs = [np.load(tmp_path / f"rank{r}_of8.npz") for r in range(8)]
+    single = np.load(tmp_path / "rank0_of1.npz")
+    assert [list(r["rows"]) for r in rs] == [[12 * r, 12] for r in range(8)]
+    for r in rs[1:]:
+        np.testing.assert_array_equal(rs[0]["ld"], r["ld"])
+        np.testing.assert_array_equal(rs[0]["losses"], r["losses"])
+    np.testing.assert_array_equal(rs[0]["ld"], single["ld"])              # x + 0 + ... + 0: the sum of eight messages is exact
+    np.testing.assert_allclose(rs[0]["losses"], single["losses"], rtol=1e-6)
+    u = np.load(ROOT / "tests" / "golden" / "umap_n96.npz")
+    np.testing.assert_allclose(rs[0]["ld"], u["coords"][n_iter - 1], rtol=0, atol=1e-5)
+    # cyclic: 2100 rows = eight full 256-row blocks + one of 52
+    n, it = 2100, 3
+    mp.spawn(_cyclic_worker, args=(8, _free_port(), it, str(tmp_path), n), nprocs=8, join=True)
+    mp.spawn(_cyclic_worker, args=(1, _free_port(), it, str(tmp_path), n), nprocs=1, join=True)
+    cs = [np.load(tmp_path / f"cyc{r}_of8_n{n}.npz") for r in range(8)]
+    one = np.load(tmp_path / f"cyc0_of1_n{n}.npz")
+    assert cs[0]["blocks"].tolist() == [[0, 256], [2048, 52]] and all(cs[r]["blocks"].tolist() == [[256 * r, 256]] for r in range(1, 8))
+    for c in cs[1:]:
+        np.testing.assert_array_equal(cs[0]["ld"], c["ld"])
+        np.testing.assert_array_equal(cs[0]["losses"], c["losses"])
+    np.testing.assert_allclose(cs[0]["losses"], one["losses"], rtol=1e-6)
+    np.testing.assert_allclose(cs[0]["ld"], one["ld"], rtol=0, atol=1e-4 * np.abs(one["ld"]).max())
+    # ragged gathers on eight ranks: five reads (ranks 5..7 own none), rank 1 without a hit
+    mp.spawn(_gather_worker, args=(8, _free_port(), str(tmp_path), 5), nprocs=8, join=True)
+    gs = [np.load(tmp_path / f"gather{r}.npz") for r in range(8)]
+    assert [len(g["mine_hits"]) for g in gs] == [1, 1, 1, 1, 1, 0, 0, 0]
+    for key, mine in (("hits", "mine_hits"), ("pos", "mine_pos"), ("nb", "mine_nb")):
+        want = np.concatenate([g[mine] for g in gs])
+        for g in gs:
+            np.testing.assert_array_equal(g[key], want)
+            assert g[key].dtype == want.dtype and g[key].shape == want.shape
+
+
+def _gather_worker(rank, world, port, out_dir, n_reads=1003):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     from kmap_amd.distributed import all_gather_concat, broadcast_seed, read_partition
@@ -194,11 +235,11 @@ def _gather_worker(rank, world, port, out_dir):
     try:
         rng = np.random.default_rng(100 + rank)
         # scan-hit shaped payloads: per-read counts (length known from the read partition) and ragged position lists
-        borders = np.zeros((1003, 2), np.int64)
+        borders = np.zeros((n_reads, 2), np.int64)
         lens = [read_partition(borders, world, r)[1] for r in range(world)]
         hits = rng.integers(0, 5, size=lens[rank]).astype(np.int32)
         pos = rng.integers(0, 1 << 20, size=int(hits.sum()) if rank != 1 else 0).astype(np.int32)   # rank 1: no hits at all
-        nb = rng.integers(0, 1003, size=(lens[rank], 20)).astype(np.int32)
+        nb = rng.integers(0, n_reads, size=(lens[rank], 20)).astype(np.int32)
         got = {"hits": all_gather_concat(dist, hits, lens), "pos": all_gather_concat(dist, pos), "nb": all_gather_concat(dist, nb, lens),
                "u16": all_gather_concat(dist, (hits * 1000).astype(np.uint16)),
                "seed_none": broadcast_seed(dist, None), "seed_given": broadcast_seed(dist, 41),
