@@ -14,6 +14,8 @@ CONFIGS = {
     "C1s": dict(n_reads=2000, read_len=60, seed=9, n_total=300, n_motif=150, iters=100),
     "C2": dict(n_reads=100_000, read_len=150, seed=1, n_total=5000, n_motif=2500, iters=2500),
     "C3": dict(n_reads=10_000_000, read_len=150, seed=2, n_total=50_000, n_motif=25_000, iters=2500),
+    # BASELINE's 8-GPU configuration; on ONE GPU: 40 GB of distances + 80 GB of neighbour sums resident, device neighbour rule (N > 65 536)
+    "C4": dict(n_reads=10_000_000, read_len=150, seed=2, n_total=200_000, n_motif=100_000, iters=2500),
 }
 
 
