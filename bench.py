@@ -660,8 +660,8 @@ def shard_proxy(G, reads, res_dir, c3s, overhead_ms):
 
 def c4_leg(dist, torch, res_dir, rank, world, barrier):
     """BASELINE config C4: N = 200 000 sampled k-mers FIXED as the GPU count grows (strong scaling).  Hamming rows of this rank
-    (HIP events, no collective) and the embedding iteration (sharded FAST loop with its one all-reduce for world > 1; phases
-    from device events)."""
+    (HIP events, no collective) and the embedding iteration in both modes (FAST, and SEQ = the package default; the sharded loop with
+    its one all-reduce for world > 1; phases from device events)."""
     from kmap_amd import _ffi, visualization as V
     from kmap_amd.distributed import row_partition
     from kmap_amd.hamdist import hamdist_matrix_dev, pitch_for
@@ -689,38 +689,41 @@ def c4_leg(dist, torch, res_dir, rank, world, barrier):
            "hamming_pairs_per_s": float(n) * n / (med * 1e-3),
            "hamming_note": "all N^2 pairs / the median launch time (HIP events, 10 launches at steady clocks) of the slowest rank's rows"}
     its = (5, 25)
-    loops, err, phases = [], "", None
     flag = torch.zeros(1, dtype=torch.int32, device="cuda")
-    for it in its:
-        if not _all_ok(dist if world > 1 else None, torch, flag):      # a rank that failed in the previous run is seen by all before the next
-            break
-        tr = {}
-        try:
-            if world > 1:
-                from kmap_amd.distributed import kmap_from_kmers_distributed
-                kmap_from_kmers_distributed(kh, np.ones(n, np.int64), lab, conseqs, K, n_max_iter=it, random_seed=7, trace=tr, mode=V.EMBED_FAST,
-                                            profile_iters=4 if it == its[0] else 0)
-                phases = tr.get("phases", phases)
-            else:
-                V.kmap_from_kmers(kh, np.ones(n, np.int64), lab, conseqs, K, n_max_iter=it, random_seed=7, trace=tr, mode=V.EMBED_FAST)
-            loops.append(tr["loop_s"])
-        except Exception as e:   # noqa: BLE001 -- reported in the line; the headline above is already measured
-            err = f"{type(e).__name__}: {e}"[:300]
-            flag.fill_(1)
-    if not _all_ok(dist if world > 1 else None, torch, flag):
-        err = err or "another rank failed"
-    if err or len(loops) < 2:
-        res["embed_error"] = err or "embedding leg did not run"
-        return res
-    per_it = (loops[1] - loops[0]) / (its[1] - its[0])
-    if world > 1:
-        t = torch.tensor([per_it], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        per_it = float(t.item())
-        res["embed_phases_ms_rank0"] = phases
-    res["embed_ms_per_iteration"] = per_it * 1e3
-    res["embed_note"] = (f"FAST, from the difference of a {its[1]}- and a {its[0]}-iteration run (max over ranks)" +
-                         ("; one all-reduce of (2 N + 8) floats per iteration" if world > 1 else "; resident single-GPU loop"))
+    # FAST (the round-1..4 number of this leg) and SEQ (the package default since round 5: the reference's summation order)
+    for key, mode, name in (("embed", V.EMBED_FAST, "FAST"), ("embed_seq", V.EMBED_SEQ, "SEQ (package default)")):
+        loops, err, phases = [], "", None
+        for it in its:
+            if not _all_ok(dist if world > 1 else None, torch, flag):      # a rank that failed in the previous run is seen by all before the next
+                break
+            tr = {}
+            try:
+                if world > 1:
+                    from kmap_amd.distributed import kmap_from_kmers_distributed
+                    kmap_from_kmers_distributed(kh, np.ones(n, np.int64), lab, conseqs, K, n_max_iter=it, random_seed=7, trace=tr, mode=mode,
+                                                profile_iters=4 if it == its[0] else 0)
+                    phases = tr.get("phases", phases)
+                else:
+                    V.kmap_from_kmers(kh, np.ones(n, np.int64), lab, conseqs, K, n_max_iter=it, random_seed=7, trace=tr, mode=mode)
+                loops.append(tr["loop_s"])
+            except Exception as e:   # noqa: BLE001 -- reported in the line; the headline above is already measured
+                err = f"{type(e).__name__}: {e}"[:300]
+                flag.fill_(1)
+        if not _all_ok(dist if world > 1 else None, torch, flag):
+            err = err or "another rank failed"
+        if err or len(loops) < 2:
+            res[key + "_error"] = err or "embedding leg did not run"
+            flag.zero_()                                                   # the other mode still runs
+            continue
+        per_it = (loops[1] - loops[0]) / (its[1] - its[0])
+        if world > 1:
+            t = torch.tensor([per_it], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            per_it = float(t.item())
+            res[key + "_phases_ms_rank0"] = phases
+        res[key + "_ms_per_iteration"] = per_it * 1e3
+        res[key + "_note"] = (f"{name}, from the difference of a {its[1]}- and a {its[0]}-iteration run (max over ranks)" +
+                              ("; one all-reduce of (2 N + 8) floats per iteration" if world > 1 else "; resident single-GPU loop"))
     return res
 
 
