@@ -270,9 +270,11 @@ int kmap_label_members_dev(const uint8_t *label_dev, const uint64_t *excl_dev, i
 int kmap_gather_dev(const void *src_dev, int elem_bytes, const int64_t *idx, int64_t m, void *out);
 
 /* ---- FASTA -> uint8 array contract (host side; proc_input / dna2arr / convert_fasta_to_binary, kmer_count.py:182-347).
- * Streaming parser (plain or .gz): header lines start with '>', sequence lines are concatenated with white space
- * removed, A/C/G/T (either case) -> 0..3, anything else -> 255, one 255 separator after every record; borders
- * [start, end) with end = index of the separator.  Two-call pattern: open parses and reports the sizes, read copies out. */
+ * Header lines start with '>', sequence lines are concatenated with white space removed, A/C/G/T (either case) -> 0..3,
+ * anything else -> 255, one 255 separator after every record; borders [start, end) with end = index of the separator; text
+ * before the first header is ignored.  Two-call pattern: open reports the sizes, read fills the caller's arrays.  A plain file
+ * is mapped and cut behind newlines into ranges that host threads walk (KMAP_IO_THREADS, default <= 16): open counts them, read
+ * encodes each range straight into seq_out / borders_out; a gzip stream is encoded by one thread while it is inflated. */
 typedef struct kmap_fasta kmap_fasta;
 int kmap_fasta_open(const char *path, kmap_fasta **f, int64_t *n_bytes, int64_t *n_seq);
 int kmap_fasta_read(kmap_fasta *f, uint8_t *seq_out, int64_t *borders_out);

@@ -95,6 +95,30 @@ def test_fasta_encoding_matches_reference_arrays(golden, tmp_path):
         K.encode_fasta(str(tmp_path / "missing.fa"))
 
 
+def test_fasta_encoder_is_the_same_for_every_range_and_thread_count(golden, tmp_path, monkeypatch):
+    """the shipped library's plain-file path: the mapped file cut into ranges behind newlines, counted and encoded on several threads
+    -- whatever the cut and the thread count, the arrays are those of the one-range walk and of the record-by-record Python encoder"""
+    import kmap_amd.kmer_count as K
+    s = golden("scan_testfa.npz")
+    big = tmp_path / "big.fa"                       # 40 copies of the reference's test.fa with CRLF records and stray text mixed in
+    text = (GOLD / "test.fa").read_bytes()
+    big.write_bytes(b"ignored\n" + b"".join(text + (b">crlf\r\nAC GT\r\nnn\r\n" if i % 3 == 0 else b"") for i in range(40)))
+    monkeypatch.setenv("KMAP_IO_THREADS", "1")
+    monkeypatch.setenv("KMAP_FASTA_MIN_CHUNK", str(1 << 40))
+    want, want_big = K.encode_fasta(str(GOLD / "test.fa")), K.encode_fasta(str(big))
+    np.testing.assert_array_equal(want[0], s["seq"])
+    ap, bp = K.encode_fasta_py(str(big))
+    np.testing.assert_array_equal(want_big[0], ap)
+    np.testing.assert_array_equal(want_big[1], bp)
+    for threads, chunk in (("2", "1"), ("8", "1"), ("8", "100"), ("16", "4096"), ("3", "65536")):
+        monkeypatch.setenv("KMAP_IO_THREADS", threads)
+        monkeypatch.setenv("KMAP_FASTA_MIN_CHUNK", chunk)
+        for f, w in ((GOLD / "test.fa", want), (big, want_big)):
+            a, b = K.encode_fasta(str(f))
+            np.testing.assert_array_equal(a, w[0], err_msg=f"{f.name} threads {threads} chunk {chunk}")
+            np.testing.assert_array_equal(b, w[1], err_msg=f"{f.name} threads {threads} chunk {chunk}")
+
+
 def test_merge_consensus_seqs_golden(golden):
     from kmap_amd.motif_discovery import merge_consensus_seqs
     g = golden("ops.npz")

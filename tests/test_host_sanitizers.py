@@ -81,24 +81,67 @@ CASES = {
 }
 
 
+# the plain-file path cuts the mapped file into ranges behind newlines and walks them on several threads (count in kmap_fasta_open,
+# encode into the caller's arrays in kmap_fasta_read); KMAP_FASTA_MIN_CHUNK lets a small file be cut as finely as a 1.6-GB one
+FA_ENVS = [{"KMAP_IO_THREADS": "1"}, {"KMAP_IO_THREADS": "4", "KMAP_FASTA_MIN_CHUNK": "1"},
+           {"KMAP_IO_THREADS": "8", "KMAP_FASTA_MIN_CHUNK": "64"}, {"KMAP_IO_THREADS": "3", "KMAP_FASTA_MIN_CHUNK": "1048576"}]
+
+
+def _fasta_env(exe, path, tmp_path, env):
+    out = _run(exe, "fasta", path, tmp_path / "s.bin", tmp_path / "b.bin", env=env)
+    nb, ns = (int(t) for t in out.split())
+    seq = np.fromfile(tmp_path / "s.bin", np.uint8)
+    borders = np.fromfile(tmp_path / "b.bin", np.int64).reshape(-1, 2)
+    assert len(seq) == nb and len(borders) == ns
+    return seq, borders
+
+
 @pytest.mark.parametrize("san", ["asan", "tsan"])
 def test_fasta_reader_edge_cases(drivers, tmp_path, san):
     for name, text in CASES.items():
-        if san == "tsan" and name in ("over_long_line", "long_header"):
-            continue                                   # single-threaded code: the slow instrumented run adds nothing
+        long_case = name in ("over_long_line", "long_header")
         p = tmp_path / f"{name}.fa"
         p.write_bytes(text.encode())
-        seq, borders = _fasta(drivers[san], p, tmp_path)
         want_s, want_b = _model(text)
-        np.testing.assert_array_equal(seq, want_s, err_msg=name)
-        np.testing.assert_array_equal(borders, want_b, err_msg=name)
-        if name in ("plain", "crlf", "over_long_line"):                       # the same through gzip
+        for env in (FA_ENVS[3:] if long_case else FA_ENVS):        # the multi-MB cases once (three threads, 1-MiB ranges)
+            seq, borders = _fasta_env(drivers[san], p, tmp_path, env)
+            np.testing.assert_array_equal(seq, want_s, err_msg=f"{name} {env}")
+            np.testing.assert_array_equal(borders, want_b, err_msg=f"{name} {env}")
+        if name in ("plain", "crlf", "over_long_line") and not (san == "tsan" and long_case):   # the same through gzip (one thread)
             pz = tmp_path / f"{name}.fa.gz"
             with gzip.open(pz, "wb") as fh:
                 fh.write(text.encode())
             seq_z, borders_z = _fasta(drivers[san], pz, tmp_path)
             np.testing.assert_array_equal(seq_z, want_s, err_msg=name + ".gz")
             np.testing.assert_array_equal(borders_z, want_b, err_msg=name + ".gz")
+
+
+@pytest.mark.parametrize("san", ["asan", "tsan"])
+def test_fasta_reader_random_texts(drivers, tmp_path, san):
+    """random line soup (headers, empty lines, white space of every kind, '>' inside lines, LF / CRLF, with and without a final
+    newline) through every range / thread setting: the ranges' encodings must concatenate to the model's arrays"""
+    import random
+    rng = random.Random(5 if san == "asan" else 6)
+    alpha = "ACGTacgtNn>> \t\r\v\fxyz-*"
+    for it in range(40):
+        lines = []
+        for _ in range(rng.randint(0, 60)):
+            kind = rng.random()
+            if kind < 0.25:
+                lines.append(">" + "".join(rng.choice("hdr >x") for _ in range(rng.randint(0, 8))))
+            elif kind < 0.35:
+                lines.append("")
+            else:
+                lines.append("".join(rng.choice(alpha) for _ in range(rng.randint(0, 30))))
+        sep = rng.choice(["\n", "\n", "\r\n"])
+        text = sep.join(lines) + (sep if rng.random() < 0.7 else "")
+        p = tmp_path / f"r{it}.fa"
+        p.write_bytes(text.encode())
+        want_s, want_b = _model(text)
+        env = FA_ENVS[it % 3]
+        seq, borders = _fasta_env(drivers[san], p, tmp_path, env)
+        np.testing.assert_array_equal(seq, want_s, err_msg=f"{it} {env} {text!r}")
+        np.testing.assert_array_equal(borders, want_b, err_msg=f"{it} {env} {text!r}")
 
 
 def test_fasta_reader_golden_test_fa(drivers, tmp_path):
