@@ -7,6 +7,22 @@ from .kmer_count import FileNameDict  # noqa: F401
 
 
 def main():
+    """`kmap <verb> ...`.  A verb that ends well leaves through os._exit once its output is flushed: every file is complete and every
+    writer thread joined by then, and unloading the HIP runtime with gigabytes still allocated costs 0.15 - 0.2 s per process (measured
+    on the three verbs at C3: tools/probes/run_prof.sh).  KMAP_FAST_EXIT=0, a torch.distributed launch (the process group wants its
+    orderly shutdown) and every failing run take the interpreter's normal way out."""
+    import os
+    import sys
     from .cli import cli, display_paper_info
     display_paper_info()
-    cli(prog_name="kmap")
+    try:
+        cli(prog_name="kmap")                       # click's standalone mode: always ends in SystemExit
+    except SystemExit as e:
+        ok = e.code in (None, 0)
+        if ok and os.environ.get("KMAP_FAST_EXIT", "1") != "0" and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+            try:
+                sys.stdout.flush()
+                sys.stderr.flush()
+            finally:
+                os._exit(0)
+        raise

@@ -608,13 +608,29 @@ def _preproc(fasta_file: str, res_dir=".", debug=False):
         cfg["general"]["input_fasta_file"] = fasta_file
         cfg["general"]["res_dir"] = res_dir
         dump_toml(cfg, cfg_path)
-    table = gen_motif_def_dict(cfg, debug=debug)
-    ks = sorted(k for k in table if isinstance(k, int))
-    with open(Path(res_dir) / FileNameDict["motif_def_file"], "w+") as fh:
-        fh.write(MotifDef.get_field_names() + "\n")
-        for k in ks:
-            fh.write(str(table[k]) + "\n")
-    proc_input(cfg["general"]["input_fasta_file"], cfg["general"]["res_dir"],
-               out_bin_file_name=FileNameDict["processed_fasta_file"],
-               out_boarder_bin_file_name=FileNameDict["processed_fasta_seqboarder_file"], debug=debug)
+    # the encoder and the two pickle writers are native / system calls that release the interpreter: they run on a helper thread
+    # beside the motif table's pandas / scipy imports (~0.8 s in a fresh process, most of what the verb took after the encoder's rebuild)
+    import threading
+    failed = []
+
+    def _encode():
+        try:
+            proc_input(cfg["general"]["input_fasta_file"], cfg["general"]["res_dir"],
+                       out_bin_file_name=FileNameDict["processed_fasta_file"],
+                       out_boarder_bin_file_name=FileNameDict["processed_fasta_seqboarder_file"], debug=debug)
+        except BaseException as e:   # noqa: BLE001 -- re-raised below
+            failed.append(e)
+    enc = threading.Thread(target=_encode)
+    enc.start()
+    try:
+        table = gen_motif_def_dict(cfg, debug=debug)
+        ks = sorted(k for k in table if isinstance(k, int))
+        with open(Path(res_dir) / FileNameDict["motif_def_file"], "w+") as fh:
+            fh.write(MotifDef.get_field_names() + "\n")
+            for k in ks:
+                fh.write(str(table[k]) + "\n")
+    finally:
+        enc.join()
+    if failed:
+        raise failed[0]
     return cfg, table

@@ -902,7 +902,6 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
     config_dict = load_toml(config_file_path)
     from . import _policy
     _policy.apply_config(config_dict)          # optional keys general.exact / visualization.embed_mode
-    motif_def_dict = gen_motif_def_dict(config_dict, debug=debug)
     md = config_dict["motif_discovery"]
     min_k, max_k = config_dict["kmer_count"]["min_k"], config_dict["kmer_count"]["max_k"]
     revcom_mode = config_dict["kmer_count"]["revcom_mode"]
@@ -929,12 +928,28 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
     check(_ffi.lib().kmap_get_device(C.byref(dev_now)))
     warm = threading.Thread(target=_warm)
     warm.start()
-    with _stage("load_inputs"):
-        # large inputs: a read-only view of the mapped file; a rank of a sharded run touches only its own slice of it
-        # (distributed.make_dist_device_seq), so no rank unpickles or pre-faults the whole input
-        seq_np_arr = load_array_pickle(proc_fasta_file_path, populate=dist is None)
-        boarder_pkl_file = res / FileNameDict["processed_fasta_seqboarder_file"]
-        boarder_mat = load_array_pickle(boarder_pkl_file, populate=dist is None)
+    boarder_pkl_file = res / FileNameDict["processed_fasta_seqboarder_file"]
+    loaded = {}
+
+    def _load():
+        try:
+            with _stage("load_inputs"):
+                # large inputs: a read-only view of the mapped file; a rank of a sharded run touches only its own slice of it
+                # (distributed.make_dist_device_seq), so no rank unpickles or pre-faults the whole input
+                loaded["seq"] = load_array_pickle(proc_fasta_file_path, populate=dist is None)
+                loaded["borders"] = load_array_pickle(boarder_pkl_file, populate=dist is None)
+        except BaseException as e:   # noqa: BLE001 -- re-raised on the main thread below
+            loaded["error"] = e
+    loader = threading.Thread(target=_load)
+    loader.start()
+    # the motif table goes through pandas.read_csv and scipy.stats.norm like the reference's (kmer_count.py:719-740): ~0.8 s of
+    # imports in a fresh process, now beside the mapping of the inputs and the HIP start-up instead of in front of them
+    motif_def_dict = gen_motif_def_dict(config_dict, debug=debug)
+    loader.join()
+    if "error" in loaded:
+        warm.join()
+        raise loaded["error"]
+    seq_np_arr, boarder_mat = loaded["seq"], loaded["borders"]
     n_all_seq = len(boarder_mat)
 
     def resident(arr):

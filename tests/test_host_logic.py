@@ -281,3 +281,27 @@ def test_occurrence_csv_writer_matches_python_formatting(tmp_path, narrow):
         want.append(f"{i};" + ";".join(cells) + f";{read_len[i]}")
     assert rows.value == len(want) - 1
     assert out.read_text() == "\n".join(want) + "\n"
+
+
+def test_cli_fast_exit_leaves_complete_output(tmp_path):
+    """`kmap preproc` (no GPU needed) through the fast exit (os._exit after the flush) and, with KMAP_FAST_EXIT=0, through the
+    interpreter's normal shutdown: same exit code, same complete stdout through a pipe, byte-identical files; a failing run keeps
+    click's exit code either way"""
+    import os
+    import subprocess
+    import sys
+    outs = {}
+    for name, env in (("fast", {}), ("normal", {"KMAP_FAST_EXIT": "0"})):
+        res = tmp_path / name
+        e = dict(os.environ, PYTHONPATH=str(ROOT) + os.pathsep + os.environ.get("PYTHONPATH", ""), **env)
+        e.pop("RANK", None)
+        e.pop("WORLD_SIZE", None)
+        r = subprocess.run([sys.executable, "-m", "kmap_amd", "preproc", "--fasta_file", str(GOLD / "test.fa"), "--res_dir", str(res)],
+                           capture_output=True, text=True, env=e, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout.rstrip().endswith("generated.")                    # the last line the verb prints made it through the pipe
+        outs[name] = {f.name: f.read_bytes() for f in sorted(res.iterdir()) if f.name != "config.toml"}   # config.toml names its res_dir
+        bad = subprocess.run([sys.executable, "-m", "kmap_amd", "preproc"], capture_output=True, text=True, env=e, timeout=300)
+        assert bad.returncode == 2 and "Missing option" in bad.stderr
+    assert outs["fast"].keys() == outs["normal"].keys() and len(outs["fast"]) == 3
+    assert outs["fast"] == outs["normal"]
