@@ -82,7 +82,7 @@ def main():
             if r.returncode != 0:
                 print(r.stdout[-1500:], r.stderr[-3000:])
                 return 1
-        print(f"  {'all three':<16} {total:6.2f} s wall; scan_motif + visualize_kmers {total - 0:.2f} s incl. preproc")
+        print(f"  {'all three':<16} {total:6.2f} s wall")
         print("  final consensus:", (res / "final_conseq.txt").read_text().split(), " rows embedded:",
               len((res / "low_dim_data.tsv").read_text().splitlines()) - 1)
         t0 = time.perf_counter()
