@@ -12,7 +12,10 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -384,32 +387,113 @@ bool fa_reserve(kmap_fasta *f, size_t want) {   // room for `want` more bytes in
     f->cap = ncap;
     return true;
 }
-int fa_open_stream(const char *path, kmap_fasta *f) {    // gzip (or anything that cannot be mapped): buffer by buffer
+// what a gzread that returned `got` <= 0 means: "" for a clean end of the stream.  A file that ends in the middle of a gzip stream is
+// NOT a clean end: gzread hands out what it could inflate and then returns 0 like at a real end -- only gzerror says Z_BUF_ERROR
+// (until round 5 a truncated .fa.gz was encoded as far as it went, without a word).
+std::string fa_gz_end(gzFile gz, int got) {
+    int errnum = Z_OK;
+    const char *msg = gzerror(gz, &errnum);
+    if (got < 0 || (errnum != Z_OK && errnum != Z_STREAM_END)) {
+        if (errnum == Z_BUF_ERROR) return "the file ends in the middle of a gzip stream (truncated?)";
+        return (msg && *msg) ? msg : "read error";
+    }
+    return "";
+}
+// gzip (or anything that cannot be mapped): the stream is inflated by a helper thread into a ring of three 4-MiB buffers while
+// this thread encodes the buffer before -- inflating is the slower half (zlib: a few hundred MB/s of text), the walk hides
+// behind it.  size_hint: the uncompressed size the gzip trailer names (modulo 2^32; 0 = unknown): one allocation instead of a
+// growing one when it holds.
+int fa_open_stream(const char *path, kmap_fasta *f, size_t size_hint) {
     gzFile gz = gzopen(path, "rb");   // transparently reads plain files too
     if (!gz) {
         kmap_set_error("fasta_open: cannot open %s: %s", path, strerror(errno));
         return KMAP_E_INVAL;
     }
     gzbuffer(gz, 1 << 20);
-    std::vector<uint8_t> in((size_t)1 << 22);
+    if (size_hint) (void)fa_reserve(f, size_hint + 1);           // a failed hint is not an error: the buffer grows as before
+    constexpr int RING = 3;
+    constexpr size_t BUF = (size_t)1 << 22;
+    std::vector<uint8_t> ring[RING];
+    int got_of[RING] = {0, 0, 0};
+    for (auto &b : ring) b.resize(BUF);
+    std::mutex mu;
+    std::condition_variable cv;
+    int filled = 0;                    // buffers inflated and not yet encoded
+    bool done = false, stop = false;   // producer reached the end (or failed) / consumer gave up
+    std::string read_error;
+    auto inflate = [&]() {
+        for (int head = 0;; head = (head + 1) % RING) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return filled < RING || stop; });
+                if (stop) return;
+            }
+            const int got = gzread(gz, ring[head].data(), (unsigned)BUF);
+            std::lock_guard<std::mutex> lk(mu);
+            if (got <= 0) {
+                read_error = fa_gz_end(gz, got);
+                done = true;
+                cv.notify_all();
+                return;
+            }
+            got_of[head] = got;
+            ++filled;
+            cv.notify_all();
+        }
+    };
+    std::thread producer;
+    bool threaded = true;
+    try {
+        producer = std::thread(inflate);
+    } catch (...) {
+        threaded = false;              // no helper thread to be had: inflate and encode in turn
+    }
+    int rc = KMAP_OK;
     FaState st;
-    for (;;) {
-        const int got = gzread(gz, in.data(), (unsigned)in.size());
-        if (got < 0) {
-            int errnum = 0;
-            kmap_set_error("fasta_open: read error in %s: %s", path, gzerror(gz, &errnum));
-            gzclose(gz);
-            return KMAP_E_INVAL;
+    auto encode = [&](const uint8_t *p, size_t n) -> bool {
+        if (!fa_reserve(f, n + 1)) return false;
+        f->len = fa_walk<true>(p, n, st, f->buf, f->len, [&](size_t, size_t at) { f->seps.push_back(at); });
+        return true;
+    };
+    if (threaded) {
+        for (int tail = 0;; tail = (tail + 1) % RING) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return filled > 0 || done; });
+                if (filled == 0) break;                          // done and drained
+            }
+            const bool ok = encode(ring[tail].data(), (size_t)got_of[tail]);
+            std::lock_guard<std::mutex> lk(mu);
+            --filled;
+            if (!ok) {
+                rc = KMAP_E_NOMEM;
+                stop = true;
+            }
+            cv.notify_all();
+            if (!ok) break;
         }
-        if (got == 0) break;
-        if (!fa_reserve(f, (size_t)got + 1)) {
-            gzclose(gz);
-            kmap_set_error("fasta_open: out of memory");
-            return KMAP_E_NOMEM;
+        producer.join();
+    } else {
+        for (;;) {
+            const int got = gzread(gz, ring[0].data(), (unsigned)BUF);
+            if (got <= 0) {
+                read_error = fa_gz_end(gz, got);
+                break;
+            }
+            if (!encode(ring[0].data(), (size_t)got)) {
+                rc = KMAP_E_NOMEM;
+                break;
+            }
         }
-        f->len = fa_walk<true>(in.data(), (size_t)got, st, f->buf, f->len, [&](size_t, size_t at) { f->seps.push_back(at); });
+    }
+    if (rc == KMAP_OK && !read_error.empty()) {
+        kmap_set_error("fasta_open: read error in %s: %s", path, read_error.c_str());
+        rc = KMAP_E_INVAL;
+    } else if (rc == KMAP_E_NOMEM) {
+        kmap_set_error("fasta_open: out of memory");
     }
     gzclose(gz);
+    if (rc != KMAP_OK) return rc;
     f->n_seq = (int64_t)f->seps.size();
     f->n_bytes = f->seps.empty() ? 0 : (int64_t)(f->len - (f->seps[0] + 1) + 1);   // without the text before the first header and its 255; + the last separator
     return KMAP_OK;
@@ -420,6 +504,7 @@ extern "C" int kmap_fasta_open(const char *path, kmap_fasta **out, int64_t *n_by
     KMAP_REQUIRE(path && out && n_bytes && n_seq, "fasta_open: null argument");
     std::unique_ptr<kmap_fasta> f(new kmap_fasta());
     f->threads = fa_threads();
+    size_t gz_hint = 0;
     {
         const int fd = open(path, O_RDONLY | O_CLOEXEC);
         if (fd < 0) {
@@ -428,18 +513,26 @@ extern "C" int kmap_fasta_open(const char *path, kmap_fasta **out, int64_t *n_by
         }
         struct stat sb;
         unsigned char magic[2] = {0, 0};
-        if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && pread(fd, magic, 2, 0) >= 1 &&
-            !(magic[0] == 0x1f && magic[1] == 0x8b)) {
-            void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
-            if (m != MAP_FAILED) {
-                f->map = (const uint8_t *)m;
-                f->map_len = (size_t)sb.st_size;
+        if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && pread(fd, magic, 2, 0) >= 1) {
+            if (!(magic[0] == 0x1f && magic[1] == 0x8b)) {
+                void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+                if (m != MAP_FAILED) {
+                    f->map = (const uint8_t *)m;
+                    f->map_len = (size_t)sb.st_size;
+                }
+            } else if (sb.st_size >= 18) {                      // gzip trailer: ISIZE, the uncompressed length modulo 2^32
+                unsigned char t[4];
+                // trusted only as far as it is plausible for one member (deflate does not shrink text below ~1 / 1000 of its size)
+                if (pread(fd, t, 4, sb.st_size - 4) == 4) {
+                    const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+                    if (isize / 1024 <= (size_t)sb.st_size) gz_hint = isize;
+                }
             }
         }
         close(fd);
     }
     if (!f->map) {
-        KMAP_TRY(fa_open_stream(path, f.get()));
+        KMAP_TRY(fa_open_stream(path, f.get(), gz_hint));
     } else {
         // ranges of >= KMAP_FASTA_MIN_CHUNK bytes (default 4 MiB; the tests cut small files finer), each cut behind a newline
         const char *mc = getenv("KMAP_FASTA_MIN_CHUNK");

@@ -93,6 +93,12 @@ def test_fasta_encoding_matches_reference_arrays(golden, tmp_path):
         np.testing.assert_array_equal(bn, bp)
     with pytest.raises(ValueError):
         K.encode_fasta(str(tmp_path / "missing.fa"))
+    # a .gz that ends in the middle of its stream is an error, not a shorter input (zlib hands out what it could inflate and then
+    # reports an ordinary end: only gzerror knows)
+    whole = (tmp_path / "m.fa.gz").read_bytes()
+    (tmp_path / "cut.fa.gz").write_bytes(whole[: len(whole) - 9])
+    with pytest.raises(ValueError, match="truncated"):
+        K.encode_fasta(str(tmp_path / "cut.fa.gz"))
 
 
 def test_fasta_encoder_is_the_same_for_every_range_and_thread_count(golden, tmp_path, monkeypatch):

@@ -144,6 +144,33 @@ def test_fasta_reader_random_texts(drivers, tmp_path, san):
         np.testing.assert_array_equal(borders, want_b, err_msg=f"{it} {env} {text!r}")
 
 
+@pytest.mark.parametrize("san", ["asan", "tsan"])
+def test_fasta_reader_gzip_ring(drivers, tmp_path, san):
+    """a gzip stream of ~19 MB of text: the inflating thread fills its ring of 4-MiB buffers several times over while the calling
+    thread encodes (records and header lines cut by the buffer ends); the same arrays as the mapped plain file and the model"""
+    rng = np.random.default_rng(3)
+    n, L = 120_000, 150
+    seqs = np.frombuffer(b"ACGTN", np.uint8)[rng.integers(0, 5, size=(n, L))]
+    text = "".join(f">read{i} len={L}\n{row.tobytes().decode()}\n" for i, row in enumerate(seqs))
+    plain, pz = tmp_path / "ring.fa", tmp_path / "ring.fa.gz"
+    plain.write_bytes(text.encode())
+    with gzip.open(pz, "wb", compresslevel=1) as fh:
+        fh.write(text.encode())
+    want_s, want_b = _model(text)
+    seq_z, borders_z = _fasta(drivers[san], pz, tmp_path)
+    np.testing.assert_array_equal(seq_z, want_s)
+    np.testing.assert_array_equal(borders_z, want_b)
+    seq_p, borders_p = _fasta_env(drivers[san], plain, tmp_path, {"KMAP_IO_THREADS": "8", "KMAP_FASTA_MIN_CHUNK": "1048576"})
+    np.testing.assert_array_equal(seq_p, want_s)
+    np.testing.assert_array_equal(borders_p, want_b)
+    # a stream cut off in the middle: an error from the inflating thread, reported by the calling one; nothing leaks, nothing hangs
+    cut = tmp_path / "cut.fa.gz"
+    cut.write_bytes(pz.read_bytes()[: pz.stat().st_size // 2])
+    e = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1", TSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([str(drivers[san]), "fasta", str(cut), "/dev/null", "/dev/null"], capture_output=True, text=True, timeout=600, env=e)
+    assert r.returncode == 2 and "read error" in r.stderr and "Sanitizer" not in r.stderr, r.stderr[-2000:]
+
+
 def test_fasta_reader_golden_test_fa(drivers, tmp_path):
     """tests/test.fa of the reference (golden G1: 45 979 bytes, 1002 reads) through the sanitized reader, plain and gzipped"""
     g = np.load(HERE / "golden" / "scan_testfa.npz")          # seq / borders as the reference's preproc wrote them
