@@ -236,6 +236,14 @@ int kmap_write_occurrence_csv_u8(const char *path, const char *header, int64_t n
                               const uint8_t *const *hits, const int32_t *const *pos, const int64_t *read_len,
                               int64_t *rows_written);
 
+/* one line of the co-occurrence distance file (write_co_occurence_dist_arr motif_discovery.py:1143-1162): the n values formatted like
+ * Python's f"{x:.2f}", tab-separated, '\n' at the end, written to the open descriptor `fd` at its position (n = 0: an empty line).
+ * Native for the same reason as the occurrence table: 3 M values per motif pair at 10^7 reads. */
+int kmap_write_f2_tsv_line(int fd, const double *v, int64_t n);
+/* np.median of every cell of one motif's hit list (get_motif_co_occurence_mat motif_discovery.py:1189-1253 takes it per row of the
+ * CSV): hits[r] ascending locations of read r, back to back in pos[n_pos]; med[r] = mean of the two middle ones, NaN when empty */
+int kmap_cell_medians_i32(const int32_t *hits, const int32_t *pos, int64_t n_seq, int64_t n_pos, double *med);
+
 /* ---- consumers of the counts / the hit list -------------------------------------------
  * Hamming ball of a consensus over counted k-mers (ex_hamball_kh_arr motif_discovery.py:924-975) fused with the
  * position count matrix (cal_cnt_mat :978-986).  uniq/cnt are HOST arrays as stored in k{k}.pkl (u32+i32 for k<16,

@@ -107,6 +107,8 @@ _SIGS = {
     "kmap_scan_summary": (i32, [vp, P(i64), P(i32), vp]),
     "kmap_write_occurrence_csv": (i32, [C.c_char_p, C.c_char_p, i64, i32, vp, vp, vp, P(i64)]),
     "kmap_write_occurrence_csv_u8": (i32, [C.c_char_p, C.c_char_p, i64, i32, vp, vp, vp, P(i64)]),
+    "kmap_write_f2_tsv_line": (i32, [i32, vp, i64]),
+    "kmap_cell_medians_i32": (i32, [vp, vp, i64, i64, vp]),
     "kmap_fasta_open": (i32, [C.c_char_p, P(vp), P(i64), P(i64)]),
     "kmap_fasta_read": (i32, [vp, vp, vp]),
     "kmap_fasta_close": (i32, [vp]),

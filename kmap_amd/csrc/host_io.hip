@@ -10,6 +10,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cmath>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -223,6 +224,117 @@ extern "C" int kmap_write_occurrence_csv_u8(const char *path, const char *header
                                             const uint8_t *const *hits, const int32_t *const *pos, const int64_t *read_len,
                                             int64_t *rows_written) {
     return write_occurrence_csv_impl<uint8_t>(path, header, n_seq, n_cons, hits, pos, read_len, rows_written);
+}
+
+// ---- "%.2f" rows (the co-occurrence distance file, reference motif_discovery.py:1143-1162) ---------------------------------
+// One line of n doubles formatted like Python's f"{x:.2f}", tab-separated, '\n' at the end, written to `fd` at its position.
+// The reference formats every value in a Python generator (1.2 s for the 3 M median differences of a C3 run); the values are
+// differences of medians of integer positions, i.e. multiples of 0.5, whose "%.2f" form is their integer part + ".00" / ".50" --
+// exact, no rounding involved; anything else goes through snprintf (correctly rounded, like Python's own formatting).
+namespace {
+inline char *put_f2(char *p, double v) {
+    const double t = v * 2.0;
+    if (v == v && t > -2e15 && t < 2e15 && t == (double)(long long)t) {     // a multiple of 0.5 of moderate size (NaN fails v == v)
+        long long h = (long long)t;
+        if (h < 0 || (h == 0 && std::signbit(v))) {
+            *p++ = '-';
+            h = -h;
+        }
+        p = put_int(p, h >> 1);
+        *p++ = '.';
+        *p++ = (h & 1) ? '5' : '0';
+        *p++ = '0';
+        return p;
+    }
+    if (v != v) {                                                            // Python prints 'nan' whatever the sign bit
+        memcpy(p, "nan", 3);
+        return p + 3;
+    }
+    return p + snprintf(p, 336, "%.2f", v);                                  // <= 1 + 309 + 3 characters + the terminator
+}
+}  // namespace
+
+extern "C" int kmap_write_f2_tsv_line(int fd, const double *v, int64_t n) {
+    KMAP_REQUIRE(fd >= 0 && n >= 0 && (n == 0 || v), "write_f2_tsv_line: bad descriptor / null values");
+    const int64_t per = 1 << 16;
+    const int64_t n_chunks = (n + per - 1) / per;
+    std::vector<std::string> parts((size_t)std::max<int64_t>(n_chunks, 1));
+    static const int thread_cap = getenv("KMAP_IO_THREADS") ? std::max(1, atoi(getenv("KMAP_IO_THREADS"))) : 16;
+    const int n_threads = (int)std::min<int64_t>(std::min<int64_t>(std::max<unsigned>(1u, std::thread::hardware_concurrency()), thread_cap),
+                                                 std::max<int64_t>(n_chunks, 1));
+    std::atomic<int64_t> next{0};
+    std::atomic<int> oom{0};
+    auto worker = [&]() {
+        char tmp[352];
+        for (;;) {
+            const int64_t c = next.fetch_add(1);
+            if (c >= n_chunks) return;
+            const int64_t lo = c * per, hi = std::min(n, lo + per);
+            try {
+                std::string &out = parts[(size_t)c];
+                out.reserve((size_t)(hi - lo) * 8);
+                for (int64_t i = lo; i < hi; ++i) {
+                    char *e = put_f2(tmp, v[i]);
+                    *e++ = (i + 1 == n) ? '\n' : '\t';
+                    out.append(tmp, (size_t)(e - tmp));
+                }
+            } catch (...) {
+                oom.store(1);
+                return;
+            }
+        }
+    };
+    {
+        std::vector<std::thread> pool;
+        try {
+            for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+        } catch (...) {
+        }
+        worker();
+        for (auto &th : pool) th.join();
+    }
+    if (oom.load()) {
+        kmap_set_error("write_f2_tsv_line: out of memory");
+        return KMAP_E_NOMEM;
+    }
+    if (n == 0) parts[0] = "\n";
+    for (const std::string &part : parts) {
+        const char *p = part.data();
+        size_t left = part.size();
+        while (left) {
+            const ssize_t w = write(fd, p, left);
+            if (w < 0) {
+                if (errno == EINTR) continue;
+                kmap_set_error("write_f2_tsv_line: write failed: %s", strerror(errno));
+                return KMAP_E_IO;
+            }
+            p += w;
+            left -= (size_t)w;
+        }
+    }
+    return KMAP_OK;
+}
+
+// np.median of every cell of one motif's hit list (reports.Occurrence.medians): hits[r] locations of read r, ascending, stored back to
+// back in pos; med[r] = the mean of the two middle ones, NaN for an empty cell.  One pass instead of numpy's six 10^7-element
+// temporaries (cumulated offsets, masks, two gathers).
+extern "C" int kmap_cell_medians_i32(const int32_t *hits, const int32_t *pos, int64_t n_seq, int64_t n_pos, double *med) {
+    KMAP_REQUIRE(n_seq >= 0 && n_pos >= 0 && (n_seq == 0 || (hits && med)) && (n_pos == 0 || pos), "cell_medians: bad sizes / null pointer");
+    int64_t o = 0;
+    for (int64_t r = 0; r < n_seq; ++r) {
+        const int64_t h = hits[r];
+        if (h < 0 || o + h > n_pos) {
+            kmap_set_error("cell_medians: the hit counts do not add up to the %lld locations given (read %lld)", (long long)n_pos, (long long)r);
+            return KMAP_E_INVAL;
+        }
+        med[r] = h ? ((double)pos[o + (h - 1) / 2] + (double)pos[o + h / 2]) / 2.0 : std::nan("");
+        o += h;
+    }
+    if (o != n_pos) {
+        kmap_set_error("cell_medians: the hit counts add up to %lld of the %lld locations given", (long long)o, (long long)n_pos);
+        return KMAP_E_INVAL;
+    }
+    return KMAP_OK;
 }
 
 // ---- FASTA encoder --------------------------------------------------------------------------------------------

@@ -861,7 +861,7 @@ def _write_co_occurrence_files(out_dir, occ, conseqs):
     """the four co-occurrence data files of scan_motif (reference motif_discovery.py:400-425 writes the same tables): pair counts,
     counts normalised by the two motifs' own read counts (Dice: 2 n_ab / (n_a + n_b)), median hit distance per pair, and the raw
     distances"""
-    counts, median_dist, dist_lists = get_motif_co_occurence_mat(occ, len(conseqs))
+    counts, median_dist, dist_lists = get_motif_co_occurence_mat(occ, len(conseqs), as_arrays=True)
     own = np.diag(counts)
     tables = {"co_occur_mat_file": counts + 0.0, "co_occur_mat_norm_file": 2 * counts / (own[None, :] + own[:, None]),
               "co_occur_dist_mat_file": median_dist}

@@ -79,12 +79,9 @@ class Occurrence:
 
     def medians(self, c):
         """np.median of every cell (NaN for an empty cell): the mean of the two middle locations of the sorted cell"""
-        h, o, p = self.hits[c].astype(np.int64), self.offs(c), self.pos[c]
-        med = np.full(len(h), np.nan)
-        has = h > 0
-        lo = o[:-1][has] + (h[has] - 1) // 2
-        hi = o[:-1][has] + h[has] // 2
-        med[has] = (p[lo].astype(np.float64) + p[hi].astype(np.float64)) / 2.0
+        h, p = self.hits[c], self.pos[c]
+        med = np.empty(len(h), np.float64)
+        check(_ffi.lib().kmap_cell_medians_i32(ptr(h), ptr(p), len(h), len(p), ptr(med)))   # one native pass (host code)
         return med
 
 
@@ -125,9 +122,10 @@ def get_motif_pos_density(occurence_file_path, motif_index: int, kmer_len: int, 
     return int(np.count_nonzero(hits)), int(hits.sum(dtype=np.int64)), out
 
 
-def get_motif_co_occurence_mat(occurence_file_path, n_conseq: int):
+def get_motif_co_occurence_mat(occurence_file_path, n_conseq: int, as_arrays=False):
     """(co-occurrence counts with per-motif row counts on the diagonal, median |distance| matrix, {(i,j): signed
-    distances median_j - median_i in row order}) -- reference motif_discovery.py:1189-1253"""
+    distances median_j - median_i in row order}) -- reference motif_discovery.py:1189-1253.  as_arrays: the distances stay float64
+    arrays instead of the reference's lists (scan_motif's own caller: 3 M values per pair at C3)"""
     assert n_conseq > 0
     occ = _as_occurrence(occurence_file_path, n_conseq)
     assert occ.n_conseq == n_conseq
@@ -140,7 +138,7 @@ def get_motif_co_occurence_mat(occurence_file_path, n_conseq: int):
         for j in range(i + 1, n_conseq):
             both = present[i] & present[j]
             d = med[j][both] - med[i][both]
-            dist_dict[(i, j)] = list(d)
+            dist_dict[(i, j)] = d if as_arrays else list(d)
             res_mat[i, j] = res_mat[j, i] = int(np.count_nonzero(both))
             dist_mat[i, j] = dist_mat[j, i] = 1e6 if len(d) == 0 else np.median(np.abs(d))
     np.fill_diagonal(res_mat, [int(np.count_nonzero(p)) for p in present])
@@ -150,13 +148,15 @@ def get_motif_co_occurence_mat(occurence_file_path, n_conseq: int):
 def write_co_occurence_dist_arr(output_file, dist_dict, conseq_list: List[str]):
     """reference motif_discovery.py:1143-1162"""
     names = [f"m{i}_{s}_{reverse_complement(s)}" for i, s in enumerate(conseq_list)]
-    with open(output_file, "w") as fh:
+    with open(output_file, "wb") as fh:
         for i, j in dist_dict:
-            vals = dist_dict[(i, j)]
+            vals = np.ascontiguousarray(dist_dict[(i, j)], dtype=np.float64)
             if len(vals) == 0:
                 continue
-            fh.write(names[i] + "-" + names[j] + "\n")
-            fh.write("\t".join(f"{n:.2f}" for n in vals) + "\n")
+            fh.write((names[i] + "-" + names[j] + "\n").encode())
+            fh.flush()
+            # "\t".join(f"{n:.2f}" for n in vals) + "\n", formatted and written natively (1.2 s of Python per 3 M values)
+            check(_ffi.lib().kmap_write_f2_tsv_line(fh.fileno(), ptr(vals), len(vals)))
 
 
 def write_co_occurence_mat(output_file, dist_mat: np.ndarray, conseq_list: List[str]):

@@ -311,3 +311,22 @@ def test_cli_fast_exit_leaves_complete_output(tmp_path):
         assert bad.returncode == 2 and "Missing option" in bad.stderr
     assert outs["fast"].keys() == outs["normal"].keys() and len(outs["fast"]) == 3
     assert outs["fast"] == outs["normal"]
+
+
+def test_co_occurrence_distance_lines_equal_python_formatting(tmp_path):
+    """write_co_occurence_dist_arr formats natively (kmap_write_f2_tsv_line): the file must be what the reference's
+    "\\t".join(f"{n:.2f}" ...) writes -- multiples of 0.5 (the values a run produces: the fast path), arbitrary doubles, ties of the
+    rounding, huge / tiny / signed-zero / non-finite values; lists and arrays; an empty pair is skipped"""
+    from kmap_amd.kmer_count import reverse_complement
+    from kmap_amd.reports import write_co_occurence_dist_arr
+    rng = np.random.default_rng(1)
+    special = [0.0, -0.0, 0.005, 0.015, 0.025, -0.005, 0.125, 0.375, 999999.995, 1e15, -1e15, 1e16, 2.5e15, 2.0 ** 52 + 0.5, 1e300, -1e300,
+               1e-320, float("inf"), float("-inf"), float("nan")]
+    vals = np.concatenate([rng.integers(-300, 300, 200_000) / 2.0, rng.normal(size=70_000) * 100, rng.normal(size=1000) * 1e-3, special])
+    conseqs = ["ACGT", "GGCC", "TTAA"]
+    d = {(0, 1): vals, (0, 2): np.array([]), (1, 2): [1.0, 2.5, -3.25]}
+    names = [f"m{i}_{s}_{reverse_complement(s)}" for i, s in enumerate(conseqs)]
+    want = "".join(names[i] + "-" + names[j] + "\n" + "\t".join(f"{n:.2f}" for n in v) + "\n" for (i, j), v in d.items() if len(v))
+    out = tmp_path / "dist.tsv"
+    write_co_occurence_dist_arr(out, d, conseqs)
+    assert out.read_text() == want
