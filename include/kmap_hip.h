@@ -251,6 +251,11 @@ int kmap_cell_medians_i32(const int32_t *hits, const int32_t *pos, int64_t n_seq
  * input order.  out_kh/out_cnt: caller-allocated, capacity n; *n_out = members; cnt_mat (optional) int64[4][k]. */
 int kmap_hamball_extract(const void *uniq_host, const void *cnt_host, int64_t n, int k, uint64_t conseq_kh, int max_ham_dist,
                          int revcom_mode, void *out_kh, void *out_cnt, int64_t *n_out, int64_t *cnt_mat);
+/* the same ball over the table a counts handle still holds in HBM (scan_motif keeps the table of the longest final consensus' k for
+ * the labelled sampling: the Hamming-ball matrices need not read the multi-GB k{k}.pkl back).  Two-call pattern: *n_out = members;
+ * they are written (hashes u32 / u64, counts i32 / i64 by k as above, table order) only when cap >= *n_out. */
+int kmap_counts_hamball_extract(kmap_counts *c, uint64_t conseq_kh, int max_ham_dist, int revcom_mode, int64_t cap, void *out_kh,
+                                void *out_cnt, int64_t *n_out, int64_t *cnt_mat);
 /* motif position density (get_motif_pos_density motif_discovery.py:1255-1327): for every read with m > 0 hits,
  * density[x] += (sum_i normpdf(x; loc_i / (seq_len - kmer_len + 1), x_step)) / m, f64.  HOST arrays: hits int32[n_seq],
  * offs int64[n_seq+1] (exclusive prefix sums of hits), pos int32[offs[n_seq]], seq_len int64[n_seq]; density f64[nx].

@@ -69,6 +69,7 @@ _SIGS = {
     "kmap_counts_write_range": (i32, [vp, i32, i64, i64, i32, i64, vp]),
     "kmap_counts_total": (i32, [vp, P(i64)]),
     "kmap_hamball_extract": (i32, [vp, vp, i64, i32, u64, i32, i32, vp, vp, P(i64), vp]),
+    "kmap_counts_hamball_extract": (i32, [vp, u64, i32, i32, i64, vp, vp, P(i64), vp]),
     "kmap_pos_density": (i32, [vp, vp, vp, vp, i64, i32, vp, i32, f64, vp]),
     "kmap_hamdist_pitch": (i64, [i64]),
     "kmap_knn_sums_kmers_u32_dev": (i32, [vp, vp, i64, i32, vp, i32, vp, i32, i64, i64, vp, i64, vp]),

@@ -3,7 +3,10 @@
 //   * motif position density (reference motif_discovery.py:1255-1327: get_motif_pos_density)
 // Integer results are exact; the density is f64 with the reference's operation order per term (no FMA: the library is
 // built with -ffp-contract=off) and a fixed, chunked summation order over reads.
+#include <vector>
+
 #include "common.h"
+#include "counts_internal.h"
 #include "scan_util.h"
 
 namespace {
@@ -98,16 +101,13 @@ __global__ __launch_bounds__(HB_TPB) void hamball_write_kernel(const H *__restri
         atomicAdd(&cnt_mat[(threadIdx.x >> 5) * k + (threadIdx.x & 31)], mat[threadIdx.x]);
 }
 
+// ball of `conseq_kh` over n (k-mer, count) entries that are ON THE DEVICE: members (re-oriented where flagged) in table order ->
+// ou / oc (device), base counts weighted by the k-mer counts -> mat (device, 4 x 32 slots), number of members -> total
 template <typename H, typename CT>
-int hamball_extract(const void *uniq_host, const void *cnt_host, int64_t n, int k, uint64_t conseq_kh, int radius, int revcom,
-                    void *out_kh, void *out_cnt, int64_t *n_out, int64_t *cnt_mat) {
+int hamball_core(const H *u_dev, const CT *c_dev, int64_t n, int k, uint64_t conseq_kh, int radius, int revcom, DevBuf &ou, DevBuf &oc,
+                 DevBuf &mat, uint64_t *total_out) {
     hipStream_t st = nullptr;
-    DevBuf u, c, ou, oc, mat;
-    KMAP_TRY(u.alloc((size_t)n * sizeof(H)));
-    KMAP_TRY(c.alloc((size_t)n * sizeof(CT)));
     KMAP_TRY(mat.alloc(4 * 32 * 8));
-    KMAP_CHECK_HIP(hipMemcpy(u.p, uniq_host, (size_t)n * sizeof(H), hipMemcpyHostToDevice));
-    KMAP_CHECK_HIP(hipMemcpy(c.p, cnt_host, (size_t)n * sizeof(CT), hipMemcpyHostToDevice));
     KMAP_CHECK_HIP(hipMemset(mat.p, 0, 4 * 32 * 8));
     const unsigned nb = (unsigned)((n + HB_TPB * HB_ITEMS - 1) / (HB_TPB * HB_ITEMS));
     uint32_t *bc = nullptr;
@@ -121,20 +121,55 @@ int hamball_extract(const void *uniq_host, const void *cnt_host, int64_t n, int 
         const H com = (H)(low_mask<H>(k) - ch);
         for (int p = 0; p < k; ++p) rc = (H)((rc << 2) | ((com >> (2 * p)) & 3));
     }
-    hamball_count_kernel<H><<<nb, HB_TPB, 0, st>>>(u.as<H>(), n, ch, rc, k, radius, revcom, bc);
+    hamball_count_kernel<H><<<nb, HB_TPB, 0, st>>>(u_dev, n, ch, rc, k, radius, revcom, bc);
     KMAP_TRY(exclusive_scan_u32(bc, nb, boff, st));
     uint64_t total = 0;
     KMAP_CHECK_HIP(hipMemcpyAsync(&total, boff + nb, 8, hipMemcpyDeviceToHost, st));
     KMAP_CHECK_HIP(hipStreamSynchronize(st));
     KMAP_TRY(ou.alloc((size_t)total * sizeof(H)));
     KMAP_TRY(oc.alloc((size_t)total * sizeof(CT)));
-    hamball_write_kernel<H, CT><<<nb, HB_TPB, 0, st>>>(u.as<H>(), c.as<CT>(), n, ch, rc, k, radius, revcom, boff, ou.as<H>(),
-                                                       oc.as<CT>(), mat.as<unsigned long long>());
+    hamball_write_kernel<H, CT><<<nb, HB_TPB, 0, st>>>(u_dev, c_dev, n, ch, rc, k, radius, revcom, boff, ou.as<H>(), oc.as<CT>(),
+                                                       mat.as<unsigned long long>());
     KMAP_CHECK_HIP(hipGetLastError());
+    *total_out = total;
+    return KMAP_OK;
+}
+
+template <typename H, typename CT>
+int hamball_extract(const void *uniq_host, const void *cnt_host, int64_t n, int k, uint64_t conseq_kh, int radius, int revcom,
+                    void *out_kh, void *out_cnt, int64_t *n_out, int64_t *cnt_mat) {
+    DevBuf u, c, ou, oc, mat;
+    KMAP_TRY(u.alloc((size_t)n * sizeof(H)));
+    KMAP_TRY(c.alloc((size_t)n * sizeof(CT)));
+    KMAP_CHECK_HIP(hipMemcpy(u.p, uniq_host, (size_t)n * sizeof(H), hipMemcpyHostToDevice));
+    KMAP_CHECK_HIP(hipMemcpy(c.p, cnt_host, (size_t)n * sizeof(CT), hipMemcpyHostToDevice));
+    uint64_t total = 0;
+    KMAP_TRY((hamball_core<H, CT>(u.as<H>(), c.as<CT>(), n, k, conseq_kh, radius, revcom, ou, oc, mat, &total)));
     KMAP_CHECK_HIP(hipMemcpy(out_kh, ou.p, (size_t)total * sizeof(H), hipMemcpyDeviceToHost));
     KMAP_CHECK_HIP(hipMemcpy(out_cnt, oc.p, (size_t)total * sizeof(CT), hipMemcpyDeviceToHost));
     if (cnt_mat) KMAP_CHECK_HIP(hipMemcpy(cnt_mat, mat.p, (size_t)4 * k * 8, hipMemcpyDeviceToHost));
     *n_out = (int64_t)total;
+    return KMAP_OK;
+}
+
+// the same over the table a counts handle still holds in HBM (uint32 counts whatever k); the members' counts reach the host in the
+// reference's dtype (int32 for k < 16, int64 otherwise).  cap < members: nothing is written, *n_out says how many there are.
+template <typename H, typename CT>
+int hamball_resident(kmap_counts *c, uint64_t conseq_kh, int radius, int revcom, int64_t cap, void *out_kh, void *out_cnt,
+                     int64_t *n_out, int64_t *cnt_mat) {
+    DevBuf ou, oc, mat;
+    uint64_t total = 0;
+    KMAP_TRY((hamball_core<H, uint32_t>((const H *)c->uniq, c->cnt, c->n_uniq, c->k, conseq_kh, radius, revcom, ou, oc, mat, &total)));
+    *n_out = (int64_t)total;
+    if ((int64_t)total > cap) return KMAP_OK;
+    if (total) {
+        std::vector<uint32_t> tmp((size_t)total);
+        KMAP_CHECK_HIP(hipMemcpy(out_kh, ou.p, (size_t)total * sizeof(H), hipMemcpyDeviceToHost));
+        KMAP_CHECK_HIP(hipMemcpy(tmp.data(), oc.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+        CT *dst = (CT *)out_cnt;
+        for (size_t i = 0; i < (size_t)total; ++i) dst[i] = (CT)tmp[i];      // uint32 bits -> int32 wrap / int64 value, as kmap_counts_fetch
+    }
+    if (cnt_mat) KMAP_CHECK_HIP(hipMemcpy(cnt_mat, mat.p, (size_t)4 * c->k * 8, hipMemcpyDeviceToHost));
     return KMAP_OK;
 }
 
@@ -191,6 +226,17 @@ int kmap_hamball_extract(const void *uniq_host, const void *cnt_host, int64_t n,
                                                   n_out, cnt_mat);
     return hamball_extract<uint64_t, int64_t>(uniq_host, cnt_host, n, k, conseq_kh, max_ham_dist, revcom_mode, out_kh, out_cnt,
                                               n_out, cnt_mat);
+}
+
+int kmap_counts_hamball_extract(kmap_counts *c, uint64_t conseq_kh, int max_ham_dist, int revcom_mode, int64_t cap, void *out_kh,
+                                void *out_cnt, int64_t *n_out, int64_t *cnt_mat) {
+    KMAP_REQUIRE(c && c->k > 0 && n_out, "counts_hamball_extract: nothing counted yet / null output");
+    KMAP_REQUIRE(cap >= 0 && (cap == 0 || (out_kh && out_cnt)), "counts_hamball_extract: null output arrays");
+    *n_out = 0;
+    if (cnt_mat) memset(cnt_mat, 0, (size_t)4 * c->k * 8);
+    if (c->n_uniq == 0) return KMAP_OK;
+    if (c->narrow) return hamball_resident<uint32_t, int32_t>(c, conseq_kh, max_ham_dist, revcom_mode, cap, out_kh, out_cnt, n_out, cnt_mat);
+    return hamball_resident<uint64_t, int64_t>(c, conseq_kh, max_ham_dist, revcom_mode, cap, out_kh, out_cnt, n_out, cnt_mat);
 }
 
 int kmap_pos_density(const int32_t *hits, const int64_t *offs, const int32_t *pos, const int64_t *seq_len, int64_t n_seq,

@@ -1186,8 +1186,12 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
                 if output_cntmat_file.exists():
                     print(f"motif matrix file {output_cntmat_file} exist, skip generating.")
                     continue
+                # the table of the longest finals' k is still in HBM (kept for the labelled sampling): its multi-GB k{k}.pkl is not
+                # read back (C3, k = 15: 1.2 s per consensus); shorter finals read their (small) files like the reference
+                sv = savers.get(len(conseq))
                 _ex_hamball(str(res), conseq, "matrix", str(output_cntmat_file),
-                            max_ham_dist=motif_def_dict[len(conseq)].max_ham_dist)
+                            max_ham_dist=motif_def_dict[len(conseq)].max_ham_dist,
+                            resident=sv.dc if isinstance(sv, TableSaver) and dist is None else None)
         print("Motif count matrix extracted.")
 
     if count_seq is not scan_seq:

@@ -183,9 +183,23 @@ def _hamball_extract(uniq_kh_arr, uniq_kh_cnt_arr, kmer_len, conseq_kh, max_ham_
     return out_u[:n_out.value], out_c[:n_out.value], mat
 
 
-def ex_hamball_kh_arr(res_dir: str, conseq: str, max_ham_dist: int = -1, motif_def_file: str = None, revcom_mode=True):
+def _hamball_extract_resident(dc, kmer_len, conseq_kh, max_ham_dist, revcom_mode):
+    """the ball over the table a DeviceCounts handle holds in HBM (two calls: how many members, then the members)"""
+    n_out = _ffi.i64(0)
+    args = (dc._h, int(conseq_kh), int(max_ham_dist), int(bool(revcom_mode)))
+    check(_ffi.lib().kmap_counts_hamball_extract(*args, 0, None, None, C.byref(n_out), None))
+    n = n_out.value
+    u, c = np.empty(n, get_hash_dtype(kmer_len)), np.empty(n, get_cnt_dtype(kmer_len))
+    if n:
+        check(_ffi.lib().kmap_counts_hamball_extract(*args, n, ptr(u), ptr(c), C.byref(n_out), None))
+        assert n_out.value == n
+    return u, c
+
+
+def ex_hamball_kh_arr(res_dir: str, conseq: str, max_ham_dist: int = -1, motif_def_file: str = None, revcom_mode=True, resident=None):
     """(hashes, counts) of the counted k-mers inside the Hamming ball of `conseq`, reverse-complement members re-oriented
-    to the consensus -- reference motif_discovery.py:924-975"""
+    to the consensus -- reference motif_discovery.py:924-975.  resident: a DeviceCounts handle that still holds the whole table of
+    k{len(conseq)}.pkl in HBM (scan_motif's own call): the file is not read back"""
     conseq = conseq.upper()
     assert all(e in ("A", "C", "G", "T") for e in conseq)
     kmer_len = len(conseq)
@@ -194,11 +208,13 @@ def ex_hamball_kh_arr(res_dir: str, conseq: str, max_ham_dist: int = -1, motif_d
         assert conseq_kh <= revcom_hash(conseq_kh, kmer_len)
     assert Path(motif_def_file).exists()
     assert Path(res_dir).exists()
+    if max_ham_dist == -1:
+        max_ham_dist = init_motif_def_dict(motif_def_file)[kmer_len].max_ham_dist
+    if resident is not None and resident.k == kmer_len and getattr(resident, "_shard", None) is None:
+        return _hamball_extract_resident(resident, kmer_len, conseq_kh, max_ham_dist, revcom_mode)
     with open(Path(res_dir) / FileNameDict["kmer_count_dir"] / f"k{kmer_len}.pkl", "rb") as fh:
         res_list = pickle.load(fh)
     assert res_list[0] == kmer_len
-    if max_ham_dist == -1:
-        max_ham_dist = init_motif_def_dict(motif_def_file)[kmer_len].max_ham_dist
     u, c, _ = _hamball_extract(res_list[1], res_list[2], kmer_len, conseq_kh, max_ham_dist, revcom_mode, want_mat=False)
     return u, c
 
@@ -209,8 +225,9 @@ def cal_cnt_mat(uniq_kh_arr, uniq_kh_cnt_arr, kmer_len):
     return mat.astype(int)
 
 
-def _ex_hamball(res_dir: str, conseq: str, return_type: str, output_file: str, max_ham_dist: int = -1):
-    """`kmap ex_hamball`: write the ball as hash,count / kmer,count lines or as the count matrix -- reference :489-530"""
+def _ex_hamball(res_dir: str, conseq: str, return_type: str, output_file: str, max_ham_dist: int = -1, resident=None):
+    """`kmap ex_hamball`: write the ball as hash,count / kmer,count lines or as the count matrix -- reference :489-530.
+    resident: see ex_hamball_kh_arr"""
     from ._toml import load_toml
     config_file_path = Path(res_dir) / FileNameDict["config_file"]
     assert config_file_path.exists()
@@ -218,7 +235,7 @@ def _ex_hamball(res_dir: str, conseq: str, return_type: str, output_file: str, m
     assert return_type in ("hash", "kmer", "matrix")
     motif_def_file_path = Path(res_dir) / FileNameDict["motif_def_file"]
     revcom_mode = config_dict["kmer_count"]["revcom_mode"]
-    uniq_kh_arr, uniq_kh_cnt_arr = ex_hamball_kh_arr(res_dir, conseq, max_ham_dist, motif_def_file_path, revcom_mode)
+    uniq_kh_arr, uniq_kh_cnt_arr = ex_hamball_kh_arr(res_dir, conseq, max_ham_dist, motif_def_file_path, revcom_mode, resident=resident)
     kmer_len = len(conseq)
     with open(output_file, "w+") as fh:
         if return_type == "hash":

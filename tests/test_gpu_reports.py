@@ -80,6 +80,37 @@ def test_hamball_extract_random_vs_oracle(R, O, k):
     assert len(R._hamball_extract(u[:0], c[:0], k, cons, 1, True)[0]) == 0
 
 
+@pytest.mark.parametrize("k", [8, 15, 16, 21])
+def test_hamball_extract_from_the_resident_table(R, O, k):
+    """scan_motif's own Hamming-ball call reads the table a counts handle still holds in HBM instead of k{k}.pkl: same members,
+    same order, same dtypes as the extraction from the host arrays (and as the oracle)"""
+    import ctypes as C
+    from kmap_amd import _ffi
+    from kmap_amd._ffi import check, ptr
+    from kmap_amd.kmer_count import DeviceCounts
+    rng = np.random.default_rng(300 + k)
+    u = np.unique(rng.integers(0, 4 ** k, size=150_000, dtype=np.uint64)).astype(O.get_hash_dtype(k))
+    c = rng.integers(1, 1000, size=len(u)).astype(O.get_cnt_dtype(k))
+    cons = int(u[len(u) // 2])
+    if cons > int(O.revcom_hash(cons, k)):
+        cons = int(O.revcom_hash(cons, k))
+    dc = DeviceCounts()
+    try:
+        check(_ffi.lib().kmap_counts_load(dc._h, ptr(u), ptr(c), len(u), k))
+        dc.k, dc.n_uniq = k, len(u)
+        for r, rc in ((0, True), (max(1, k // 3), True), (k // 2, False), (k, True)):
+            hu, hc, _ = R._hamball_extract(u, c, k, cons, r, rc, want_mat=False)
+            du, dcnt = R._hamball_extract_resident(dc, k, cons, r, rc)
+            assert du.dtype == hu.dtype and dcnt.dtype == hc.dtype
+            np.testing.assert_array_equal(du, hu)
+            np.testing.assert_array_equal(dcnt, hc)
+            ou, oc = O.ex_hamball(u, c, k, cons, r, rc)
+            np.testing.assert_array_equal(du, ou)
+            np.testing.assert_array_equal(dcnt, oc)
+    finally:
+        dc.close()
+
+
 def test_pos_density_golden(R, golden):
     g = golden("report.npz")
     x_arr = np.arange(0, 1.01, 0.01)
