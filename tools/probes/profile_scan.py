@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""cProfile of a C3 `scan_motif` (k = 6..9) in-process: where the host time of the verb goes (second run: warm library)."""
+"""cProfile of a C3 `scan_motif` in-process: where the host time of the verb goes (second run: warm library).
+    python tools/probes/profile_scan.py [C3] [max_k = 9] [reports]"""
 import cProfile
 import io
 import pstats
@@ -16,10 +17,11 @@ def main():
     from kmap_amd import e2e, synth, motif_discovery as md
     cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
     max_k = int(sys.argv[2]) if len(sys.argv) > 2 else 9
+    reports = len(sys.argv) > 3 and sys.argv[3] == "reports"      # the reference's default report flags on
     c = e2e.CONFIGS[cfg]
     reads = e2e.synth_config_reads(cfg)
     over = {"kmer_count": {"min_k": 6, "max_k": max_k},
-            "motif_discovery": {"motif_pos_density_flag": False, "motif_co_occurence_flag": False, "gen_hamball_flag": False,
+            "motif_discovery": {"motif_pos_density_flag": reports, "motif_co_occurence_flag": reports, "gen_hamball_flag": reports,
                                 "n_total_sample": c["n_total"], "n_motif_sample": c["n_motif"]},
             "visualization": {"gen_fig_flag": False, "random_seed": 7, "n_max_iter": 10}}
     for rep in range(2):
