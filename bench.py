@@ -1138,13 +1138,17 @@ def main():
                             "exact": pack(run_e2e("C3", "exact", reads=reads))}}
             if args.e2e == "full":
                 e2e["k6_16"] = {"default": pack(run_e2e("C3", "default", min_k=6, max_k=16, reads=reads))}
+                # BASELINE.md switches the report flags off on both sides; a user of the reference's config.toml has them ON: the
+                # position-density, co-occurrence and Hamming-ball DATA files (no figures) next to the k = 6..9 run
+                e2e["k6_9"]["reports"] = pack(run_e2e("C3", "default", reads=reads, reports=True))
             e2e["workload"] = (f"C3: {first['n_reads']} x {first['read_len']} bp synthetic reads, N={first['n_total']} sampled k-mers, "
                                f"{first['iters']} iterations, 1 GPU, clean res_dir; k6_9: k = 6..9 (longest final = the configs' k = 8), k6_16: the "
                                f"reference's default k range (default_config.toml:7-8); default = the package default = SEQ, the reference's "
                                f"arithmetic and summation order at every N, neighbours by np.argpartition up to N = 65536 (the parity-grade number; "
                                f"top-k / draws by the device rules above 4e6 unique k-mers), fast = config.toml visualization.embed_mode = \"fast\" (opt-in: wavefront-parallel "
                                f"row sums, per-step pinned), exact = config.toml general.exact = true (SEQ + np.argpartition neighbours / top-k + "
-                               f"np.random.multinomial at every size: the strict drop-in run)")
+                               f"np.random.multinomial at every size: the strict drop-in run), reports = default + the reference's default report flags "
+                               f"(motif_pos_density_flag, motif_co_occurence_flag, gen_hamball_flag) on")
             reads = None          # 1.5 GB of host memory back before the next legs
             c2 = run_e2e("C2", "default")
             e2e["c2"] = {"default": pack(c2), "workload": (f"C2: {c2['n_reads']} x {c2['read_len']} bp synthetic reads, N={c2['n_total']} sampled k-mers, "

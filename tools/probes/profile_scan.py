@@ -35,7 +35,7 @@ def main():
         md._scan_motif(str(res))
         pr.disable()
         print(f"run {rep}: {time.perf_counter() - t0:.3f} s", {k: round(v, 3) for k, v in md.STAGE_TIMES.items()})
-        if rep == 1:
+        if rep == int(__import__('os').environ.get('PROFILE_REP', '1')):
             s = io.StringIO()
             pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
             print(s.getvalue())
