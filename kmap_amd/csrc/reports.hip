@@ -163,11 +163,19 @@ int hamball_resident(kmap_counts *c, uint64_t conseq_kh, int radius, int revcom,
     *n_out = (int64_t)total;
     if ((int64_t)total > cap) return KMAP_OK;
     if (total) {
-        std::vector<uint32_t> tmp((size_t)total);
         KMAP_CHECK_HIP(hipMemcpy(out_kh, ou.p, (size_t)total * sizeof(H), hipMemcpyDeviceToHost));
-        KMAP_CHECK_HIP(hipMemcpy(tmp.data(), oc.p, (size_t)total * 4, hipMemcpyDeviceToHost));
-        CT *dst = (CT *)out_cnt;
-        for (size_t i = 0; i < (size_t)total; ++i) dst[i] = (CT)tmp[i];      // uint32 bits -> int32 wrap / int64 value, as kmap_counts_fetch
+        // counts: uint32 on the device -> the caller's int32 (same bits) / int64 (widened in place, from the back: the uint32 values
+        // are first copied into the low half of the caller's own buffer -- no host temporary, whatever the radius)
+        char *bytes = (char *)out_cnt;
+        KMAP_CHECK_HIP(hipMemcpy(bytes, oc.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+        if (sizeof(CT) == 8) {
+            for (size_t i = (size_t)total; i-- > 0;) {                       // entry i's 8 bytes cover the uint32 entries 2 i, 2 i + 1 >= i
+                uint32_t v;
+                memcpy(&v, bytes + 4 * i, 4);
+                const int64_t w = (int64_t)v;
+                memcpy(bytes + 8 * i, &w, 8);
+            }
+        }
     }
     if (cnt_mat) KMAP_CHECK_HIP(hipMemcpy(cnt_mat, mat.p, (size_t)4 * c->k * 8, hipMemcpyDeviceToHost));
     return KMAP_OK;
