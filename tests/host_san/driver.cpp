@@ -5,12 +5,14 @@
 //   driver fasta <in.fa[.gz]> <seq.bin> <borders.bin>      arrays as kmap_fasta_open / _read return them
 //   driver csv <out_i32.csv> <out_u8.csv> <n_seq> <seed>    the same synthetic hit lists through both CSV entry points
 //   driver pool <n>                                         u32 -> i64 (unaligned destination), u32 -> u64, u32 -> u32 conversions
+//   driver f2 <values.f64> <out.tsv> <medians.f64>          the "%.2f" line writer of the co-occurrence file and the per-read medians
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <cmath>
 #include <vector>
 
 #include "../../include/kmap_hip.h"
@@ -110,6 +112,49 @@ int main(int argc, char **argv) {
         printf("%zu\n", n);
         return 0;
     }
-    fprintf(stderr, "usage: driver fasta|csv|pool ...\n");
+    if (argc >= 5 && !strcmp(argv[1], "f2")) {      // driver f2 <values.f64> <out.tsv> <medians.f64>: the "%.2f" line writer + the cell medians
+        FILE *fh = fopen(argv[2], "rb");
+        if (!fh) return fail("open values", -1);
+        std::vector<double> v;
+        double x;
+        while (fread(&x, 8, 1, fh) == 1) v.push_back(x);
+        fclose(fh);
+        FILE *out = fopen(argv[3], "wb");
+        if (!out) return fail("open output", -1);
+        fputs("pair\n", out);
+        fflush(out);
+        int rc = kmap_write_f2_tsv_line(fileno(out), v.data(), (int64_t)v.size());
+        if (rc == KMAP_OK) rc = kmap_write_f2_tsv_line(fileno(out), nullptr, 0);          // an empty line
+        fclose(out);
+        if (rc != KMAP_OK) return fail("kmap_write_f2_tsv_line", rc);
+        if (kmap_write_f2_tsv_line(-1, v.data(), 1) == KMAP_OK) return fail("a bad descriptor must fail", 0);
+        // medians: cells of 0..4 ascending locations cut from the values' integer parts
+        std::vector<int32_t> hits, pos;
+        size_t at = 0;
+        for (size_t r = 0; at < v.size() && r < 200000; ++r) {
+            const int h = (int)(r % 5);
+            int32_t p = 0;
+            int got = 0;
+            for (; got < h && at < v.size(); ++got, ++at) {
+                const double a = std::isfinite(v[at]) ? std::fabs(v[at]) : 0.0;
+                p += (int32_t)std::fmod(a, 1000.0);
+                pos.push_back(p);
+            }
+            hits.push_back(got);
+        }
+        std::vector<double> med(hits.size());
+        rc = kmap_cell_medians_i32(hits.data(), pos.data(), (int64_t)hits.size(), (int64_t)pos.size(), med.data());
+        if (rc != KMAP_OK) return fail("kmap_cell_medians_i32", rc);
+        if (!hits.empty() && kmap_cell_medians_i32(hits.data(), pos.data(), (int64_t)hits.size(), (int64_t)pos.size() + 1, med.data()) == KMAP_OK)
+            return fail("hit counts that do not add up must fail", 0);
+        std::vector<double> packed;                                                         // hits, then positions, then medians, as f64
+        for (int32_t h : hits) packed.push_back(h);
+        for (int32_t p : pos) packed.push_back(p);
+        for (double m : med) packed.push_back(m);
+        if (!dump(argv[4], packed.data(), packed.size() * 8)) return fail("dump", -1);
+        printf("%zu %zu %zu\n", v.size(), hits.size(), pos.size());
+        return 0;
+    }
+    fprintf(stderr, "usage: driver fasta|csv|pool|f2 ...\n");
     return 64;
 }

@@ -210,3 +210,22 @@ def test_conversion_pool(drivers, san):
     """u32 -> i64 into an UNALIGNED destination (the memory-mapped pickle view of TableSaver), u32 -> u64, u32 -> u32, empty input"""
     assert int(_run(drivers[san], "pool", 2_500_000).strip()) == 2_500_000
     assert int(_run(drivers[san], "pool", 1000).strip()) == 1000
+
+
+@pytest.mark.parametrize("san,threads", [("asan", "16"), ("tsan", "8"), ("tsan", "1")])
+def test_f2_line_writer_and_cell_medians(drivers, tmp_path, san, threads):
+    """kmap_write_f2_tsv_line (formatter threads, one writer) and kmap_cell_medians_i32 under the sanitizers: the line equals
+    Python's f"{x:.2f}" join, the medians equal numpy's per cell"""
+    rng = np.random.default_rng(11)
+    vals = np.concatenate([rng.integers(-300, 300, 150_000) / 2.0, rng.normal(size=50_000) * 37,
+                           [0.0, -0.0, 0.005, 0.015, 1e15, -1e15, 1e16, 1e300, float("inf"), float("-inf"), float("nan"), 2.0 ** 52 + 0.5]])
+    (tmp_path / "v.f64").write_bytes(vals.astype(np.float64).tobytes())
+    out = _run(drivers[san], "f2", tmp_path / "v.f64", tmp_path / "o.tsv", tmp_path / "m.f64", env={"KMAP_IO_THREADS": threads})
+    n, n_cells, n_pos = (int(t) for t in out.split())
+    assert n == len(vals)
+    assert (tmp_path / "o.tsv").read_text() == "pair\n" + "\t".join(f"{x:.2f}" for x in vals.tolist()) + "\n\n"
+    packed = np.fromfile(tmp_path / "m.f64", np.float64)
+    hits, pos, med = packed[:n_cells].astype(np.int64), packed[n_cells:n_cells + n_pos], packed[n_cells + n_pos:]
+    offs = np.concatenate([[0], np.cumsum(hits)])
+    want = np.array([np.median(pos[offs[r]:offs[r + 1]]) if hits[r] else np.nan for r in range(n_cells)])
+    np.testing.assert_array_equal(med, want)
