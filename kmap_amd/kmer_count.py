@@ -366,14 +366,94 @@ class MotifDef:
         return ",".join(str(getattr(self, f.name)) for f in fields(self))
 
 
+def norm_ppf(q, loc, scale):
+    """scipy.stats.norm.ppf(q, loc=loc, scale=scale) for scalars, without importing scipy.stats (0.5 s in a fresh process, of which this
+    package needs two functions): the same scipy.special call behind it (norm._ppf = special.ndtri; rv_continuous.ppf returns
+    _ppf(q) * scale + loc, NaN for scale <= 0 / NaN arguments / q outside [0, 1]) -- bit-identical, asserted by test_host_logic.py"""
+    from scipy.special import ndtri
+    q, loc, scale = float(q), float(loc), float(scale)
+    if not (scale > 0.0) or loc != loc or not (0.0 <= q <= 1.0):
+        return np.float64(np.nan)
+    return np.float64(ndtri(q) * scale + loc)
+
+
+def norm_logsf(x, loc, scale):
+    """scipy.stats.norm.logsf(x, loc=loc, scale=scale) for scalars: special.log_ndtr(-((x - loc) / scale)), NaN for scale <= 0 / NaN
+    arguments (norm._logsf(x) = _norm_logcdf(-x) = special.log_ndtr(-x))"""
+    from scipy.special import log_ndtr
+    x, loc, scale = float(x), float(loc), float(scale)
+    if not (scale > 0.0) or loc != loc or x != x:
+        return np.float64(np.nan)
+    z = (x - loc) / scale
+    if z == float("-inf"):
+        return np.float64(0.0)                      # scipy assigns log(1) = +0.0 below the support; log_ndtr(inf) is -0.0
+    return np.float64(log_ndtr(-z))
+
+
+_TABLE_NEED = ("kmer_len", "max_ham_dist", "p_uniform", "ratio_mu", "ratio_std")
+
+
+def _read_motif_table_plain(motif_def_file):
+    """The rows of a motif table as (kmer_len, max_ham_dist, p_uniform, ratio_mu, ratio_std) WITHOUT pandas -- or None when the file
+    holds anything on which `pandas.read_csv` (the reference's reader, kmer_count.py:719-740) and Python's float() could disagree.
+    pandas' C parser is not correctly rounded (30 % of 17-digit strings come back up to 13 ulp off, long runs of leading zeros lose
+    digits), but a plain decimal of at most 15 digit characters is one exact integer divided by one exact power of ten in both (0
+    mismatches in 2 M random tokens); the packaged table and the one `preproc` writes are of that kind.  Everything else -- exponents,
+    longer numbers, other NA spellings, quotes, spaces, ragged rows -- returns None and the caller takes pandas."""
+    import csv
+    import re
+    try:
+        with open(motif_def_file, newline="") as fh:
+            rows = list(csv.reader(fh))
+    except (OSError, UnicodeDecodeError, csv.Error):
+        return None
+    if not rows:
+        return None
+    header = rows[0]
+    if len(set(header)) != len(header) or any(c not in header for c in _TABLE_NEED):
+        return None
+    col = {c: header.index(c) for c in _TABLE_NEED}
+    plain_int, plain_dec = re.compile(r"^[0-9]{1,9}$"), re.compile(r"^-?[0-9]*\.?[0-9]*$")
+    out, fractional = [], False
+    for r in rows[1:]:
+        if not r:
+            continue                                  # pandas skips blank lines
+        if len(r) != len(header):
+            return None
+        vals = []
+        for c in _TABLE_NEED:
+            tok = r[col[c]]
+            if c in ("kmer_len", "max_ham_dist"):
+                if not plain_int.match(tok):
+                    return None
+                vals.append(int(tok))
+            elif tok in ("", "nan", "NaN"):
+                vals.append(float("nan"))
+            else:
+                n_digits = sum(ch.isdigit() for ch in tok)
+                if not plain_dec.match(tok) or not 1 <= n_digits <= 15:
+                    return None
+                fractional = fractional or "." in tok
+                vals.append(float(tok))
+        out.append(tuple(vals))
+    # pandas hands iterrows() one float64 row as soon as any column is float: with an all-integer table it would hand out integers
+    return out if fractional else None
+
+
 def init_motif_def_dict(motif_def_file, p_value_cutoff=1e-10) -> dict:
-    import pandas as pd
-    from scipy.stats import norm
+    """reference kmer_count.py:719-740 (`pd.read_csv(...).iterrows()` + `norm.ppf`).  A fresh process pays 0.35 s for importing pandas
+    and 0.5 s for scipy.stats -- most of `scan_motif` / `preproc` at the reference's default input size -- so tables on which the plain
+    reader provably agrees with pandas are read without it (_read_motif_table_plain), and the two normal-distribution functions come
+    from scipy.special (norm_ppf / norm_logsf).  test_host_logic.py holds both to the pandas / scipy.stats path bit for bit."""
     table = {"p_value_cutoff": p_value_cutoff}
-    for _, row in pd.read_csv(motif_def_file).iterrows():
-        k = int(row["kmer_len"])
-        cutoff = norm.ppf(1 - p_value_cutoff, loc=row["ratio_mu"], scale=row["ratio_std"])
-        table[k] = MotifDef(k, row["p_uniform"], int(row["max_ham_dist"]), row["ratio_mu"], row["ratio_std"], cutoff)
+    rows = _read_motif_table_plain(motif_def_file)
+    if rows is None:
+        import pandas as pd
+        rows = [(int(row["kmer_len"]), int(row["max_ham_dist"]), row["p_uniform"], row["ratio_mu"], row["ratio_std"])
+                for _, row in pd.read_csv(motif_def_file).iterrows()]
+    for k, max_ham_dist, p_uniform, ratio_mu, ratio_std in rows:
+        cutoff = norm_ppf(1 - p_value_cutoff, loc=ratio_mu, scale=ratio_std)
+        table[k] = MotifDef(k, p_uniform, max_ham_dist, ratio_mu, ratio_std, cutoff)
     return table
 
 

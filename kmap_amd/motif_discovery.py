@@ -24,7 +24,7 @@ from . import _ffi
 from ._ffi import check, ptr
 from .hamdist import _convert_to_block_arr, cal_samp_kmer_hamdist_mat  # noqa: F401  (re-exported, reference names)
 from .kmer_count import (DeviceCounts, FileNameDict, cal_hamming_dist_head, cal_hamming_dist_tail, encode_fasta,
-                         gen_motif_def_dict, get_cnt_dtype, get_hash_dtype, get_revcom_hash_arr, hash2kmer, init_motif_def_dict,
+                         gen_motif_def_dict, get_cnt_dtype, get_hash_dtype, get_revcom_hash_arr, hash2kmer, init_motif_def_dict, norm_logsf,
                          hashes2kmers, kmer2hash, load_array_pickle,
                          mask_ham_ball, revcom_hash, reverse_complement)
 
@@ -418,7 +418,6 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
         else:
             h.close()
 
-    from scipy.stats import norm
     if boarder_pkl_file:
         assert Path(boarder_pkl_file).exists()
     own = dev_seq is None
@@ -500,7 +499,7 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
             if not hamball_ratio > ratio_cutoff:
                 break
             res[consensus_kh] = (hamball_proportion, hamball_ratio,
-                                 norm.logsf(hamball_ratio, loc=ratio_mu, scale=ratio_std) / np.log(10))
+                                 norm_logsf(hamball_ratio, loc=ratio_mu, scale=ratio_std) / np.log(10))
             cons = [consensus_kh, revcom_hash(consensus_kh, kmer_len)] if merge_revcom_mode else [consensus_kh]
             dev_seq.mask(kmer_len, np.array(cons), np.array([max_ham_dist] * len(cons)))
             dev_seq.count(dc, kmer_len, dedupe=False, merge_revcom=merge_revcom_mode)   # later rounds: no dedupe (:695)

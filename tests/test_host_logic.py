@@ -330,3 +330,91 @@ def test_co_occurrence_distance_lines_equal_python_formatting(tmp_path):
     out = tmp_path / "dist.tsv"
     write_co_occurence_dist_arr(out, d, conseqs)
     assert out.read_text() == want
+
+
+def _motif_table_by_pandas(path, p_value_cutoff=1e-10):
+    """the reference's reader, verbatim in behaviour (kmer_count.py:719-740): pandas.read_csv + iterrows + scipy.stats.norm.ppf"""
+    import pandas as pd
+    from scipy.stats import norm
+    out = {}
+    for _, row in pd.read_csv(path).iterrows():
+        k = int(row["kmer_len"])
+        out[k] = (row["p_uniform"], int(row["max_ham_dist"]), row["ratio_mu"], row["ratio_std"],
+                  norm.ppf(1 - p_value_cutoff, loc=row["ratio_mu"], scale=row["ratio_std"]))
+    return out
+
+
+def _same_float(a, b):
+    a, b = float(a), float(b)
+    return (a != a and b != b) or a.hex() == b.hex()
+
+
+def test_motif_table_without_pandas_equals_the_reference_reader(tmp_path):
+    """init_motif_def_dict reads tables of plain short decimals without importing pandas / scipy.stats (0.85 s of a fresh process):
+    bit for bit the pandas + scipy.stats result on the packaged table, on the table `preproc` writes from it, and on random tables of
+    that kind; anything pandas' parser could read differently (long numbers, exponents, odd NA spellings, spaces) is left to pandas"""
+    import random
+    import kmap_amd.kmer_count as K
+    default = K._pkg_file(K.FileNameDict["default_motif_def_file"])
+    written = tmp_path / "motif_def_table.csv"                       # as _preproc writes it: str() of every field, cut-offs included
+    tab = K.init_motif_def_dict(default)
+    written.write_text(K.MotifDef.get_field_names() + "\n" + "".join(str(tab[k]) + "\n" for k in sorted(k for k in tab if isinstance(k, int))))
+    for path, cut in ((default, 1e-10), (written, 1e-10), (default, 0.05)):
+        assert K._read_motif_table_plain(path) is not None
+        got, want = K.init_motif_def_dict(path, p_value_cutoff=cut), _motif_table_by_pandas(path, cut)
+        assert sorted(k for k in got if isinstance(k, int)) == sorted(want)
+        for k, w in want.items():
+            g = got[k]
+            assert g.max_ham_dist == w[1] and all(_same_float(a, b) for a, b in zip((g.p_uniform, g.ratio_mu, g.ratio_std, g.ratio_cutoff),
+                                                                                    (w[0], w[2], w[3], w[4]))), (path, k, g, w)
+    rng = random.Random(3)
+    n_plain = 0
+    for it in range(300):
+        lines = ["kmer_len,max_ham_dist,p_uniform,ratio_mu,ratio_std"]
+        risky = it % 3 == 0
+        for k in range(3, 3 + rng.randint(1, 12)):
+            def num():
+                r = rng.random()
+                if r < 0.15:
+                    return rng.choice(["", "nan"])
+                if risky and r < 0.4:                       # what only pandas may read: many digits, exponents, other NA words, spaces
+                    return rng.choice(["0.%017d" % rng.randint(1, 10 ** 17 - 1), "1.5e-3", "NA", " 0.5", "0.00000000468636788280", "1e-5"])
+                d = rng.randint(1, 14)
+                return "0." + "0" * rng.randint(0, 14 - d) + str(rng.randint(1, 10 ** d - 1)) if rng.random() < 0.7 else \
+                    str(rng.randint(0, 999)) + "." + str(rng.randint(0, 10 ** 8))
+            lines.append(f"{k},{rng.randint(0, 8)},{'0.' + str(rng.randint(1, 10 ** 9))},{num()},{num()}")
+        p = tmp_path / f"t{it}.csv"
+        p.write_text("\n".join(lines) + "\n")
+        plain = K._read_motif_table_plain(p)
+        n_plain += plain is not None
+        try:
+            want = _motif_table_by_pandas(p)
+        except Exception:                                   # noqa: BLE001 -- a table pandas itself rejects (e.g. " 0.5" as text)
+            assert plain is None
+            continue
+        got = K.init_motif_def_dict(p)
+        for k, w in want.items():
+            g = got[k]
+            assert g.max_ham_dist == w[1] and all(_same_float(a, b) for a, b in zip((g.p_uniform, g.ratio_mu, g.ratio_std, g.ratio_cutoff),
+                                                                                    (w[0], w[2], w[3], w[4]))), (it, k, g, w, lines)
+    assert n_plain >= 150                                   # the plain reader did take the tables meant for it
+
+
+def test_norm_functions_equal_scipy_stats():
+    """norm_ppf / norm_logsf (scipy.special behind them) against scipy.stats.norm for scalars: bit-identical, NaN where scipy says NaN"""
+    from scipy.stats import norm
+    import kmap_amd.kmer_count as K
+    rng = np.random.default_rng(0)
+    for _ in range(20_000):
+        mu, sd = rng.normal() * 3, abs(rng.normal()) * 2 + 1e-3
+        x = mu + rng.normal() * sd * rng.choice([0.1, 1, 5, 20, 60])
+        p = rng.random() * rng.choice([1, 1e-3, 1e-6, 1e-10])
+        assert _same_float(K.norm_logsf(x, mu, sd), norm.logsf(x, loc=mu, scale=sd))
+        assert _same_float(K.norm_ppf(1 - p, mu, sd), norm.ppf(1 - p, loc=mu, scale=sd))
+    nan, inf = float("nan"), float("inf")
+    for q, mu, sd in ((0.5, 1.0, 0.0), (0.5, 1.0, -1.0), (0.5, nan, 1.0), (0.5, 1.0, nan), (0.0, 1.0, 2.0), (1.0, 1.0, 2.0), (1.5, 0.0, 1.0),
+                      (-0.1, 0.0, 1.0), (1 - 1e-10, 1.0, 0.05)):
+        assert _same_float(K.norm_ppf(q, mu, sd), norm.ppf(q, loc=mu, scale=sd)), (q, mu, sd)
+    for x, mu, sd in ((1.0, 0.0, 0.0), (1.0, 0.0, -2.0), (nan, 0.0, 1.0), (1.0, nan, 1.0), (1.0, 0.0, nan), (inf, 0.0, 1.0), (-inf, 0.0, 1.0),
+                      (40.0, 1.0, 0.05), (1.3, 1.0, 0.05)):
+        assert _same_float(K.norm_logsf(x, mu, sd), norm.logsf(x, loc=mu, scale=sd)), (x, mu, sd)
