@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -254,7 +255,7 @@ inline char *put_f2(char *p, double v) {
 }
 }  // namespace
 
-extern "C" int kmap_write_f2_tsv_line(int fd, const double *v, int64_t n) {
+static int write_f2_tsv_line_impl(int fd, const double *v, int64_t n) {
     KMAP_REQUIRE(fd >= 0 && n >= 0 && (n == 0 || v), "write_f2_tsv_line: bad descriptor / null values");
     const int64_t per = 1 << 16;
     const int64_t n_chunks = (n + per - 1) / per;
@@ -313,6 +314,15 @@ extern "C" int kmap_write_f2_tsv_line(int fd, const double *v, int64_t n) {
         }
     }
     return KMAP_OK;
+}
+
+extern "C" int kmap_write_f2_tsv_line(int fd, const double *v, int64_t n) {
+    try {                                              // no C++ exception crosses the C ABI
+        return write_f2_tsv_line_impl(fd, v, n);
+    } catch (const std::bad_alloc &) {
+        kmap_set_error("write_f2_tsv_line: out of memory");
+        return KMAP_E_NOMEM;
+    }
 }
 
 // np.median of every cell of one motif's hit list (reports.Occurrence.medians): hits[r] locations of read r, ascending, stored back to
@@ -612,7 +622,7 @@ int fa_open_stream(const char *path, kmap_fasta *f, size_t size_hint) {
 }
 }  // namespace
 
-extern "C" int kmap_fasta_open(const char *path, kmap_fasta **out, int64_t *n_bytes, int64_t *n_seq) {
+static int fasta_open_impl(const char *path, kmap_fasta **out, int64_t *n_bytes, int64_t *n_seq) {
     KMAP_REQUIRE(path && out && n_bytes && n_seq, "fasta_open: null argument");
     std::unique_ptr<kmap_fasta> f(new kmap_fasta());
     f->threads = fa_threads();
@@ -702,7 +712,16 @@ extern "C" int kmap_fasta_open(const char *path, kmap_fasta **out, int64_t *n_by
     return KMAP_OK;
 }
 
-extern "C" int kmap_fasta_read(kmap_fasta *f, uint8_t *seq_out, int64_t *borders_out) {
+extern "C" int kmap_fasta_open(const char *path, kmap_fasta **out, int64_t *n_bytes, int64_t *n_seq) {
+    try {                                              // the handle's vectors / the header positions of a gzip stream may not fit
+        return fasta_open_impl(path, out, n_bytes, n_seq);
+    } catch (const std::bad_alloc &) {
+        kmap_set_error("fasta_open: out of memory");
+        return KMAP_E_NOMEM;
+    }
+}
+
+static int fasta_read_impl(kmap_fasta *f, uint8_t *seq_out, int64_t *borders_out) {
     KMAP_REQUIRE(f, "fasta_read: null handle");
     KMAP_REQUIRE((f->n_bytes == 0 || seq_out) && (f->n_seq == 0 || borders_out), "fasta_read: null output");
     if (f->n_seq == 0) return KMAP_OK;
@@ -736,6 +755,15 @@ extern "C" int kmap_fasta_read(kmap_fasta *f, uint8_t *seq_out, int64_t *borders
     seq_out[total - 1] = 255;
     borders_out[2 * ((size_t)f->n_seq - 1) + 1] = (int64_t)(total - 1);
     return KMAP_OK;
+}
+
+extern "C" int kmap_fasta_read(kmap_fasta *f, uint8_t *seq_out, int64_t *borders_out) {
+    try {
+        return fasta_read_impl(f, seq_out, borders_out);
+    } catch (const std::bad_alloc &) {
+        kmap_set_error("fasta_read: out of memory");
+        return KMAP_E_NOMEM;
+    }
 }
 
 extern "C" int kmap_fasta_close(kmap_fasta *f) {
