@@ -384,8 +384,11 @@ const FaLut g_fa_lut;
 // (at most one byte per input byte, and exactly the bytes the counting walk of the same range counted); otherwise only
 // positions are counted.  on_header(input offset of the '>', output
 // position of its 255) is called for every header line that begins in the range.
+// cap (WRITE): positions the walk may fill; a walk that would go past it stops and returns FA_OVERRUN (the mapped file is not
+// what kmap_fasta_open counted any more: somebody wrote to it in between).
+constexpr size_t FA_OVERRUN = ~(size_t)0;
 template <bool WRITE, typename OnHeader>
-size_t fa_walk(const uint8_t *p0, size_t n, FaState &s, uint8_t *out, size_t k, OnHeader on_header) {
+size_t fa_walk(const uint8_t *p0, size_t n, FaState &s, uint8_t *out, size_t k, size_t cap, OnHeader on_header) {
     const uint8_t *p = p0;
     const uint8_t *const e = p0 + n;
     const uint8_t *const lut = g_fa_lut.v;
@@ -400,6 +403,7 @@ size_t fa_walk(const uint8_t *p0, size_t n, FaState &s, uint8_t *out, size_t k, 
         }
         if (s.at_line_start) {
             if (*p == '>') {
+                if (WRITE && k >= cap) return FA_OVERRUN;
                 on_header((size_t)(p - p0), k);
                 if (WRITE) out[k] = 255;
                 ++k;
@@ -419,6 +423,7 @@ size_t fa_walk(const uint8_t *p0, size_t n, FaState &s, uint8_t *out, size_t k, 
         if (body > p && body[-1] == '\r') --body;                       // CRLF files: the line's own '\r' is white space like any other
         uint32_t ws = 0;                                                // ' ', \t, \v, \f, \r (a segment holds no \n): byte compares, vectorised
         for (const uint8_t *q = p; q < body; ++q) ws += (uint32_t)((*q == 32) | ((uint8_t)(*q - 9) <= 4));
+        if (WRITE && k + ((size_t)(body - p) - ws) > cap) return FA_OVERRUN;
         if (!WRITE) {
             k += (size_t)(body - p) - ws;
         } else if (ws == 0) {
@@ -574,7 +579,7 @@ int fa_open_stream(const char *path, kmap_fasta *f, size_t size_hint) {
     FaState st;
     auto encode = [&](const uint8_t *p, size_t n) -> bool {
         if (!fa_reserve(f, n + 1)) return false;
-        f->len = fa_walk<true>(p, n, st, f->buf, f->len, [&](size_t, size_t at) { f->seps.push_back(at); });
+        f->len = fa_walk<true>(p, n, st, f->buf, f->len, f->cap, [&](size_t, size_t at) { f->seps.push_back(at); });
         return true;
     };
     if (threaded) {
@@ -678,7 +683,7 @@ static int fasta_open_impl(const char *path, kmap_fasta **out, int64_t *n_bytes,
             r.lo = cut[i];
             r.hi = cut[i + 1];
             FaState st;
-            r.out = fa_walk<false>(f->map + r.lo, r.hi - r.lo, st, nullptr, 0, [&](size_t in_at, size_t out_at) {
+            r.out = fa_walk<false>(f->map + r.lo, r.hi - r.lo, st, nullptr, 0, FA_OVERRUN, [&](size_t in_at, size_t out_at) {
                 if (r.headers++ == 0) {
                     r.first_hdr_in = in_at;
                     r.first_hdr_out = out_at;
@@ -732,6 +737,7 @@ static int fasta_read_impl(kmap_fasta *f, uint8_t *seq_out, int64_t *borders_out
         borders_out[2 * r] = (int64_t)(g + 1);
     };
     borders_out[0] = 0;
+    std::atomic<int> changed{0};
     if (f->map) {
         fa_parallel(f->ranges.size() - f->first_range, f->threads, [&](size_t j) {
             const size_t i = f->first_range + j;
@@ -745,8 +751,19 @@ static int fasta_read_impl(kmap_fasta *f, uint8_t *seq_out, int64_t *borders_out
                 st.in_header = true;
                 rank = 1;
             }
-            (void)fa_walk<true>(p, n, st, seq_out + r.base, 0, [&](size_t, size_t at) { border(rank++, r.base + at); });
+            // exactly the bytes / headers counted at open: a file that changed in between must not write past its share
+            const size_t share = i == f->first_range ? r.out - (r.first_hdr_out + 1) : r.out;
+            const size_t rank_end = r.rank0 + r.headers;
+            const size_t end = fa_walk<true>(p, n, st, seq_out + r.base, 0, share, [&](size_t, size_t at) {
+                if (rank < rank_end) border(rank, r.base + at);
+                ++rank;
+            });
+            if (end != share || rank != rank_end) changed.store(1);
         });
+        if (changed.load()) {
+            kmap_set_error("fasta_read: the file is not what fasta_open counted (modified while it was read?)");
+            return KMAP_E_STATE;
+        }
     } else {
         const size_t drop = f->seps[0] + 1;
         memcpy(seq_out, f->buf + drop, f->len - drop);

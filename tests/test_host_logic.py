@@ -418,3 +418,27 @@ def test_norm_functions_equal_scipy_stats():
     for x, mu, sd in ((1.0, 0.0, 0.0), (1.0, 0.0, -2.0), (nan, 0.0, 1.0), (1.0, nan, 1.0), (1.0, 0.0, nan), (inf, 0.0, 1.0), (-inf, 0.0, 1.0),
                       (40.0, 1.0, 0.05), (1.3, 1.0, 0.05)):
         assert _same_float(K.norm_logsf(x, mu, sd), norm.logsf(x, loc=mu, scale=sd)), (x, mu, sd)
+
+
+def test_fasta_file_changed_between_open_and_read_is_an_error(tmp_path):
+    """kmap_fasta_open counts the mapped file, kmap_fasta_read encodes it into arrays of exactly that size: a file rewritten in between
+    (more sequence bytes / other header lines than counted) must end in an error, never in a write past the caller's arrays"""
+    import ctypes as C
+    from kmap_amd import _ffi
+    lib = _ffi.lib()
+    text = b"".join(b">r%d\nACGTACGTAC\n" % i for i in range(20000))
+    for new in (b"A" * len(text), b">x\n" * (len(text) // 3) + b"\n" * (len(text) % 3), text.replace(b">r19999\n", b"ACGTACG\n")):
+        assert len(new) == len(text)
+        p = tmp_path / "c.fa"
+        p.write_bytes(text)
+        h, nb, ns = C.c_void_p(), C.c_int64(0), C.c_int64(0)
+        assert lib.kmap_fasta_open(str(p).encode(), C.byref(h), C.byref(nb), C.byref(ns)) == 0
+        with open(p, "r+b") as fh:                      # same length, other content: the private mapping shows the new bytes
+            fh.write(new)
+        guard = 4096
+        seq = np.full(nb.value + guard, 77, np.uint8)
+        borders = np.full((ns.value + 8, 2), -7, np.int64)
+        rc = lib.kmap_fasta_read(h, seq.ctypes.data_as(C.c_void_p), borders.ctypes.data_as(C.c_void_p))
+        lib.kmap_fasta_close(h)
+        assert rc != 0 and b"not what fasta_open counted" in lib.kmap_last_error()
+        assert (seq[nb.value:] == 77).all() and (borders[ns.value:] == -7).all()      # nothing behind the caller's arrays was touched
