@@ -660,6 +660,53 @@ def load_array_pickle(path, min_bytes=None, populate=True):
     return np.frombuffer(mm, dt, count=int(np.prod(shape, dtype=np.int64)), offset=offset).reshape(shape)
 
 
+class _ArrayPayload:
+    """stands for the data bytes of an ndarray inside dump_array_pickle's pickler"""
+
+    def __init__(self, view):
+        self.view = view
+
+
+class _NoCopyArrayPickler(pickle._Pickler):
+    """The Python pickler writing ONE large C-contiguous ndarray exactly as `pickle.dump(arr, fh)` does -- same opcodes, same framing
+    (a large bytes object ends the current frame and goes out as header + payload) -- except that the payload is the array's own
+    memory instead of the `arr.tobytes()` copy numpy's __reduce__ makes for protocols below 5."""
+
+    def __init__(self, fh, arr, protocol):
+        super().__init__(fh, protocol)
+        self._arr = arr
+        self.dispatch = dict(pickle._Pickler.dispatch)
+        self.dispatch[_ArrayPayload] = _NoCopyArrayPickler._save_payload
+
+    def save(self, obj, save_persistent_id=True):
+        if obj is self._arr:
+            func, args, state = np.empty(0, obj.dtype).__reduce__()          # numpy's own constructor call and state layout
+            state = (state[0], obj.shape, state[2], False, _ArrayPayload(memoryview(obj).cast("B")))
+            self.save_reduce(func, args, state, obj=obj)
+            return
+        super().save(obj, save_persistent_id)
+
+    def _save_payload(self, obj):                                             # pickle._Pickler.save_bytes, payload by reference
+        import struct
+        n = obj.view.nbytes
+        if n > 0xFFFFFFFF:
+            self._write_large_bytes(pickle.BINBYTES8 + struct.pack("<Q", n), obj.view)
+        else:
+            self._write_large_bytes(pickle.BINBYTES + struct.pack("<I", n), obj.view)
+        self.memoize(obj)
+
+
+def dump_array_pickle(arr, fh):
+    """`pickle.dump(arr, fh)` (reference kmer_count.py:333,341) without the second copy of the array: under protocol 4 numpy's
+    __reduce__ hands the pickler `arr.tobytes()` -- 1.5 GB more memory and 0.25 s at C3, 15 GB at C5's size.  Byte for byte the same
+    file (test_host_logic.py compares); small arrays, other layouts and other default protocols take pickle.dump itself."""
+    if (pickle.DEFAULT_PROTOCOL == 4 and type(arr) is np.ndarray and arr.flags.c_contiguous and arr.ndim in (1, 2) and arr.size
+            and arr.dtype.kind in "ui" and arr.dtype.isnative and arr.nbytes >= (1 << 20)):
+        _NoCopyArrayPickler(fh, arr, 4).dump(arr)
+    else:
+        pickle.dump(arr, fh)
+
+
 def proc_input(input_fasta_file: str, res_dir=".", out_bin_file_name: str = "input.bin.pkl",
                out_boarder_bin_file_name: str = "input.seqboarder.bin.pkl", debug=True):
     assert Path(input_fasta_file).exists()
@@ -670,9 +717,9 @@ def proc_input(input_fasta_file: str, res_dir=".", out_bin_file_name: str = "inp
     if debug:
         print(f"Convert input file={input_fasta_file} into binary file {out}. buffer_size={len(arr) / 2 ** 30}GB.")
     with open(out, "wb") as fh:
-        pickle.dump(arr, fh)
+        dump_array_pickle(arr, fh)
     with open(Path(res_dir) / out_boarder_bin_file_name, "wb") as fh:
-        pickle.dump(borders, fh)
+        dump_array_pickle(borders, fh)
     print(f"input binary file {out} generated.\n")
 
 

@@ -442,3 +442,28 @@ def test_fasta_file_changed_between_open_and_read_is_an_error(tmp_path):
         lib.kmap_fasta_close(h)
         assert rc != 0 and b"not what fasta_open counted" in lib.kmap_last_error()
         assert (seq[nb.value:] == 77).all() and (borders[ns.value:] == -7).all()      # nothing behind the caller's arrays was touched
+
+
+def test_dump_array_pickle_is_pickle_dump_byte_for_byte(tmp_path):
+    """preproc writes its two pickles without the `arr.tobytes()` copy numpy's __reduce__ makes under protocol 4: the same bytes as
+    `pickle.dump(arr, fh)` (what the reference writes, kmer_count.py:333,341) for the layouts it takes itself, pickle.dump for the rest;
+    the mapped loader finds the payload"""
+    import io
+    import pickle
+    import kmap_amd.kmer_count as K
+    rng = np.random.default_rng(0)
+    cases = [rng.integers(0, 5, 3_000_000, dtype=np.uint8), rng.integers(0, 1 << 40, (200_000, 2), dtype=np.int64),
+             rng.integers(0, 255, 1 << 20, dtype=np.uint8), rng.integers(0, 9, (1 << 20) + 1, dtype=np.uint8)[1:],          # offset view
+             rng.integers(0, 255, 1000, dtype=np.uint8), np.zeros(0, np.uint8),                                                 # small: pickle.dump
+             np.asfortranarray(rng.integers(0, 9, (2000, 1000), dtype=np.int64)), rng.random(300_000),                           # other layouts / dtypes
+             rng.integers(0, 9, 2_000_000, dtype=np.uint8)[::2]]
+    for a in cases:
+        want, got = io.BytesIO(), io.BytesIO()
+        pickle.dump(a, want)
+        K.dump_array_pickle(a, got)
+        assert got.getvalue() == want.getvalue(), (a.dtype, a.shape)
+    p = tmp_path / "input.bin.pkl"
+    with open(p, "wb") as fh:
+        K.dump_array_pickle(cases[0], fh)
+    assert K.locate_pickled_array(p) is not None
+    np.testing.assert_array_equal(K.load_array_pickle(p), cases[0])
