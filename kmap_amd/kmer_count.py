@@ -661,30 +661,32 @@ def load_array_pickle(path, min_bytes=None, populate=True):
 
 
 class _ArrayPayload:
-    """stands for the data bytes of an ndarray inside dump_array_pickle's pickler"""
+    """stands for the data bytes of an ndarray inside the no-copy pickler"""
 
     def __init__(self, view):
         self.view = view
 
 
-class _NoCopyArrayPickler(pickle._Pickler):
-    """The Python pickler writing ONE large C-contiguous ndarray exactly as `pickle.dump(arr, fh)` does -- same opcodes, same framing
-    (a large bytes object ends the current frame and goes out as header + payload) -- except that the payload is the array's own
-    memory instead of the `arr.tobytes()` copy numpy's __reduce__ makes for protocols below 5."""
+def _plain_big_array(obj):
+    return (type(obj) is np.ndarray and obj.flags.c_contiguous and obj.ndim in (1, 2) and obj.dtype.kind in "ui" and obj.dtype.isnative
+            and obj.nbytes >= (1 << 20))
 
-    def __init__(self, fh, arr, protocol):
+
+class _NoCopyPickler(pickle._Pickler):
+    """The Python pickler writing what `pickle.dump(obj, fh)` writes -- same opcodes, same framing (a large bytes object ends the
+    current frame and goes out as header + payload) -- except that the payload of every large plain ndarray inside `obj` is the
+    array's own memory instead of the `arr.tobytes()` copy numpy's __reduce__ makes for protocols below 5."""
+
+    def __init__(self, fh, protocol):
         super().__init__(fh, protocol)
-        self._arr = arr
         self.dispatch = dict(pickle._Pickler.dispatch)
-        self.dispatch[_ArrayPayload] = _NoCopyArrayPickler._save_payload
+        self.dispatch[_ArrayPayload] = _NoCopyPickler._save_payload
 
-    def save(self, obj, save_persistent_id=True):
-        if obj is self._arr:
-            func, args, state = np.empty(0, obj.dtype).__reduce__()          # numpy's own constructor call and state layout
-            state = (state[0], obj.shape, state[2], False, _ArrayPayload(memoryview(obj).cast("B")))
-            self.save_reduce(func, args, state, obj=obj)
-            return
-        super().save(obj, save_persistent_id)
+    def reducer_override(self, obj):                                          # asked for every object that is not in the memo yet
+        if not _plain_big_array(obj):
+            return NotImplemented
+        func, args, state = np.empty(0, obj.dtype).__reduce__()              # numpy's own constructor call and state layout
+        return func, args, (state[0], obj.shape, state[2], False, _ArrayPayload(memoryview(obj).cast("B")))
 
     def _save_payload(self, obj):                                             # pickle._Pickler.save_bytes, payload by reference
         import struct
@@ -696,15 +698,20 @@ class _NoCopyArrayPickler(pickle._Pickler):
         self.memoize(obj)
 
 
-def dump_array_pickle(arr, fh):
-    """`pickle.dump(arr, fh)` (reference kmer_count.py:333,341) without the second copy of the array: under protocol 4 numpy's
-    __reduce__ hands the pickler `arr.tobytes()` -- 1.5 GB more memory and 0.25 s at C3, 15 GB at C5's size.  Byte for byte the same
-    file (test_host_logic.py compares); small arrays, other layouts and other default protocols take pickle.dump itself."""
-    if (pickle.DEFAULT_PROTOCOL == 4 and type(arr) is np.ndarray and arr.flags.c_contiguous and arr.ndim in (1, 2) and arr.size
-            and arr.dtype.kind in "ui" and arr.dtype.isnative and arr.nbytes >= (1 << 20)):
-        _NoCopyArrayPickler(fh, arr, 4).dump(arr)
+def dump_pickle_nocopy(obj, fh, protocol=None):
+    """`pickle.dump(obj, fh)` (reference kmer_count.py:333,341, motif_discovery.py:331-345) without a second copy of the large arrays
+    in `obj`: under protocol 4 numpy's __reduce__ hands the pickler `arr.tobytes()` -- 1.5 GB more memory and 0.3 s for C3's
+    input.bin.pkl, 15 GB at C5's size.  Byte for byte the same file (test_host_logic.py compares); objects without such an array,
+    and interpreters whose default protocol is not 4, take pickle.dump itself."""
+    protocol = pickle.DEFAULT_PROTOCOL if protocol is None else protocol
+    seq = obj if isinstance(obj, (list, tuple)) else (obj,)
+    if protocol == 4 and any(_plain_big_array(x) for x in seq):
+        _NoCopyPickler(fh, 4).dump(obj)
     else:
-        pickle.dump(arr, fh)
+        pickle.dump(obj, fh, protocol=protocol)
+
+
+dump_array_pickle = dump_pickle_nocopy
 
 
 def proc_input(input_fasta_file: str, res_dir=".", out_bin_file_name: str = "input.bin.pkl",

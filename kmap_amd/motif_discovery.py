@@ -23,7 +23,7 @@ import numpy as np
 from . import _ffi
 from ._ffi import check, ptr
 from .hamdist import _convert_to_block_arr, cal_samp_kmer_hamdist_mat  # noqa: F401  (re-exported, reference names)
-from .kmer_count import (DeviceCounts, FileNameDict, cal_hamming_dist_head, cal_hamming_dist_tail, encode_fasta,
+from .kmer_count import (DeviceCounts, FileNameDict, cal_hamming_dist_head, cal_hamming_dist_tail, dump_pickle_nocopy, encode_fasta,
                          gen_motif_def_dict, get_cnt_dtype, get_hash_dtype, get_revcom_hash_arr, hash2kmer, init_motif_def_dict, norm_logsf,
                          hashes2kmers, kmer2hash, load_array_pickle,
                          mask_ham_ball, revcom_hash, reverse_complement)
@@ -463,7 +463,7 @@ def find_motif(seq_np_arr, kmer_len: int, max_ham_dist, p_unif, ratio_mu, ratio_
                 tmp = str(kmer_cnt_pkl_file) + ".tmp"
                 try:
                     with open(tmp, "wb") as fh:
-                        pickle.dump([kmer_len, uniq_kh_arr, uniq_kh_cnt_arr], fh, protocol=4)
+                        dump_pickle_nocopy([kmer_len, uniq_kh_arr, uniq_kh_cnt_arr], fh, protocol=4)   # without the arrays' tobytes() copies
                     os.replace(tmp, kmer_cnt_pkl_file)      # never a truncated k{k}.pkl under the cached name
                 except BaseException:
                     if os.path.exists(tmp):
@@ -1169,7 +1169,7 @@ def _scan_motif_impl(res_dir, debug, dist, rank, savers):
             print(f"N={len(label_arr)} > {DENSE_PKL_MAX_N}: int64 matrix not materialised (compact hand-off).")
         with _stage("write_hamdist_pkl"):
             with open(res / FileNameDict["sample_kmer_hamdist_mat_file"], "wb") as fh:
-                pickle.dump([kmer_len, hamdist_mat, label_arr], fh)
+                dump_pickle_nocopy([kmer_len, hamdist_mat, label_arr], fh)   # 200 MB of int64 at the reference's default size
         print("Hamming distance matrix of sampled kmers are generated.")
 
     with _stage("join_table_writers"):       # the k{k}.pkl files of the large tables and the occurrence CSVs are complete from here on

@@ -77,7 +77,7 @@ def synth_reads_dev(n_reads, read_len, seed, motifs=(MOTIF_A, MOTIF_B), fraction
 def write_res_dir(res_dir, seq, borders, overrides=None, fasta_name="synthetic.fa"):
     """Create a res_dir as `kmap preproc` would leave it (config.toml, motif_def_table.csv, the two pickles)."""
     from ._toml import dump_toml
-    from .kmer_count import FileNameDict, MotifDef, gen_motif_def_dict, read_default_config_file
+    from .kmer_count import FileNameDict, MotifDef, dump_pickle_nocopy, gen_motif_def_dict, read_default_config_file
     res = Path(res_dir)
     res.mkdir(parents=True, exist_ok=True)
     cfg = read_default_config_file()
@@ -92,7 +92,7 @@ def write_res_dir(res_dir, seq, borders, overrides=None, fasta_name="synthetic.f
         for k in sorted(k for k in table if isinstance(k, int)):
             fh.write(str(table[k]) + "\n")
     with open(res / FileNameDict["processed_fasta_file"], "wb") as fh:
-        pickle.dump(seq, fh, protocol=4)
+        dump_pickle_nocopy(seq, fh, protocol=4)
     with open(res / FileNameDict["processed_fasta_seqboarder_file"], "wb") as fh:
-        pickle.dump(borders, fh, protocol=4)
+        dump_pickle_nocopy(borders, fh, protocol=4)
     return cfg

@@ -462,6 +462,16 @@ def test_dump_array_pickle_is_pickle_dump_byte_for_byte(tmp_path):
         pickle.dump(a, want)
         K.dump_array_pickle(a, got)
         assert got.getvalue() == want.getvalue(), (a.dtype, a.shape)
+    m, lab = rng.integers(0, 9, (1200, 1200)).astype(np.int64), rng.integers(0, 3, 1200).astype(np.int64)
+    containers = [[8, m, lab], [8, None, rng.integers(0, 3, 200_000).astype(np.int64)], [8, m, m], (m,), [1, 2, "x"],
+                  [rng.integers(0, 1 << 16, 300_000).astype(np.uint32), rng.integers(1, 9, 300_000).astype(np.int64),
+                   rng.integers(0, 3, 300_000).astype(np.int64), ["ACGTACGT", "GGGTTTAA"]]]            # the shapes scan_motif writes
+    for o in containers:
+        for proto in (None, 4, 5, 3):
+            want, got = io.BytesIO(), io.BytesIO()
+            pickle.dump(o, want, **({} if proto is None else {"protocol": proto}))
+            K.dump_pickle_nocopy(o, got, protocol=proto)
+            assert got.getvalue() == want.getvalue(), (type(o), proto)
     p = tmp_path / "input.bin.pkl"
     with open(p, "wb") as fh:
         K.dump_array_pickle(cases[0], fh)
