@@ -604,8 +604,27 @@ def _visualize_kmers_impl(res_dir, debug, mode, dist, rank, neighbor_inds_mat=No
         random_seed = None
     else:
         assert isinstance(random_seed, (int, float))
-    with open(Path(res_dir) / FileNameDict["sample_kmer_hamdist_mat_file"], "rb") as fh:
-        kmer_len, hamdist_mat, label_arr = pickle.load(fh)
+    warm = None
+    if dist is None:
+        # a fresh process pays 0.1 - 0.2 s for loading the library, the HIP runtime and the first allocation: beside the unpickling of
+        # the hand-over (200 MB of int64 at the reference's default size) instead of behind it
+        import threading
+
+        def _warm():
+            try:
+                b = _ffi.DeviceBuffer.from_numpy(np.zeros(1 << 16, np.uint8))
+                _ffi.sync()
+                b.free()
+            except Exception:     # noqa: BLE001 -- warm-up only: a real problem surfaces on the main thread
+                pass
+        warm = threading.Thread(target=_warm)
+        warm.start()
+    try:
+        with open(Path(res_dir) / FileNameDict["sample_kmer_hamdist_mat_file"], "rb") as fh:
+            kmer_len, hamdist_mat, label_arr = pickle.load(fh)
+    finally:
+        if warm is not None:
+            warm.join()
     if hamdist_mat is None:
         # compact hand-off written by scan_motif above the int64-matrix size threshold
         with open(Path(res_dir) / FileNameDict["sample_kmer_pkl_file"], "rb") as fh:
