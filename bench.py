@@ -331,6 +331,8 @@ def cpu_baseline(kh, lab, conseq_lens, quick=False):
                                                "one_core_rows": rows1, "loss_first_iteration_x2": 2.0 * loss0}},
         "extrapolated_to_c3": {"find_motif_k6_9_s": {"all_cores": fm_all * c3_reads / n_reads_all, "one_core": fm_one * c3_reads / n_reads_one},
                                "embedding_2500_iterations_s": {"all_cores": it_all * c3_iters, "one_core": it_one * c3_iters},
+                               "total_s": {"all_cores": fm_all * c3_reads / n_reads_all + it_all * c3_iters,
+                                           "one_core": fm_one * c3_reads / n_reads_one + it_one * c3_iters},
                                "note": "linear extrapolation (reads x, iterations x); the occurrence scans, neighbour smoothing and file "
                                        "writing of the two verbs are NOT included -- a lower bound of the CPU job"},
         "sample": (f"oracle/kmap_cpu_baseline.c (gcc -O2 -fopenmp): find_motif k=6..9 on {n_reads_all} x 150 bp synthetic reads with {T} threads and on "
@@ -542,7 +544,7 @@ def e2e_dist_leg(dist, rank, reads, modes=("default", "fast")):
     return out
 
 
-def shard_proxy(G, reads, res_dir, c3s, overhead_ms):
+def shard_proxy(G, reads, res_dir, c3s, overhead_ms, first=None):
     """ONE GPU, N = 1 only: every rank's share of a G-GPU run, one after the other on this GPU, so that the shapes a G-GPU node will
     run are measured before such a node exists.  Per stage: `shard_ms` (HIP-event median per shard), `max_shard_ms`,
     `one_gpu_ms` (the unsharded stage, same code, same run), `work_inflation` = sum of the shards / one_gpu_ms, and
@@ -653,9 +655,65 @@ def shard_proxy(G, reads, res_dir, c3s, overhead_ms):
     for name, v in t.items():
         out["stages"]["reads_" + name] = entry(v[1:], v[0], 0.0, "collective not included: " + coll[name])
     out["exchange_overhead_ms_per_iteration"] = overhead_ms
+    if first is not None:
+        out.update(predict_e2e(G, first, out["stages"]))
     out["what"] = (f"every rank's share of a {G}-GPU run timed on ONE GPU, shard after shard (HIP events, median); predicted_ms = slowest shard "
                    f"(+ the measured one-rank exchange overhead for the embedding stages); not a measurement on {G} GPUs")
     return out
+
+
+def predict_e2e(G, first, st):
+    """What the C3 default run (k = 6..9, SEQ) measured at the top of this process would take on G GPUs, stage by stage, from the
+    one-GPU stage timers of that run and the proxy's slowest-shard ratios -- the arithmetic is in `e2e_prediction` so that it can be
+    checked line by line.  A stage either SHARDS (its one-GPU seconds x predicted_ms / one_gpu_ms of the matching proxy stage; the read
+    stages' collectives are 256 KiB .. 1 MiB tables at k <= 9 and are not added) or stays SERIAL on rank 0 (as measured).  What the
+    stage timers do not cover (interpreter work between stages, file writing) is the `untimed` remainder and stays serial."""
+    S = dict(first["stages"])
+    iters = first["iters"]
+
+    def ratio(name):
+        e = st.get(name)
+        return min(1.0, e["predicted_ms"] / e["one_gpu_ms"]) if e else 1.0
+    rows = []
+
+    def add(stage, how, factor, seconds=None):
+        t = S.get(stage, 0.0) if seconds is None else seconds
+        rows.append({"stage": stage, "one_gpu_s": t, "how": how, "factor": factor, "predicted_s": t * factor})
+    # scan_motif: the per-k stages are count + mask + top-k passes over the reads (first round with dedupe, later rounds without)
+    r_cnt = ratio("reads_count_k8_dedupe")
+    r_scan = ratio("reads_scan_k8_r2")
+    add("load_inputs", "sharded: a rank maps the pickles and touches only its read range", 1.0 / G)
+    add("upload", "sharded: a rank uploads and packs its read range", 1.0 / G)
+    add("find_motif", "sharded reads (count / mask passes; ratio of reads_count_k8_dedupe) ", r_cnt)
+    add("occurrence_per_k", "sharded reads (ratio of reads_scan_k8_r2); rank 0 writes the CSV", r_scan)
+    add("occurrence_final", "sharded reads (ratio of reads_scan_k8_r2)", r_scan)
+    for name in ("sample_kmers", "write_hamdist_pkl", "join_table_writers", "hamdist_matrix_int64"):
+        if name in S:
+            add(name, "serial on rank 0", 1.0)
+    sm_known = sum(S.get(k_, 0.0) for k_ in ("load_inputs", "upload", "find_motif", "occurrence_per_k", "occurrence_final", "sample_kmers",
+                                             "write_hamdist_pkl", "join_table_writers", "hamdist_matrix_int64"))
+    add("scan_motif untimed", "serial (config, tables, merge of consensuses, file names)", 1.0, max(0.0, first["times"]["scan_motif_s"] - sm_known))
+    # visualize_kmers
+    add("viz_hamdist_matrix", "row blocks (ratio of c3_hamming_rows)", ratio("c3_hamming_rows"))
+    add("viz_knn_select", "row blocks: every rank runs the reference's np.argpartition call on ITS rows of D, one all-gather of the indices", 1.0 / G)
+    add("viz_knn_sums", "row blocks (ratio of c3_knn_sums)", ratio("c3_knn_sums"))
+    if "viz_dedupe_sums" in S:
+        add("viz_dedupe_sums", "row blocks", 1.0 / G)
+    e = st.get("c3_embed_forces_seq")
+    loop = S.get("viz_embed_loop", 0.0)
+    if e:
+        per_it_other = max(0.0, loop / iters * 1e3 - e["one_gpu_ms"])           # apply, loss, host logic per iteration: stays
+        rows.append({"stage": "viz_embed_loop", "one_gpu_s": loop, "how": f"{iters} iterations x (slowest shard's SEQ forces {e['max_shard_ms']:.3f} ms + exchange "
+                     f"{e['predicted_ms'] - e['max_shard_ms']:.3f} ms + per-iteration remainder {per_it_other:.3f} ms that does not shard)",
+                     "factor": (e["predicted_ms"] + per_it_other) / max(loop / iters * 1e3, 1e-9), "predicted_s": iters * (e["predicted_ms"] + per_it_other) * 1e-3})
+    else:
+        add("viz_embed_loop", "no proxy stage: as measured", 1.0)
+    vz_known = sum(S.get(k_, 0.0) for k_ in ("viz_hamdist_matrix", "viz_knn_select", "viz_knn_sums", "viz_dedupe_sums", "viz_embed_loop"))
+    add("visualize_kmers untimed", "serial (reading the hand-over, writing low_dim_data.tsv)", 1.0, max(0.0, first["times"]["visualize_kmers_s"] - vz_known))
+    total = sum(r_["predicted_s"] for r_ in rows)
+    return {"e2e_predicted_s": total, "e2e_one_gpu_s": first["times"]["e2e_s"], "e2e_predicted_speedup": first["times"]["e2e_s"] / total,
+            "e2e_prediction": rows,
+            "e2e_prediction_note": f"C3 k = 6..9 default (SEQ) at G = {G}: sum of the rows; a prediction from one-GPU shard timings, not a measurement on {G} GPUs"}
 
 
 def c4_leg(dist, torch, res_dir, rank, world, barrier):
@@ -786,33 +844,165 @@ def fill_rate(nbytes, reps=7):
             "what": "hipMemsetAsync of the same byte count, HIP events, same stream, same run"}
 
 
-class LegGuard:
-    """Deadline per optional multi-GPU leg: on expiry rank 0 writes the JSON line as it stands (+ "watchdog") and every rank leaves
-    with os._exit(WATCHDOG_RC) (3: the launcher and the driver see a failed run, and the line -- which carries the measured headline --
-    says which leg hung; a collective that never completes cannot be cancelled from Python)."""
+LINE_LIMIT = 4096       # bytes: the one JSON line on stdout never exceeds this (asserted before it is written)
+T_START = time.perf_counter()
 
-    def __init__(self, active, rank, fd, line, limit_s):
-        self.active, self.rank, self.fd, self.line, self.limit = active, rank, fd, line, limit_s
-        self.timer, self.name = None, None
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 1] + "~"
+
+
+def compact_line(line, detail_path):
+    """The ONE line of stdout: the contract keys, `config` (short strings), `roofline`, `cpu_baseline`, the rank identity counts and a
+    handful of scalars of the other legs.  Everything else (stages, shard_proxy, e2e stage tables, embed_dist, c4, c5, per-rank
+    identities, the prose) lives in the detail file named by `detail`.  Strict JSON (no NaN / Infinity), re-parsed and
+    length-checked here; a line that would not fit loses its optional scalars first and is asserted to fit after that."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: line[k] for k in keep}
+    c = line["config"]
+    out["config"] = {"workload": _short(c["workload"], 160), "n_kmers": c["n_kmers"], "k": c["k"], "rows_per_gpu": c["rows_per_gpu"],
+                     "final_conseq": "/".join(c["final_conseq"])[:64], "parallelism": c["parallelism"]}
+    r = line["roofline"]
+    out["roofline"] = {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
+                       "traffic": r.get("traffic"), "kernel": _short(r["kernel"], 64), "kernel_ms": r["kernel_ms"],
+                       "algorithmic_bytes": r["algorithmic_bytes"], "frac_of_achievable": r.get("frac_of_achievable")}
+    cb = line.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                               "model": _short(cb.get("cpu", {}).get("model", ""), 64), "sample": _short(cb["sample"], 200)}
+    for k in ("ranks_seen", "distinct_gpus", "dist_backend", "rccl_version"):
+        out[k] = line.get(k)
+    opt = {}
+
+    def put(name, *path):
+        d = line
+        for p_ in path:
+            if not isinstance(d, dict) or p_ not in d:
+                return
+            d = d[p_]
+        if isinstance(d, float) and not math.isfinite(d):
+            return
+        if isinstance(d, (int, float, str, bool)):
+            opt[name] = _short(d, 120) if isinstance(d, str) else d
+    put("e2e_c3_s", "e2e", "k6_9", "default", "e2e_s")                 # N = 1: both verbs, C3 k 6..9, SEQ (package default)
+    put("e2e_c3_s", "e2e", "default", "e2e_s")                         # N > 1: the same under the process group (max over ranks)
+    put("e2e_c3_fast_s", "e2e", "k6_9", "fast", "e2e_s")
+    put("e2e_c3_fast_s", "e2e", "fast", "e2e_s")
+    put("e2e_c3_k6_16_s", "e2e", "k6_16", "default", "e2e_s")
+    put("e2e_c2_s", "e2e", "c2", "default", "e2e_s")
+    put("e2e_c4_s", "c4", "e2e_s")
+    put("c5_frac", "c5", "frac")
+    put("c5_ms", "c5", "ms_median")
+    put("embed_seq_ms_per_iter", "embed_dist", "seq", "ms_per_iteration")
+    put("embed_fast_ms_per_iter", "embed_dist", "ms_per_iteration")
+    put("c4_hamming_pairs_per_s", "c4", "hamming_pairs_per_s")
+    put("c4_embed_seq_ms_per_iter", "c4", "embed_seq_ms_per_iteration")
+    put("e2e_predicted_s_g8", "shard_proxy", "e2e_predicted_s")
+    put("cpu_e2e_c3_s", "cpu_baseline", "e2e", "extrapolated_to_c3", "total_s", "all_cores")
+    put("watchdog", "watchdog")
+    sk = line.get("skipped_legs")
+    if sk:
+        opt["skipped_legs"] = _short(",".join(sk), 160)
+    er = line.get("leg_errors")
+    if er:
+        opt["leg_errors"] = _short(",".join(er), 160)
+    out["detail"] = detail_path
+    out["wall_s"] = round(time.perf_counter() - T_START, 1)
+    names = list(opt)
+    while True:
+        cand = _clean(dict(out, **{k: opt[k] for k in names}))
+        text = json.dumps(cand, allow_nan=False, separators=(",", ":"))
+        if len(text.encode()) <= LINE_LIMIT or not names:
+            break
+        names.pop()
+    assert len(text.encode()) <= LINE_LIMIT, f"bench line is {len(text.encode())} bytes"
+    back = json.loads(text)
+    assert back["metric"] == line["metric"] and "roofline" in back and "config" in back
+    return text
+
+
+def _clean(o):
+    """detail file: strict JSON too (non-finite floats -> null, numpy scalars -> Python)"""
+    if isinstance(o, dict):
+        return {str(k): _clean(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_clean(v) for v in o]
+    if isinstance(o, (np.integer,)):
+        return int(o)
+    if isinstance(o, (np.floating, float)):
+        return float(o) if math.isfinite(float(o)) else None
+    if isinstance(o, (str, int, bool)) or o is None:
+        return o
+    return str(o)
+
+
+def write_detail(line, world):
+    """the full record (every leg, stage table, per-rank identity, prose) -> gpurun_out/bench_detail_n{N}.json; returns the
+    path relative to the repo root (or None when the directory cannot be written)"""
+    rel = f"gpurun_out/bench_detail_n{world}.json"
+    try:
+        (ROOT / "gpurun_out").mkdir(exist_ok=True)
+        (ROOT / rel).write_text(json.dumps(_clean(line), allow_nan=False, indent=1) + "\n")
+        return rel
+    except Exception as e:   # noqa: BLE001
+        print(f"bench.py: detail file not written: {e}", file=sys.stderr)
+        return None
+
+
+def emit(fd, line, world):
+    """detail file + stderr summary, then the compact line to the saved stdout descriptor"""
+    rel = write_detail(line, world)
+    text = compact_line(line, rel)
+    print(f"bench.py: full record in {rel} ({(ROOT / rel).stat().st_size if rel else 0} bytes); line {len(text)} bytes", file=sys.stderr, flush=True)
+    os.write(fd, (text + "\n").encode())
+
+
+class Budget:
+    """ONE deadline for the whole command (--time-budget seconds from process start) instead of per-leg limits that add up.
+    A leg states what it is expected to cost; it starts only if that still fits (all ranks agree: MIN over ranks), otherwise its
+    name goes to `skipped_legs`.  For world > 1 a watchdog thread fires at the deadline + grace: rank 0 writes the line as it
+    stands (+ "watchdog"), every rank leaves with os._exit(WATCHDOG_RC) -- a collective that never completes cannot be
+    cancelled from Python, and the headline is already measured."""
+
+    def __init__(self, total_s, grace_s, world, rank, fd, dist=None, torch=None):
+        self.total, self.world, self.rank, self.fd, self.dist, self.torch = total_s, world, rank, fd, dist, torch
+        self.line, self.name, self.skipped, self.timer = None, "start-up", [], None
+        if world > 1:
+            import threading
+            self.timer = threading.Timer(max(1.0, total_s + grace_s - self.elapsed()), self._fire)
+            self.timer.daemon = True
+            self.timer.start()
+
+    def elapsed(self):
+        return time.perf_counter() - T_START
+
+    def left(self):
+        return self.total - self.elapsed()
 
     def _fire(self):
         if self.rank == 0 and self.line is not None:
-            self.line["watchdog"] = f"leg '{self.name}' did not return within {self.limit:.0f} s; later legs skipped, process ended by the watchdog"
+            self.line["watchdog"] = f"leg '{self.name}' still running at the deadline ({self.total:.0f} s + grace); ended by the watchdog"
+            self.line["skipped_legs"] = self.skipped
             try:
-                os.write(self.fd, (json.dumps(self.line, default=str) + "\n").encode())
+                emit(self.fd, self.line, self.world)
             except Exception:   # noqa: BLE001
                 pass
         os._exit(WATCHDOG_RC)
 
-    def leg(self, name):
-        import threading
-        self.done()
-        if not self.active:
-            return
-        self.name = name
-        self.timer = threading.Timer(self.limit, self._fire)
-        self.timer.daemon = True
-        self.timer.start()
+    def can(self, name, est_s):
+        ok = self.left() >= est_s
+        if self.dist is not None:
+            t = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device="cuda")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+            ok = bool(int(t.item()))
+        if ok:
+            self.name = name
+            print(f"bench.py: [{self.elapsed():6.1f} s] leg {name} (expected <= {est_s:.0f} s, {self.left():.0f} s left)", file=sys.stderr, flush=True)
+        else:
+            self.skipped.append(name)
+            print(f"bench.py: [{self.elapsed():6.1f} s] leg {name} SKIPPED: needs ~{est_s:.0f} s, {self.left():.0f} s left", file=sys.stderr, flush=True)
+        return ok
 
     def done(self):
         if self.timer is not None:
@@ -820,7 +1010,7 @@ class LegGuard:
             self.timer = None
 
 
-WATCHDOG_RC = 3         # exit code of every rank when a multi-GPU leg's collective never returned (the partial line is still printed)
+WATCHDOG_RC = 3         # exit code of every rank when the run hit the global deadline inside a leg (the line is still printed)
 
 
 def self_launch(n_gpus):
@@ -892,7 +1082,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-embed-dist", action="store_true", help="skip the sharded-embedding leg")
     ap.add_argument("--no-c4", action="store_true", help="skip the N = 200 000 strong-scaling leg")
-    ap.add_argument("--leg-limit", type=float, default=300.0, help="seconds an optional multi-GPU leg may take before the watchdog prints the line and ends the run")
+    ap.add_argument("--time-budget", type=float, default=270.0,
+                    help="seconds the WHOLE command may take (one deadline): an optional leg starts only if its expected cost still fits; skipped legs are named in the line")
+    ap.add_argument("--grace", type=float, default=45.0, help="multi-rank: seconds past the budget after which the watchdog prints the line as it stands and ends every rank")
+    ap.add_argument("--no-c4-e2e", action="store_true", help="skip the whole C4 run on one GPU (N=1 only; ~50 s)")
     ap.add_argument("--no-count-dist", action="store_true", help="skip the multi-GPU counting leg (k = 15: all-reduce vs key-range shards)")
     ap.add_argument("--no-c5", action="store_true", help="skip the full-size C5 scan leg (N=1 only)")
     ap.add_argument("--quick", action="store_true", help="smaller CPU-baseline samples (rehearsals)")
@@ -1022,6 +1215,7 @@ def main():
                                    f"(finals {'/'.join(conseqs)}), uint8 out, row-sharded over {world} GPU(s)",
                        "n_kmers": n, "k": K, "final_conseq": conseqs, "conseq_lens": lens, "rows_of_short_consensus_labels": short_rows,
                        "rows_per_gpu": rows_per, "pairs_per_gpu_per_step": float(nrows) * n,
+                       "parallelism": f"row blocks over {world} GPU(s); every rank holds all N hashes; no data-path collective",
                        "sample": "sample_kmers.pkl of scan_motif on 10M x 150 bp synthetic reads (k=6..9), expanded by counts"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -1046,101 +1240,80 @@ def main():
                 line["roofline"]["traffic_source"] = f"profiles/{pmc[-1].name}"
             except Exception:
                 pass
-    # ---- the optional legs (all ranks take part).  The headline above is measured and in `line`: if a leg's collective never
-    # returns on some node, the watchdog lets rank 0 print the line with what has finished and ends every rank, instead of the
-    # whole run -- headline included -- dying at the launcher's limit
-    guard = LegGuard(world > 1, rank, json_fd, line, args.leg_limit)
-    embed_dist = None
-    if not args.no_embed_dist:
-        own_group = False
-        try:
-            if dist is None:        # one GPU: the sharded loop runs on a one-rank RCCL group, so its overhead is a number in the line
-                import socket
-                import torch.distributed as dist1
-                with socket.socket() as sk:
-                    sk.bind(("127.0.0.1", 0))
-                    port = sk.getsockname()[1]
-                dist1.init_process_group("nccl" if backend == "nccl" else backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
-                                         **({"device_id": torch.device("cuda", dev)} if backend == "nccl" else {}))
-                own_group = True
-                from kmap_amd.visualization import EMBED_SEQ
-                embed_dist = embed_dist_leg(dist1, torch, 1, *c3s)
-                embed_dist["seq"] = embed_dist_leg(dist1, torch, 1, *c3s, iters=100, mode=EMBED_SEQ)
-            else:
-                from kmap_amd.visualization import EMBED_SEQ
-                guard.leg("embed_dist")
-                embed_dist = embed_dist_leg(dist, torch, world, *c3s)
-                guard.leg("embed_dist.seq")
-                embed_dist["seq"] = embed_dist_leg(dist, torch, world, *c3s, iters=100, mode=EMBED_SEQ)
-        except Exception as e:   # noqa: BLE001 -- reported, the headline is already measured
-            embed_dist = {"error": f"{type(e).__name__}: {e}"[:300]}
-        finally:
-            if own_group:
-                try:
-                    dist1.destroy_process_group()
-                except Exception:   # noqa: BLE001
-                    pass
-        if line is not None:
-            line["embed_dist"] = embed_dist
-    count_dist = None
-    if dist is not None and not args.no_count_dist:
-        _ffi.check(_ffi.lib().kmap_scratch_release(1 << 30))
-        guard.leg("count_dist")
-        count_dist = count_dist_leg(dist, torch, world)
-        _ffi.check(_ffi.lib().kmap_scratch_release(1 << 30))
-        if line is not None:
-            line["count_dist"] = count_dist
-    if dist is not None and not args.no_reads_dist:
-        if dist is not None:
-            box = [res_dir]
-            dist.broadcast_object_list(box, 0)
-            res_dir_all = box[0]
-        guard.leg("reads_dist")
-        rd = reads_dist_leg(dist, torch, world, rank, res_dir_all)
-        _ffi.check(_ffi.lib().kmap_scratch_release(1 << 30))
-        if line is not None:
-            line["reads_dist"] = rd
-    c4 = None
-    if not args.no_c4:
-        guard.leg("c4")
-        if dist is not None:
-            box = [res_dir]
-            dist.broadcast_object_list(box, 0)
-        c4 = c4_leg(dist, torch, res_dir, rank, world, barrier)
-        if line is not None:
-            line["c4"] = c4
+    # ---- the optional legs (all ranks take part), most important first, under ONE deadline (Budget): a leg starts only if its
+    # expected cost still fits.  The headline above is measured and in `line`; for world > 1 a watchdog lets rank 0 print the line
+    # with what has finished if a collective never returns, instead of the whole run -- headline included -- dying at the launcher.
+    budget = Budget(args.time_budget, args.grace, world, rank, json_fd, dist, torch)
+    budget.line = line
+    errors = []
 
-    if dist is not None and not args.no_e2e_dist:
-        guard.limit = max(guard.limit, 600.0)        # two whole runs of both verbs
-        guard.leg("e2e")
-        ed = e2e_dist_leg(dist, rank, reads)
-        if line is not None:
-            line["e2e"] = ed
-    guard.done()
-    if rank == 0:
-        if world == 1 and args.shard_proxy > 1:
-            ov = (embed_dist or {}).get("seq", {}).get("overhead_ms_per_iter") or (embed_dist or {}).get("overhead_ms_per_iter") or 0.0
-            try:
-                line["shard_proxy"] = shard_proxy(args.shard_proxy, reads, res_dir, c3s, max(float(ov), 0.0))
-            except Exception as e:   # noqa: BLE001 -- reported, the headline is already measured
-                line["shard_proxy"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        if world == 1 and not args.no_stages:
-            line["roofline"]["stages"] = stage_rooflines(reads, kh, lab, lens)
-        kh_d.free()
-        lab_d.free()
-        if world == 1 and args.e2e != "none":
+    def leg(name, est_s, fn, key=None):
+        """run one optional leg: budget-gated, its exception reported (`leg_errors`), its result under line[key or name]"""
+        if not budget.can(name, est_s):
+            return None
+        t0 = time.perf_counter()
+        try:
+            res = fn()
+        except AssertionError:
+            raise                                   # a timed result that differs from the oracle is not a result
+        except Exception as e:   # noqa: BLE001 -- reported; the headline is already measured
+            res = {"error": f"{type(e).__name__}: {e}"[:300]}
+            errors.append(name)
+        if isinstance(res, dict):
+            res["leg_wall_s"] = time.perf_counter() - t0
+        if line is not None and res is not None:
+            line[key or name] = res
+        return res
+
+    G = max(world, 1)
+    from kmap_amd.visualization import EMBED_SEQ
+    if line is not None and world == 1 and not args.no_cpu_baseline:
+        leg("cpu_baseline", 12 if args.quick else 40, lambda: cpu_baseline(kh, lab, lens, quick=args.quick))
+
+    if dist is not None:
+        box = [res_dir]
+        dist.broadcast_object_list(box, 0)
+        res_dir_all = box[0]
+        if not args.no_e2e_dist:          # north_star's own metric first: both verbs under the process group, SEQ default
+            leg("e2e", 25 + 60 / G, lambda: e2e_dist_leg(dist, rank, reads, modes=("default",)))
+        if not args.no_embed_dist:
+            leg("embed_dist.seq", 10 + 30 / G, lambda: embed_dist_leg(dist, torch, world, *c3s, iters=100, mode=EMBED_SEQ), key="embed_dist_seq")
+        if not args.no_c4:
+            leg("c4", 25 + 60 / G, lambda: c4_leg(dist, torch, res_dir_all, rank, world, barrier))
+        if not args.no_reads_dist:
+            def _reads():
+                r_ = reads_dist_leg(dist, torch, world, rank, res_dir_all)
+                _ffi.check(_ffi.lib().kmap_scratch_release(1 << 30))
+                return r_
+            leg("reads_dist", 30, _reads)
+        if not args.no_count_dist:
+            def _count():
+                _ffi.check(_ffi.lib().kmap_scratch_release(1 << 30))
+                r_ = count_dist_leg(dist, torch, world)
+                _ffi.check(_ffi.lib().kmap_scratch_release(1 << 30))
+                return r_
+            leg("count_dist", 40, _count)
+        if not args.no_embed_dist:
+            leg("embed_dist", 10 + 20 / G, lambda: embed_dist_leg(dist, torch, world, *c3s))
+        if not args.no_e2e_dist:
+            leg("e2e.fast", 25 + 40 / G, lambda: e2e_dist_leg(dist, rank, reads, modes=("fast",)), key="e2e_fast")
+        if line is not None:              # one shape for the record whatever ran: embed_dist{..., seq}, e2e{default, fast, workload}
+            ed = line.pop("embed_dist", None) or {}
+            if "embed_dist_seq" in line:
+                ed["seq"] = line.pop("embed_dist_seq")
+            if ed:
+                line["embed_dist"] = ed
+            if "e2e_fast" in line:
+                line.setdefault("e2e", {}).update({k_: v for k_, v in line.pop("e2e_fast").items() if k_ in ("fast",)})
+    else:
+        if args.e2e != "none":
             # the other half of BASELINE.json's metric: end-to-end wall time on a clean res_dir (synthetic reads are generated
             # and written outside the timed stages; scan_motif loads them from the pickles like the reference)
             def pack(r):
                 return {"scan_motif_s": r["times"]["scan_motif_s"], "visualize_kmers_s": r["times"]["visualize_kmers_s"],
                         "e2e_s": r["times"]["e2e_s"], "final_conseq": r["final_conseq"], "stages": r["stages"]}
-            e2e = {"k6_9": {"default": pack(first), "fast": pack(run_e2e("C3", "fast", reads=reads)),
-                            "exact": pack(run_e2e("C3", "exact", reads=reads))}}
-            if args.e2e == "full":
-                e2e["k6_16"] = {"default": pack(run_e2e("C3", "default", min_k=6, max_k=16, reads=reads))}
-                # BASELINE.md switches the report flags off on both sides; a user of the reference's config.toml has them ON: the
-                # position-density, co-occurrence and Hamming-ball DATA files (no figures) next to the k = 6..9 run
-                e2e["k6_9"]["reports"] = pack(run_e2e("C3", "default", reads=reads, reports=True))
+            e2e = {"k6_9": {"default": pack(first)}}
+            line["e2e"] = e2e
             e2e["workload"] = (f"C3: {first['n_reads']} x {first['read_len']} bp synthetic reads, N={first['n_total']} sampled k-mers, "
                                f"{first['iters']} iterations, 1 GPU, clean res_dir; k6_9: k = 6..9 (longest final = the configs' k = 8), k6_16: the "
                                f"reference's default k range (default_config.toml:7-8); default = the package default = SEQ, the reference's "
@@ -1149,24 +1322,76 @@ def main():
                                f"row sums, per-step pinned), exact = config.toml general.exact = true (SEQ + np.argpartition neighbours / top-k + "
                                f"np.random.multinomial at every size: the strict drop-in run), reports = default + the reference's default report flags "
                                f"(motif_pos_density_flag, motif_co_occurence_flag, gen_hamball_flag) on")
-            reads = None          # 1.5 GB of host memory back before the next legs
-            c2 = run_e2e("C2", "default")
-            e2e["c2"] = {"default": pack(c2), "workload": (f"C2: {c2['n_reads']} x {c2['read_len']} bp synthetic reads, N={c2['n_total']} sampled k-mers, "
-                                                           f"{c2['iters']} iterations (the reference's default size, default_config.toml:24-32), k = 6..9, "
-                                                           f"package default embedding mode = SEQ (the reference's summation order), 1 GPU, clean res_dir")}
-            line["e2e"] = e2e
-        reads = None
-        if world == 1 and not args.no_c5:
-            try:
-                line["c5"] = c5_leg()
-            except AssertionError:
-                raise
-            except Exception as e:   # noqa: BLE001 -- e.g. a box without the memory for it: reported, the rest of the line stands
-                line["c5"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(kh, lab, lens, quick=args.quick)
+
+            def into(d, key, fn):
+                def run():
+                    d[key] = pack(fn())
+                    return None
+                return run
+            leg("e2e.fast", 8, into(e2e["k6_9"], "fast", lambda: run_e2e("C3", "fast", reads=reads)))
+            if args.e2e == "full":
+                leg("e2e.k6_16", 12, into(e2e.setdefault("k6_16", {}), "default", lambda: run_e2e("C3", "default", min_k=6, max_k=16, reads=reads)))
+                leg("e2e.exact", 10, into(e2e["k6_9"], "exact", lambda: run_e2e("C3", "exact", reads=reads)))
+                # BASELINE.md switches the report flags off on both sides; a user of the reference's config.toml has them ON: the
+                # position-density, co-occurrence and Hamming-ball DATA files (no figures) next to the k = 6..9 run
+                leg("e2e.reports", 10, into(e2e["k6_9"], "reports", lambda: run_e2e("C3", "default", reads=reads, reports=True)))
+
+            def _c2():
+                c2 = run_e2e("C2", "default")
+                e2e["c2"] = {"default": pack(c2), "workload": (f"C2: {c2['n_reads']} x {c2['read_len']} bp synthetic reads, N={c2['n_total']} sampled k-mers, "
+                                                               f"{c2['iters']} iterations (the reference's default size, default_config.toml:24-32), k = 6..9, "
+                                                               f"package default embedding mode = SEQ (the reference's summation order), 1 GPU, clean res_dir")}
+            leg("e2e.c2", 6, _c2)
+        if not args.no_stages:
+            def _stages():
+                line["roofline"]["stages"] = stage_rooflines(reads, kh, lab, lens)
+            leg("stages", 20, _stages)
+        if not args.no_embed_dist:
+            def _embed1():
+                # one GPU: the sharded loop runs on a one-rank RCCL group, so its overhead is a number in the record
+                import socket
+                import torch.distributed as dist1
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    port = sk.getsockname()[1]
+                dist1.init_process_group("nccl" if backend == "nccl" else backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                         **({"device_id": torch.device("cuda", dev)} if backend == "nccl" else {}))
+                try:
+                    ed = embed_dist_leg(dist1, torch, 1, *c3s)
+                    ed["seq"] = embed_dist_leg(dist1, torch, 1, *c3s, iters=100, mode=EMBED_SEQ)
+                    return ed
+                finally:
+                    try:
+                        dist1.destroy_process_group()
+                    except Exception:   # noqa: BLE001
+                        pass
+            leg("embed_dist", 20, _embed1)
+        if not args.no_c4:
+            leg("c4", 25, lambda: c4_leg(None, torch, res_dir, rank, world, barrier))
+        if args.shard_proxy > 1:
+            ed = line.get("embed_dist") or {}
+            ov = (ed.get("seq") or {}).get("overhead_ms_per_iter") or ed.get("overhead_ms_per_iter") or 0.0
+            leg("shard_proxy", 35, lambda: shard_proxy(args.shard_proxy, reads, res_dir, c3s, max(float(ov), 0.0), first))
+        reads = None              # 1.5 GB of host memory back before the next legs
+        if not args.no_c5:
+            leg("c5", 20, c5_leg)
+        if not args.no_c4 and not args.no_c4_e2e:
+            def _c4e2e():
+                r_ = run_e2e("C4", "default")
+                line.setdefault("c4", {}).update({"e2e_s": r_["times"]["e2e_s"], "e2e": {
+                    "scan_motif_s": r_["times"]["scan_motif_s"], "visualize_kmers_s": r_["times"]["visualize_kmers_s"], "final_conseq": r_["final_conseq"],
+                    "n_embedded": r_["n_embedded"], "stages": r_["stages"],
+                    "workload": "C4 on ONE GPU: 10 M x 150 bp synthetic reads, k = 6..9, N = 200 000 sampled k-mers, 2500 iterations, SEQ (package default), clean res_dir"}})
+            leg("c4.e2e", 75, _c4e2e)
+    budget.done()
+    kh_d.free()
+    lab_d.free()
+    if rank == 0:
+        line["skipped_legs"] = budget.skipped
+        line["leg_errors"] = errors
+        line["time_budget_s"] = args.time_budget
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        emit(json_fd, line, world)
     if res_dir:
         import shutil
         shutil.rmtree(res_dir, ignore_errors=True)

@@ -245,8 +245,11 @@ __global__ __launch_bounds__(LDSMODE ? HP_TPB : BLK) void hist_packed_kernel(con
 // ---- the same with 16-bit LDS counters: 65 536 bins per pass (k = 8 in ONE pass instead of two, k = 9 in four instead of eight) ----
 // Two counters per LDS word, plain (non-returning) adds of 1 or 1 << 16.  A block adds at most 1024 x 16 = 16 384 windows per round of its
 // loop; every HP16_ROUNDS = 3 rounds the block meets at a barrier and sweeps the table (32 words per thread): a word with a half at or
-// above 0x4000 is emptied (atomic exchange) into the global bins.  Between two looks at a word at most 49 152 adds can land on it, so a
-// half stays below 0x4000 + 49 152 = 65 536: no carry ever reaches the neighbour.  (The returning form of the add with a check of the
+// above 0x4000 is emptied (atomic exchange) into the global bins.  A second barrier BEHIND the sweep keeps the waves that finish it early
+// from adding the next interval's windows before a slower wave has looked at its words: between two looks at a word exactly one
+// interval's adds (at most 49 152) can land on it, so a half stays below 0x4000 + 49 152 = 65 536 and no carry ever reaches the
+// neighbour -- also when ONE k-mer takes every window of a block (poly-A: tests/test_gpu_packed.py::test_hist16_single_kmer_no_carry).
+// (The returning form of the add with a check of the
 // returned word was measured first: 0.97 against 0.94 ms for the two 32-bit passes -- the returned data costs what the second pass did.)
 constexpr int HP16_BINS = 65536;
 constexpr int HP16_ROUNDS = 3;
@@ -295,6 +298,7 @@ __global__ __launch_bounds__(HP_TPB) void hist_packed16_kernel(const uint32_t *_
         if (r && r % HP16_ROUNDS == 0) {
             __syncthreads();
             sweep();
+            __syncthreads();    // no wave adds for the next interval before every word has been looked at (see above)
         }
         const uint32_t hi = nc0, lo = nc1;
         uint64_t bad = ((uint64_t)nf0 << 32) | ((uint64_t)nf1 << 16) | nf2;

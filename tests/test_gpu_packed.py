@@ -357,6 +357,30 @@ def test_hist_counter_width_switch(k):
     assert r.returncode == 0 and "case ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+@pytest.mark.parametrize("base,k", [(0, 8), (1, 8), (2, 9)])
+def test_hist16_single_kmer_no_carry(env, base, k):
+    """ONE k-mer takes every window of every block (homopolymer reads, 64 M positions = 16 rounds of the 256 x 1024-thread
+    grid, five sweeps): a 16-bit LDS half must never carry into its neighbour (even bins: the low half, carry -> the next k-mer's
+    count; odd bins: the high half, carry lost).  The count is known in closed form: sum over the reads of (len - k + 1)."""
+    _ffi, DeviceCounts, DeviceSeq, O = env
+    rng = np.random.default_rng(77 + base)
+    n_reads = 200_000
+    lens = rng.integers(250, 391, n_reads)
+    starts = np.concatenate([[0], np.cumsum(lens + 1)[:-1]])
+    seq = np.full(int((lens + 1).sum()), base, np.uint8)
+    seq[starts + lens] = 255
+    borders = np.stack([starts, starts + lens], axis=1).astype(np.int64)
+    assert len(seq) >= 256 * 1024 * 16 * 15
+    ds, dc = DeviceSeq(seq, borders), DeviceCounts()
+    ds.count(dc, k, dedupe=False, merge_revcom=False)
+    u, c = dc.fetch()
+    kmer = int(sum(base << (2 * i) for i in range(k)))
+    np.testing.assert_array_equal(u, [kmer])
+    np.testing.assert_array_equal(c, [int((lens - k + 1).sum())])
+    dc.close()
+    ds.close()
+
+
 @pytest.mark.parametrize("max_len", [512, 513])
 def test_dedupe_long_reads_both_paths(env, max_len):
     """Per-read dedupe at the length limit of the LDS-bitmap kernel: reads up to 512 positions (9 steps of 64 windows, claim masks

@@ -290,14 +290,14 @@ def test_occurrence_csv_writer_matches_python_formatting(tmp_path, narrow):
 
 
 def test_cli_fast_exit_leaves_complete_output(tmp_path):
-    """`kmap preproc` (no GPU needed) through the fast exit (os._exit after the flush) and, with KMAP_FAST_EXIT=0, through the
-    interpreter's normal shutdown: same exit code, same complete stdout through a pipe, byte-identical files; a failing run keeps
-    click's exit code either way"""
+    """`kmap preproc` (no GPU needed) through the interpreter's normal shutdown (the default) and, with KMAP_FAST_EXIT=1, through the
+    opt-in fast exit (os._exit after the flush): same exit code, same complete stdout through a pipe, byte-identical files; a failing
+    run keeps click's exit code either way; with a tool preloaded (ROCPROFILER_* in the environment) the fast exit is not taken"""
     import os
     import subprocess
     import sys
     outs = {}
-    for name, env in (("fast", {}), ("normal", {"KMAP_FAST_EXIT": "0"})):
+    for name, env in (("fast", {"KMAP_FAST_EXIT": "1"}), ("normal", {})):
         res = tmp_path / name
         e = dict(os.environ, PYTHONPATH=str(ROOT) + os.pathsep + os.environ.get("PYTHONPATH", ""), **env)
         e.pop("RANK", None)
@@ -311,6 +311,18 @@ def test_cli_fast_exit_leaves_complete_output(tmp_path):
         assert bad.returncode == 2 and "Missing option" in bad.stderr
     assert outs["fast"].keys() == outs["normal"].keys() and len(outs["fast"]) == 3
     assert outs["fast"] == outs["normal"]
+    # which way out was taken: an atexit hook (registered through sitecustomize-free -c code) runs only on the normal path
+    code = ("import atexit, sys; atexit.register(lambda: sys.stderr.write('ATEXIT_RAN\\n')); import kmap_amd; "
+            f"sys.argv = ['kmap', 'preproc', '--fasta_file', {str(GOLD / 'test.fa')!r}, '--res_dir', {str(tmp_path / 'x')!r}]; kmap_amd.main()")
+    for env, ran in (({}, True), ({"KMAP_FAST_EXIT": "1"}, False), ({"KMAP_FAST_EXIT": "1", "ROCPROFILER_TEST": "1"}, True)):
+        e = dict(os.environ, PYTHONPATH=str(ROOT) + os.pathsep + os.environ.get("PYTHONPATH", ""), **env)
+        for k_ in ("RANK", "WORLD_SIZE", "LD_PRELOAD"):
+            e.pop(k_, None)
+        if "ROCPROFILER_TEST" not in env:
+            e = {k_: v for k_, v in e.items() if not (k_.startswith("ROCPROFILER_") or k_ == "ROCP_TOOL_LIBRARIES")}
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert ("ATEXIT_RAN" in r.stderr) == ran, (env, r.stderr[-500:])
 
 
 def test_co_occurrence_distance_lines_equal_python_formatting(tmp_path):
@@ -477,3 +489,45 @@ def test_dump_array_pickle_is_pickle_dump_byte_for_byte(tmp_path):
         K.dump_array_pickle(cases[0], fh)
     assert K.locate_pickled_array(p) is not None
     np.testing.assert_array_equal(K.load_array_pickle(p), cases[0])
+
+
+def test_bench_line_is_compact_strict_json(tmp_path, monkeypatch):
+    """the ONE stdout line of bench.py is <= 4 KB strict JSON with the contract keys, `config`, `roofline`, `cpu_baseline` and
+    the rank counts, at N = 1 and at N = 8, whatever the legs put into the record (long prose, 8 per-rank identities, NaN in a
+    leg); everything else goes to the detail file, which is strict JSON too"""
+    import importlib
+    import json
+    import sys
+    sys.path.insert(0, str(ROOT))
+    bench = importlib.import_module("bench")
+    monkeypatch.setattr(bench, "ROOT", tmp_path)
+    for world in (1, 8):
+        line = {"metric": "hamming_pairs_per_s", "value": 6.1e12 * world, "unit": "pairs/s", "n_gpus": world, "steps": 20, "warmup": 5, "ms_per_step": 0.41,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                "config": {"workload": "C3 Hamming stage " + "x" * 900, "n_kmers": 50000, "k": 8, "final_conseq": ["CCTACGTA", "ATCGATA"], "conseq_lens": [8, 7],
+                           "rows_of_short_consensus_labels": 8733, "rows_per_gpu": 50000 // world, "pairs_per_gpu_per_step": 2.5e9, "parallelism": "row blocks " + "y" * 300,
+                           "sample": "s" * 500},
+                "roofline": {"bound": "hbm", "achieved": 6144.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.768, "traffic": 2503029091.2, "achievable": {"a": 1},
+                             "frac_of_achievable": 0.94, "kernel": "hamdist_tile_kernel" + "k" * 400, "kernel_ms": 0.4069, "algorithmic_bytes": 2500250000,
+                             "clock_ramp": "c" * 2000, "stages": {f"stage{i}": {"what": "w" * 300, "frac": float("nan")} for i in range(12)}},
+                "cpu_baseline": {"value": 1.0e10, "unit": "pairs/s", "cores": 16, "kind": "port", "cpu": {"model": "AMD EPYC 9575F 64-Core Processor"},
+                                 "sample": "z" * 3000, "e2e": {"extrapolated_to_c3": {"total_s": {"all_cores": 1234.5}}}},
+                "ranks_seen": world, "distinct_gpus": world, "dist_backend": "nccl", "rccl_version": "2.26.6",
+                "ranks": [{"rank": r, "device_name": "AMD Instinct MI355X", "uuid": "u" * 40, "pci_bus": "0000:05:00"} for r in range(world)],
+                "e2e": {"k6_9": {"default": {"e2e_s": 4.5, "stages": {f"s{i}": 0.1 for i in range(40)}}, "fast": {"e2e_s": 2.7}}, "workload": "p" * 4000},
+                "c5": {"frac": 0.5, "ms_median": 3.9, "what": "q" * 800}, "shard_proxy": {"e2e_predicted_s": 1.3, "stages": {f"p{i}": {"shard_ms": [1.0] * 8} for i in range(20)}},
+                "embed_dist": {"ms_per_iteration": 0.9, "seq": {"ms_per_iteration": float("inf")}}, "skipped_legs": ["c4.e2e"], "leg_errors": []}
+        text = bench.compact_line(line, f"gpurun_out/bench_detail_n{world}.json")
+        assert len(text.encode()) <= 4096 and "\n" not in text
+        back = json.loads(text, parse_constant=lambda c: pytest.fail(f"non-finite constant {c} in the line"))
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                    "config", "roofline", "cpu_baseline", "ranks_seen", "distinct_gpus", "rccl_version", "detail"):
+            assert key in back, key
+        assert back["n_gpus"] == world and back["ranks_seen"] == world and back["config"]["n_kmers"] == 50000
+        assert set(back["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes"}
+        assert set(back["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample", "model"}
+        assert back["e2e_c3_s"] == 4.5 and back["c5_frac"] == 0.5 and back["e2e_predicted_s_g8"] == 1.3 and back["skipped_legs"] == "c4.e2e"
+        assert "embed_seq_ms_per_iter" not in back or back["embed_seq_ms_per_iter"] is not None      # the inf of a leg never reaches the line
+        rel = bench.write_detail(line, world)
+        det = json.loads((tmp_path / rel).read_text(), parse_constant=lambda c: pytest.fail(f"non-finite constant {c} in the detail file"))
+        assert det["roofline"]["stages"]["stage0"]["frac"] is None and len(det["ranks"]) == world
