@@ -161,6 +161,14 @@ int kmap_hash_kmers_packed_dev(const uint32_t *codes_dev, const uint16_t *inval_
 int kmap_counts_run_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n,
                                const int64_t *borders_dev, int64_t n_seq, int k, int dedupe_per_read, int merge_revcom,
                                int64_t *n_uniq, void *stream);
+/* multi-GPU counting by KEY SPACE (11 <= k <= 16; reference kmer_count.py:476-491,643-685): every rank holds all packed reads and
+ * computes the positions [first_bin, first_bin + n_bins) -- in key order, first_bin a multiple of 8 -- of the table
+ * kmap_counts_run_packed_dev would produce from the same input, from the windows that decide those entries alone (a window with k-mer
+ * x is kept when x, or else rc(x), lies in the range): no table collective, the histogram passes shrink with the number of ranks.
+ * The handle then holds the shard (kmap_counts_table_dev / _fetch); shards concatenated in rank order are the single-GPU table. */
+int kmap_counts_run_packed_range_dev(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n,
+                                     const int64_t *borders_dev, int64_t n_seq, int k, int dedupe_per_read, int merge_revcom,
+                                     uint64_t first_bin, uint64_t n_bins, int64_t *n_uniq, void *stream);
 /* multi-GPU counting: every rank histograms ITS reads (`kmap_counts_hist_packed_dev`, k <= 16, bins zeroed
  * first; the per-read dedupe is local to a read), the caller all-reduces the 4^k uint32 bins in place
  * (`kmap_counts_bins` returns the device pointer), then every rank compacts identically (`kmap_counts_finish`). */

@@ -87,6 +87,7 @@ _SIGS = {
     "kmap_unpack_reads_dev": (i32, [vp, vp, i64, vp, vp]),
     "kmap_hash_kmers_packed_dev": (i32, [vp, vp, i64, i32, vp, vp]),
     "kmap_counts_run_packed_dev": (i32, [vp, vp, vp, i64, vp, i64, i32, i32, i32, P(i64), vp]),
+    "kmap_counts_run_packed_range_dev": (i32, [vp, vp, vp, i64, vp, i64, i32, i32, i32, u64, u64, P(i64), vp]),
     "kmap_counts_hist_packed_dev": (i32, [vp, vp, vp, i64, vp, i64, i32, i32, vp]),
     "kmap_counts_bins": (i32, [vp, P(vp), P(i64)]),
     "kmap_counts_finish": (i32, [vp, i32, i32, P(i64), vp]),

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "common.h"
+#include "counts_internal.h"
 #include "scan_util.h"
 
 int kmap_hash_launch_u32(const uint8_t *seq, int64_t n, int k, uint32_t *out, void *stream);
@@ -85,13 +86,28 @@ __device__ __forceinline__ uint64_t rc_bits(uint64_t x, int k) { return revcom_h
 
 // keep/emit decision for bin x (see merge_revcom, kmer_count.py:643-685): returns true if an
 // entry is emitted; key/cnt are the emitted values.
+// merge 3 (key-space-sharded counting, counts_internal.h): `bins` is a rank's range-mode table -- T1 = bins[0, len) holds the counts of
+// the positions lo .. lo + len, T2 = bins[half, half + len) the counts of their reverse complements that lie OUTSIDE the range (a
+// partner inside the range was counted into T1 at its own position).
 __device__ __forceinline__ bool bin_entry(const uint32_t *__restrict__ bins, uint64_t x, uint32_t c, int k, int merge, uint64_t &key,
-                                          uint32_t &cnt) {
+                                          uint32_t &cnt, const kmap_key_range &kr = kmap_key_range{}) {
     if (c == 0) return false;
     key = x;
     cnt = c;
     if (!merge) return true;
     const uint64_t r = rc_bits(x, k);
+    if (merge == 3) {
+        if (r == x) {
+            cnt = c + c;
+            return true;
+        }
+        const uint64_t ro = r - kr.lo;
+        const uint32_t cr = ro < (uint64_t)kr.len ? bins[ro] : bins[(uint64_t)kr.half + (x - kr.lo)];
+        if (cr > 0 && x > r) return false;
+        key = (x > r) ? r : x;
+        cnt = c + cr;
+        return true;
+    }
     if (merge == 2) {   // table already merged in place by rc_merge_tiles_kernel: a surviving x > rc(x) had no partner
         key = (x > r) ? r : x;
         return true;
@@ -225,7 +241,8 @@ __device__ __forceinline__ void load_bins(const uint32_t *__restrict__ bins, uin
 constexpr int CT_TPB = 8;
 // x_base: `bins` is the slice [x_base, x_base + n_bins) of the table (key-range-sharded counting; merge 0 or 2 only: no partner gathers)
 __global__ __launch_bounds__(BLK) void compact_count_kernel(const uint32_t *__restrict__ bins, uint64_t n_bins, int k,
-                                                            int merge, uint32_t *__restrict__ block_counts, unsigned n_tiles, uint64_t x_base) {
+                                                            int merge, uint32_t *__restrict__ block_counts, unsigned n_tiles, uint64_t x_base,
+                                                            kmap_key_range kr) {
     __shared__ uint32_t wsum[CT_TPB][BLK / 64];
     uint32_t m[CT_TPB];
 #pragma unroll
@@ -239,7 +256,7 @@ __global__ __launch_bounds__(BLK) void compact_count_kernel(const uint32_t *__re
         for (int j = 0; j < CT_PER_THREAD; ++j) {
             uint64_t key;
             uint32_t cnt;
-            m[t] += bin_entry(bins, x_base + x0 + j, c8[j], k, merge, key, cnt);      // bins past the end were loaded as 0
+            m[t] += bin_entry(bins, x_base + x0 + j, c8[j], k, merge, key, cnt, kr);  // bins past the end were loaded as 0
         }
     }
 #pragma unroll
@@ -257,7 +274,8 @@ __global__ __launch_bounds__(BLK) void compact_count_kernel(const uint32_t *__re
 template <typename H>
 __global__ __launch_bounds__(BLK) void compact_write_kernel(const uint32_t *__restrict__ bins, uint64_t n_bins, int k,
                                                             int merge, const uint64_t *__restrict__ block_off,
-                                                            H *__restrict__ uniq, uint32_t *__restrict__ cnt_out, uint64_t x_base) {
+                                                            H *__restrict__ uniq, uint32_t *__restrict__ cnt_out, uint64_t x_base,
+                                                            kmap_key_range kr) {
     __shared__ uint32_t wsum[BLK / 64];
     __shared__ H skey[CT_TILE];
     __shared__ uint32_t scnt[CT_TILE];
@@ -273,7 +291,7 @@ __global__ __launch_bounds__(BLK) void compact_write_kernel(const uint32_t *__re
     load_bins(bins, x0, n_bins, c8);
 #pragma unroll
     for (int j = 0; j < CT_PER_THREAD; ++j) {
-        if (bin_entry(bins, x_base + x0 + j, c8[j], k, merge, keys[j], cnts[j])) {
+        if (bin_entry(bins, x_base + x0 + j, c8[j], k, merge, keys[j], cnts[j], kr)) {
             flags |= 1u << j;
             ++m;
         }
@@ -490,19 +508,19 @@ int kmap_counts_prepare_bins(kmap_counts *c, int k, hipStream_t st) {
 // order-preserving compaction of the bins [first, first + n_bins) of the table into the handle's uniq/cnt arrays; merge: 0, 1 (partner
 // gathers over the WHOLE table: first must be 0), 2 (table merged in place beforehand)
 static int compact_range(kmap_counts *c, int k, int merge, uint64_t first, uint64_t n_bins, int64_t *n_uniq, hipStream_t st,
-                         bool merge_tiles_first = false) {
+                         bool merge_tiles_first = false, kmap_key_range kr = kmap_key_range{}) {
     const unsigned nb = grid_for((int64_t)n_bins, CT_TILE);
     uint32_t *bc = nullptr;
     uint64_t *boff = nullptr;
     KMAP_TRY(kmap_scratch((void **)&bc, (size_t)nb * 4, st, KMAP_SLOT_A));
     KMAP_TRY(kmap_scratch((void **)&boff, ((size_t)nb + 1) * 8, st, KMAP_SLOT_B));
-    const uint32_t *bins = c->bins + first;
+    const uint32_t *bins = kr.len ? c->bins : c->bins + first;          // a range-mode table (kr) starts at the range's first position
     const unsigned nblk = (nb + CT_TPB - 1) / CT_TPB;
     if (merge_tiles_first) {   // whole table, k >= 11: merge it in place; the merge counts the survivors per compaction tile as it goes
         KMAP_CHECK_HIP(hipMemsetAsync(bc, 0, (size_t)nb * 4, st));
         rc_merge_tiles_kernel<false><<<(unsigned)((size_t)1 << (2 * (k - 6))), BLK, 0, st>>>(c->bins, k, nullptr, bc);
     } else {
-        compact_count_kernel<<<nblk, BLK, 0, st>>>(bins, n_bins, k, merge, bc, nb, first);
+        compact_count_kernel<<<nblk, BLK, 0, st>>>(bins, n_bins, k, merge, bc, nb, first, kr);
     }
     KMAP_TRY(exclusive_scan_u32(bc, nb, boff, st));
     uint64_t total = 0;
@@ -520,8 +538,8 @@ static int compact_range(kmap_counts *c, int k, int merge, uint64_t first, uint6
         c->cap = cap;
     }
     if (total) {
-        if (k < 16) compact_write_kernel<uint32_t><<<nblk, BLK, 0, st>>>(bins, n_bins, k, merge, boff, (uint32_t *)c->uniq, c->cnt, first);
-        else compact_write_kernel<uint64_t><<<nblk, BLK, 0, st>>>(bins, n_bins, k, merge, boff, (uint64_t *)c->uniq, c->cnt, first);
+        if (k < 16) compact_write_kernel<uint32_t><<<nblk, BLK, 0, st>>>(bins, n_bins, k, merge, boff, (uint32_t *)c->uniq, c->cnt, first, kr);
+        else compact_write_kernel<uint64_t><<<nblk, BLK, 0, st>>>(bins, n_bins, k, merge, boff, (uint64_t *)c->uniq, c->cnt, first, kr);
     }
     KMAP_CHECK_HIP(hipGetLastError());
     c->k = k;
@@ -536,6 +554,19 @@ int kmap_counts_finish_hist(kmap_counts *c, int k, int merge, int64_t *n_uniq, h
     if (merge == 1 && k >= 11)                 // merge the table in place first; the compaction then needs no partner gathers
         return compact_range(c, k, 2, 0, (uint64_t)1 << (2 * k), n_uniq, st, true);
     return compact_range(c, k, merge, 0, (uint64_t)1 << (2 * k), n_uniq, st);
+}
+
+// compaction of a rank's range-mode table (counts_internal.h: kmap_key_range): positions lo .. lo + len in key order
+int kmap_counts_finish_key_range(kmap_counts *c, int k, kmap_key_range r, int64_t *n_uniq, hipStream_t st) {
+    return compact_range(c, k, r.half ? 3 : 0, r.lo, r.len, n_uniq, st, false, r);
+}
+// the whole table is in c->bins: merge it in place (k >= 11), then compact positions [first, first + n_bins)
+int kmap_counts_finish_hist_slice(kmap_counts *c, int k, int merge, uint64_t first, uint64_t n_bins, int64_t *n_uniq, hipStream_t st) {
+    if (merge) {
+        KMAP_REQUIRE(k >= 11, "counts: a merged slice needs k >= 11 (k=%d)", k);
+        rc_merge_tiles_kernel<false><<<(unsigned)((size_t)1 << (2 * (k - 6))), BLK, 0, st>>>(c->bins, k, nullptr, nullptr);
+    }
+    return compact_range(c, k, merge ? 2 : 0, first, n_bins, n_uniq, st);
 }
 
 namespace {

@@ -40,3 +40,34 @@ bool kmap_counts_fine_applies(int k);
 int kmap_counts_fine_hist(kmap_counts *c, const uint32_t *hash_dev, const uint32_t *codes_dev, const uint16_t *inval_dev,
                           const uint32_t *skip_dev, int64_t n, int k, hipStream_t st);
 int kmap_counts_part_add_bin(kmap_counts *c, size_t bin, const unsigned long long *extra_dev, hipStream_t st);
+
+// ---- key-space-sharded counting (multi-GPU, 11 <= k <= 16): every rank holds ALL reads and counts only the windows that decide the
+// entries of ITS key range [lo, lo + len) of the table -- no table collective.  The entry at position y of the merged table
+// (merge_revcom, kmer_count.py:643-685) depends on c(y) and c(rc y) only, so a window with key x is kept when x lies in the range
+// (virtual key x - lo: table T1) or, failing that, when rc(x) does (virtual key half + rc(x) - lo: table T2 = the partner counts of
+// the range's positions, already transposed: no reverse-complement transpose of the table is needed afterwards).  The virtual keys
+// live in a 4^vk-bin table (half = 4^vk / 2 >= len), so the partitioned histogram of a smaller k serves them: at G = 8, k = 14 a
+// rank's pass is a k = 13-shaped histogram over a quarter of the windows.
+struct kmap_key_range {
+    uint32_t lo, len;        // the rank's positions [lo, lo + len)
+    uint32_t half;           // first virtual key of the partner table T2 (0: no reverse-complement merge, own keys only)
+    int sh;                  // 32 - 2 k
+};
+__device__ __forceinline__ uint32_t kmap_range_key(uint32_t x, const kmap_key_range &r) {
+    // x: a valid k-mer hash or 0xFFFFFFFF; -> its virtual key, or 0xFFFFFFFF when neither x nor rc(x) lies in the range
+    const uint32_t own = x - r.lo;
+    uint32_t t = __builtin_bitreverse32(~x);                  // rc(x): complement, reverse the bits, restore the order inside the pairs
+    t = ((t >> 1) & 0x55555555u) | ((t & 0x55555555u) << 1);
+    const uint32_t par = (t >> r.sh) - r.lo;
+    const uint32_t v = own < r.len ? own : ((r.half && par < r.len) ? r.half + par : 0xFFFFFFFFu);
+    return x == 0xFFFFFFFFu ? x : v;
+}
+// the partitioned histogram of the virtual keys: bins [0, 4^vk) of c's table <- counts (every bin written)
+int kmap_counts_fine_hist_range(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, const uint32_t *skip_dev, int64_t n,
+                                int k, int vk, kmap_key_range r, hipStream_t st);
+int kmap_counts_part_hist_range(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, const uint32_t *skip_dev, int64_t n,
+                                int k, int vk, kmap_key_range r, unsigned long long **all_ones_dev, hipStream_t st);
+// compaction of a range-mode table (T1 = bins [0, len), T2 = bins [half, half + len)) into the handle's uniq / cnt arrays
+int kmap_counts_finish_key_range(kmap_counts *c, int k, kmap_key_range r, int64_t *n_uniq, hipStream_t st);
+// the WHOLE table is in c's bins (small inputs, reads too long for the LDS dedupe): merged in place, positions [first, first + n_bins) compacted
+int kmap_counts_finish_hist_slice(kmap_counts *c, int k, int merge, uint64_t first, uint64_t n_bins, int64_t *n_uniq, hipStream_t st);

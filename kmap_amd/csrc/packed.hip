@@ -1244,6 +1244,48 @@ int kmap_counts_run_packed_dev(kmap_counts *c, const uint32_t *codes_dev, const 
     return kmap_counts_finish_hist(c, k, merge_revcom, n_uniq, st);
 }
 
+/* Key-space-sharded counting (include/kmap_hip.h; counts_internal.h: kmap_key_range): the slice [first_bin, first_bin + n_bins) -- by
+ * POSITION in key order -- of the table kmap_counts_run_packed_dev would produce from the same reads, computed from the windows that
+ * decide it alone.  Every rank of a multi-GPU run holds all reads and calls this with its own range; the shards, concatenated in rank
+ * order, are the single-GPU table, and no table bytes are exchanged.  The histogram passes are those of a table of 2 n_bins (with
+ * merge) or n_bins (without) entries over the windows that fall into it: they shrink with the number of ranks. */
+int kmap_counts_run_packed_range_dev(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n,
+                                     const int64_t *borders_dev, int64_t n_seq, int k, int dedupe_per_read, int merge_revcom,
+                                     uint64_t first_bin, uint64_t n_bins, int64_t *n_uniq, void *stream) {
+    KMAP_REQUIRE(c, "counts_run_packed_range: null handle");
+    KMAP_REQUIRE(k >= 11 && k <= 16, "counts_run_packed_range: key ranges serve 11 <= k <= 16 (k=%d)", k);
+    KMAP_REQUIRE(n >= 0 && codes_dev && inval_dev, "counts_run_packed_range: bad input");
+    const uint64_t table = (uint64_t)1 << (2 * k);
+    KMAP_REQUIRE(n_bins > 0 && first_bin < table && n_bins <= table - first_bin && first_bin % 8 == 0,
+                 "counts_run_packed_range: range [%llu, +%llu) outside the 4^%d table or not 8-aligned", (unsigned long long)first_bin,
+                 (unsigned long long)n_bins, k);
+    hipStream_t st = as_stream(stream);
+    // the virtual table: 4^vk bins with half = 4^vk / 2 >= n_bins (merge), or 4^vk >= n_bins (no merge); at least 4^10
+    int vk = 10;
+    while ((merge_revcom ? ((uint64_t)1 << (2 * vk - 1)) : ((uint64_t)1 << (2 * vk))) < n_bins) ++vk;
+    if (k == 16 && vk < 15) vk = 15;   // the all-T 16-mer's hash is the invalid marker: only the two-level passes count its windows aside
+    uint32_t *skip = nullptr;
+    if (dedupe_per_read) {
+        KMAP_REQUIRE(n_seq == 0 || borders_dev, "counts_run_packed_range: dedupe needs borders");
+        KMAP_TRY(dedupe_skip_bits(codes_dev, inval_dev, n, borders_dev, n_seq, k, st, &skip));
+    }
+    // no gain, or no room: the whole table by the usual passes, then the slice.  (vk > k: the range is more than half of the table;
+    // vk == 16 with a range that reaches virtual key 0xFFFFFFFF = the invalid marker; small inputs; reads beyond the LDS dedupe's length.)
+    const bool ranged = kmap_counts_part_applies(k, n) && vk <= k && !(dedupe_per_read && !skip) &&
+                        !(vk == 16 && merge_revcom && n_bins > ((uint64_t)1 << 31) - 8);
+    if (!ranged) {
+        KMAP_TRY(kmap_counts_hist_packed_dev(c, codes_dev, inval_dev, n, borders_dev, n_seq, k, dedupe_per_read, stream));
+        return kmap_counts_finish_hist_slice(c, k, merge_revcom, first_bin, n_bins, n_uniq, st);
+    }
+    kmap_key_range kr;
+    kr.lo = (uint32_t)first_bin;
+    kr.len = (uint32_t)n_bins;
+    kr.half = merge_revcom ? (uint32_t)((uint64_t)1 << (2 * vk - 1)) : 0u;
+    kr.sh = 32 - 2 * k;
+    KMAP_TRY(kmap_counts_part_hist_range(c, codes_dev, inval_dev, skip, n, k, vk, kr, nullptr, st));
+    return kmap_counts_finish_key_range(c, k, kr, n_uniq, st);
+}
+
 // k <= 16: the bit-sliced formulation (bitslice.hip) on the reads' bit planes; the per-window kernels of this file serve k > 16
 static bool bitslice_on(int k) { return k <= 16; }
 

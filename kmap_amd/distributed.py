@@ -248,8 +248,18 @@ class PeerExchange:
                 why.append(_ffi.last_error())
             return rc == 0
 
+        # KMAP_PEER_TIMEOUT_MS is validated HERE, inside the first agreed step: a value that only one rank has, or that only one
+        # rank cannot parse, must fail on every rank together, not leave the others in a barrier
+        ms_env, timeout_ms = os.environ.get("KMAP_PEER_TIMEOUT_MS"), None
+        if ms_env:
+            try:
+                timeout_ms = int(ms_env)
+                if timeout_ms <= 0:
+                    raise ValueError("must be positive")
+            except ValueError as e:
+                why.append(f"KMAP_PEER_TIMEOUT_MS={ms_env!r}: {e}")
         h = _ffi.vp()
-        ok = attempt(lib.kmap_peer_create, C.byref(h), world, rank, int(lib.kmap_embed_msg_floats(n)))
+        ok = not why and attempt(lib.kmap_peer_create, C.byref(h), world, rank, int(lib.kmap_embed_msg_floats(n)))
         self._p = h.value if ok else None
         mine = np.zeros(PEER_HANDLE_BYTES + PEER_BUS_ID_BYTES, np.uint8)       # [IPC handle | PCI bus id]
         if ok:
@@ -282,10 +292,8 @@ class PeerExchange:
         if miss.value:
             why.append(f"{miss.value} of {world} handshake words did not arrive in this rank's area")
         agree(ok, "the handshake check")
-        ms = os.environ.get("KMAP_PEER_TIMEOUT_MS")
-        if ms:
-            _ffi.check(lib.kmap_peer_set_timeout_ms(self._p, int(ms)))
-        dist.barrier(group=group)                 # nobody pushes before everybody's area is mapped everywhere
+        ok = timeout_ms is None or attempt(lib.kmap_peer_set_timeout_ms, self._p, timeout_ms)
+        agree(ok, "setting the wait bound (KMAP_PEER_TIMEOUT_MS)")   # doubles as the barrier: nobody pushes before every area is mapped everywhere
 
     def _destroy_now(self):
         from . import _ffi
@@ -458,7 +466,7 @@ def kmap_from_kmers_distributed(samp_kh, samp_cnts, samp_label, conseq_list, kme
         sess = vz.EmbedSession(n, n_best_result, learning_rate, mode, row0=row0, nrows=nrows)
     rowmap_d, stored = None, nrows
     if not cyclic and mode == vz.EMBED_SEQ and nrows:
-        sums_d, rowmap_d, stored = vz.dedupe_sums_rows(sums_d, nrows, lds)     # the repeated rows of this rank's block, stored once
+        sums_d, rowmap_d, stored = vz.dedupe_sums_rows(sums_d, nrows, lds, n=n)     # the repeated rows of this rank's block, stored once
     try:
         sess.set_prob_lut(sums_d, lds, lut, rowmap_d, stored)
         sess.set_coords(ld_data, placeholders)
@@ -562,7 +570,10 @@ def _gathered_hits_cls():
     return GatheredHits
 
 
-def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None, shard_counts=None):
+KEY_SPACE_MIN_K = 12     # from here on a multi-rank count owns KEY RANGES over all reads instead of read ranges + a table collective
+
+
+def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None, shard_counts=None, key_space=None):
     """A DeviceSeq holding only this rank's reads whose count()/scan() results are global:
     count = local histogram -> all-reduce(SUM) of the 4^k uint32 bins -> identical compaction on every rank
     (k <= 16; per-read dedupe, masking and scanning are local to a read, hence to a rank).  Because every rank then
@@ -575,6 +586,15 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None, shard_counts
     at all: the table stays sharded (DeviceCounts._shard / CountShard) and find_motif works on local partials.  The reverse-complement merge pairs
     bins of different slices: it runs BEFORE the reduction on each rank's local table, steered by an all-reduced presence map
     (half a byte per bin) so that merged(sum over ranks) == sum over ranks(merged); see include/kmap_hip.h.
+    key_space (None = for KEY_SPACE_MIN_K <= k <= 16 on more than one rank; True / False force it for 11 <= k <= 16; KMAP_DIST_KEYSPACE=0 / 1
+    overrides): counting by KEY SPACE -- every rank ALSO holds all packed reads (uploaded on the first such count: 0.625 B / position) and
+    computes positions [4^k r / G, 4^k (r + 1) / G) of the table from the windows that decide them alone
+    (kmap_counts_run_packed_range_dev: a window whose k-mer, or else its reverse complement, lies in the range) -- no table bytes are
+    exchanged at all, and the histogram passes are those of a table 2 / G the size over 2 / G of the windows.  What is exchanged
+    afterwards is what the key-range form exchanges: the shard sizes, and the (k-mer, count) shards only when the table is small
+    enough not to stay sharded (CountShard).  Read-sharded counting all-reduces 4^k x 4 B per count pass (1 GiB at k = 14: >= 12 ms on
+    a ring over xGMI) and its table passes do not shrink with the ranks; masking is replayed on the full copy (a mask pass over all
+    reads per masked consensus, not sharded).
     scan() returns the hits of ALL reads (all-gathered in read order); `out_n_seq` / `out_read_len` describe the reads those
     results cover (all of them), `n_seq` / `read_len` stay the local shard the kernels run on.
     On RCCL the hit lists never pass through the host on their way to the collective: the shards are gathered as device
@@ -622,7 +642,49 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None, shard_counts
         def out_read_len(self, value):      # DeviceSeq.__init__ assigns the local shard's lengths: not what scan() covers here
             pass
 
+        # masks are LOGGED and applied on demand: to the shard before a read-sharded count of the working mask, to the full copy before
+        # a key-space count -- a k that counts by key space never pays the shard's mask passes, and vice versa
+        _full, _mask_log, _done_shard, _done_full = None, None, 0, 0
+
+        def _full_seq(self):
+            """all reads, packed, on THIS rank (key-space counting): uploaded on first use; pending masks applied"""
+            if self._full is None:
+                self._full = DeviceSeq(seq_np_arr, borders)
+                self._done_full = 0
+            log = self._mask_log or []
+            for k_, cons_, rad_ in log[self._done_full:]:     # the full copy has the reference's own cross-separator behaviour
+                DeviceSeq.mask(self._full, k_, cons_, rad_)
+            self._done_full = len(log)
+            return self._full
+
+        def _sync_shard(self):
+            log = self._mask_log or []
+            for k_, cons_, rad_ in log[self._done_shard:]:
+                self._mask_shard(k_, cons_, rad_)
+            self._done_shard = len(log)
+
+        def reset(self):
+            DeviceSeq.reset(self)
+            self._mask_log, self._done_shard, self._done_full = [], 0, 0
+            if self._full is not None:
+                self._full.reset()
+
+        def close(self):
+            if self._full is not None:
+                self._full.close()
+                self._full = None
+            DeviceSeq.close(self)
+
+        def download(self):
+            self._sync_shard()
+            return DeviceSeq.download(self)
+
         def mask(self, k, consensus_kh_arr, max_ham_dist_arr):
+            if self._mask_log is None:
+                self._mask_log = []
+            self._mask_log.append((k, np.array(consensus_kh_arr, dtype=np.uint64), np.array(max_ham_dist_arr, dtype=np.int32)))
+
+        def _mask_shard(self, k, consensus_kh_arr, max_ham_dist_arr):
             """mask_input on this rank's reads, plus the one effect that crosses a shard boundary: a window that touches a separator
             has the reference's all-ones hash ("compared like any value", kmer_count.py:580-610), so a consensus within its radius
             of the all-T k-mer also masks the window that STARTS AT the separator in front of this shard -- on the rank before --
@@ -649,6 +711,13 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None, shard_counts
                 raise ValueError("sharded counting all-reduces the 4^k histogram and needs k <= 16")
             if on_dev:
                 assert_default_stream()
+            ks = key_space
+            if os.environ.get("KMAP_DIST_KEYSPACE") in ("0", "1"):
+                ks = os.environ["KMAP_DIST_KEYSPACE"] == "1"
+            if 11 <= k <= 16 and ((ks is None and k >= KEY_SPACE_MIN_K and world > 1 and shard_counts is None) or ks):
+                return self._count_by_key_space(dc, k, dedupe, merge_revcom, use_work, gather_full)
+            if use_work:
+                self._sync_shard()
             inval = self.inval_work if use_work else self.inval_orig
             dc._unshard()
             check(_ffi.lib().kmap_counts_hist_packed_dev(dc._h, self.codes.ptr, inval.ptr, self.n, self.borders.ptr,
@@ -685,6 +754,24 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None, shard_counts
             nu = _ffi.i64(0)
             check(lib.kmap_counts_finish_range(dc._h, k, int(bool(merge_revcom)), bounds[rank], bounds[rank + 1] - bounds[rank],
                                                C.byref(nu), None))
+            return self._finish_shards(dc, k, nu, gather_full)
+
+        def _count_by_key_space(self, dc, k, dedupe, merge_revcom, use_work, gather_full):
+            """this rank's key range of the table from ALL reads (no table collective); then the shard bookkeeping of the key-range form"""
+            full = self._full_seq()
+            n_bins = 4 ** k
+            bounds = [(n_bins * r // world) & ~7 for r in range(world)] + [n_bins]
+            inval = full.inval_work if use_work else full.inval_orig
+            nu = _ffi.i64(0)
+            dc._unshard()
+            check(_ffi.lib().kmap_counts_run_packed_range_dev(dc._h, full.codes.ptr, inval.ptr, full.n, full.borders.ptr, full.n_seq, k,
+                                                              int(dedupe), int(bool(merge_revcom)), bounds[rank],
+                                                              bounds[rank + 1] - bounds[rank], C.byref(nu), None))
+            return self._finish_shards(dc, k, nu, gather_full)
+
+        def _finish_shards(self, dc, k, nu, gather_full):
+            """dc holds this rank's shard (nu entries) of a table cut by key range"""
+            lib = _ffi.lib()
             # the shards, concatenated in rank order, are the table every rank would have compacted from the all-reduced bins
             sizes = torch.empty(world, dtype=torch.int64, device="cuda")
             dist.all_gather_into_tensor(sizes, torch.tensor([nu.value], dtype=torch.int64, device="cuda"), group=group)

@@ -404,8 +404,14 @@ def _read_motif_table_plain(motif_def_file):
     import re
     try:
         with open(motif_def_file, newline="") as fh:
-            rows = list(csv.reader(fh))
-    except (OSError, UnicodeDecodeError, csv.Error):
+            text = fh.read()
+    except (OSError, UnicodeDecodeError):
+        return None
+    if '"' in text:                                   # quoted fields: pandas' business (csv.reader would unquote them silently)
+        return None
+    try:
+        rows = list(csv.reader(text.splitlines(), quoting=csv.QUOTE_NONE))
+    except csv.Error:
         return None
     if not rows:
         return None

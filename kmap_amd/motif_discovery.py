@@ -127,6 +127,17 @@ class DeviceSeq:
         dc.k, dc.n_uniq = k, nu.value
         return dc.n_uniq
 
+    def count_range(self, dc: DeviceCounts, k, dedupe, merge_revcom, first_bin, n_bins, use_work=True):
+        """positions [first_bin, first_bin + n_bins) -- in key order -- of the table count() would produce, from the windows that
+        decide them alone (kmap_counts_run_packed_range_dev, 11 <= k <= 16): a rank's share of a key-space-sharded count"""
+        inval = self.inval_work if use_work else self.inval_orig
+        nu = _ffi.i64(0)
+        dc._unshard()
+        check(_ffi.lib().kmap_counts_run_packed_range_dev(dc._h, self.codes.ptr, inval.ptr, self.n, self.borders.ptr, self.n_seq, k,
+                                                          int(dedupe), int(merge_revcom), int(first_bin), int(n_bins), C.byref(nu), None))
+        dc.k, dc.n_uniq = k, nu.value
+        return dc.n_uniq
+
     def mask(self, k, consensus_kh_arr, max_ham_dist_arr):
         cons = np.ascontiguousarray(consensus_kh_arr, dtype=np.uint64)
         rad = np.ascontiguousarray(max_ham_dist_arr, dtype=np.int32)

@@ -31,6 +31,7 @@ def default_mode(n=None):
 
 
 STAGE_TIMES = {}          # cumulative wall-clock per stage (tools/e2e.py, bench.py report it)
+TRACE_SINK = None         # a dict set by a test / bench.py receives the embedding loop's trace of the next `_visualize_kmers` (losses, state, loop_s)
 
 
 class _stage:
@@ -165,17 +166,19 @@ def knn_sums_dev(D_dev_ptr, ldd, nb, n, n_nb, row0=0, nrows=None, stream=None, o
     return sums_d, lds
 
 
-def dedupe_sums_rows(sums_d, nrows, lds, min_gain=0.9, free_input=True):
+def dedupe_sums_rows(sums_d, nrows, lds, min_gain=0.9, free_input=True, n=None):
     """Store the repeated rows of a neighbour-sum matrix once.  A sample repeats its k-mers in runs (motif_discovery.py:759-772), the
     sums row of a repeated k-mer equals the row above it, and a SEQ session reads its rows through a map (kmap_embed_set_row_map): the
     wave's loads then touch one row per run instead of one per point (C3: 17 554 stored rows for 50 000 points; force evaluation
     1.56 -> 1.3x ms).  The device compares the bytes; nothing is assumed about the sample.
     -> (sums_d', rowmap_d, stored_rows); rowmap_d is None (and sums_d' is sums_d) when fewer than 1 - min_gain of the rows repeat.
-    The input buffer is freed when a compacted copy replaces it (free_input)."""
+    The input buffer is freed when a compacted copy replaces it (free_input).  n: the payload columns of a row (default: the whole
+    pitch): only they are compared -- the sums kernels never write the pad columns [n, lds), and what a recycled allocation holds
+    there must not make equal rows look different."""
     lib = _ffi.lib()
     fresh_d = _ffi.DeviceBuffer(max(nrows, 1))
     try:
-        check(lib.kmap_rows_fresh_u8_dev(sums_d.ptr, lds * 2, lds * 2, 0, nrows, fresh_d.ptr, None))
+        check(lib.kmap_rows_fresh_u8_dev(sums_d.ptr, lds * 2, (lds if n is None else n) * 2, 0, nrows, fresh_d.ptr, None))
         fresh = fresh_d.to_numpy(np.uint8, (nrows,)).astype(bool)
     finally:
         fresh_d.free()
@@ -481,7 +484,7 @@ def kmap(hamdist_mat: np.ndarray, kmer_len: int, n_neighbour=20, n_max_iter=2500
         ld_data, placeholders = _init_draws(n, n_best_result, random_seed)
         rowmap_d, stored = None, n
         if mode == EMBED_SEQ:
-            sums_d, rowmap_d, stored = dedupe_sums_rows(sums_d, n, lds)
+            sums_d, rowmap_d, stored = dedupe_sums_rows(sums_d, n, lds, n=n)
         sess = EmbedSession(n, n_best_result, learning_rate, mode)
         try:
             sess.set_prob_lut(sums_d, lds, lut, rowmap_d, stored)
@@ -536,7 +539,7 @@ def kmap_from_kmers(samp_kh, samp_cnts, samp_label, conseq_list, kmer_len, n_nei
     rowmap_d, stored = None, n
     if mode == EMBED_SEQ:
         with _stage("dedupe_sums"):
-            sums_d, rowmap_d, stored = dedupe_sums_rows(sums_d, n, lds)
+            sums_d, rowmap_d, stored = dedupe_sums_rows(sums_d, n, lds, n=n)
     sess = EmbedSession(n, n_best_result, learning_rate, mode)
     try:
         sess.set_prob_lut(sums_d, lds, lut, rowmap_d, stored)
@@ -639,7 +642,9 @@ def _visualize_kmers_impl(res_dir, debug, mode, dist, rank, neighbor_inds_mat=No
             ld_data, _ = kmap_from_kmers(samp_kh, samp_cnts, samp_label, conseq_list, kmer_len, n_neighbour=vz["n_neighbour"],
                                          n_max_iter=vz["n_max_iter"], learning_rate=vz["learning_rate"],
                                          n_best_result=vz["n_best_result"], random_seed=random_seed, debug=debug, mode=mode,
-                                         neighbor_inds_mat=neighbor_inds_mat)
+                                         neighbor_inds_mat=neighbor_inds_mat, trace=TRACE_SINK)
+            if TRACE_SINK is not None:
+                TRACE_SINK["best"] = np.array(ld_data)
     elif rank != 0:
         return None      # dense hand-off: rank 0 embeds alone
     else:

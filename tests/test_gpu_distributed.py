@@ -410,6 +410,119 @@ def test_find_motif_on_counts_that_stay_sharded(tmp_path):
             assert r["motifs"][h] == single[h]
 
 
+def _keyspace_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import pickle
+    import torch
+    import torch.distributed as dist
+    import kmap_amd.motif_discovery as md
+    from kmap_amd import distributed as D
+    from kmap_amd.kmer_count import DeviceCounts
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seq, borders = _range_inputs()
+        out = {}
+        # a spy on the collectives: key-space counting must not move a single table byte (sizes and, for small tables, the
+        # (k-mer, count) shards are all that is exchanged)
+        moved = {"all_reduce": 0, "reduce": 0}
+        real_ar, real_red = dist.all_reduce, dist.reduce
+
+        def spy_ar(t, *a, **kw):
+            moved["all_reduce"] += t.numel() * t.element_size()
+            return real_ar(t, *a, **kw)
+
+        def spy_red(t, *a, **kw):
+            moved["reduce"] += t.numel() * t.element_size()
+            return real_red(t, *a, **kw)
+        dist.all_reduce, dist.reduce = spy_ar, spy_red
+        ds = D.make_dist_device_seq(seq, borders, dist, key_space=True)       # forced: k = 11 lies below KEY_SPACE_MIN_K
+        dc = DeviceCounts()
+        for k in (11, 14, 16):
+            for dedupe in (True, False):
+                for merge in (True, False):
+                    ds.count(dc, k, dedupe=dedupe, merge_revcom=merge)
+                    out[(k, dedupe, merge)] = dc.fetch()
+        out["moved"] = dict(moved)
+        dist.all_reduce, dist.reduce = real_ar, real_red
+        # the default rule: k >= KEY_SPACE_MIN_K counts by key space, smaller k by read shards + all-reduce; masks reach both copies
+        ds.close()
+        md.TOPK_DEVICE_MIN = 1000
+        ds = D.make_dist_device_seq(seq, borders, dist)
+        ds.keep_sharded = True
+        ds.reset()
+        r13 = md.find_motif(None, 13, 3, 3.0e-6, 1.0, 0.05, 1.3, top_k=5, n_trial=3, save_kmer_cnt_flag=False, dev_seq=ds)
+        assert ds._full is not None and ds._done_full > 0 and ds._done_shard == 0        # k = 13 never masked the shard
+        out["motifs13"] = {int(h): v for h, v in r13.items()}
+        ds.reset()
+        r8 = md.find_motif(None, 8, 2, 0.004241943, 1.0, 0.04864974, 1.3094, save_kmer_cnt_flag=False, dev_seq=ds)
+        assert ds._done_full == 0                                                          # k = 8 never masked the full copy
+        out["motifs8"] = {int(h): v for h, v in r8.items()}
+        ds.reset()
+        # a mask applied before the full copy exists is replayed onto it; the working reads agree
+        ds2 = D.make_dist_device_seq(seq, borders, dist)
+        cons = np.array([0x1B1B1B1, 4 ** 13 - 1], np.uint64)
+        ds2.mask(13, cons, np.array([2, 1], np.int32))
+        ds2.count(dc, 13, dedupe=False, merge_revcom=True)
+        out["masked13"] = dc.fetch()
+        with open(Path(out_dir) / f"ks_rank{rank}.pkl", "wb") as fh:
+            pickle.dump(out, fh)
+        dc.close()
+        ds.close()
+        ds2.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_key_space_counting_three_ranks(tmp_path):
+    """counting by KEY SPACE under a process group (three ranks sharing the test box's GPU): every rank holds all reads and
+    computes only its key range (kmap_counts_run_packed_range_dev) -- the gathered tables equal the oracle's single-process count bit for
+    bit at k = 11, 14, 16 with and without per-read dedupe and revcom merge, with ZERO table bytes through all_reduce / reduce; the
+    default rule takes key space from k = 12 on, find_motif on a table that stays sharded == one GPU on all reads, masks applied before
+    and after the full copy exists reach it (reference kmer_count.py:476-491,580-610,643-685)."""
+    import pickle
+    import torch.multiprocessing as mp
+    import kmap_amd.motif_discovery as md
+    from kmap_amd.kmer_count import DeviceCounts
+    from kmap_amd.motif_discovery import DeviceSeq
+    from oracle import oracle as O
+    mp.spawn(_keyspace_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    res = [pickle.load(open(tmp_path / f"ks_rank{r}.pkl", "rb")) for r in range(3)]
+    seq, borders = _range_inputs()
+    for k in (11, 14, 16):
+        for dedupe in (True, False):
+            for merge in (True, False):
+                ou, oc = O.count_kmers(seq, borders, k, rep_mode=not dedupe, revcom_mode=merge)
+                for r in res:
+                    u, c = r[(k, dedupe, merge)]
+                    np.testing.assert_array_equal(u, ou)
+                    np.testing.assert_array_equal(c, oc)
+                    assert u.dtype == ou.dtype and c.dtype == oc.dtype
+    for r in res:                # 12 count passes: no all-reduce / reduce of anything table-sized (the 16-GiB table of k = 16 included)
+        assert r["moved"]["reduce"] == 0 and r["moved"]["all_reduce"] < 4096, r["moved"]
+    old = md.TOPK_DEVICE_MIN
+    md.TOPK_DEVICE_MIN = 1000
+    try:
+        ds, dc = DeviceSeq(seq, borders), DeviceCounts()
+        s13 = md.find_motif(None, 13, 3, 3.0e-6, 1.0, 0.05, 1.3, top_k=5, n_trial=3, save_kmer_cnt_flag=False, dev_seq=ds)
+        ds.reset()
+        s8 = md.find_motif(None, 8, 2, 0.004241943, 1.0, 0.04864974, 1.3094, save_kmer_cnt_flag=False, dev_seq=ds)
+        ds.reset()
+        ds.mask(13, np.array([0x1B1B1B1, 4 ** 13 - 1], np.uint64), np.array([2, 1], np.int32))
+        ds.count(dc, 13, dedupe=False, merge_revcom=True)
+        mu, mc = dc.fetch()
+        dc.close()
+        ds.close()
+    finally:
+        md.TOPK_DEVICE_MIN = old
+    assert len(s13) >= 1 and len(s8) >= 1
+    for r in res:
+        assert r["motifs13"] == {int(h): v for h, v in s13.items()}
+        assert r["motifs8"] == {int(h): v for h, v in s8.items()}
+        np.testing.assert_array_equal(r["masked13"][0], mu)
+        np.testing.assert_array_equal(r["masked13"][1], mc)
+
+
 def test_read_sharded_counting_scan_and_find_motif(tmp_path):
     """Reads sharded over two ranks (histogram all-reduce): counts, scan hits and find_motif decisions equal the
     single-GPU run and the CPU oracle."""

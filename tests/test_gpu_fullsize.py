@@ -423,6 +423,105 @@ def test_c2_whole_run():
         shutil.rmtree(res, ignore_errors=True)
 
 
+def test_c4_whole_run():
+    """BASELINE config C4 as ONE run of both verbs on one GPU, clean res_dir, package default (SEQ): 10 M x 150 bp reads, k = 6..9,
+    N = 200 000 sampled k-mers, 2500 iterations (reference motif_discovery.py:759-808 -> visualization.py:259-326; ~47 s).
+      * the planted motifs' cores come out as the finals; the hand-over is the compact one (no 320 GB int64 matrix), 200 000 points;
+      * low_dim_data.tsv has the contract's shape and is the lowest-loss snapshot printed with %3.3f;
+      * the loss trace is finite, 2500 long (or ends by the reference's stop rule) and falls;
+      * the FIRST FIVE ITERATIONS from the same hand-over, one at a time: on >= 128 sampled rows (every form of the SEQ split) the
+        device's gradient equals the oracle's row sums (kb_embed_forces_rows: IEEE f32, j ascending, no FMA) BIT for bit, and the
+        coordinates after the step equal y + (-(4 g) lr) bit for bit -- each iteration checked from the device's own previous
+        coordinates, so the chain covers five iterations without an O(N^2) CPU pass."""
+    import pickle
+    import shutil
+    from kmap_amd import _ffi, synth, visualization as V
+    from kmap_amd.e2e import run_e2e
+    from kmap_amd.hamdist import hamdist_matrix_dev, pitch_for
+    from kmap_amd.kmer_count import get_hash_dtype
+    from oracle import baseline as B, oracle as O
+    n = 200_000
+    V.TRACE_SINK = tr = {}
+    try:
+        r = run_e2e("C4", "default", keep=True)
+    finally:
+        V.TRACE_SINK = None
+    res = Path(r["res_dir"])
+    try:
+        finals = r["final_conseq"]
+        planted = [synth.MOTIF_A, synth.MOTIF_B]
+        both = planted + [O.reverse_complement(m) for m in planted]
+        assert 2 <= len(finals) <= 3 and all(any(f in m for m in both) for f in finals[:2]), finals
+        assert {next(i for i, m in enumerate(both) if f in m) % 2 for f in finals[:2]} == {0, 1}
+        with open(res / "sample_kmer_hamdist_mat.pkl", "rb") as fh:
+            klen, D, labels = pickle.load(fh)
+        assert D is None and klen == max(len(f) for f in finals) and len(labels) == n          # compact hand-over above DENSE_PKL_MAX_N
+        with open(res / "sample_kmers.pkl", "rb") as fh:
+            samp_kh, samp_cnts, samp_label, conseqs = pickle.load(fh)
+        assert int(np.sum(samp_cnts)) == n and list(conseqs) == finals
+        rows_txt = (res / "low_dim_data.tsv").read_text().splitlines()
+        assert rows_txt[0] == "x\ty\tlabel" and len(rows_txt) == n + 1
+        tab = np.array([ln.split("\t") for ln in rows_txt[1:]], dtype=np.float64)
+        assert tab.shape == (n, 3) and np.isfinite(tab).all() and set(np.unique(tab[:, 2])) <= set(map(float, range(len(finals) + 1)))
+        np.testing.assert_array_equal(tab[:, 2].astype(np.int64), np.asarray(labels, np.int64))
+        np.testing.assert_allclose(np.round(tr["best"].astype(np.float64), 3).T, tab[:, :2], atol=1.1e-3)
+        losses = np.asarray(tr["losses"])
+        assert (len(losses) == 2500 or tr["state"]["stopped"]) and np.isfinite(losses).all() and losses.min() < 0.5 * losses[0]
+        run_best = np.minimum.accumulate(losses)
+        assert run_best[-1] <= run_best[len(run_best) // 2] <= run_best[10] < losses[0]
+        assert r["times"]["e2e_s"] < 120.0                                   # a whole run, not a stage: ~47 s on one MI355X
+        # ---- the first five iterations, from the hand-over, against the oracle's arithmetic on sampled rows
+        kh = np.repeat(np.asarray(samp_kh), samp_cnts).astype(get_hash_dtype(klen))
+        lab = np.repeat(np.asarray(samp_label), samp_cnts).astype(np.int32)
+        lens = [len(c) for c in conseqs]
+        ldd = pitch_for(n)
+        kh_d, lab_d, D_d = _ffi.DeviceBuffer.from_numpy(kh), _ffi.DeviceBuffer.from_numpy(lab), _ffi.DeviceBuffer(n * ldd)
+        hamdist_matrix_dev(kh_d.ptr, lab_d.ptr, n, klen, lens, D_d.ptr, ldd)
+        assert V.knn_mode(n) == "device"
+        nb_d = V.knn_select_dev(D_d.ptr, ldd, n, 20)
+        D_d.free()
+        sums_d, lds = V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, klen, lens, nb_d, 20)
+        for b in (nb_d, kh_d, lab_d):
+            b.free()
+        lut = V.hd_prob_lut(klen, 20, 400 * klen)
+        rows = _seq_form_rows(n)
+        rows = rows[rows >= 2]                                               # add_jitter (as written) only ever touches points 0 / 1
+        P = np.empty((len(rows), n), np.float32)
+        for t, rr in enumerate(rows):
+            P[t] = lut[sums_d.to_numpy(np.uint16, (lds,), offset=int(rr) * lds * 2)[:n]]
+        comp_d, rowmap_d, stored = V.dedupe_sums_rows(sums_d, n, lds, n=n)   # as the verb does: repeated rows stored once
+        assert rowmap_d is not None and stored < n                           # 31 298 distinct k-mers; rows of copies differ on their diagonals where S[i, i'] != 0: 98 177 stored
+        ld0, ph = V._init_draws(n, 10, 7)
+        sess = V.EmbedSession(n, 10, 0.01, V.EMBED_SEQ)
+        try:
+            sess.set_prob_lut(comp_d, lds, lut, rowmap_d, stored)
+            sess.set_coords(ld0, ph)
+            sess.set_jitter(np.random.normal(0, 0.01, 4096))                # the global stream right behind the initial draws, as _run_loop draws it
+            g_d, l_d = _ffi.DeviceBuffer(2 * n * 4), _ffi.DeviceBuffer(8)
+            lr = np.float32(0.01)
+            for it in range(5):
+                y0 = sess.coords()
+                g_d.zero()
+                sess.forces(g_d.ptr, l_d.ptr)
+                _ffi.sync()
+                g = g_d.to_numpy(np.float32, (2, n))
+                want = B.embed_forces_rows(P, rows, y0, threads=8)
+                got = np.ascontiguousarray(g[:, rows])
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"iteration {it}: SEQ gradient rows differ from the oracle"
+                sess.step(1)
+                y1 = sess.coords()
+                upd = y0[:, rows] + (-(np.float32(4.0) * want) * lr)
+                assert np.array_equal(y1[:, rows].view(np.uint32), upd.astype(np.float32).view(np.uint32)), f"iteration {it}: coordinates after the step"
+            first5 = sess.losses()
+            np.testing.assert_allclose(first5, losses[:5], rtol=1e-6)       # the verb's run started the same way (same seed, same hand-over)
+            g_d.free()
+            l_d.free()
+        finally:
+            sess.close()
+    finally:
+        shutil.rmtree(res, ignore_errors=True)
+
+
 def test_c4_embedding_force_evaluation_full_size():
     """BASELINE config C4's embedding stage at N = 200 000 (80 GB of neighbour sums on one GPU): one force evaluation of the
     symmetric FAST kernel (4x the tiles of C3; 782 row blocks) against the SEQ kernel (the reference's summation order) -- loss

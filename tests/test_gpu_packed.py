@@ -381,6 +381,114 @@ def test_hist16_single_kmer_no_carry(env, base, k):
     ds.close()
 
 
+def _key_range_reads(rng, n_reads=9000):
+    """~1.4 M positions (>= 2^20: the partitioned passes run) with what the range rule must get right: planted motifs (heavy buckets),
+    N's, poly-A / poly-T reads (k = 16: the all-T 16-mer's hash is the invalid marker, its partner all-A is position 0), reads made of
+    ACGT repeats (even-k palindromes: their own partner) and reads followed by their reverse complement (pairs inside and across ranges)"""
+    seq, borders = synth(rng, n_reads, 120, 190, p_n=0.002)
+    comp = np.array([3, 2, 1, 0], np.uint8)
+    for r in range(len(borders)):
+        st, en = borders[r]
+        m = r % 50
+        if m == 0:
+            seq[st:en] = 0
+        elif m == 1:
+            seq[st:en] = 3
+        elif m == 2:
+            seq[st:en] = np.resize(np.array([0, 1, 2, 3], np.uint8), en - st)
+        elif m == 3 and r > 0:
+            pst, pen = borders[r - 1]
+            L = min(en - st, pen - pst)
+            prev = seq[pst:pst + L]
+            ok = prev != 255
+            rc = np.where(ok, comp[np.where(ok, prev, 0)], 255)[::-1]
+            seq[st:st + L] = rc
+        elif m < 24:
+            p0 = st + int(rng.integers(0, en - st - 20))
+            seq[p0:p0 + 20] = np.array([0, 2, 2, 0, 1, 1, 3, 0, 1, 2, 3, 0, 1, 0, 2, 2, 3, 1, 1, 0], np.uint8)
+    return seq, borders
+
+
+@pytest.mark.parametrize("k", [11, 13, 14, 15, 16])
+def test_key_range_counting_equals_slices_of_the_table(env, k):
+    """kmap_counts_run_packed_range_dev (key-space-sharded counting; reference kmer_count.py:476-491,643-685): for G = 2, 3,
+    8 ranks the shards [4^k r / G, 4^k (r + 1) / G) -- each computed from the windows that decide it alone, in a virtual table of a
+    smaller k -- concatenated in rank order ARE the single-GPU table, key for key and count for count, with and without the
+    reverse-complement merge and the per-read dedupe; k = 14 also against the oracle.  Masked reads (the working mask) included."""
+    _ffi, DeviceCounts, DeviceSeq, O = env
+    rng = np.random.default_rng(1400 + k)
+    seq, borders = _key_range_reads(rng)
+    assert len(seq) >= 1 << 20
+    ds, dc, ds_small = DeviceSeq(seq, borders), DeviceCounts(), None
+    n_bins = 4 ** k
+    try:
+        for merge, dedupe in ((True, False), (True, True), (False, False), (False, True)):
+            ds.count(dc, k, dedupe=dedupe, merge_revcom=merge)
+            u, c = dc.fetch()
+            if k == 14 and merge:
+                ou, oc = O.count_kmers(seq, borders, k, rep_mode=not dedupe, revcom_mode=True)
+                np.testing.assert_array_equal(u, ou)
+                np.testing.assert_array_equal(c, oc)
+            for G in (2, 3, 8):
+                bounds = [(n_bins * r // G) & ~7 for r in range(G)] + [n_bins]
+                us, cs = [], []
+                for r in range(G):
+                    ds.count_range(dc, k, dedupe, merge, bounds[r], bounds[r + 1] - bounds[r])
+                    su, sc = dc.fetch()
+                    us.append(su)
+                    cs.append(sc)
+                np.testing.assert_array_equal(np.concatenate(us), u, err_msg=f"k={k} merge={merge} dedupe={dedupe} G={G}: keys")
+                np.testing.assert_array_equal(np.concatenate(cs), c, err_msg=f"k={k} merge={merge} dedupe={dedupe} G={G}: counts")
+        # after masking (find_motif's later rounds count the working mask), and an odd range that is no multiple of the rank rule
+        cons = np.array([int(O.kmer2hash("AGGACCTACGTACAGG"[:k])) if k <= 16 else 0], np.uint64)
+        ds.mask(k, cons, np.array([2], np.int32))
+        ds.count(dc, k, dedupe=False, merge_revcom=True)
+        u, c = dc.fetch()
+        cuts = [0, 8 * 1237, (n_bins // 3) & ~7, (n_bins // 3 + 4096) & ~7, n_bins]
+        us, cs = [], []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ds.count_range(dc, k, False, True, a, b - a)
+            su, sc = dc.fetch()
+            us.append(su)
+            cs.append(sc)
+        np.testing.assert_array_equal(np.concatenate(us), u)
+        np.testing.assert_array_equal(np.concatenate(cs), c)
+        ds.reset()
+        # small inputs (below the partitioned passes' threshold) take the whole-table path and must give the same slices
+        sseq, sborders = synth(rng, 300, 60, 100)
+        ds_small = DeviceSeq(sseq, sborders)
+        ds_small.count(dc, k, dedupe=True, merge_revcom=True)
+        u, c = dc.fetch()
+        us, cs = [], []
+        for r in range(3):
+            a, b = (n_bins * r // 3) & ~7, ((n_bins * (r + 1) // 3) & ~7) if r < 2 else n_bins
+            ds_small.count_range(dc, k, True, True, a, b - a)
+            su, sc = dc.fetch()
+            us.append(su)
+            cs.append(sc)
+        np.testing.assert_array_equal(np.concatenate(us), u)
+        np.testing.assert_array_equal(np.concatenate(cs), c)
+    finally:
+        dc.close()
+        ds.close()
+        if ds_small is not None:
+            ds_small.close()
+
+
+def test_key_range_counting_argument_errors(env):
+    _ffi, DeviceCounts, DeviceSeq, O = env
+    rng = np.random.default_rng(5)
+    seq, borders = synth(rng, 50, 60, 100)
+    ds, dc = DeviceSeq(seq, borders), DeviceCounts()
+    try:
+        for k, first, nb in ((10, 0, 4 ** 10), (17, 0, 64), (12, 4, 64), (12, 0, 0), (12, 4 ** 12 - 8, 16), (12, 4 ** 12, 8)):
+            with pytest.raises(ValueError):
+                ds.count_range(dc, k, False, True, first, nb)
+    finally:
+        dc.close()
+        ds.close()
+
+
 @pytest.mark.parametrize("max_len", [512, 513])
 def test_dedupe_long_reads_both_paths(env, max_len):
     """Per-read dedupe at the length limit of the LDS-bitmap kernel: reads up to 512 positions (9 steps of 64 windows, claim masks

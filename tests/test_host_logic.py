@@ -410,6 +410,14 @@ def test_motif_table_without_pandas_equals_the_reference_reader(tmp_path):
             assert g.max_ham_dist == w[1] and all(_same_float(a, b) for a, b in zip((g.p_uniform, g.ratio_mu, g.ratio_std, g.ratio_cutoff),
                                                                                     (w[0], w[2], w[3], w[4]))), (it, k, g, w, lines)
     assert n_plain >= 150                                   # the plain reader did take the tables meant for it
+    # quoted fields are pandas' business: the plain reader declines, the result is still the pandas one
+    q = tmp_path / "quoted.csv"
+    q.write_text('kmer_len,max_ham_dist,p_uniform,ratio_mu,ratio_std\n8,2,"0.0042",3.5,"0.25"\n9,2,0.0011,"3.25",0.5\n')
+    assert K._read_motif_table_plain(q) is None
+    got, want = K.init_motif_def_dict(q), _motif_table_by_pandas(q)
+    for k, w in want.items():
+        g = got[k]
+        assert all(_same_float(a, b) for a, b in zip((g.p_uniform, g.ratio_mu, g.ratio_std, g.ratio_cutoff), (w[0], w[2], w[3], w[4])))
 
 
 def test_norm_functions_equal_scipy_stats():
