@@ -656,6 +656,21 @@ def shard_proxy(G, reads, res_dir, c3s, overhead_ms, first=None):
             "scan_k8_r2": "all-gather of the hit lists"}
     for name, v in t.items():
         out["stages"]["reads_" + name] = entry(v[1:], v[0], 0.0, "collective not included: " + coll[name])
+    # counting by KEY SPACE (the multi-rank form from k = 13 on): every rank holds all reads and computes its key range of the table --
+    # a rank's pass is the whole exchange-free job (only the shard sizes travel afterwards)
+    ds = DeviceSeq(seq, borders)
+    dc = DeviceCounts()
+    for k in (14, 16):
+        nb = 4 ** k
+        bounds = [(nb * r // G) & ~7 for r in range(G)] + [nb]
+        one = med(lambda: ds.count(dc, k, dedupe=False, merge_revcom=True), 3)
+        sh = [med(lambda: ds.count_range(dc, k, False, True, bounds[r], bounds[r + 1] - bounds[r]), 3) for r in range(G)]
+        e = entry(sh, one, 0.0, "key-space form: all reads on every rank, the rank's key range of the table from the windows that decide it; "
+                                "table bytes exchanged: 0 (read-sharded form above: + an all-reduce of 4^k x 4 B)")
+        e["table_bytes_exchanged"] = 0
+        out["stages"][f"reads_count_k{k}_keyspace"] = e
+    dc.close()
+    ds.close()
     out["exchange_overhead_ms_per_iteration"] = overhead_ms
     if first is not None:
         out.update(predict_e2e(G, first, out["stages"]))

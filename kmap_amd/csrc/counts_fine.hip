@@ -96,10 +96,10 @@ __device__ __forceinline__ void raw_pair_keys(const RawPair &r, int64_t n, int k
 // (1) valid keys per (class, bucket): gcount[class * NB + bucket].  (Measured: a bucket-only extraction -- five instead of eleven
 // vector instructions per window, byte offsets straight into the counters -- 0.48 against 0.43 ms: the pass sits at the LDS atomic rate.)  The grid is a multiple of 8, so all tiles of a block share
 // their class (tile = blockIdx + i * gridDim).
-template <bool PACKED, int GPT, bool RANGE>
+template <bool PACKED, int GPT>
 __global__ __launch_bounds__(FS_TPB) void fine_count_kernel(const uint32_t *__restrict__ h, const uint16_t *__restrict__ inval,
                                                             const uint32_t *__restrict__ skip, int k, int64_t n, int low_bits, int NB,
-                                                            uint32_t *__restrict__ gcount, kmap_key_range kr) {
+                                                            uint32_t *__restrict__ gcount) {
     extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];         // NB + 64 (the lanes' private counters for invalid keys)
     constexpr int KPT = 16 * GPT;
     for (int b = threadIdx.x; b < NB + 64; b += FS_TPB) cnt[b] = 0;
@@ -114,10 +114,6 @@ __global__ __launch_bounds__(FS_TPB) void fine_count_kernel(const uint32_t *__re
             raw_pair_load(nxt, h, inval, skip, n, g0_of(tile + gridDim.x));          // next tile's loads in flight (clamped behind the array)
             uint32_t v[KPT];
             raw_pair_keys(cur, n, k, g0_of(tile), v);
-            if constexpr (RANGE) {
-#pragma unroll
-                for (int j = 0; j < KPT; ++j) v[j] = kmap_range_key(v[j], kr);
-            }
 #pragma unroll
             for (int j = 0; j < KPT; ++j) atomicAdd(&cnt[v[j] == INV32 ? dummy : v[j] >> low_bits], 1u);
             cur = nxt;
@@ -126,10 +122,6 @@ __global__ __launch_bounds__(FS_TPB) void fine_count_kernel(const uint32_t *__re
         for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
             uint32_t v[KPT];
             tile_keys<PACKED, GPT>(h, inval, skip, k, n, tile, v);
-            if constexpr (RANGE) {
-#pragma unroll
-                for (int j = 0; j < KPT; ++j) v[j] = kmap_range_key(v[j], kr);
-            }
 #pragma unroll
             for (int j = 0; j < KPT; ++j) atomicAdd(&cnt[v[j] == INV32 ? dummy : v[j] >> low_bits], 1u);
         }
@@ -239,11 +231,10 @@ template <int GPT, int BPT>
 constexpr size_t fine_scatter_lds() {
     return (size_t)FS_TPB * 16 * GPT * 2 + (size_t)BPT * 1024 * 4 + (size_t)BPT * 1024 * 8 + 3 * (size_t)FS_TPB * 16 * GPT / 8 + 3 * 64;
 }
-template <bool PACKED, int GPT, int BPT, bool RANGE>
+template <bool PACKED, int GPT, int BPT>
 __global__ __launch_bounds__(FS_TPB) void fine_scatter_kernel(const uint32_t *__restrict__ h, const uint16_t *__restrict__ inval,
                                                               const uint32_t *__restrict__ skip, int k, int64_t n, int low_bits,
-                                                              unsigned long long *__restrict__ cursor, uint16_t *__restrict__ out,
-                                                              kmap_key_range kr) {
+                                                              unsigned long long *__restrict__ cursor, uint16_t *__restrict__ out) {
     constexpr int KPT = 16 * GPT, FT = FS_TPB * KPT, NB = BPT * 1024, SW = FT / 32, WPW = SW / 16;   // bitmap words, words per wave
     static_assert(FT < 65536, "tile positions and run ranks share a 16 + 16 bit scan word");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -271,10 +262,6 @@ __global__ __launch_bounds__(FS_TPB) void fine_scatter_kernel(const uint32_t *__
         uint32_t v[KPT];
         if constexpr (PREF) raw_pair_keys(raw_cur, n, k, g0_of(tile), v);
         else tile_keys<PACKED, GPT>(h, inval, skip, k, n, tile, v);
-        if constexpr (RANGE) {
-#pragma unroll
-            for (int j = 0; j < KPT; ++j) v[j] = kmap_range_key(v[j], kr);
-        }
         // (taking each key's rank from the returning form of this atomic, so that the placement below is a plain read instead of a
         // second atomic, needs 16 more registers per thread at the 128 this block size allows: spills, 6.8 instead of 5.9 ms)
 #pragma unroll
@@ -448,22 +435,20 @@ __global__ void fine_spill_kernel(uint32_t *__restrict__ table, const unsigned l
         atomicAdd(&table[spill[i]], FH_LIMIT);
 }
 
-template <bool PACKED, int GPT, int BPT, bool RANGE>
+template <bool PACKED, int GPT, int BPT>
 int fine_scatter_launch(const uint32_t *src, const uint16_t *inval, const uint32_t *skip, int k, int64_t n, int low_bits,
-                        unsigned long long *cursor, uint16_t *keys, unsigned grid, hipStream_t st, kmap_key_range kr) {
+                        unsigned long long *cursor, uint16_t *keys, unsigned grid, hipStream_t st) {
     constexpr size_t lds = fine_scatter_lds<GPT, BPT>();
-    KMAP_TRY(kmap_allow_lds((const void *)fine_scatter_kernel<PACKED, GPT, BPT, RANGE>, (int)lds));
-    fine_scatter_kernel<PACKED, GPT, BPT, RANGE><<<grid, FS_TPB, lds, st>>>(src, inval, skip, k, n, low_bits, cursor, keys, kr);
+    KMAP_TRY(kmap_allow_lds((const void *)fine_scatter_kernel<PACKED, GPT, BPT>, (int)lds));
+    fine_scatter_kernel<PACKED, GPT, BPT><<<grid, FS_TPB, lds, st>>>(src, inval, skip, k, n, low_bits, cursor, keys);
     return KMAP_OK;
 }
 
-// vk: the table has 4^vk bins (vk = k, or the virtual k of a key-range pass whose keys are mapped by `kr`)
-template <bool PACKED, int GPT, bool RANGE>
-int fine_hist(kmap_counts *c, const uint32_t *src, const uint16_t *inval, const uint32_t *skip, int64_t n, int k, int vk, kmap_key_range kr,
-              hipStream_t st) {
-    const int nb_bits = 12, NB = 1 << nb_bits, low_bits = 2 * vk - nb_bits;   // 4096 buckets of 4^vk / 4096 <= 65 536 bins
-    KMAP_REQUIRE(vk >= 10 && vk <= 14, "counts: fine partition needs a table of 4^10 .. 4^14 bins (k=%d, table 4^%d)", k, vk);
-    KMAP_TRY(kmap_counts_reserve_bins(c, vk));
+template <bool PACKED, int GPT>
+int fine_hist(kmap_counts *c, const uint32_t *src, const uint16_t *inval, const uint32_t *skip, int64_t n, int k, hipStream_t st) {
+    const int nb_bits = 12, NB = 1 << nb_bits, low_bits = 2 * k - nb_bits;   // 4096 buckets of 4^k / 4096 <= 65 536 bins
+    KMAP_REQUIRE(k >= 10 && k <= 14, "counts: fine partition needs 10 <= k <= 14 (k=%d)", k);
+    KMAP_TRY(kmap_counts_reserve_bins(c, k));
     const size_t m = (size_t)NB * FC;
     void *small = nullptr;
     KMAP_TRY(kmap_scratch(&small, (m + 1) * 8 + m * 8 + m * 4 + 16 + (4 + (size_t)3 * NB) * 4, st, KMAP_SLOT_A));
@@ -478,10 +463,10 @@ int fine_hist(kmap_counts *c, const uint32_t *src, const uint16_t *inval, const 
     int64_t tiles = (n + FT - 1) / FT;
     tiles = (tiles + FC - 1) / FC * FC;                                      // a multiple of 8: the tiles of a block share their class
     const unsigned grid = (unsigned)(tiles > 1024 ? 1024 : tiles);
-    KMAP_TRY(kmap_allow_lds((const void *)fine_count_kernel<PACKED, GPT, RANGE>, (NB + 64) * 4));
-    fine_count_kernel<PACKED, GPT, RANGE><<<grid, FS_TPB, (size_t)(NB + 64) * 4, st>>>(src, inval, skip, k, n, low_bits, NB, gcb, kr);
+    KMAP_TRY(kmap_allow_lds((const void *)fine_count_kernel<PACKED, GPT>, (NB + 64) * 4));
+    fine_count_kernel<PACKED, GPT><<<grid, FS_TPB, (size_t)(NB + 64) * 4, st>>>(src, inval, skip, k, n, low_bits, NB, gcb);
     fine_offsets_kernel<<<1, FS_TPB, 0, st>>>(gcb, NB, goff, cursor, plan);        // goff[m] = number of valid keys
-    KMAP_TRY((fine_scatter_launch<PACKED, GPT, 4, RANGE>(src, inval, skip, k, n, low_bits, cursor, keys, grid, st, kr)));
+    KMAP_TRY((fine_scatter_launch<PACKED, GPT, 4>(src, inval, skip, k, n, low_bits, cursor, keys, grid, st)));
     if (low_bits == 16) {
         void *sp = nullptr;
         const size_t cap = (size_t)(n / (int64_t)FH_LIMIT) + 16;
@@ -506,10 +491,6 @@ bool kmap_counts_fine_applies(int k) { return k >= 10 && k <= 14; }
 int kmap_counts_fine_hist(kmap_counts *c, const uint32_t *hash_dev, const uint32_t *codes_dev, const uint16_t *inval_dev,
                           const uint32_t *skip_dev, int64_t n, int k, hipStream_t st) {
     // two 16-position groups per thread: 32 768-window tiles (three: 24-byte runs at k = 14, but 29 spilled registers -- 6.9 against 6.5 ms)
-    if (hash_dev) return fine_hist<false, 2, false>(c, hash_dev, nullptr, nullptr, n, k, k, kmap_key_range{}, st);
-    return fine_hist<true, 2, false>(c, codes_dev, inval_dev, skip_dev, n, k, k, kmap_key_range{}, st);
-}
-int kmap_counts_fine_hist_range(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, const uint32_t *skip_dev, int64_t n,
-                                int k, int vk, kmap_key_range r, hipStream_t st) {
-    return fine_hist<true, 2, true>(c, codes_dev, inval_dev, skip_dev, n, k, vk, r, st);
+    if (hash_dev) return fine_hist<false, 2>(c, hash_dev, nullptr, nullptr, n, k, st);
+    return fine_hist<true, 2>(c, codes_dev, inval_dev, skip_dev, n, k, st);
 }

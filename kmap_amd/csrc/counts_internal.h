@@ -53,20 +53,11 @@ struct kmap_key_range {
     uint32_t half;           // first virtual key of the partner table T2 (0: no reverse-complement merge, own keys only)
     int sh;                  // 32 - 2 k
 };
-__device__ __forceinline__ uint32_t kmap_range_key(uint32_t x, const kmap_key_range &r) {
-    // x: a valid k-mer hash or 0xFFFFFFFF; -> its virtual key, or 0xFFFFFFFF when neither x nor rc(x) lies in the range
-    const uint32_t own = x - r.lo;
-    uint32_t t = __builtin_bitreverse32(~x);                  // rc(x): complement, reverse the bits, restore the order inside the pairs
-    t = ((t >> 1) & 0x55555555u) | ((t & 0x55555555u) << 1);
-    const uint32_t par = (t >> r.sh) - r.lo;
-    const uint32_t v = own < r.len ? own : ((r.half && par < r.len) ? r.half + par : 0xFFFFFFFFu);
-    return x == 0xFFFFFFFFu ? x : v;
-}
-// the partitioned histogram of the virtual keys: bins [0, 4^vk) of c's table <- counts (every bin written)
-int kmap_counts_fine_hist_range(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, const uint32_t *skip_dev, int64_t n,
-                                int k, int vk, kmap_key_range r, hipStream_t st);
-int kmap_counts_part_hist_range(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, const uint32_t *skip_dev, int64_t n,
-                                int k, int vk, kmap_key_range r, unsigned long long **all_ones_dev, hipStream_t st);
+// counts_range.hip: ONE pass over the packed reads -> the dense list of the virtual keys of the windows the range keeps (in the stream's
+// KMAP_SLOT_HASH scratch, padded with 0xFFFFFFFF to whole 32 768-key chunks); the partitioned histogram of a 4^vk-bin table then runs
+// on that list (kmap_counts_part_hist_u32 with k = vk)
+int kmap_counts_range_stage(const uint32_t *codes_dev, const uint16_t *inval_dev, const uint32_t *skip_dev, int64_t n, int k, kmap_key_range kr,
+                            uint32_t **keys_out, int64_t *n_keys, hipStream_t st);
 // compaction of a range-mode table (T1 = bins [0, len), T2 = bins [half, half + len)) into the handle's uniq / cnt arrays
 int kmap_counts_finish_key_range(kmap_counts *c, int k, kmap_key_range r, int64_t *n_uniq, hipStream_t st);
 // the WHOLE table is in c's bins (small inputs, reads too long for the LDS dedupe): merged in place, positions [first, first + n_bins) compacted

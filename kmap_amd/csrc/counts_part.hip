@@ -42,11 +42,9 @@ __global__ __launch_bounds__(PT_TPB) void part_count_kernel(const uint32_t *__re
 
 // the same count with the keys taken from the packed reads (thread = one 16-position group); k = 16: the all-T 16-mer's valid
 // windows are counted here (all_ones), once
-template <bool RANGE>
 __global__ __launch_bounds__(PT_TPB) void part_count_packed_kernel(const uint32_t *__restrict__ codes, const uint16_t *__restrict__ inval,
                                                                    const uint32_t *__restrict__ skip, int64_t n, int k, int shift,
-                                                                   uint32_t *__restrict__ gcount, unsigned long long *__restrict__ all_ones,
-                                                                   kmap_key_range kr) {
+                                                                   uint32_t *__restrict__ gcount, unsigned long long *__restrict__ all_ones) {
     __shared__ uint32_t cnt[NBK + 64];
     for (int b = threadIdx.x; b < NBK + 64; b += PT_TPB) cnt[b] = 0;
     __syncthreads();
@@ -57,10 +55,6 @@ __global__ __launch_bounds__(PT_TPB) void part_count_packed_kernel(const uint32_
         uint32_t keys[16], n1;
         packed_group_keys(codes, inval, skip, n, k, g, keys, n1);
         ones += n1;
-        if constexpr (RANGE) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) keys[i] = kmap_range_key(keys[i], kr);
-        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const uint32_t b = keys[i] == INV32 ? dummy : keys[i] >> shift;
@@ -83,11 +77,10 @@ __global__ void part_init_cursor_kernel(const uint64_t *__restrict__ goff, unsig
 // L2: 27 ms for 1.5e9 hashes against 6 GB of output).  LDS: sorted tile 128 KiB + offsets 4 KiB + global bases 8 KiB.
 constexpr int PS_TPB = 1024, PS_PER = PT_TILE / PS_TPB;   // 32 hashes per thread
 static_assert(PS_TPB == NBK, "one thread per bucket in the scan / reservation steps");
-template <bool PACKED, bool RANGE>   // PACKED: keys hashed on the fly from the packed reads (h = codes), thread = two 16-position groups of the tile
+template <bool PACKED>   // PACKED: keys hashed on the fly from the packed reads (h = codes), thread = two 16-position groups of the tile
 __global__ __launch_bounds__(PS_TPB) void part_scatter_kernel(const uint32_t *__restrict__ h, const uint16_t *__restrict__ inval,
                                                               const uint32_t *__restrict__ skip, int k, int64_t n, int shift,
-                                                              unsigned long long *__restrict__ cursor, uint32_t *__restrict__ out,
-                                                              kmap_key_range kr) {
+                                                              unsigned long long *__restrict__ cursor, uint32_t *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sorted[];      // PT_TILE entries
     __shared__ uint32_t cnt[NBK];                                           // counts -> exclusive offsets -> running cursors
     __shared__ uint32_t loff[NBK];                                          // exclusive offsets of the buckets inside the tile
@@ -105,10 +98,6 @@ __global__ __launch_bounds__(PS_TPB) void part_scatter_kernel(const uint32_t *__
             uint32_t n1;
             packed_group_keys(h, inval, skip, n, k, g0, v, n1);            // groups behind the array: all keys invalid (n test inside;
             packed_group_keys(h, inval, skip, n, k, g0 + 1, v + 16, n1);   //  the two padding groups keep the loads in bounds)
-            if constexpr (RANGE) {
-#pragma unroll
-                for (int j = 0; j < PS_PER; ++j) v[j] = kmap_range_key(v[j], kr);
-            }
 #pragma unroll
             for (int j = 0; j < PS_PER; ++j)
                 if (v[j] != INV32) atomicAdd(&cnt[v[j] >> shift], 1u);
@@ -312,15 +301,12 @@ bool kmap_counts_part_applies(int k, int64_t n) { return k >= 10 && k <= 16 && n
 // bins of c <- histogram of the valid (!= 0xFFFFFFFF) keys; the whole table is written (no prior memset needed).  Keys: a hash
 // array (hash_dev), or -- hash_dev null -- hashed on the fly from the packed reads in the count and the scatter pass (no 4 B /
 // position array written and read twice: 18 GB of the ~36 GB a k = 14 count pass moved at C3)
-// vk / kr (key-range pass, packed source only): the table has 4^vk bins and holds the virtual keys kmap_range_key makes of the k-mers
-template <bool RANGE>
 static int part_hist_any(kmap_counts *c, const uint32_t *hash_dev, const uint32_t *codes_dev, const uint16_t *inval_dev,
-                         const uint32_t *skip_dev, int64_t n, int k, hipStream_t st, int vk = 0, kmap_key_range kr = kmap_key_range{}) {
-    if (!RANGE) vk = k;
-    if (!RANGE && kmap_counts_fine_applies(k)) return kmap_counts_fine_hist(c, hash_dev, codes_dev, inval_dev, skip_dev, n, k, st);
-    const size_t n_bins = (size_t)1 << (2 * vk);
-    KMAP_TRY(kmap_counts_reserve_bins(c, vk));
-    const int shift = 2 * vk - PB;
+                         const uint32_t *skip_dev, int64_t n, int k, hipStream_t st) {
+    if (kmap_counts_fine_applies(k)) return kmap_counts_fine_hist(c, hash_dev, codes_dev, inval_dev, skip_dev, n, k, st);
+    const size_t n_bins = (size_t)1 << (2 * k);
+    KMAP_TRY(kmap_counts_reserve_bins(c, k));
+    const int shift = 2 * k - PB;
     uint32_t *gcount = nullptr, *keys = nullptr;
     uint64_t *goff = nullptr;
     unsigned long long *cursor = nullptr;
@@ -336,7 +322,7 @@ static int part_hist_any(kmap_counts *c, const uint32_t *hash_dev, const uint32_
     if (packed) {
         int64_t g = (((n + 15) >> 4) + PT_TPB - 1) / PT_TPB;
         if (g > 2048) g = 2048;
-        part_count_packed_kernel<RANGE><<<(unsigned)g, PT_TPB, 0, st>>>(codes_dev, inval_dev, skip_dev, n, k, shift, gcount, k == 16 ? all_ones : nullptr, kr);
+        part_count_packed_kernel<<<(unsigned)g, PT_TPB, 0, st>>>(codes_dev, inval_dev, skip_dev, n, k, shift, gcount, k == 16 ? all_ones : nullptr);
     } else {
         int64_t g = (n + PT_TPB - 1) / PT_TPB;
         if (g > 2048) g = 2048;
@@ -347,15 +333,15 @@ static int part_hist_any(kmap_counts *c, const uint32_t *hash_dev, const uint32_
     int64_t tiles = (n + PT_TILE - 1) / PT_TILE;
     if (tiles > 1024) tiles = 1024;
     if (packed) {
-        KMAP_TRY(kmap_allow_lds((const void *)part_scatter_kernel<true, RANGE>, PT_TILE * 4));
-        part_scatter_kernel<true, RANGE><<<(unsigned)tiles, PS_TPB, (size_t)PT_TILE * 4, st>>>(codes_dev, inval_dev, skip_dev, k, n, shift, cursor, keys, kr);
+        KMAP_TRY(kmap_allow_lds((const void *)part_scatter_kernel<true>, PT_TILE * 4));
+        part_scatter_kernel<true><<<(unsigned)tiles, PS_TPB, (size_t)PT_TILE * 4, st>>>(codes_dev, inval_dev, skip_dev, k, n, shift, cursor, keys);
     } else {
-        KMAP_TRY(kmap_allow_lds((const void *)part_scatter_kernel<false, false>, PT_TILE * 4));
-        part_scatter_kernel<false, false><<<(unsigned)tiles, PS_TPB, (size_t)PT_TILE * 4, st>>>(hash_dev, nullptr, nullptr, k, n, shift, cursor, keys, kr);
+        KMAP_TRY(kmap_allow_lds((const void *)part_scatter_kernel<false>, PT_TILE * 4));
+        part_scatter_kernel<false><<<(unsigned)tiles, PS_TPB, (size_t)PT_TILE * 4, st>>>(hash_dev, nullptr, nullptr, k, n, shift, cursor, keys);
     }
     const uint32_t bins_per_bucket = (uint32_t)(n_bins >> PB);
     const int passes = (int)(bins_per_bucket / (uint32_t)PH_BINS);
-    KMAP_REQUIRE(vk >= 15 && passes <= P2_MAX, "counts: the two-level partition serves tables of 4^15 and 4^16 bins (k=%d, table 4^%d)", k, vk);
+    KMAP_REQUIRE(k >= 15 && passes <= P2_MAX, "counts: the two-level partition serves k = 15, 16 (k=%d)", k);
     KMAP_TRY(kmap_allow_lds((const void *)part_hist_kernel, (PH_BINS + 64) * 4));
     // second level: S = passes sub-buckets of 32768 bins per bucket; keys re-sorted tile by tile inside their bucket
     const int S = passes, shift2 = 15;                               // sub-bucket = bits [15, 15 + log2 S) of the hash
@@ -381,28 +367,17 @@ static int part_hist_any(kmap_counts *c, const uint32_t *hash_dev, const uint32_
     part2_scatter_kernel<<<1024, PS_TPB, (size_t)PT_TILE * 4, st>>>(keys, goff, tile_off, shift2, S, cursor2, keys2);
     // one pass per sub-bucket: "bucket" = sub-bucket index, 32768 bins each
     part_hist_kernel<<<(unsigned)m, PH_TPB, (size_t)(PH_BINS + 64) * 4, st>>>(keys2, goff2, (uint32_t)PH_BINS, c->bins);
-    if (packed && k == 16) {
-        // the all-T 16-mer (hash = the invalid marker: counted aside): its own bin, or -- key-range pass -- T1 when it lies in the range,
-        // else T2's slot of its partner, the all-A 16-mer (position 0), when that does
-        if (!RANGE) part_add_bin_kernel<<<1, 1, 0, st>>>(c->bins, (size_t)0xFFFFFFFFu, all_ones);
-        else if (0xFFFFFFFFu - kr.lo < kr.len) part_add_bin_kernel<<<1, 1, 0, st>>>(c->bins, (size_t)(0xFFFFFFFFu - kr.lo), all_ones);
-        else if (kr.half && kr.lo == 0 && kr.len > 0) part_add_bin_kernel<<<1, 1, 0, st>>>(c->bins, (size_t)kr.half, all_ones);
-    }
+    if (packed && k == 16) part_add_bin_kernel<<<1, 1, 0, st>>>(c->bins, (size_t)0xFFFFFFFFu, all_ones);
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;
 }
 
 int kmap_counts_part_hist_u32(kmap_counts *c, const uint32_t *hash_dev, int64_t n, int k, hipStream_t st) {
-    return part_hist_any<false>(c, hash_dev, nullptr, nullptr, nullptr, n, k, st);
+    return part_hist_any(c, hash_dev, nullptr, nullptr, nullptr, n, k, st);
 }
 int kmap_counts_part_hist_packed(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, const uint32_t *skip_dev,
                                  int64_t n, int k, hipStream_t st) {
-    return part_hist_any<false>(c, nullptr, codes_dev, inval_dev, skip_dev, n, k, st);
-}
-int kmap_counts_part_hist_range(kmap_counts *c, const uint32_t *codes_dev, const uint16_t *inval_dev, const uint32_t *skip_dev, int64_t n,
-                                int k, int vk, kmap_key_range r, unsigned long long **, hipStream_t st) {
-    if (vk <= 14) return kmap_counts_fine_hist_range(c, codes_dev, inval_dev, skip_dev, n, k, vk < 10 ? 10 : vk, r, st);
-    return part_hist_any<true>(c, nullptr, codes_dev, inval_dev, skip_dev, n, k, st, vk, r);
+    return part_hist_any(c, nullptr, codes_dev, inval_dev, skip_dev, n, k, st);
 }
 
 int kmap_counts_part_add_bin(kmap_counts *c, size_t bin, const unsigned long long *extra_dev, hipStream_t st) {

@@ -1263,7 +1263,6 @@ int kmap_counts_run_packed_range_dev(kmap_counts *c, const uint32_t *codes_dev, 
     // the virtual table: 4^vk bins with half = 4^vk / 2 >= n_bins (merge), or 4^vk >= n_bins (no merge); at least 4^10
     int vk = 10;
     while ((merge_revcom ? ((uint64_t)1 << (2 * vk - 1)) : ((uint64_t)1 << (2 * vk))) < n_bins) ++vk;
-    if (k == 16 && vk < 15) vk = 15;   // the all-T 16-mer's hash is the invalid marker: only the two-level passes count its windows aside
     uint32_t *skip = nullptr;
     if (dedupe_per_read) {
         KMAP_REQUIRE(n_seq == 0 || borders_dev, "counts_run_packed_range: dedupe needs borders");
@@ -1271,7 +1270,7 @@ int kmap_counts_run_packed_range_dev(kmap_counts *c, const uint32_t *codes_dev, 
     }
     // no gain, or no room: the whole table by the usual passes, then the slice.  (vk > k: the range is more than half of the table;
     // vk == 16 with a range that reaches virtual key 0xFFFFFFFF = the invalid marker; small inputs; reads beyond the LDS dedupe's length.)
-    const bool ranged = kmap_counts_part_applies(k, n) && vk <= k && !(dedupe_per_read && !skip) &&
+    const bool ranged = kmap_counts_part_applies(k, n) && vk <= k && !(dedupe_per_read && !skip) && n_bins <= 0xFFFFFFF0ull &&
                         !(vk == 16 && merge_revcom && n_bins > ((uint64_t)1 << 31) - 8);
     if (!ranged) {
         KMAP_TRY(kmap_counts_hist_packed_dev(c, codes_dev, inval_dev, n, borders_dev, n_seq, k, dedupe_per_read, stream));
@@ -1282,7 +1281,10 @@ int kmap_counts_run_packed_range_dev(kmap_counts *c, const uint32_t *codes_dev, 
     kr.len = (uint32_t)n_bins;
     kr.half = merge_revcom ? (uint32_t)((uint64_t)1 << (2 * vk - 1)) : 0u;
     kr.sh = 32 - 2 * k;
-    KMAP_TRY(kmap_counts_part_hist_range(c, codes_dev, inval_dev, skip, n, k, vk, kr, nullptr, st));
+    uint32_t *keys = nullptr;
+    int64_t n_keys = 0;
+    KMAP_TRY(kmap_counts_range_stage(codes_dev, inval_dev, skip, n, k, kr, &keys, &n_keys, st));
+    KMAP_TRY(kmap_counts_part_hist_u32(c, keys, n_keys, vk, st));      // the table of the virtual keys: 4^vk bins, every bin written
     return kmap_counts_finish_key_range(c, k, kr, n_uniq, st);
 }
 

@@ -570,7 +570,9 @@ def _gathered_hits_cls():
     return GatheredHits
 
 
-KEY_SPACE_MIN_K = 12     # from here on a multi-rank count owns KEY RANGES over all reads instead of read ranges + a table collective
+KEY_SPACE_MIN_K = 13     # from here on a multi-rank count owns KEY RANGES over all reads instead of read ranges + a table collective
+                         # (C3 at G = 8, one rank's pass: k = 12 3.1 ms against 0.74 ms + an all-reduce of 64 MiB; k = 13 about even;
+                         # k = 14 2.8 ms against 2.1 ms + an all-reduce of 1 GiB, >= 12 ms on a ring: tools/probes/keyspace_proxy.py)
 
 
 def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None, shard_counts=None, key_space=None):

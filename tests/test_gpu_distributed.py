@@ -478,7 +478,7 @@ def test_key_space_counting_three_ranks(tmp_path):
     """counting by KEY SPACE under a process group (three ranks sharing the test box's GPU): every rank holds all reads and
     computes only its key range (kmap_counts_run_packed_range_dev) -- the gathered tables equal the oracle's single-process count bit for
     bit at k = 11, 14, 16 with and without per-read dedupe and revcom merge, with ZERO table bytes through all_reduce / reduce; the
-    default rule takes key space from k = 12 on, find_motif on a table that stays sharded == one GPU on all reads, masks applied before
+    default rule takes key space from k = 13 on, find_motif on a table that stays sharded == one GPU on all reads, masks applied before
     and after the full copy exists reach it (reference kmer_count.py:476-491,580-610,643-685)."""
     import pickle
     import torch.multiprocessing as mp
