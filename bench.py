@@ -223,7 +223,7 @@ def stage_rooflines(reads, kh, lab, conseq_lens):
     out["knn_select"] = roof(float(n) * n, timed_launches(select, 6), "20 nearest rows per row of D (device tie rule), one read of D")
     lds = (n + 127) & ~127
     sums_d = _ffi.DeviceBuffer(n * lds * 2)
-    out["knn_sums"] = roof(3.0 * n * n, timed_launches(lambda: V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, K, conseq_lens, nb_d, 20, out=sums_d.ptr), 4),
+    out["knn_sums"] = roof(3.0 * n * n, timed_launches(lambda: V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, K, conseq_lens, nb_d, 20, out=sums_d.ptr, natural_diag=True), 4),
                            "neighbour sums from base-count profiles (8d: N^2 read at ideal reuse + 2 N^2 written; this kernel reads no matrix)")
     D_d.free()
     lut = V.hd_prob_lut(K, 20, 400 * K)
@@ -597,7 +597,7 @@ def shard_proxy(G, reads, res_dir, c3s, overhead_ms, first=None):
         # pass 2: neighbour sums + SEQ forces of the share's rows
         for row0, nrows in parts:
             sums_d = _ffi.DeviceBuffer(nrows * lds * 2)
-            sums_ms.append(med(lambda: V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, K, lens, nb_all, 20, row0=row0, nrows=nrows, out=sums_d.ptr), reps))
+            sums_ms.append(med(lambda: V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, K, lens, nb_all, 20, row0=row0, nrows=nrows, out=sums_d.ptr, natural_diag=True), reps))
             sess = V.EmbedSession(n, 1, 0.01, V.EMBED_SEQ, row0=row0, nrows=nrows)
             sums_d, rowmap_d, stored = V.dedupe_sums_rows(sums_d, nrows, lds, n=n)       # as the product does (repeated rows stored once)
             _ffi.check(lib.kmap_embed_set_prob_lut(sess._h, sums_d.ptr, lds, _ffi.ptr(lut), len(lut)))

@@ -340,6 +340,10 @@ int kmap_knn_sums_u8_dev(const uint8_t *D_dev, int64_t ldd, const int32_t *nb_de
  * the matrix rule of cal_samp_kmer_hamdist_mat motif_discovery.py:789-800); identical to kmap_knn_sums_u8_dev on the matrix
  * kmap_hamdist_matrix_* writes for (kh, label, clen).  k <= 16, at most 4 labels with clen < k, n_nb^2 k <= 65535; returns
  * KMAP_E_UNSUP otherwise (use the matrix-based entry point). */
+/* n_nb | KMAP_KNN_NATURAL_DIAG: S[i][i] keeps the value the formula gives it (= S[i][i'] for a repeated k-mer i') instead of the reference's
+ * 0 (visualization.py:103,107).  Nothing on the embedding path reads the diagonal (taichi_core.py:320-326 skips j == i, the loss takes
+ * i < j), and with it the rows of a repeated k-mer are equal byte for byte, so that they can be stored once (kmap_embed_set_row_map). */
+#define KMAP_KNN_NATURAL_DIAG (1 << 30)
 int kmap_knn_sums_kmers_u32_dev(const uint32_t *kh_dev, const int32_t *label_dev, int64_t n, int k, const int32_t *clen, int n_lab,
                                 const int32_t *nb_dev, int n_nb, int64_t row0, int64_t nrows, uint16_t *sums_dev, int64_t lds,
                                 void *stream);

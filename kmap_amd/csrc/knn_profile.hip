@@ -84,7 +84,7 @@ __global__ __launch_bounds__(KMAP_WAVE *KP_WAVES) void knn_sums_profile_kernel(c
                                                                               const uint32_t *__restrict__ Vg,
                                                                               const uint8_t *__restrict__ cg, int64_t n, int k,
                                                                               int n_nb, GroupTab gt, int64_t row0, int64_t nrows,
-                                                                              uint16_t *__restrict__ T, int64_t ldt) {
+                                                                              uint16_t *__restrict__ T, int64_t ldt, int zero_diag) {
     extern __shared__ uint4 kp_lds[];                           // [g][c][h][lane]
     constexpr int QH = KD / 4;                                  // 16-byte pieces per profile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(KMAP_WAVE *KP_WAVES) void knn_sums_profile_kernel(c
                 s[c] -= tc * cj - d;                           // cj = 0: the column's group profile is all zero, d = 0
             }
         }
-        if (i >= jw0 && i < jw0 + KMAP_WAVE * KP_CPL) {        // the diagonal crosses this block's columns (wave-uniform)
+        if (zero_diag && i >= jw0 && i < jw0 + KMAP_WAVE * KP_CPL) {   // the diagonal crosses this block's columns (wave-uniform)
 #pragma unroll
             for (int c = 0; c < KP_CPL; ++c)
                 if (j0 + c == i) s[c] = 0;                     // diagonal forced to 0 (visualization.py:103,107)
@@ -200,7 +200,7 @@ template <int KD>
 __global__ __launch_bounds__(KMAP_WAVE *KM_WAVES) void knn_sums_mfma_kernel(const uint32_t *__restrict__ V, const uint32_t *__restrict__ GA,
                                                                            const uint32_t *__restrict__ GB, int n_groups, int64_t n,
                                                                            uint32_t base, int64_t row0, int64_t nrows,
-                                                                           uint16_t *__restrict__ T, int64_t ldt) {
+                                                                           uint16_t *__restrict__ T, int64_t ldt, int zero_diag) {
     extern __shared__ uint4 km_lds[];
     constexpr int NK = KD / 8, NT = KM_COLS / 32;               // MFMAs per profile (32 bytes of K each), tiles per strip
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(KMAP_WAVE *KM_WAVES) void knn_sums_mfma_kernel(cons
                     }
                 }
             }
-            const bool on_diag = i0 < jt + 32 && jt < i0 + 32;  // wave-uniform
+            const bool on_diag = zero_diag && i0 < jt + 32 && jt < i0 + 32;  // wave-uniform
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int row = (q & 3) + 8 * (q >> 2) + 4 * h;  // C / D layout of the 32 x 32 forms: column = lane & 31
@@ -303,6 +303,9 @@ __global__ void kp_gid_kernel(const int32_t *__restrict__ label, int64_t n, cons
 template <typename H>
 int knn_sums_kmers(const H *kh_dev, const int32_t *label_dev, int64_t n, int k, const int32_t *clen, int n_lab,
                    const int32_t *nb_dev, int n_nb, int64_t row0, int64_t nrows, uint16_t *sums_dev, int64_t lds, void *stream) {
+    // KMAP_KNN_NATURAL_DIAG (kmap_hip.h): S[i][i] keeps the value the formula gives it instead of the reference's 0
+    const int zero_diag = (n_nb & KMAP_KNN_NATURAL_DIAG) ? 0 : 1;
+    n_nb &= ~KMAP_KNN_NATURAL_DIAG;
     KMAP_REQUIRE(n >= 0 && nrows >= 0 && row0 >= 0 && row0 + nrows <= n, "knn_sums_kmers: bad row range");
     KMAP_REQUIRE(n_nb > 0 && n_nb <= 255 && lds >= n, "knn_sums_kmers: bad n_nb / leading dimension");
     KMAP_REQUIRE(n_lab >= 0 && n_lab <= 255 && (n_lab == 0 || clen), "knn_sums_kmers: bad label table");
@@ -351,10 +354,10 @@ int knn_sums_kmers(const H *kh_dev, const int32_t *label_dev, int64_t n, int k, 
         const uint32_t base = (uint32_t)(n_nb * n_nb * k);
         if (kd == 8) {
             KMAP_TRY(kmap_allow_lds((const void *)knn_sums_mfma_kernel<8>, (int)lds_b));
-            knn_sums_mfma_kernel<8><<<grid, KMAP_WAVE * KM_WAVES, lds_b, st>>>(V, GA, GB, gt.n, n, base, row0, nrows, sums_dev, lds);
+            knn_sums_mfma_kernel<8><<<grid, KMAP_WAVE * KM_WAVES, lds_b, st>>>(V, GA, GB, gt.n, n, base, row0, nrows, sums_dev, lds, zero_diag);
         } else {
             KMAP_TRY(kmap_allow_lds((const void *)knn_sums_mfma_kernel<16>, (int)lds_b));
-            knn_sums_mfma_kernel<16><<<grid, KMAP_WAVE * KM_WAVES, lds_b, st>>>(V, GA, GB, gt.n, n, base, row0, nrows, sums_dev, lds);
+            knn_sums_mfma_kernel<16><<<grid, KMAP_WAVE * KM_WAVES, lds_b, st>>>(V, GA, GB, gt.n, n, base, row0, nrows, sums_dev, lds, zero_diag);
         }
         KMAP_CHECK_HIP(hipGetLastError());
         return KMAP_OK;
@@ -364,9 +367,9 @@ int knn_sums_kmers(const H *kh_dev, const int32_t *label_dev, int64_t n, int k, 
                     (unsigned)((nrows + KP_ROWS * KP_WAVES - 1) / (KP_ROWS * KP_WAVES)));
     KMAP_REQUIRE(grid.y <= 65535u, "knn_sums_kmers: nrows too large for one launch");
     const size_t lds_b = (size_t)gt.n * cpl * (kd / 4) * 64 * 16;   // <= 64 KiB (four groups)
-    if (kd == 8 && cpl == 8) knn_sums_profile_kernel<8, 8><<<grid, KMAP_WAVE * KP_WAVES, lds_b, st>>>(V, Vg, cg, n, k, n_nb, gt, row0, nrows, sums_dev, lds);
-    else if (kd == 8) knn_sums_profile_kernel<8, 4><<<grid, KMAP_WAVE * KP_WAVES, lds_b, st>>>(V, Vg, cg, n, k, n_nb, gt, row0, nrows, sums_dev, lds);
-    else knn_sums_profile_kernel<16, 4><<<grid, KMAP_WAVE * KP_WAVES, lds_b, st>>>(V, Vg, cg, n, k, n_nb, gt, row0, nrows, sums_dev, lds);
+    if (kd == 8 && cpl == 8) knn_sums_profile_kernel<8, 8><<<grid, KMAP_WAVE * KP_WAVES, lds_b, st>>>(V, Vg, cg, n, k, n_nb, gt, row0, nrows, sums_dev, lds, zero_diag);
+    else if (kd == 8) knn_sums_profile_kernel<8, 4><<<grid, KMAP_WAVE * KP_WAVES, lds_b, st>>>(V, Vg, cg, n, k, n_nb, gt, row0, nrows, sums_dev, lds, zero_diag);
+    else knn_sums_profile_kernel<16, 4><<<grid, KMAP_WAVE * KP_WAVES, lds_b, st>>>(V, Vg, cg, n, k, n_nb, gt, row0, nrows, sums_dev, lds, zero_diag);
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;
 }

@@ -446,7 +446,8 @@ def kmap_from_kmers_distributed(samp_kh, samp_cnts, samp_label, conseq_list, kme
     full_D = None
     for b, (r0, nr) in enumerate(blocks):
         dst = sums_d.ptr + b * blk_bytes
-        if nr and vz.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, kmer_len, lens, nb, n_neighbour, row0=r0, nrows=nr, out=dst) is None:
+        if nr and vz.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, kmer_len, lens, nb, n_neighbour, row0=r0, nrows=nr, out=dst,
+                                        natural_diag=(mode == vz.EMBED_SEQ and not cyclic)) is None:
             if full_D is None:     # profile kernel does not cover this request: the matrix-based sums gather arbitrary rows of D
                 D_d.free()
                 full_D = _ffi.DeviceBuffer(n * ldd)

@@ -211,9 +211,15 @@ def cyclic_blocks(n, world, rank):
     return out
 
 
-def knn_sums_kmers_dev(kh_dev_ptr, lab_dev_ptr, n, kmer_len, conseq_lens, nb, n_nb, row0=0, nrows=None, stream=None, out=None):
+KNN_NATURAL_DIAG = 1 << 30      # kmap_hip.h KMAP_KNN_NATURAL_DIAG
+
+
+def knn_sums_kmers_dev(kh_dev_ptr, lab_dev_ptr, n, kmer_len, conseq_lens, nb, n_nb, row0=0, nrows=None, stream=None, out=None, natural_diag=False):
     """Same sums as knn_sums_dev but from the k-mers themselves (base-count profiles, csrc/knn_profile.hip): no matrix is
-    read.  Returns None when the profile kernel does not cover the request (k > 16, more than 4 short consensuses)."""
+    read.  Returns None when the profile kernel does not cover the request (k > 16, more than 4 short consensuses).
+    natural_diag (the embedding's own calls): S[i][i] keeps the formula's value instead of the reference's 0 -- no force or loss term
+    reads the diagonal, and the rows of a repeated k-mer then agree byte for byte wherever they are compared (dedupe_sums_rows: C4's
+    200 000 rows are 31 298 stored rows instead of 98 177)."""
     nrows = n - row0 if nrows is None else nrows
     lds = (n + 127) & ~127
     clen = np.ascontiguousarray(conseq_lens, dtype=np.int32)
@@ -222,8 +228,8 @@ def knn_sums_kmers_dev(kh_dev_ptr, lab_dev_ptr, n, kmer_len, conseq_lens, nb, n_
     sums_d = _ffi.DeviceBuffer(max(nrows, 1) * lds * 2) if out is None else None
     dst = sums_d.ptr if out is None else out              # out: device address of a caller-owned [nrows x lds] uint16 block
     fn = _ffi.lib().kmap_knn_sums_kmers_u32_dev if get_hash_dtype(kmer_len) == np.uint32 else _ffi.lib().kmap_knn_sums_kmers_u64_dev
-    rc = fn(kh_dev_ptr, lab_dev_ptr, n, kmer_len, ptr(clen) if len(clen) else None, len(clen), nb_d.ptr, n_nb, row0, nrows,
-            dst, lds, stream)
+    rc = fn(kh_dev_ptr, lab_dev_ptr, n, kmer_len, ptr(clen) if len(clen) else None, len(clen), nb_d.ptr,
+            n_nb | (KNN_NATURAL_DIAG if natural_diag else 0), row0, nrows, dst, lds, stream)
     if own:
         nb_d.free()
     if rc == -4:                      # KMAP_E_UNSUP
@@ -528,7 +534,7 @@ def kmap_from_kmers(samp_kh, samp_cnts, samp_label, conseq_list, kmer_len, n_nei
     if trace is not None and not isinstance(neighbor_inds_mat, _ffi.DeviceBuffer):
         trace["nb"] = np.asarray(neighbor_inds_mat)            # the host-chosen neighbours (numpy mode / injected)
     with _stage("knn_sums"):
-        res = knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, kmer_len, lens, neighbor_inds_mat, n_neighbour)
+        res = knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, kmer_len, lens, neighbor_inds_mat, n_neighbour, natural_diag=mode == EMBED_SEQ)
         sums_d, lds = res if res is not None else knn_sums_dev(D_d.ptr, ldd, neighbor_inds_mat, n, n_neighbour)
     if isinstance(neighbor_inds_mat, _ffi.DeviceBuffer):
         neighbor_inds_mat.free()

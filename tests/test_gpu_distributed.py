@@ -465,6 +465,15 @@ def _keyspace_worker(rank, world, port, out_dir):
         ds2.mask(13, cons, np.array([2, 1], np.int32))
         ds2.count(dc, 13, dedupe=False, merge_revcom=True)
         out["masked13"] = dc.fetch()
+        # KMAP_DIST_KEYSPACE overrides the rule: 0 = read shards + table all-reduce at every k, 1 = key space from k = 11 on
+        ds2.reset()
+        os.environ["KMAP_DIST_KEYSPACE"] = "0"
+        ds2.count(dc, 14, dedupe=False, merge_revcom=True)
+        out["k14_allreduce_form"] = dc.fetch()
+        os.environ["KMAP_DIST_KEYSPACE"] = "1"
+        ds2.count(dc, 11, dedupe=True, merge_revcom=True)
+        out["k11_keyspace_by_switch"] = dc.fetch()
+        os.environ.pop("KMAP_DIST_KEYSPACE")
         with open(Path(out_dir) / f"ks_rank{rank}.pkl", "wb") as fh:
             pickle.dump(out, fh)
         dc.close()
@@ -521,6 +530,9 @@ def test_key_space_counting_three_ranks(tmp_path):
         assert r["motifs8"] == {int(h): v for h, v in s8.items()}
         np.testing.assert_array_equal(r["masked13"][0], mu)
         np.testing.assert_array_equal(r["masked13"][1], mc)
+        for key, ref in (("k14_allreduce_form", (14, False, True)), ("k11_keyspace_by_switch", (11, True, True))):
+            np.testing.assert_array_equal(r[key][0], r[ref][0])
+            np.testing.assert_array_equal(r[key][1], r[ref][1])
 
 
 def test_read_sharded_counting_scan_and_find_motif(tmp_path):

@@ -480,7 +480,7 @@ def test_c4_whole_run():
         assert V.knn_mode(n) == "device"
         nb_d = V.knn_select_dev(D_d.ptr, ldd, n, 20)
         D_d.free()
-        sums_d, lds = V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, klen, lens, nb_d, 20)
+        sums_d, lds = V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, klen, lens, nb_d, 20, natural_diag=True)     # as the verb's SEQ path calls it
         for b in (nb_d, kh_d, lab_d):
             b.free()
         lut = V.hd_prob_lut(klen, 20, 400 * klen)
@@ -490,7 +490,7 @@ def test_c4_whole_run():
         for t, rr in enumerate(rows):
             P[t] = lut[sums_d.to_numpy(np.uint16, (lds,), offset=int(rr) * lds * 2)[:n]]
         comp_d, rowmap_d, stored = V.dedupe_sums_rows(sums_d, n, lds, n=n)   # as the verb does: repeated rows stored once
-        assert rowmap_d is not None and stored < n                           # 31 298 distinct k-mers; rows of copies differ on their diagonals where S[i, i'] != 0: 98 177 stored
+        assert rowmap_d is not None and stored <= len(samp_kh)              # at most one stored row per distinct sampled k-mer (31 249 of 31 298; with the reference's zero diagonal: 98 177)
         ld0, ph = V._init_draws(n, 10, 7)
         sess = V.EmbedSession(n, 10, 0.01, V.EMBED_SEQ)
         try:
