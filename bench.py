@@ -131,6 +131,9 @@ def roof(bytes_per_launch, ms_list, what, note=None):
 # FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes) make up `moved_bytes` of a stage
 STAGE_KERNELS = {
     "count_pass_k8": ("e2e", [("hist_packed16_kernel", 1), ("compact_count_kernel", 1), ("compact_write_kernel<unsigned int>", 1)]),
+    "count_k14_keyspace_rank": ("keyspace14", [("range_stage_kernel", 1), ("fine_count_kernel", 1), ("fine_offsets_kernel", 1), ("fine_scatter_kernel", 1),
+                                               ("fine_zero_heavy_kernel", 1), ("fine_hist_kernel", 1), ("compact_count_kernel", 1),
+                                               ("compact_write_kernel<unsigned int>", 1)]),
     "count_pass_k8_dedupe": ("e2e", [("dedupe_bitmap_packed_kernel<true>", 1), ("max_read_len_kernel", 1), ("hist_packed16_kernel", 1),
                                      ("compact_count_kernel", 1), ("compact_write_kernel<unsigned int>", 1)]),
     "count_pass_k14": ("count14", [("fine_count_kernel", 1), ("fine_offsets_kernel", 1), ("fine_scatter_kernel", 1), ("fine_zero_heavy_kernel", 1),
@@ -170,6 +173,11 @@ def add_moved_bytes(stages):
             st["moved_bytes"] = total
             st["frac_moved"] = total / (st["ms_median"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             st["moved_source"] = f"profiles/{pmc[-1].name} [{w}]" + (f"; no counters for {missing}" if missing else "")
+            # the number to quote: where the kernels do not move SURVEY 8(d)'s bytes (they read no matrix, or each pair once, or move more
+            # than the algorithm needs) the fraction of the bytes actually moved, otherwise the algorithmic one
+            off = abs(total - st["algorithmic_bytes"]) > 0.1 * st["algorithmic_bytes"]
+            st["frac_quote"] = st["frac_moved"] if off else st["frac"]
+            st["frac_quote_is"] = "frac_moved" if off else "frac"
 
 
 def stage_rooflines(reads, kh, lab, conseq_lens):
@@ -192,6 +200,9 @@ def stage_rooflines(reads, kh, lab, conseq_lens):
                                        "first find_motif round: per-read de-duplication fused in front of the histogram")
     out["count_pass_k14"] = roof(npos + 4 ** 14 * 4, timed_launches(lambda: ds.count(dc, 14, dedupe=False, merge_revcom=True), 4),
                                  "partitioned histogram (11 <= k <= 15) + tiled revcom merge")
+    b14 = [(4 ** 14 * r // 8) & ~7 for r in range(9)]
+    out["count_k14_keyspace_rank"] = roof(npos + 4 ** 14 * 4 / 8, timed_launches(lambda: ds.count_range(dc, 14, False, True, b14[3], b14[4] - b14[3]), 4),
+                                         "ONE rank's count pass of a key-space-sharded run at G = 8 (rank 3): all reads in, its eighth of the merged k = 14 table out, no collective")
     cons = int(kmer2hash("CCTACGTA"))
     out["mask_k8"] = roof(npos, timed_launches(lambda: (ds.reset(), ds.mask(8, np.array([cons, cons ^ 0x1B]), np.array([2, 2]))), 6),
                           "mask_input: Hamming-ball flag + cover of two consensuses (incl. the n/8-byte restore)")
@@ -343,6 +354,15 @@ def cpu_baseline(kh, lab, conseq_lens, quick=False):
 
 
 # ---- multi-GPU legs ----------------------------------------------------------------------------------------------------
+def _barrier(dist, torch):
+    """every rank has arrived: a one-element all-reduce on the device + its read-back.  (torch's dist.barrier() on the gloo group of the
+    one-GPU rehearsals never returned once the key-range legs had run -- all five ranks stood in it: gpurun_out/r6_reh5d.err -- while
+    the all-reduces around it kept completing; on RCCL a barrier IS such an all-reduce.)"""
+    t = torch.zeros(1, dtype=torch.int32, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
 def _all_ok(dist, torch, flag):
     """has any rank failed so far (a rank that failed sets its flag; every rank sees it before anyone enters the next phase)"""
     if dist is None:
@@ -367,7 +387,7 @@ def embed_dist_leg(dist, torch, world, kh, lab, conseqs, iters=200, mode=None, w
     for it, prof in ((24, 20), (iters, 0)):
         if not _all_ok(dist, torch, flag):
             break
-        dist.barrier()
+        _barrier(dist, torch)
         tr = {}
         try:
             kmap_from_kmers_distributed(kh, ones, lab, conseqs, K, n_max_iter=it, random_seed=7, trace=tr, mode=mode,
@@ -377,6 +397,8 @@ def embed_dist_leg(dist, torch, world, kh, lab, conseqs, iters=200, mode=None, w
         except Exception as e:   # noqa: BLE001
             err = f"{type(e).__name__}: {e}"[:300]
             flag.fill_(1)
+            import traceback
+            print(f"bench.py: embed_dist_leg failed on rank {dist.get_rank()}: {err}\n{traceback.format_exc()}", file=sys.stderr, flush=True)
     if not _all_ok(dist, torch, flag):
         return {"error": err or "another rank failed"}
     t = torch.tensor([loop_s], dtype=torch.float64, device="cuda")
@@ -392,7 +414,7 @@ def embed_dist_leg(dist, torch, world, kh, lab, conseqs, iters=200, mode=None, w
         for it in (24, iters):
             if not _all_ok(dist, torch, flag):
                 break
-            dist.barrier()
+            _barrier(dist, torch)
             tr = {}
             try:
                 kmap_from_kmers_distributed(kh, ones, lab, conseqs, K, n_max_iter=it, random_seed=7, trace=tr, mode=mode, exchange="direct")
@@ -446,7 +468,7 @@ def count_dist_leg(dist, torch, world, k=15, n_reads=1_000_000, read_len=150, re
             dc = DeviceCounts()
             best = None
             for rep in range(reps + 1):                                  # the first pass allocates the table and the communicator's buffers
-                dist.barrier()
+                _barrier(dist, torch)
                 _ffi.sync()
                 t0 = time.perf_counter()
                 ds.count(dc, k, dedupe=True, merge_revcom=True)
@@ -502,7 +524,7 @@ def reads_dist_leg(dist, torch, world, rank, res_dir, reps=3):
         for name, fn in passes.items():
             best = None
             for rep in range(reps + 1):                   # the first pass allocates tables / communicator buffers
-                dist.barrier()
+                _barrier(dist, torch)
                 torch.cuda.synchronize()
                 _ffi.sync()
                 t0 = time.perf_counter()
@@ -998,6 +1020,11 @@ class Budget:
         return self.total - self.elapsed()
 
     def _fire(self):
+        try:                                        # where every thread of this rank stands, for the post-mortem (stderr)
+            import faulthandler
+            faulthandler.dump_traceback(all_threads=True)
+        except Exception:   # noqa: BLE001
+            pass
         if self.rank == 0 and self.line is not None:
             self.line["watchdog"] = f"leg '{self.name}' still running at the deadline ({self.total:.0f} s + grace); ended by the watchdog"
             self.line["skipped_legs"] = self.skipped
@@ -1152,7 +1179,7 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            _barrier(dist, torch)
         torch.cuda.synchronize()
         _ffi.sync()
 
@@ -1418,7 +1445,7 @@ def main():
         import shutil
         shutil.rmtree(res_dir, ignore_errors=True)
     if dist is not None:
-        dist.barrier()
+        _barrier(dist, torch)
         dist.destroy_process_group()
 
 

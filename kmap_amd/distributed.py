@@ -37,6 +37,16 @@ def _coll_device(dist, group=None):
     return "cuda" if dist.get_backend(group) == "nccl" else "cpu"
 
 
+def barrier(dist, group=None):
+    """every rank of the group has arrived: a one-element SUM all-reduce + its read-back -- what a barrier is on RCCL anyway.  torch's
+    own dist.barrier() on a gloo group never returned once the key-range count's concurrent asynchronous reduces had run (all ranks
+    stood in it while all-reduces around it kept completing: the five-rank rehearsal of bench.py, round 6)."""
+    import torch
+    t = torch.zeros(1, dtype=torch.int32, device=_coll_device(dist, group))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return int(t.item())
+
+
 def all_gather_concat(dist, arr, lengths=None, group=None):
     """Concatenation, in rank order, of every rank's array (same dtype and trailing shape, different leading lengths) through
     one all_gather of padded tensors -- device tensors on RCCL, host tensors on gloo; no pickling.  `lengths` (leading length
@@ -318,7 +328,7 @@ class PeerExchange:
     def close(self):
         from . import _ffi
         if self._p:
-            self.dist.barrier(group=self.group)   # no rank unmaps an area a peer may still push into
+            barrier(self.dist, self.group)        # no rank unmaps an area a peer may still push into
             _ffi.lib().kmap_peer_destroy(self._p)
             self._p = None
 

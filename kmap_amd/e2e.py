@@ -92,7 +92,7 @@ def run_e2e_dist(dist, config="C3", mode="default", min_k=6, max_k=9, iters=None
     import io
     import torch
     from . import motif_discovery as md, synth, visualization as vz
-    from .distributed import _coll_device
+    from .distributed import _coll_device, barrier as _dist_barrier
     assert mode in ("default", "seq", "fast", "exact"), mode
     c = CONFIGS[config]
     rank = dist.get_rank()
@@ -125,7 +125,7 @@ def run_e2e_dist(dist, config="C3", mode="default", min_k=6, max_k=9, iters=None
     try:
         with contextlib.redirect_stdout(io.StringIO()):
             np.random.seed(123)
-            dist.barrier()
+            _dist_barrier(dist)
             t0 = time.perf_counter()
             md._scan_motif(str(res))              # ends with a barrier of its own
             t["scan_motif_s"] = slowest(time.perf_counter() - t0)
@@ -144,6 +144,6 @@ def run_e2e_dist(dist, config="C3", mode="default", min_k=6, max_k=9, iters=None
     finally:
         if prev_mode is not None:
             os.environ["KMAP_EMBED_MODE"] = prev_mode
-        dist.barrier()
+        _dist_barrier(dist)
         if rank == 0:
             shutil.rmtree(res, ignore_errors=True)

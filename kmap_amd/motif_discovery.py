@@ -862,7 +862,8 @@ def _scan_motif(res_dir: str, debug=False):
             except BaseException:    # noqa: BLE001 -- a writer's failure already surfaced through join(), or the run is failing anyway
                 pass
     if dist is not None:            # success path only (a failing rank re-raises and the launcher tears the job down)
-        dist.barrier()
+        from .distributed import barrier as _dist_barrier
+        _dist_barrier(dist)
         if owns_group:
             dist.destroy_process_group()
 

@@ -592,7 +592,8 @@ def _visualize_kmers(res_dir: str, debug=False, mode=None, neighbor_inds_mat=Non
     # success path only: a rank that raised must not park in a barrier its peers may never reach -- it re-raises, exits
     # non-zero and the launcher tears the other ranks down
     if dist is not None:
-        dist.barrier()
+        from .distributed import barrier as _dist_barrier
+        _dist_barrier(dist)
         if owns_group:
             dist.destroy_process_group()
     return out

@@ -13,11 +13,11 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = ROOT / "gpurun_out" / "round_prof"
 dst = ROOT / "profiles"
 dst.mkdir(exist_ok=True)
-for name in ("bench_trace", "e2e_trace", "embed_trace", "seqshard_trace", "scan_trace", "count_trace"):
+for name in ("bench_trace", "e2e_trace", "embed_trace", "seqshard_trace", "scan_trace", "count_trace", "keyspace_trace"):
     f = glob.glob(str(src / name / "*" / "*kernel_stats.csv"))
     if f:
         shutil.copyfile(f[0], dst / f"{tag}_{name}_kernel_stats.csv")
-for name in ("bench_trace.json", "e2e_trace.json", "embed_trace.txt", "seqshard_trace.txt", "scan_trace.json", "count_trace.txt"):
+for name in ("bench_trace.json", "e2e_trace.json", "embed_trace.txt", "seqshard_trace.txt", "scan_trace.json", "count_trace.txt", "keyspace_trace.txt"):
     if (src / name).exists():
         shutil.copyfile(src / name, dst / f"{tag}_{name}")
 out = {"command": "rocprofv3 --pmc WRITE_SIZE (and, separately, FETCH_SIZE) --output-format csv -- python3 bench.py --no-cpu-baseline --no-c4 --no-stages --e2e none --steps 5 --warmup 1",

@@ -17,6 +17,7 @@ for s in sq_a sq_b fetch write; do
   echo "== pass $s: ${SETS[$s]}"
   rocprofv3 --pmc ${SETS[$s]} --output-format csv -d $OUT/e2e_$s -- python3 $R/tools/e2e.py --config C3 --mode fast --iters 12 > $OUT/e2e_$s.json 2> $OUT/e2e_$s.err || { tail -5 $OUT/e2e_$s.err; echo "pass $s (e2e) failed"; }
   rocprofv3 --pmc ${SETS[$s]} --output-format csv -d $OUT/count14_$s -- python3 $R/tools/probes/count_only.py 14 3 0 > $OUT/count14_$s.txt 2> $OUT/count14_$s.err || { tail -5 $OUT/count14_$s.err; echo "pass $s (count14) failed"; }
+  rocprofv3 --pmc ${SETS[$s]} --output-format csv -d $OUT/keyspace14_$s -- python3 $R/tools/probes/keyspace_one.py 14 8 3 > $OUT/keyspace14_$s.txt 2> $OUT/keyspace14_$s.err || { tail -5 $OUT/keyspace14_$s.err; echo "pass $s (keyspace14) failed"; }
   rocprofv3 --pmc ${SETS[$s]} --output-format csv -d $OUT/seq_$s -- python3 $R/tools/bench_embed.py --n 50000 --iters 3 --modes seq > $OUT/seq_$s.txt 2> $OUT/seq_$s.err || { tail -5 $OUT/seq_$s.err; echo "pass $s (seq) failed"; }
   rocprofv3 --pmc ${SETS[$s]} --output-format csv -d $OUT/seqshard_$s -- python3 $R/tools/probes/seq_shard_only.py adder > $OUT/seqshard_$s.txt 2> $OUT/seqshard_$s.err || { tail -5 $OUT/seqshard_$s.err; echo "pass $s (seqshard) failed"; }
 done

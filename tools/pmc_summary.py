@@ -52,7 +52,7 @@ def main():
     out_path = Path(sys.argv[2]) if len(sys.argv) > 2 else None
     result = {"source": str(root), "units": "counter means per launch; FETCH_SIZE / WRITE_SIZE in KB as reported; hbm_bytes corrected",
               "workloads": {}}
-    for wl in ("e2e", "seq", "seqshard", "count14"):
+    for wl in ("e2e", "seq", "seqshard", "count14", "keyspace14"):
         kern = collections.defaultdict(dict)
         for s in ("sq_a", "sq_b", "fetch", "write"):
             for k, cs in load(root / f"{wl}_{s}").items():

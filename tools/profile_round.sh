@@ -16,6 +16,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/seqshard_trace -- p
 # (the full-size C5 scan is part of bench_trace: bench.py's c5 leg generates its 50 M x 300 bp reads in HBM)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scan_trace -- python3 $R/tools/bench_scan.py --reads 10000000 --read_len 150 --k 8 --radius 2 --reps 5 > $OUT/scan_trace.json 2> $OUT/scan_trace.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/count_trace -- python3 $R/tools/probes/count_only.py 14 5 0 > $OUT/count_trace.txt 2> $OUT/count_trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/keyspace_trace -- python3 $R/tools/probes/keyspace_one.py 14 8 3 > $OUT/keyspace_trace.txt 2> $OUT/keyspace_trace.err
 # counters for every kernel DESIGN.md calls "bound by ..." (C3 pipeline + SEQ micro-benchmark, four PMC passes)
 bash $R/tools/pmc_round.sh round > $OUT/pmc_round.log 2>&1 || true
 python3 $R/tools/pmc_summary.py $R/gpurun_out/pmc_round $OUT/pmc_summary.json > $OUT/pmc_summary.txt 2>&1 || true
