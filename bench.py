@@ -448,10 +448,11 @@ def embed_dist_leg(dist, torch, world, kh, lab, conseqs, iters=200, mode=None, w
 
 
 def count_dist_leg(dist, torch, world, k=15, n_reads=1_000_000, read_len=150, reps=3):
-    """Multi-GPU counting at a k whose 4^k table is large (k = 15: 4 GiB): reads sharded over the ranks, one count pass with per-read
-    dedupe and reverse-complement merge -- (a) all-reduce of the whole table, every rank compacts it; (b) bins owned by key range:
-    presence all-reduce (half a byte per bin) + one SUM-reduce per slice + all-gather of the compacted shards
-    (kmap_amd.distributed.make_dist_device_seq(shard_counts=...)).  ms per pass (max over ranks, best of `reps`), and that both
+    """Multi-GPU counting at a k whose 4^k table is large (k = 15: 4 GiB), one count pass with per-read dedupe and reverse-complement
+    merge in three forms -- (a) reads sharded, all-reduce of the whole table, every rank compacts it; (b) reads sharded, bins owned by key
+    range: presence all-reduce (half a byte per bin) + one SUM-reduce per slice + all-gather of the compacted shards
+    (make_dist_device_seq(shard_counts=True)); (c) KEY SPACE (the default from k = 13): every rank holds all reads and computes its key
+    range alone, no table bytes exchanged (key_space=True).  ms per pass (max over ranks, best of `reps`), and that both
     give the same table.  1 M x 150 bp reads: 1.5e8 windows against 1.07e9 bins -- the sparse regime in which make_dist_device_seq
     picks the key-range form by itself (every rank wants the WHOLE list, so its all-gather, 12 B per distinct k-mer, must stay
     below what the slices save: windows < 4^k / 4).  Errors are reported in the line, not raised."""
@@ -463,8 +464,10 @@ def count_dist_leg(dist, torch, world, k=15, n_reads=1_000_000, read_len=150, re
     try:
         seq, borders = synth.synth_reads(n_reads, read_len, 11)          # the same array on every rank; a rank uploads its slice
         sums = {}
-        for name, by_range in (("all_reduce", False), ("key_range", True)):
-            ds = make_dist_device_seq(seq, borders, dist, shard_counts=by_range)
+        forms = (("all_reduce", dict(shard_counts=False, key_space=False)), ("key_range", dict(shard_counts=True, key_space=False)),
+                 ("key_space", dict(key_space=True)))
+        for name, kw in forms:
+            ds = make_dist_device_seq(seq, borders, dist, **kw)
             dc = DeviceCounts()
             best = None
             for rep in range(reps + 1):                                  # the first pass allocates the table and the communicator's buffers
@@ -482,7 +485,7 @@ def count_dist_leg(dist, torch, world, k=15, n_reads=1_000_000, read_len=150, re
             sums[name] = (int(dc.n_uniq), int(dc.total()))
             dc.close()
             ds.close()
-        res["same_table"] = sums["all_reduce"] == sums["key_range"]
+        res["same_table"] = sums["all_reduce"] == sums["key_range"] == sums["key_space"]
         res["n_uniq"], res["total_count"] = sums["key_range"]
     except Exception as e:   # noqa: BLE001
         err = f"{type(e).__name__}: {e}"[:300]
@@ -491,7 +494,10 @@ def count_dist_leg(dist, torch, world, k=15, n_reads=1_000_000, read_len=150, re
         return {"error": err or "another rank failed"}
     tb = 4 ** k * 4
     res.update({"k": k, "reads": n_reads, "read_len": read_len, "table_bytes": tb,
-                "bytes_received_per_rank": {"all_reduce": 2 * tb * (world - 1) // world,
+                "forms": "all_reduce: read shards + SUM all-reduce of the 4^k table; key_range (round 4): read shards + presence nibbles + one SUM-reduce per "
+                         "slice; key_space (round 6, the default from k = 13): all reads on every rank, the rank's key range from the windows that decide it, "
+                         "no table bytes exchanged",
+                "bytes_received_per_rank": {"key_space": 0, "all_reduce": 2 * tb * (world - 1) // world,
                                             "key_range": (tb + 2 * (tb // 8) + (12 * res.get("n_uniq", 0) if res.get("n_uniq", 0) <= 4_000_000 else 0)) * (world - 1) // world,
                                             "note": "ring estimates; key_range = table slices + presence nibbles (all-reduced); above 4e6 distinct k-mers the "
                                                     "(k-mer, count) shards are NOT exchanged: the table stays sharded and find_motif works on local partials "
