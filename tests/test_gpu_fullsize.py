@@ -91,6 +91,31 @@ def test_c3_counting_full_size(c3_reads, c3_dev):
     dc.close()
 
 
+@pytest.mark.parametrize("k,G", [(13, 8), (14, 8), (14, 3), (16, 8)])
+def test_c3_key_space_shards_full_size(c3_dev, k, G):
+    """Counting by key space at C3's full size (1.51e9 positions; round 6, reference kmer_count.py:476-491,643-685): the G shards of
+    kmap_counts_run_packed_range_dev -- each from the windows that decide it alone -- concatenated in rank order are the one-GPU
+    table, key for key and count for count, with the per-read dedupe of find_motif's first round and without (k = 16: 16-GiB table,
+    64-bit keys, the two-level partition behind the staging pass)."""
+    from kmap_amd.kmer_count import DeviceCounts
+    dc = DeviceCounts()
+    n_bins = 4 ** k
+    bounds = [(n_bins * r // G) & ~7 for r in range(G)] + [n_bins]
+    try:
+        for dedupe in ((True, False) if k == 14 and G == 8 else (False,)):
+            c3_dev.count(dc, k, dedupe=dedupe, merge_revcom=True)
+            u, c = dc.fetch()
+            at = 0
+            for r in range(G):
+                c3_dev.count_range(dc, k, dedupe, True, bounds[r], bounds[r + 1] - bounds[r])
+                su, sc = dc.fetch()
+                assert np.array_equal(su, u[at:at + len(su)]) and np.array_equal(sc, c[at:at + len(sc)]), (k, G, dedupe, r)
+                at += len(su)
+            assert at == len(u)
+    finally:
+        dc.close()
+
+
 def test_c3_masking_full_size(c3_reads, c3_dev):
     from kmap_amd.kmer_count import kmer2hash, revcom_hash
     from oracle import oracle as O
@@ -193,9 +218,20 @@ def test_c5_counting_beyond_2_32_positions(c5_reads):
             part.count(dc, k, dedupe=True, merge_revcom=True)
             acc[k] += _dense(*dc.fetch(), k)
         part.close()
-    dc.close()
     for k in (8, 14):
         np.testing.assert_array_equal(acc[k], full[k])
+    # the same table from eight key-space shards (positions and group indices beyond 2^32 in the staging pass; 459 000 output chunks)
+    ds = DeviceSeq(seq, borders)
+    bounds = [(4 ** 14 * r // 8) & ~7 for r in range(8)] + [4 ** 14]
+    acc14 = np.zeros(4 ** 14, np.int64)
+    for r in range(8):
+        ds.count_range(dc, 14, True, True, bounds[r], bounds[r + 1] - bounds[r])
+        su, sc = dc.fetch()
+        assert len(su) == 0 or (len(np.unique(su)) == len(su))
+        acc14 += _dense(su, sc, 14)
+    ds.close()
+    dc.close()
+    np.testing.assert_array_equal(acc14, full[14])
 
 
 def _pipeline_like_sample(n, seed):

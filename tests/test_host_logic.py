@@ -539,3 +539,25 @@ def test_bench_line_is_compact_strict_json(tmp_path, monkeypatch):
         rel = bench.write_detail(line, world)
         det = json.loads((tmp_path / rel).read_text(), parse_constant=lambda c: pytest.fail(f"non-finite constant {c} in the detail file"))
         assert det["roofline"]["stages"]["stage0"]["frac"] is None and len(det["ranks"]) == world
+
+
+def test_bench_budget_skips_legs_that_do_not_fit(monkeypatch, capsys):
+    """bench.py's ONE deadline: a leg starts only if its expected cost fits what is left of --time-budget; a skipped leg is named; no
+    watchdog thread at N = 1"""
+    import importlib
+    import sys
+    sys.path.insert(0, str(ROOT))
+    bench = importlib.import_module("bench")
+    now = [100.0]
+    monkeypatch.setattr(bench.time, "perf_counter", lambda: now[0])
+    monkeypatch.setattr(bench, "T_START", 100.0)
+    b = bench.Budget(60.0, 10.0, 1, 0, 1)
+    assert b.timer is None and abs(b.left() - 60.0) < 1e-9
+    assert b.can("a", 50.0) and b.name == "a"
+    now[0] = 130.0
+    assert not b.can("b", 31.0) and b.skipped == ["b"]
+    assert b.can("c", 30.0)
+    now[0] = 170.0
+    assert not b.can("d", 0.5) and b.skipped == ["b", "d"] and b.left() < 0
+    b.done()
+    assert "SKIPPED" in capsys.readouterr().err
