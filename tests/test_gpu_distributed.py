@@ -809,6 +809,47 @@ def test_scan_motif_cli_under_torchrun(tmp_path):
     assert len((tmp_path / "dist" / "final_conseq.txt").read_text().split()) >= 1
 
 
+def test_scan_motif_cli_key_space_under_torchrun(tmp_path):
+    """`scan_motif` for k = 12..14 under two ranks: k = 12 counts read shards + a table all-reduce, k = 13 / 14 count by KEY SPACE (every
+    rank holds all reads and computes its half of the table; the masked re-counts of find_motif's later rounds replay the masks on the
+    full copy) -- every output file, k{k}.pkl included, equals the single-process verb's."""
+    import pickle
+    import subprocess
+    from kmap_amd import synth
+    seq, borders = synth.synth_reads(40_001, 60, 12)
+    outs = {}
+    for tag in ("single", "dist"):
+        res = tmp_path / tag
+        res.mkdir()
+        over = {"kmer_count": {"min_k": 12, "max_k": 14},
+                "motif_discovery": {"motif_pos_density_flag": False, "motif_co_occurence_flag": False, "gen_hamball_flag": False,
+                                    "n_total_sample": 400, "n_motif_sample": 200},
+                "visualization": {"gen_fig_flag": False, "random_seed": 7, "n_max_iter": 10}}
+        synth.write_res_dir(res, seq, borders, over)
+        env = dict(os.environ, PYTHONPATH=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        seeded = "import sys, numpy as np; np.random.seed(123); from kmap_amd.motif_discovery import _scan_motif; _scan_motif(sys.argv[1])"
+        if tag == "single":
+            cmd = [sys.executable, "-c", seeded, str(res)]
+        else:
+            env.update(KMAP_DIST_BACKEND="gloo", KMAP_DIST_SAME_GPU="1")
+            (tmp_path / "seeded_scan.py").write_text(seeded + "\n")
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                   "--master-port", str(_free_port()), str(tmp_path / "seeded_scan.py"), str(res)]
+        r = subprocess.run(cmd, env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[tag] = {str(f.relative_to(res)): f.read_bytes() for f in sorted(res.rglob("*"))
+                     if f.is_file() and f.name not in ("input.bin.pkl", "input.seqboarder.bin.pkl", "config.toml")}
+    assert sorted(outs["single"]) == sorted(outs["dist"]) and {"kmer_count/k13.pkl", "kmer_count/k14.pkl"} <= set(outs["single"])
+    for name, blob in outs["single"].items():
+        if name.endswith(".pkl"):
+            a, b = pickle.loads(blob), pickle.loads(outs["dist"][name])
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(np.asarray(x, dtype=object) if isinstance(x, list) else x,
+                                              np.asarray(y, dtype=object) if isinstance(y, list) else y, err_msg=name)
+        else:
+            assert blob == outs["dist"][name], name
+
+
 def _nccl_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import pickle
@@ -842,6 +883,11 @@ def _nccl_worker(rank, world, port, out_dir):
         ds_r.count(dc, 12, dedupe=True, merge_revcom=True)
         out["counts_range"] = dc.fetch()
         ds_r.close()
+        # ... and by key space on RCCL (the shard bookkeeping on device tensors; a one-rank group owns the whole key range)
+        ds_k = make_dist_device_seq(seq, borders, dist, key_space=True)
+        ds_k.count(dc, 12, dedupe=True, merge_revcom=True)
+        out["counts_keyspace"] = dc.fetch()
+        ds_k.close()
         out["scan"] = ds.scan(8, kmer2hash("ATCGATAG"), 2, True)
         # the device-gathered hit list (GatheredHits) through the background CSV writer, fetched on the writer's thread
         from kmap_amd.kmer_count import _pkg_file, init_motif_def_dict
@@ -892,6 +938,8 @@ def test_rccl_backend_single_rank(tmp_path):
     u, c = dc.fetch()
     np.testing.assert_array_equal(got["counts_range"][0], u)
     np.testing.assert_array_equal(got["counts_range"][1], c)
+    np.testing.assert_array_equal(got["counts_keyspace"][0], u)
+    np.testing.assert_array_equal(got["counts_keyspace"][1], c)
     hits, pos = ds.scan(8, kmer2hash("ATCGATAG"), 2, True)
     np.testing.assert_array_equal(got["scan"][0], hits)
     np.testing.assert_array_equal(got["scan"][1], pos)
