@@ -209,6 +209,7 @@ def stage_rooflines(reads, kh, lab, conseq_lens):
     lib = _ffi.lib()
     h = _ffi.vp()
     _ffi.check(lib.kmap_scan_create(C.byref(h)))
+    ds.declare_layout(h.value)          # fixed-length reads: the per-read pass derives the borders from the read index (as DeviceSeq.scan does)
     tot = _ffi.i64(0)
 
     def scan(k, kh_, r):
@@ -672,6 +673,7 @@ def shard_proxy(G, reads, res_dir, c3s, overhead_ms, first=None):
     for r0, nr in [(0, nreads)] + [row_partition(nreads, G, r) for r in range(G)]:
         lo, hi = int(borders[r0, 0]), int(borders[r0 + nr - 1, 1]) + 1
         ds = DeviceSeq(np.ascontiguousarray(seq[lo:hi]), borders[r0:r0 + nr] - lo)
+        ds.declare_layout(h.value)
         dc = DeviceCounts()
         t["count_k8_dedupe"].append(med(lambda: ds.count(dc, 8, dedupe=True, merge_revcom=True), 4))
         t["count_k14"].append(med(lambda: ds.count(dc, 14, dedupe=False, merge_revcom=True), 4))
@@ -848,6 +850,7 @@ def c5_leg(reps=5):
     lib = _ffi.lib()
     h = _ffi.vp()
     _ffi.check(lib.kmap_scan_create(C.byref(h)))
+    ds.declare_layout(h.value)          # as DeviceSeq.scan does: fixed-length reads, borders derived from the read index
     tot = _ffi.i64(0)
     cons = int(kmer2hash(motif))
 

@@ -215,6 +215,11 @@ int kmap_scan_create(kmap_scan **s);
 int kmap_scan_destroy(kmap_scan *s);
 int kmap_scan_run_dev(kmap_scan *s, const uint8_t *seq_dev, int64_t n, const int64_t *borders_dev, int64_t n_seq,
                       int k, uint64_t cons, int radius, int revcom, int64_t *total_hits, void *stream);
+/* Optional: the caller declares that read s of `borders_dev` is [s * stride, s * stride + read_len) (fixed-length reads, as the reference's
+ * FASTA encoder lays them out: motif_discovery.py:1422-1477 walks such reads one by one).  Verified on the device; *accepted = 1 when
+ * true.  Runs of this handle on the same border array then derive the borders from s instead of loading them (16 B per read).  The
+ * declaration ends when the handle runs on other borders; renew it if the CONTENT of the array at that address changes. */
+int kmap_scan_declare_uniform(kmap_scan *s, const int64_t *borders_dev, int64_t n_seq, int64_t read_len, int64_t stride, int *accepted, void *stream);
 int kmap_scan_run_packed_dev(kmap_scan *s, const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n,
                              const int64_t *borders_dev, int64_t n_seq, int k, uint64_t cons, int radius, int revcom,
                              int64_t *total_hits, const uint32_t *planes_dev /* optional, see above */, void *stream);

@@ -100,6 +100,7 @@ _SIGS = {
     "kmap_pack_planes_dev": (i32, [vp, i64, vp, vp]),
     "kmap_scan_run_packed_dev": (i32, [vp, vp, vp, i64, vp, i64, i32, u64, i32, i32, P(i64), vp, vp]),
     "kmap_scan_create": (i32, [P(vp)]),
+    "kmap_scan_declare_uniform": (i32, [vp, vp, i64, i64, i64, P(i32), vp]),
     "kmap_scan_destroy": (i32, [vp]),
     "kmap_scan_run_dev": (i32, [vp, vp, i64, vp, i64, i32, u64, i32, i32, P(i64), vp]),
     "kmap_scan_fetch": (i32, [vp, vp, vp, vp]),

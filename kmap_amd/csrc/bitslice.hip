@@ -231,6 +231,7 @@ struct HrCtx {
     int64_t n_alloc;                     // groups the code / flag arrays hold (kmap_packed_groups(n))
     int k, revcom, d_inv, radius;
     uint32_t km, cons, rcc;
+    int64_t uni_len = 0, uni_stride = 0;  // stride > 0: read s = [s * stride, s * stride + len) -- the borders need not be loaded
 };
 struct HrRead {
     int64_t st = 0, stop = 0;
@@ -240,8 +241,14 @@ struct HrRead {
 };
 __device__ __forceinline__ void hr_setup(const HrCtx &c, const int64_t *__restrict__ borders, int64_t s, int64_t n_seq, HrRead &r) {
     if (s < n_seq) {
-        r.st = borders[2 * s];
-        int64_t en = borders[2 * s + 1];
+        int64_t en;
+        if (c.uni_stride > 0) {                                          // wave-uniform: the layout was verified on the device
+            r.st = s * c.uni_stride;
+            en = r.st + c.uni_len;
+        } else {
+            r.st = borders[2 * s];
+            en = borders[2 * s + 1];
+        }
         if (r.st < 0) r.st = 0;
         if (en > c.n) en = c.n;
         const int64_t L = en > r.st ? en - r.st : 0;
@@ -751,6 +758,46 @@ int kmap_bitslice_hits(const uint32_t *planes, const uint16_t *inval, int64_t n,
 }
 
 // the scan's per-read passes on the hit bits (counts + minimum, then -- after the caller's scan of the counts -- the positions)
+namespace {
+// flag[0] |= 1 when some read s is not [s * stride, s * stride + len)
+__global__ __launch_bounds__(256) void borders_uniform_kernel(const int64_t *__restrict__ borders, int64_t n_seq, int64_t len, int64_t stride,
+                                                              unsigned int *__restrict__ flag) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_seq) return;
+    const bool bad = borders[2 * s] != s * stride || borders[2 * s + 1] != s * stride + len;
+    if (bad && *reinterpret_cast<volatile unsigned int *>(flag) == 0u) atomicOr(flag, 1u);
+}
+}  // namespace
+// The caller DECLARES that read s of `borders` is [s * stride, s * stride + len) (fixed-length reads: every BASELINE configuration);
+// the declaration is verified on the device (one pass over the borders + a 4-byte read-back) and, if true, kept in the handle: the
+// per-read kernels of later runs on the same border array take the borders from s instead of loading 16 bytes per read (0.8 GB of the
+// pass's 6.7 GB at C5).  It holds until the handle sees other borders -- and must be renewed by the caller if the CONTENT of the array
+// at that address changes (kmap_hip.h).  No automatic detection: a cache keyed by a device address could outlive the array it described.
+int kmap_bitslice_declare_uniform(kmap_scan *s, const int64_t *borders, int64_t n_seq, int64_t len, int64_t stride, int *accepted, hipStream_t st) {
+    s->geo_borders = nullptr; s->geo_n_seq = -1; s->geo_len = 0; s->geo_stride = 0;
+    if (accepted) *accepted = 0;
+    static const bool off = [] { const char *v = getenv("KMAP_SCAN_UNIFORM"); return v && v[0] == '0'; }();   // A/B switch: always load the borders
+    if (off || n_seq < 1 || len < 0 || stride <= 0 || stride < len) return KMAP_OK;
+    unsigned int *flag = nullptr;
+    KMAP_TRY(kmap_scratch((void **)&flag, 64, st, KMAP_SLOT_D));
+    KMAP_CHECK_HIP(hipMemsetAsync(flag, 0, 4, st));
+    borders_uniform_kernel<<<(unsigned)((n_seq + 255) / 256), 256, 0, st>>>(borders, n_seq, len, stride, flag);
+    unsigned int h = 1;
+    KMAP_CHECK_HIP(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, st));
+    KMAP_CHECK_HIP(hipStreamSynchronize(st));
+    if (h == 0) {
+        s->geo_borders = borders; s->geo_n_seq = n_seq; s->geo_len = len; s->geo_stride = stride;
+        if (accepted) *accepted = 1;
+    }
+    return KMAP_OK;
+}
+// the declared layout applies to this run's borders?
+static void scan_geometry(const kmap_scan *s, const int64_t *borders, int64_t n_seq, HrCtx &c) {
+    const bool same = s->geo_stride > 0 && s->geo_borders == borders && s->geo_n_seq == n_seq;
+    c.uni_len = same ? s->geo_len : 0;
+    c.uni_stride = same ? s->geo_stride : 0;
+}
+
 static HrCtx make_ctx(const uint32_t *hit32, const uint32_t *codes, const uint16_t *inval, int64_t n, int k, uint64_t cons, int revcom,
                       int radius) {
     HrCtx c;
@@ -769,7 +816,8 @@ static HrCtx make_ctx(const uint32_t *hit32, const uint32_t *codes, const uint16
 int kmap_bitslice_scan_reads(bool write, const uint32_t *hit32, const uint32_t *codes, const uint16_t *inval, int64_t n,
                              const int64_t *borders, int64_t n_seq, int k, uint64_t cons, int revcom, int radius, kmap_scan *s,
                              hipStream_t st) {
-    const HrCtx c = make_ctx(hit32, codes, inval, n, k, cons, revcom, radius);
+    HrCtx c = make_ctx(hit32, codes, inval, n, k, cons, revcom, radius);
+    scan_geometry(s, borders, n_seq, c);
     const unsigned grid = grid_of(n_seq, HR_TPB);
     const bool chk = c.d_inv <= radius;            // only then can a hit be a window that touches an invalid position
     // s->offs doubles as [block offsets uint64 (n_blocks + 1) | block sums uint32 (n_blocks)]: n_seq + 1 uint64 are allocated
@@ -789,7 +837,8 @@ int kmap_bitslice_scan_reads(bool write, const uint32_t *hit32, const uint32_t *
 int kmap_bitslice_scan_reads_all(const uint32_t *hit32, const uint32_t *codes, const uint16_t *inval, int64_t n, const int64_t *borders,
                                  int64_t n_seq, int k, uint64_t cons, int revcom, int radius, kmap_scan *s, uint64_t *total_out,
                                  hipStream_t st) {
-    const HrCtx c = make_ctx(hit32, codes, inval, n, k, cons, revcom, radius);
+    HrCtx c = make_ctx(hit32, codes, inval, n, k, cons, revcom, radius);
+    scan_geometry(s, borders, n_seq, c);
     const int64_t nblk = (n_seq + HR_TPB - 1) / HR_TPB;
     const bool chk = c.d_inv <= radius;
     if (c.n_alloc < hf_row_words<HF_WORDS / 2>()) {                          // an input shorter than one row of code words: the two-pass form

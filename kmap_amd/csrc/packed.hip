@@ -1367,6 +1367,11 @@ int kmap_mask_hamball_packed_dev(const uint32_t *codes_dev, uint16_t *inval_dev,
     return KMAP_OK;
 }
 
+int kmap_scan_declare_uniform(kmap_scan *s, const int64_t *borders_dev, int64_t n_seq, int64_t read_len, int64_t stride, int *accepted, void *stream) {
+    KMAP_REQUIRE(s && (n_seq == 0 || borders_dev), "scan_declare_uniform: null");
+    return kmap_bitslice_declare_uniform(s, borders_dev, n_seq, read_len, stride, accepted, as_stream(stream));
+}
+
 int kmap_scan_run_packed_dev(kmap_scan *s, const uint32_t *codes_dev, const uint16_t *inval_dev, int64_t n,
                              const int64_t *borders_dev, int64_t n_seq, int k, uint64_t cons, int radius, int revcom,
                              int64_t *total_hits, const uint32_t *planes_dev, void *stream) {

@@ -8,6 +8,10 @@ struct kmap_scan {
     int8_t *mind = nullptr;
     uint64_t *offs = nullptr;           // exclusive scan of hits (run); afterwards scratch: summary words, byte-narrowed hits
     int32_t *pos = nullptr;
+    // the caller's declaration (kmap_scan_declare_uniform, verified on the device) that read s of these borders is
+    // [s * stride, s * stride + len): the per-read kernels then take the borders from s instead of loading 16 bytes per read (bitslice.hip)
+    const void *geo_borders = nullptr;
+    int64_t geo_n_seq = -1, geo_len = 0, geo_stride = 0;   // stride 0: not uniform
 };
 int kmap_scan_reserve(kmap_scan *s, int64_t n_seq);
 int kmap_scan_reserve_pos(kmap_scan *s, uint64_t total);
@@ -24,3 +28,4 @@ int kmap_bitslice_scan_reads(bool write, const uint32_t *hit32, const uint32_t *
 int kmap_bitslice_scan_reads_all(const uint32_t *hit32, const uint32_t *codes, const uint16_t *inval, int64_t n, const int64_t *borders,
                                  int64_t n_seq, int k, uint64_t cons, int revcom, int radius, kmap_scan *s, uint64_t *total_out,
                                  hipStream_t st);
+int kmap_bitslice_declare_uniform(kmap_scan *s, const int64_t *borders, int64_t n_seq, int64_t len, int64_t stride, int *accepted, hipStream_t st);

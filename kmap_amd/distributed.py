@@ -865,6 +865,7 @@ def make_dist_device_seq(seq_np_arr, boarder_mat, dist, group=None, shard_counts
                 h = _ffi.vp()
                 check(lib.kmap_scan_create(C.byref(h)))
                 self._scan = h.value
+                self.declare_layout(self._scan)
             tot, nhit, mx = _ffi.i64(0), _ffi.i64(0), _ffi.i32(0)
             check(lib.kmap_scan_run_packed_dev(self._scan, self.codes.ptr, self.inval_orig.ptr, self.n, self.borders.ptr, self.n_seq, k,
                                                int(consensus_kh), int(radius), int(revcom), C.byref(tot), self.planes.ptr, None))

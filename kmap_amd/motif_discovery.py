@@ -99,6 +99,7 @@ class DeviceSeq:
         check(_ffi.lib().kmap_pack_planes_dev(self.codes.ptr, self.n, self.planes.ptr, None))
         _ffi.sync()
         raw.free()                      # the uint8 array does not stay on the device
+        self._layout = False            # not looked at yet (_uniform_layout)
         self.reset()
         self._scan = None
         dev = _ffi.i32(0)
@@ -152,6 +153,34 @@ class DeviceSeq:
         out_d.free()
         return out
 
+    def _uniform_layout(self):
+        """(read_len, stride) when read s is [s * stride, s * stride + read_len) -- fixed-length reads -- else None; from the host
+        borders (one vectorised comparison, once), or the caller's fixed length for reads that only exist in HBM"""
+        if self._layout is False:
+            self._layout = None
+            bh = self.borders_host
+            if bh is not None and len(bh) >= 1 and bh[0, 0] == 0:
+                ln = int(bh[0, 1] - bh[0, 0])
+                stride = int(bh[1, 0] - bh[0, 0]) if len(bh) > 1 else ln + 1
+                if stride >= max(ln, 1):
+                    idx = np.arange(len(bh), dtype=np.int64) * stride
+                    if np.array_equal(bh[:, 0], idx) and np.array_equal(bh[:, 1], idx + ln):
+                        self._layout = (ln, stride)
+            elif bh is None and self.read_len is not None and self.n_seq >= 1:
+                ln = int(self.read_len[0])
+                self._layout = (ln, ln + 1)         # synth_reads_dev: a separator behind every read (verified on the device below)
+        return self._layout
+
+    def declare_layout(self, handle):
+        """tell a scan handle that these reads are laid out uniformly (kmap_scan_declare_uniform verifies it on the device): its runs on
+        these borders then derive them from the read index instead of loading 16 bytes per read"""
+        lay = self._uniform_layout()
+        if lay is None:
+            return False
+        ok = _ffi.i32(0)
+        check(_ffi.lib().kmap_scan_declare_uniform(handle, self.borders.ptr, self.n_seq, lay[0], lay[1], C.byref(ok), None))
+        return bool(ok.value)
+
     def scan(self, k, consensus_kh, radius, revcom):
         """positions at each read's minimum hit distance (original, unmasked reads):
         returns (hits_per_read int32[n_seq], positions int32[total])."""
@@ -159,6 +188,7 @@ class DeviceSeq:
             h = _ffi.vp()
             check(_ffi.lib().kmap_scan_create(C.byref(h)))
             self._scan = h.value
+            self.declare_layout(self._scan)
         tot = _ffi.i64(0)
         check(_ffi.lib().kmap_scan_run_packed_dev(self._scan, self.codes.ptr, self.inval_orig.ptr, self.n, self.borders.ptr,
                                                   self.n_seq, k, int(consensus_kh), int(radius), int(revcom), C.byref(tot),
@@ -179,6 +209,7 @@ class DeviceSeq:
             hv = _ffi.vp()
             check(_ffi.lib().kmap_scan_create(C.byref(hv)))
             h = hv.value
+            self.declare_layout(h)
             self._lazy_all.append(h)
         tot, nhit, mx = _ffi.i64(0), _ffi.i64(0), _ffi.i32(0)
         check(_ffi.lib().kmap_scan_run_packed_dev(h, self.codes.ptr, self.inval_orig.ptr, self.n, self.borders.ptr,

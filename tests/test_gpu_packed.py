@@ -381,6 +381,82 @@ def test_hist16_single_kmer_no_carry(env, base, k):
     ds.close()
 
 
+def _uniform_scan_case():
+    import hashlib
+    from kmap_amd.kmer_count import kmer2hash
+    from kmap_amd.motif_discovery import DeviceSeq
+    rng = np.random.default_rng(5150)
+    h = hashlib.sha256()
+    for L, nr in ((150, 3000), (31, 2000), (300, 1500)):
+        seq, borders = synth(rng, nr, L, L, p_n=0.003)
+        ds = DeviceSeq(seq, borders)
+        for k, cons, rad in ((14, "AGGACCTACGTACA", 5), (8, "CCTACGTA", 2), (6, "TTTTTT", 1)):
+            hits, pos = ds.scan(k, kmer2hash(cons), rad, True)
+            h.update(hits.tobytes())
+            h.update(pos.tobytes())
+        ds.close()
+    return h.hexdigest()
+
+
+def test_scan_uniform_layout_declaration(env):
+    """kmap_scan_declare_uniform (round 6): for fixed-length reads the per-read pass of the scan derives the borders from the read index
+    instead of loading them.  DeviceSeq declares it for its own handles after a host check; the library verifies the declaration on the
+    device.  Same hits and positions as an undeclared handle and as the oracle; a wrong declaration and ragged reads are refused;
+    KMAP_SCAN_UNIFORM=0 switches the path off (child process, same digest)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    _ffi, _, DeviceSeq, O = env
+    from kmap_amd.kmer_count import kmer2hash
+    lib = _ffi.lib()
+    rng = np.random.default_rng(9)
+    seq, borders = synth(rng, 2500, 120, 120, p_n=0.004)
+    ds = DeviceSeq(seq, borders)
+    assert ds._uniform_layout() == (120, 121)
+    cons = int(kmer2hash("CCTACGTA"))
+    hits, pos = ds.scan(8, cons, 2, True)                            # the DeviceSeq's own handle: declared
+    raw = _ffi.vp()
+    _ffi.check(lib.kmap_scan_create(C.byref(raw)))
+    ok = _ffi.i32(7)
+    _ffi.check(lib.kmap_scan_declare_uniform(raw.value, ds.borders.ptr, ds.n_seq, 121, 121, C.byref(ok), None))   # wrong length
+    assert ok.value == 0
+    _ffi.check(lib.kmap_scan_declare_uniform(raw.value, ds.borders.ptr, ds.n_seq, 120, 122, C.byref(ok), None))   # wrong stride
+    assert ok.value == 0
+    tot = _ffi.i64(0)
+    _ffi.check(lib.kmap_scan_run_packed_dev(raw.value, ds.codes.ptr, ds.inval_orig.ptr, ds.n, ds.borders.ptr, ds.n_seq, 8, cons, 2, 1,
+                                            C.byref(tot), ds.planes.ptr, None))                                   # undeclared: borders loaded
+    h2, p2 = np.empty(ds.n_seq, np.int32), np.empty(tot.value, np.int32)
+    _ffi.check(lib.kmap_scan_fetch(raw.value, _ffi.ptr(h2), None, _ffi.ptr(p2)))
+    np.testing.assert_array_equal(h2, hits)
+    np.testing.assert_array_equal(p2, pos)
+    assert ds.declare_layout(raw.value)                                                                            # now declared: same again
+    _ffi.check(lib.kmap_scan_run_packed_dev(raw.value, ds.codes.ptr, ds.inval_orig.ptr, ds.n, ds.borders.ptr, ds.n_seq, 8, cons, 2, 1,
+                                            C.byref(tot), ds.planes.ptr, None))
+    _ffi.check(lib.kmap_scan_fetch(raw.value, _ffi.ptr(h2), None, _ffi.ptr(p2)))
+    np.testing.assert_array_equal(h2, hits)
+    np.testing.assert_array_equal(p2, pos)
+    buf, md, off = np.empty(4096, np.int32), C.c_int(0), 0
+    for i, (a, b) in enumerate(borders):
+        m = O.lib().ko_scan_read(np.ascontiguousarray(seq[a:b]), b - a, 8, cons, 2, 1, buf, C.byref(md))
+        assert hits[i] == m
+        np.testing.assert_array_equal(pos[off:off + m], buf[:m])
+        off += m
+    lib.kmap_scan_destroy(raw.value)
+    ds.close()
+    rag_seq, rag_borders = synth(rng, 500, 50, 90)
+    rag = DeviceSeq(rag_seq, rag_borders)
+    assert rag._uniform_layout() is None
+    rag.scan(8, cons, 2, True)
+    rag.close()
+    root = str(Path(__file__).resolve().parent.parent)
+    here = _uniform_scan_case()
+    code = "import sys; sys.path.insert(0, sys.argv[1]); import tests.test_gpu_packed as T; print('digest', T._uniform_scan_case())"
+    r = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, KMAP_SCAN_UNIFORM="0"), cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert f"digest {here}" in r.stdout
+
+
 def _key_range_reads(rng, n_reads=9000):
     """~1.4 M positions (>= 2^20: the partitioned passes run) with what the range rule must get right: planted motifs (heavy buckets),
     N's, poly-A / poly-T reads (k = 16: the all-T 16-mer's hash is the invalid marker, its partner all-A is position 0), reads made of
