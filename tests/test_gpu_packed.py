@@ -551,6 +551,61 @@ def test_key_range_counting_equals_slices_of_the_table(env, k):
             ds_small.close()
 
 
+def test_key_range_counting_random_ranges(env):
+    """40 random (k, range, merge, dedupe) cases on the reads of the case above: kmap_counts_run_packed_range_dev == the matching slice
+    -- by position -- of the one-GPU table.  Positions are not stored in a merged table (an unpaired higher member sits at its own position
+    with its key replaced by rc(x), kmer_count.py:643-685), so the expected slice comes from the UNMERGED table and a numpy restatement of
+    the merge that keeps the positions; ranges from 8 bins up to the whole table, ends at the table's end included."""
+    _ffi, DeviceCounts, DeviceSeq, O = env
+    rng = np.random.default_rng(4711)
+    seq, borders = _key_range_reads(rng)
+    ds, dc = DeviceSeq(seq, borders), DeviceCounts()
+    try:
+        for case in range(40):
+            k = int(rng.choice([11, 12, 13, 14, 15, 16]))
+            merge, dedupe = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+            n_bins = 4 ** k
+            span = int(min(n_bins, 8 * 4 ** int(rng.integers(0, k - 1))))
+            first = int(rng.integers(0, (n_bins - span) // 8 + 1)) * 8
+            if case % 7 == 0:
+                first = n_bins - span                                       # a range that ends at the table's end
+            if k == 16 and merge and span > 2 ** 31 - 8:
+                span = 2 ** 31 - 8                                          # beyond: the whole-table path (covered by the G = 2 case above)
+            # the table WITHOUT the merge holds every position's own count; the reference's merge (kmer_count.py:643-685) restated on
+            # it with the positions kept: the higher member of a present pair is deleted, a palindrome doubles, an unpaired higher member
+            # stays at ITS position with its key replaced by the reverse complement
+            ds.count(dc, k, dedupe=dedupe, merge_revcom=False)
+            u0, c0 = dc.fetch()
+            p0 = u0.astype(np.uint64)
+            if merge:
+                t = np.uint64(4 ** k - 1) - p0
+                r0 = np.zeros_like(p0)
+                for _ in range(k):
+                    r0 = (r0 << np.uint64(2)) | (t & np.uint64(3))
+                    t = t >> np.uint64(2)
+                idx = np.minimum(np.searchsorted(p0, r0), len(p0) - 1)
+                present = p0[idx] == r0
+                cr = np.where(present, c0[idx], 0).astype(c0.dtype)
+                keep = ~(present & (p0 > r0))
+                pos = p0[keep]
+                u = np.minimum(p0, r0)[keep].astype(u0.dtype)
+                c = (c0 + cr)[keep]                                        # a palindrome is its own partner: c0 + c0
+                ds.count(dc, k, dedupe=dedupe, merge_revcom=True)           # ... which is the device's merged table
+                du, dcnt = dc.fetch()
+                np.testing.assert_array_equal(du, u)
+                np.testing.assert_array_equal(dcnt, c)
+            else:
+                pos, u, c = p0, u0, c0
+            sel = (pos >= np.uint64(first)) & (pos < np.uint64(first + span))
+            ds.count_range(dc, k, dedupe, merge, first, span)
+            su, sc = dc.fetch()
+            np.testing.assert_array_equal(su, u[sel], err_msg=f"case {case}: k={k} merge={merge} dedupe={dedupe} range=[{first}, +{span})")
+            np.testing.assert_array_equal(sc, c[sel], err_msg=f"case {case}: counts")
+    finally:
+        dc.close()
+        ds.close()
+
+
 def test_key_range_counting_argument_errors(env):
     _ffi, DeviceCounts, DeviceSeq, O = env
     rng = np.random.default_rng(5)
