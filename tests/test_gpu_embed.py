@@ -633,3 +633,62 @@ def test_seq_row_map_is_validated(V):
         md.free()
     finally:
         f.close()
+
+
+@pytest.mark.parametrize("n,k,lens", [(700, 8, [8, 8]), (900, 12, [12, 7]), (640, 16, [16, 3])])
+def test_knn_sums_natural_diagonal(V, n, k, lens):
+    """KMAP_KNN_NATURAL_DIAG: S[i][i] = sum of D over nb(i) x nb(i) instead of the reference's 0 (visualization.py:36-38 sets the
+    diagonal of the smoothed matrix to 0 after the fact); every other entry is unchanged, in the matrix-core and the v_dot4 kernel,
+    whole and as a row block.  With it two rows of the same k-mer and the same neighbours are equal, which is what lets
+    dedupe_sums_rows store them once."""
+    from kmap_amd import _ffi
+    from kmap_amd.hamdist import hamdist_matrix_dev, pitch_for
+    from kmap_amd.kmer_count import get_hash_dtype
+    rng = np.random.default_rng(3 * n + k)
+    n_nb = 20
+    kh = rng.integers(0, 4 ** k, size=n, dtype=np.uint64).astype(get_hash_dtype(k))
+    kh[1::2] = kh[0::2]                                                 # every k-mer twice, next to each other
+    lab = np.repeat(np.sort(rng.integers(0, len(lens) + 1, size=n // 2)), 2).astype(np.int32)
+    nb = np.repeat(np.stack([rng.choice(n, size=n_nb, replace=False) for _ in range(n // 2)]), 2, axis=0).astype(np.int32)
+    kh_d, lab_d = _ffi.DeviceBuffer.from_numpy(kh), _ffi.DeviceBuffer.from_numpy(lab)
+    ldd = pitch_for(n)
+    D_d = _ffi.DeviceBuffer(n * ldd)
+    hamdist_matrix_dev(kh_d.ptr, lab_d.ptr, n, k, lens, D_d.ptr, ldd)
+    D = D_d.to_numpy(np.uint8, (n, ldd))[:, :n].astype(np.int64)
+    zero_d, lds = V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, k, lens, nb, n_nb)
+    zero = zero_d.to_numpy(np.uint16, (n, lds))[:, :n]
+    nat_d, lds2 = V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, k, lens, nb, n_nb, natural_diag=True)
+    nat = nat_d.to_numpy(np.uint16, (n, lds2))[:, :n]
+    assert not zero.diagonal().any()
+    off = ~np.eye(n, dtype=bool)
+    np.testing.assert_array_equal(nat[off], zero[off])
+    want_diag = np.array([D[np.ix_(nb[i], nb[i])].sum() for i in range(n)])
+    np.testing.assert_array_equal(nat.diagonal().astype(np.int64), want_diag)
+    np.testing.assert_array_equal(nat[0::2], nat[1::2])                 # the twin rows are equal only with the natural diagonal
+    assert (zero[0::2] != zero[1::2]).any(axis=1).all()
+    r0, nr = n // 4, n // 2
+    blk_d, lds3 = V.knn_sums_kmers_dev(kh_d.ptr, lab_d.ptr, n, k, lens, nb, n_nb, row0=r0, nrows=nr, natural_diag=True)
+    np.testing.assert_array_equal(blk_d.to_numpy(np.uint16, (nr, lds3))[:, :n], nat[r0:r0 + nr])
+    _, _, stored_nat = V.dedupe_sums_rows(nat_d, n, lds2, n=n)
+    assert stored_nat <= n // 2
+
+
+def test_seq_run_is_the_same_with_either_diagonal(V, monkeypatch):
+    """The SEQ embedding never reads S[i][i] (no force or loss term pairs a point with itself -- visualization.py:116-118 skips
+    i == j), so the run with the natural diagonal (fewer stored rows) equals the run with the reference's zero diagonal bit for bit."""
+    rng = np.random.default_rng(77)
+    k, conseqs = 8, ["ACGTACGT", "TTGACA"]
+    samp_kh = rng.integers(0, 4 ** k, size=260, dtype=np.uint64)
+    samp_cnts = rng.integers(1, 5, size=260)                            # repeated k-mers, as visualize_kmers expands them
+    samp_label = np.sort(rng.integers(0, 3, size=260))
+    runs = {}
+    real = V.knn_sums_kmers_dev
+    for tag in ("natural", "zero"):
+        if tag == "zero":
+            monkeypatch.setattr(V, "knn_sums_kmers_dev", lambda *a, **kw: real(*a, **{**kw, "natural_diag": False}))
+        tr = {}
+        best, _ = V.kmap_from_kmers(samp_kh, samp_cnts, samp_label, conseqs, k, n_max_iter=60, random_seed=5, debug=False,
+                                    mode=V.EMBED_SEQ, trace=tr)
+        runs[tag] = (np.asarray(best), np.asarray(tr["losses"]), np.asarray(tr["last_coords"]))
+    for a, b in zip(runs["natural"], runs["zero"]):
+        np.testing.assert_array_equal(a, b)
