@@ -125,26 +125,143 @@ __device__ __forceinline__ uint32_t strand_gt(const uint32_t (&hs)[K], const uin
     return count_greater_than<K>(m, radius);
 }
 
-// hit16[g]: bit (15 - i) set when the window at position 16 g + i is within radius of any table entry (invalid windows: the
-// entry's inv_hit).  Thread = groups 2t, 2t + 1.  planes / inval are read up to group 2t + 3 (inside the array: see kmap_packed_groups).
-// WORDS: store the 32 hit bits as ONE word, window i in bit 31 - i (hit32[t], the scan's per-read passes); otherwise as the
-// two uint16 of the mask's coverage pass.
-template <int K, bool WORDS>
-__global__ __launch_bounds__(BS_TPB) void hits_planes_kernel(const uint32_t *__restrict__ planes, const uint16_t *__restrict__ inval,
-                                                            int64_t n, int64_t n_alloc_groups, HitTab tab,
-                                                            uint16_t *__restrict__ hit16) {
-    const int64_t t = (int64_t)blockIdx.x * BS_TPB + threadIdx.x;
-    const int64_t g0 = 2 * t;
-    if (16 * g0 >= n) return;
-    // groups g0 .. g0 + 3 as two aligned pairs: g0 is even and < the number of data groups, and the array holds an even number of
-    // groups of which at least the last two are all-invalid halo groups (kmap_packed_groups), so g0 + 3 is inside it
+// ---- mismatch planes through the VGPR index mode ---------------------------------------------------------------------------
+// (h ^ ch) | (l ^ cl) has four inputs, two of them the consensus base: as written above a mismatch plane costs the strand two
+// instructions on top of the shared funnel shifts (3 per plane and strand in all).  The base only SELECTS one of four functions of
+// (h, l): E_A = h | l, E_C = h | ~l, E_G = ~h | l, E_T = ~h | ~l -- "the base here is not b" for the 64 positions a thread holds,
+// 8 instructions shared by every strand and table entry.  The mismatch plane of consensus position j is then the funnel shift by
+// j of E_b with b = the consensus base, and gfx9's VGPR index mode lets a SCALAR pick the register: with
+// s_set_gpr_idx_on / _idx (M0[7:0] = b, SRC0 and SRC1 relative) `v_alignbit_b32 m, v40, v44, 32 - j` reads v[40 + b], v[44 + b]:
+// ONE vector instruction per plane and strand.  A thread carries TWO 32-window words (E planes in v40..v47 and v48..v55, pinned by
+// explicit-register constraints), so that one scalar index change serves two vector instructions and the scalar unit, which
+// issues beside the vector unit, stays the smaller stream.  Blocks hold 8 / 4 / 2 / 1 planes (an asm statement takes 30
+// operands); every block leaves the index mode switched off.  M0 is not on the clobber lists: the compiler reserves it (it
+// sets M0 itself right before the few instructions that read it) and rejects it there.
+// HAZARD (measured, not in the ISA manual's table): a vector instruction issued right behind the s_set_gpr_idx_* that changes
+// M0 can still see the OLD index -- without a wait state ~1 wave in 10^4 produced hit words of the wrong planes at C5 size, a
+// different set of waves every run; with `s_nop 0` (one wait state, what the manual asks between an M0 write and s_movrel /
+// LDS-add-TID / interp) none in repeated full-size runs.  KMAP_IDX_WAIT is two wait states; tests/test_gpu_fullsize.py holds the
+// full-size comparison against the formulation without the index mode.
+#define KMAP_IDX_WAIT "s_nop 1\n\t"
+typedef uint32_t EPlanes __attribute__((ext_vector_type(8)));   // {A, C, G, T} of word 0 (positions P .. P + 31), of word 1 (the next 32)
+#define KMAP_E_INS "{v[40:47]}"(ea), "{v[48:55]}"(eb)
+__device__ __forceinline__ EPlanes make_eplanes(uint32_t H, uint32_t L, uint32_t H2, uint32_t L2) {
+    EPlanes e;
+    e[0] = H | L, e[1] = H | ~L, e[2] = ~H | L, e[3] = ~(H & L);
+    e[4] = H2 | L2, e[5] = H2 | ~L2, e[6] = ~H2 | L2, e[7] = ~(H2 & L2);
+    return e;
+}
+// plane 0 needs no shift: the selected word 0 itself
+__device__ __forceinline__ void idx_plane0(const EPlanes &ea, const EPlanes &eb, uint32_t c0, uint32_t &ma, uint32_t &mb) {
+    asm("s_set_gpr_idx_on %[c0], gpr_idx(SRC0)\n\t" KMAP_IDX_WAIT
+        "v_mov_b32 %[a0], v40\n\t"
+        "v_mov_b32 %[b0], v48\n\t"
+        "s_set_gpr_idx_off"
+        : [a0] "=&v"(ma), [b0] "=&v"(mb)
+        : [c0] "s"(c0), KMAP_E_INS);
+}
+// planes J0 .. J0 + N - 1 (J0 >= 1) of both words: m[j] = funnel shift of E_{c[j]} by j
+template <int J0>
+__device__ __forceinline__ void idx_planes1(const EPlanes &ea, const EPlanes &eb, const uint32_t *c, uint32_t *ma, uint32_t *mb) {
+    asm("s_set_gpr_idx_on %[c0], gpr_idx(SRC0,SRC1)\n\t" KMAP_IDX_WAIT
+        "v_alignbit_b32 %[a0], v40, v44, %[s]\n\t"
+        "v_alignbit_b32 %[b0], v48, v52, %[s]\n\t"
+        "s_set_gpr_idx_off"
+        : [a0] "=&v"(ma[J0 + 0]), [b0] "=&v"(mb[J0 + 0])
+        : [c0] "s"(c[J0 + 0]), [s] "n"(32 - J0), KMAP_E_INS);
+}
+template <int J0>
+__device__ __forceinline__ void idx_planes2(const EPlanes &ea, const EPlanes &eb, const uint32_t *c, uint32_t *ma, uint32_t *mb) {
+    asm("s_set_gpr_idx_on %[c0], gpr_idx(SRC0,SRC1)\n\t" KMAP_IDX_WAIT
+        "v_alignbit_b32 %[a0], v40, v44, %[s]\n\t"
+        "v_alignbit_b32 %[b0], v48, v52, %[s]\n\t"
+        "s_set_gpr_idx_idx %[c1]\n\t" KMAP_IDX_WAIT
+        "v_alignbit_b32 %[a1], v40, v44, %[s]-1\n\t"
+        "v_alignbit_b32 %[b1], v48, v52, %[s]-1\n\t"
+        "s_set_gpr_idx_off"
+        : [a0] "=&v"(ma[J0 + 0]), [b0] "=&v"(mb[J0 + 0]), [a1] "=&v"(ma[J0 + 1]), [b1] "=&v"(mb[J0 + 1])
+        : [c0] "s"(c[J0 + 0]), [c1] "s"(c[J0 + 1]), [s] "n"(32 - J0), KMAP_E_INS);
+}
+template <int J0>
+__device__ __forceinline__ void idx_planes4(const EPlanes &ea, const EPlanes &eb, const uint32_t *c, uint32_t *ma, uint32_t *mb) {
+    asm("s_set_gpr_idx_on %[c0], gpr_idx(SRC0,SRC1)\n\t" KMAP_IDX_WAIT
+        "v_alignbit_b32 %[a0], v40, v44, %[s]\n\t"
+        "v_alignbit_b32 %[b0], v48, v52, %[s]\n\t"
+        "s_set_gpr_idx_idx %[c1]\n\t" KMAP_IDX_WAIT
+        "v_alignbit_b32 %[a1], v40, v44, %[s]-1\n\t"
+        "v_alignbit_b32 %[b1], v48, v52, %[s]-1\n\t"
+        "s_set_gpr_idx_idx %[c2]\n\t" KMAP_IDX_WAIT
+        "v_alignbit_b32 %[a2], v40, v44, %[s]-2\n\t"
+        "v_alignbit_b32 %[b2], v48, v52, %[s]-2\n\t"
+        "s_set_gpr_idx_idx %[c3]\n\t" KMAP_IDX_WAIT
+        "v_alignbit_b32 %[a3], v40, v44, %[s]-3\n\t"
+        "v_alignbit_b32 %[b3], v48, v52, %[s]-3\n\t"
+        "s_set_gpr_idx_off"
+        : [a0] "=&v"(ma[J0 + 0]), [b0] "=&v"(mb[J0 + 0]), [a1] "=&v"(ma[J0 + 1]), [b1] "=&v"(mb[J0 + 1]), [a2] "=&v"(ma[J0 + 2]), [b2] "=&v"(mb[J0 + 2]), [a3] "=&v"(ma[J0 + 3]), [b3] "=&v"(mb[J0 + 3])
+        : [c0] "s"(c[J0 + 0]), [c1] "s"(c[J0 + 1]), [c2] "s"(c[J0 + 2]), [c3] "s"(c[J0 + 3]), [s] "n"(32 - J0), KMAP_E_INS);
+}
+template <int J0>
+__device__ __forceinline__ void idx_planes8(const EPlanes &ea, const EPlanes &eb, const uint32_t *c, uint32_t *ma, uint32_t *mb) {
+    asm("s_set_gpr_idx_on %[c0], gpr_idx(SRC0,SRC1)\n\t" KMAP_IDX_WAIT
+        "v_alignbit_b32 %[a0], v40, v44, %[s]\n\t"
+        "v_alignbit_b32 %[b0], v48, v52, %[s]\n\t"
+        "s_set_gpr_idx_idx %[c1]\n\t" KMAP_IDX_WAIT
+        "v_alignbit_b32 %[a1], v40, v44, %[s]-1\n\t"
+        "v_alignbit_b32 %[b1], v48, v52, %[s]-1\n\t"
+        "s_set_gpr_idx_idx %[c2]\n\t" KMAP_IDX_WAIT
+        "v_alignbit_b32 %[a2], v40, v44, %[s]-2\n\t"
+        "v_alignbit_b32 %[b2], v48, v52, %[s]-2\n\t"
+        "s_set_gpr_idx_idx %[c3]\n\t" KMAP_IDX_WAIT
+        "v_alignbit_b32 %[a3], v40, v44, %[s]-3\n\t"
+        "v_alignbit_b32 %[b3], v48, v52, %[s]-3\n\t"
+        "s_set_gpr_idx_idx %[c4]\n\t" KMAP_IDX_WAIT
+        "v_alignbit_b32 %[a4], v40, v44, %[s]-4\n\t"
+        "v_alignbit_b32 %[b4], v48, v52, %[s]-4\n\t"
+        "s_set_gpr_idx_idx %[c5]\n\t" KMAP_IDX_WAIT
+        "v_alignbit_b32 %[a5], v40, v44, %[s]-5\n\t"
+        "v_alignbit_b32 %[b5], v48, v52, %[s]-5\n\t"
+        "s_set_gpr_idx_idx %[c6]\n\t" KMAP_IDX_WAIT
+        "v_alignbit_b32 %[a6], v40, v44, %[s]-6\n\t"
+        "v_alignbit_b32 %[b6], v48, v52, %[s]-6\n\t"
+        "s_set_gpr_idx_idx %[c7]\n\t" KMAP_IDX_WAIT
+        "v_alignbit_b32 %[a7], v40, v44, %[s]-7\n\t"
+        "v_alignbit_b32 %[b7], v48, v52, %[s]-7\n\t"
+        "s_set_gpr_idx_off"
+        : [a0] "=&v"(ma[J0 + 0]), [b0] "=&v"(mb[J0 + 0]), [a1] "=&v"(ma[J0 + 1]), [b1] "=&v"(mb[J0 + 1]), [a2] "=&v"(ma[J0 + 2]), [b2] "=&v"(mb[J0 + 2]), [a3] "=&v"(ma[J0 + 3]), [b3] "=&v"(mb[J0 + 3]), [a4] "=&v"(ma[J0 + 4]), [b4] "=&v"(mb[J0 + 4]), [a5] "=&v"(ma[J0 + 5]), [b5] "=&v"(mb[J0 + 5]), [a6] "=&v"(ma[J0 + 6]), [b6] "=&v"(mb[J0 + 6]), [a7] "=&v"(ma[J0 + 7]), [b7] "=&v"(mb[J0 + 7])
+        : [c0] "s"(c[J0 + 0]), [c1] "s"(c[J0 + 1]), [c2] "s"(c[J0 + 2]), [c3] "s"(c[J0 + 3]), [c4] "s"(c[J0 + 4]), [c5] "s"(c[J0 + 5]), [c6] "s"(c[J0 + 6]), [c7] "s"(c[J0 + 7]), [s] "n"(32 - J0), KMAP_E_INS);
+}
+#undef KMAP_E_INS
+// windows of the two words whose distance to `code` exceeds the radius
+template <int K>
+__device__ __forceinline__ void strand_gt_idx(const EPlanes &ea, const EPlanes &eb, uint32_t code, int radius, uint32_t &gta, uint32_t &gtb) {
+    uint32_t c[K], ma[K], mb[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) c[j] = (code >> (2 * (K - 1 - j))) & 3u;   // scalar: the consensus base of plane j
+    idx_plane0(ea, eb, c[0], ma[0], mb[0]);
+    constexpr int R = K - 1;                                                // planes 1 .. K - 1 in blocks of 8, 4, 2, 1
+    if constexpr (R >= 8) idx_planes8<1>(ea, eb, c, ma, mb);
+    constexpr int J4 = 1 + (R & 8);
+    if constexpr ((R & 4) != 0) idx_planes4<J4>(ea, eb, c, ma, mb);
+    constexpr int J2 = J4 + (R & 4);
+    if constexpr ((R & 2) != 0) idx_planes2<J2>(ea, eb, c, ma, mb);
+    constexpr int J1 = J2 + (R & 2);
+    if constexpr ((R & 1) != 0) idx_planes1<J1>(ea, eb, c, ma, mb);
+    gta = count_greater_than<K>(ma, radius);
+    gtb = count_greater_than<K>(mb, radius);
+}
+
+// the 64 positions from group g0 (even) on as bit planes, and the windows among the first 32 that touch an invalid position.
+// Groups g0 .. g0 + 3 as two aligned pairs: g0 < the number of data groups, and the array holds an even number of groups of
+// which at least the last two are all-invalid halo groups (kmap_packed_groups), so g0 + 3 is inside it.
+template <int K>
+__device__ __forceinline__ void load_word(const uint32_t *__restrict__ planes, const uint16_t *__restrict__ inval, int64_t g0, uint32_t &H,
+                                          uint32_t &L, uint32_t &H2, uint32_t &L2, uint32_t &bad) {
     const uint2 pa = *reinterpret_cast<const uint2 *>(planes + g0), pb = *reinterpret_cast<const uint2 *>(planes + g0 + 2);
     const uint32_t ia = *reinterpret_cast<const uint32_t *>(inval + g0), ib = *reinterpret_cast<const uint32_t *>(inval + g0 + 2);
-    const uint32_t pl[4] = {pa.x, pa.y, pb.x, pb.y};
-    const uint32_t H = (pl[0] & 0xFFFF0000u) | (pl[1] >> 16), L = (pl[0] << 16) | (pl[1] & 0xFFFFu);
-    const uint32_t H2 = (pl[2] & 0xFFFF0000u) | (pl[3] >> 16), L2 = (pl[2] << 16) | (pl[3] & 0xFFFFu);
-    // windows that touch an invalid position: OR of the invalid flags of positions p .. p + K - 1 (doubling on the 64-bit stream);
-    // a little-endian pair of flag words has the first group in its low half: rotate by 16
+    H = (pa.x & 0xFFFF0000u) | (pa.y >> 16), L = (pa.x << 16) | (pa.y & 0xFFFFu);
+    H2 = (pb.x & 0xFFFF0000u) | (pb.y >> 16), L2 = (pb.x << 16) | (pb.y & 0xFFFFu);
+    // OR of the invalid flags of positions p .. p + K - 1 (doubling on the 64-bit stream); a little-endian pair of flag words has
+    // the first group in its low half: rotate by 16
     uint64_t acc = ((uint64_t)__builtin_amdgcn_alignbit(ia, ia, 16) << 32) | __builtin_amdgcn_alignbit(ib, ib, 16);
 #pragma unroll
     for (int have = 1; have < K;) {
@@ -152,7 +269,28 @@ __global__ __launch_bounds__(BS_TPB) void hits_planes_kernel(const uint32_t *__r
         acc |= acc << step;
         have += step;
     }
-    const uint32_t bad = (uint32_t)(acc >> 32);
+    bad = (uint32_t)(acc >> 32);
+}
+template <bool WORDS>
+__device__ __forceinline__ void store_word(uint16_t *__restrict__ hit16, int64_t w, uint32_t hit, int64_t n) {
+    const int64_t left = n - 32 * w;                                      // positions past the end do not exist
+    if (left < 32) hit &= ~((1u << (32 - (int)left)) - 1u);
+    if (WORDS) reinterpret_cast<uint32_t *>(hit16)[w] = hit;
+    else *reinterpret_cast<uint32_t *>(hit16 + 2 * w) = (hit << 16) | (hit >> 16);   // little-endian halves: hit16[2 w] = windows 0..15
+}
+
+// hit16[g]: bit (15 - i) set when the window at position 16 g + i is within radius of any table entry (invalid windows: the
+// entry's inv_hit).  Thread = word t = groups 2t, 2t + 1.  planes / inval are read up to group 2t + 3 (inside the array: see kmap_packed_groups).
+// WORDS: store the 32 hit bits as ONE word, window i in bit 31 - i (hit32[t], the scan's per-read passes); otherwise as the
+// two uint16 of the mask's coverage pass.
+template <int K, bool WORDS>
+__global__ __launch_bounds__(BS_TPB) void hits_planes_kernel(const uint32_t *__restrict__ planes, const uint16_t *__restrict__ inval,
+                                                            int64_t n, int64_t n_alloc_groups, HitTab tab,
+                                                            uint16_t *__restrict__ hit16) {
+    const int64_t t = (int64_t)blockIdx.x * BS_TPB + threadIdx.x;
+    if (32 * t >= n) return;
+    uint32_t H, L, H2, L2, bad;
+    load_word<K>(planes, inval, 2 * t, H, L, H2, L2, bad);
     uint32_t hs[K], ls[K];
     hs[0] = H;
     ls[0] = L;
@@ -168,10 +306,39 @@ __global__ __launch_bounds__(BS_TPB) void hits_planes_kernel(const uint32_t *__r
         if (e.two) gt &= strand_gt<K>(hs, ls, e.rc, e.radius);           // within radius on either strand <=> not (both exceed)
         hit |= (~gt & ~bad) | (bad & e.inv_hit);
     }
-    const int64_t left = n - 16 * g0;                                     // positions past the end do not exist
-    if (left < 32) hit &= ~((1u << (32 - (int)left)) - 1u);
-    if (WORDS) reinterpret_cast<uint32_t *>(hit16)[t] = hit;
-    else *reinterpret_cast<uint32_t *>(hit16 + g0) = (hit << 16) | (hit >> 16);   // little-endian halves: hit16[g0] = windows 0..15
+    store_word<WORDS>(hit16, t, hit, n);
+}
+
+// The same through the index mode: a block takes 2 * BS_TPB consecutive words, thread i the words i and BS_TPB + i of them.
+template <int K, bool WORDS>
+__global__ __launch_bounds__(BS_TPB) void hits_planes_idx_kernel(const uint32_t *__restrict__ planes, const uint16_t *__restrict__ inval,
+                                                                int64_t n, int64_t n_alloc_groups, HitTab tab,
+                                                                uint16_t *__restrict__ hit16) {
+    const int64_t wa = (int64_t)blockIdx.x * (2 * BS_TPB) + threadIdx.x;
+    if (32 * wa >= n) return;
+    const int64_t wb = wa + BS_TPB;
+    const bool has_b = 32 * wb < n;                                       // otherwise: word a once more, not stored
+    uint32_t H, L, H2, L2, bad_a, bad_b;
+    load_word<K>(planes, inval, 2 * wa, H, L, H2, L2, bad_a);
+    const EPlanes ea = make_eplanes(H, L, H2, L2);
+    load_word<K>(planes, inval, 2 * (has_b ? wb : wa), H, L, H2, L2, bad_b);
+    const EPlanes eb = make_eplanes(H, L, H2, L2);
+    uint32_t hit_a = 0, hit_b = 0;
+    for (int c = 0; c < tab.n; ++c) {
+        const HitCons e = tab.c[c];
+        uint32_t gta, gtb;
+        strand_gt_idx<K>(ea, eb, e.fwd, e.radius, gta, gtb);
+        if (e.two) {
+            uint32_t ra, rb;
+            strand_gt_idx<K>(ea, eb, e.rc, e.radius, ra, rb);
+            gta &= ra;
+            gtb &= rb;
+        }
+        hit_a |= (~gta & ~bad_a) | (bad_a & e.inv_hit);
+        hit_b |= (~gtb & ~bad_b) | (bad_b & e.inv_hit);
+    }
+    store_word<WORDS>(hit16, wa, hit_a, n);
+    if (has_b) store_word<WORDS>(hit16, wb, hit_b, n);
 }
 
 // ---- per-read passes of the scan on the hit bits ---------------------------------------------------------------------
@@ -718,8 +885,13 @@ uint32_t rc_host(uint32_t c, int k) {
 template <int K>
 void launch_hits(const uint32_t *planes, const uint16_t *inval, int64_t n, int64_t n_alloc, const HitTab &tab, uint16_t *hit16, bool words,
                  hipStream_t st) {
-    if (words) hits_planes_kernel<K, true><<<grid_of((n + 31) / 32, BS_TPB), BS_TPB, 0, st>>>(planes, inval, n, n_alloc, tab, hit16);
-    else hits_planes_kernel<K, false><<<grid_of((n + 31) / 32, BS_TPB), BS_TPB, 0, st>>>(planes, inval, n, n_alloc, tab, hit16);
+    const char *v = getenv("KMAP_SCAN_PLANES");                          // "plain": the formulation without the index mode (tests compare the two)
+    const bool idx = !(v && !strcmp(v, "plain"));
+    const int64_t n_words = (n + 31) / 32;
+    if (idx && words) hits_planes_idx_kernel<K, true><<<grid_of(n_words, 2 * BS_TPB), BS_TPB, 0, st>>>(planes, inval, n, n_alloc, tab, hit16);
+    else if (idx) hits_planes_idx_kernel<K, false><<<grid_of(n_words, 2 * BS_TPB), BS_TPB, 0, st>>>(planes, inval, n, n_alloc, tab, hit16);
+    else if (words) hits_planes_kernel<K, true><<<grid_of(n_words, BS_TPB), BS_TPB, 0, st>>>(planes, inval, n, n_alloc, tab, hit16);
+    else hits_planes_kernel<K, false><<<grid_of(n_words, BS_TPB), BS_TPB, 0, st>>>(planes, inval, n, n_alloc, tab, hit16);
 }
 
 }  // namespace
