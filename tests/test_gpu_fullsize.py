@@ -175,7 +175,7 @@ def c5_reads():
     return seq, borders
 
 
-def test_c5_scan_full_size(c5_reads):
+def test_c5_scan_full_size(c5_reads, monkeypatch):
     """BASELINE config C5: k = 14, max_ham_dist = 5 Hamming-ball scan over 50 M x 300 bp reads (1.505e10 positions)."""
     from kmap_amd.kmer_count import kmer2hash
     from kmap_amd.motif_discovery import DeviceSeq
@@ -183,6 +183,17 @@ def test_c5_scan_full_size(c5_reads):
     seq, borders = c5_reads
     ds = DeviceSeq(seq, borders)
     hits, pos = ds.scan(14, kmer2hash(motif), 5, True)
+    # The hit planes come from a kernel that selects its operands through the VGPR index mode (bitslice.hip): a vector instruction
+    # right behind the scalar index change saw the OLD index in ~1 wave of 10^4 -- a different set of waves every run, visible
+    # only at this size -- until a wait state was put between them.  The formulation without the index mode is the witness: the
+    # whole result must be the same, run after run.
+    monkeypatch.setenv("KMAP_SCAN_PLANES", "plain")
+    hits_plain, pos_plain = ds.scan(14, kmer2hash(motif), 5, True)
+    monkeypatch.delenv("KMAP_SCAN_PLANES")
+    for rep in range(3):
+        h2, p2 = ds.scan(14, kmer2hash(motif), 5, True)
+        assert np.array_equal(h2, hits_plain) and np.array_equal(p2, pos_plain), f"index-mode planes differ from the plain ones (run {rep})"
+    assert np.array_equal(hits, hits_plain) and np.array_equal(pos, pos_plain)
     ds.close()
     assert len(hits) == 50_000_000 and int(hits.sum(dtype=np.int64)) == len(pos)
     assert np.count_nonzero(hits) > 0.4 * len(hits)                                # radius 5 of 14: most reads have a nearest hit

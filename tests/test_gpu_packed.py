@@ -792,3 +792,48 @@ def test_fine_partition_edge_inputs(env, case):
             np.testing.assert_array_equal(c, oc)
     dc.close()
     ds.close()
+
+
+@pytest.mark.parametrize("k", [1, 2, 5, 8, 9, 13, 14, 16])
+def test_hit_planes_index_mode_equals_plain_at_block_edges(env, k, monkeypatch):
+    """The hit planes come from a kernel whose thread holds two 32-window words 256 words apart (a block = 16 384 positions) and picks
+    its operand registers through the VGPR index mode; KMAP_SCAN_PLANES=plain selects the one-word formulation without it.  Array
+    lengths around the block size (second word missing / partly there / just there), both output forms (scan: hit words, mask:
+    16-bit halves), several table entries, every asm block size (k - 1 = 8 + 4 + 2 + 1 planes): the two agree and equal the oracle."""
+    _ffi, _, DeviceSeq, O = env
+    rng = np.random.default_rng(900 + k)
+    for total in (16384 - 33, 16384 - 1, 16384, 16384 + 1, 16384 + 31, 2 * 16384 + 8192 - 7, 2 * 16384 + 8192 + 5, 3 * 16384 + 37):
+        L = 173
+        n_reads = total // (L + 1)
+        lens = [L] * n_reads
+        lens[-1] += total - n_reads * (L + 1)                               # the array (reads + separators) has exactly `total` positions
+        parts, borders, st = [], [], 0
+        for ln in lens:
+            rd = rng.integers(0, 4, size=ln).astype(np.uint8)
+            rd[rng.random(ln) < 0.01] = 255
+            parts += [rd, np.array([255], np.uint8)]
+            borders.append((st, st + ln))
+            st += ln + 1
+        seq, borders = np.concatenate(parts), np.array(borders, np.int64)
+        assert len(seq) == total
+        cons = int(rng.integers(0, 4 ** k, dtype=np.uint64))
+        r = max(0, k // 3)
+        cons3 = np.array([cons, int(rng.integers(0, 4 ** k, dtype=np.uint64)), 4 ** k - 1], np.uint64)
+        rad3 = np.array([r, max(0, k // 4), 0])
+        out = {}
+        for mode in ("idx", "plain"):
+            monkeypatch.setenv("KMAP_SCAN_PLANES", mode)
+            ds = DeviceSeq(seq, borders)
+            hits, pos = ds.scan(k, cons, r, True)
+            ds.mask(k, cons3, rad3)
+            out[mode] = (hits, pos, ds.download())
+            ds.close()
+        for a, b in zip(out["idx"], out["plain"]):
+            np.testing.assert_array_equal(a, b, err_msg=f"k={k} total={total}")
+        np.testing.assert_array_equal(out["idx"][2], O.mask_input(seq.copy(), k, cons3, rad3))
+        buf, md, off = np.empty(4096, np.int32), C.c_int(0), 0
+        for i, (a, b) in enumerate(borders):
+            m = O.lib().ko_scan_read(np.ascontiguousarray(seq[a:b]), b - a, k, cons, r, 1, buf, C.byref(md))
+            assert out["idx"][0][i] == m
+            np.testing.assert_array_equal(out["idx"][1][off:off + m], buf[:m])
+            off += m
