@@ -7,8 +7,8 @@
 // mask_flag_packed_kernel in packed.hip: alignbit, shift, xor, 2-bit popcount, compare per window and strand: ~21 vector
 // instructions per window, VALU-issue bound at 0.85 ms per consensus on the C3 reads) is replaced by:
 //
-//   * bit planes of the reads, built once per upload: planes[g] = (H16 << 16) | L16 for the 16 positions of group g, H / L =
-//     the high / low bit of every base code, first position most significant (same order as the invalid mask);
+//   * bit planes of the reads, built once per upload: planes[2w] = H, planes[2w + 1] = L for the 32 positions of word w (groups
+//     2w, 2w + 1), H / L = the high / low bit of every base code, first position most significant (same order as the invalid mask);
 //   * a thread takes 32 positions: H, L (and the following 32 for the window tails).  For consensus base j the mismatch plane
 //     over the 32 windows is M_j = ((H << j) ^ CH_j) | ((L << j) ^ CL_j) with CH_j / CL_j = 0 or ~0 (scalar): 2 funnel shifts
 //     shared by both strands + 3 logic ops per strand;
@@ -38,11 +38,15 @@ __device__ __forceinline__ uint32_t squeeze_even_bits(uint32_t x) {   // bits 30
     x = (x | (x >> 8)) & 0x0000FFFFu;
     return x;
 }
-__global__ __launch_bounds__(BS_TPB) void planes_kernel(const uint32_t *__restrict__ codes, int64_t n_groups, uint32_t *__restrict__ planes) {
-    const int64_t g = (int64_t)blockIdx.x * BS_TPB + threadIdx.x;
-    if (g >= n_groups) return;
-    const uint32_t w = codes[g];
-    planes[g] = (squeeze_even_bits(w >> 1) << 16) | squeeze_even_bits(w);
+// thread = one 32-position word: groups 2w, 2w + 1 (the array holds an even number of groups) -> planes[2w] = H, planes[2w + 1] = L
+__global__ __launch_bounds__(BS_TPB) void planes_kernel(const uint32_t *__restrict__ codes, int64_t n_words, uint32_t *__restrict__ planes) {
+    const int64_t w = (int64_t)blockIdx.x * BS_TPB + threadIdx.x;
+    if (w >= n_words) return;
+    const uint2 c = *reinterpret_cast<const uint2 *>(codes + 2 * w);
+    uint2 o;
+    o.x = (squeeze_even_bits(c.x >> 1) << 16) | squeeze_even_bits(c.y >> 1);
+    o.y = (squeeze_even_bits(c.x) << 16) | squeeze_even_bits(c.y);
+    *reinterpret_cast<uint2 *>(planes + 2 * w) = o;
 }
 
 // ---- bit-sliced counters --------------------------------------------------------------------------------------------
@@ -146,9 +150,11 @@ __device__ __forceinline__ uint32_t strand_gt(const uint32_t (&hs)[K], const uin
 typedef uint32_t EPlanes __attribute__((ext_vector_type(8)));   // {A, C, G, T} of word 0 (positions P .. P + 31), of word 1 (the next 32)
 #define KMAP_E_INS "{v[40:47]}"(ea), "{v[48:55]}"(eb)
 __device__ __forceinline__ EPlanes make_eplanes(uint32_t H, uint32_t L, uint32_t H2, uint32_t L2) {
-    EPlanes e;
-    e[0] = H | L, e[1] = H | ~L, e[2] = ~H | L, e[3] = ~(H & L);
-    e[4] = H2 | L2, e[5] = H2 | ~L2, e[6] = ~H2 | L2, e[7] = ~(H2 & L2);
+    EPlanes e;                           // one instruction each (left to itself the compiler spent a v_not and a 64-bit move on some)
+    e[0] = H | L, e[4] = H2 | L2;
+    e[1] = __builtin_amdgcn_bitop3_b32(H, L, L, 0xF3), e[5] = __builtin_amdgcn_bitop3_b32(H2, L2, L2, 0xF3);      // a | ~b
+    e[2] = __builtin_amdgcn_bitop3_b32(H, L, L, 0xCF), e[6] = __builtin_amdgcn_bitop3_b32(H2, L2, L2, 0xCF);      // ~a | b
+    e[3] = __builtin_amdgcn_bitop3_b32(H, L, L, 0x3F), e[7] = __builtin_amdgcn_bitop3_b32(H2, L2, L2, 0x3F);      // ~(a & b)
     return e;
 }
 // plane 0 needs no shift: the selected word 0 itself
@@ -258,18 +264,20 @@ __device__ __forceinline__ void load_word(const uint32_t *__restrict__ planes, c
                                           uint32_t &L, uint32_t &H2, uint32_t &L2, uint32_t &bad) {
     const uint2 pa = *reinterpret_cast<const uint2 *>(planes + g0), pb = *reinterpret_cast<const uint2 *>(planes + g0 + 2);
     const uint32_t ia = *reinterpret_cast<const uint32_t *>(inval + g0), ib = *reinterpret_cast<const uint32_t *>(inval + g0 + 2);
-    H = (pa.x & 0xFFFF0000u) | (pa.y >> 16), L = (pa.x << 16) | (pa.y & 0xFFFFu);
-    H2 = (pb.x & 0xFFFF0000u) | (pb.y >> 16), L2 = (pb.x << 16) | (pb.y & 0xFFFFu);
+    H = pa.x, L = pa.y, H2 = pb.x, L2 = pb.y;
     // OR of the invalid flags of positions p .. p + K - 1 (doubling on the 64-bit stream); a little-endian pair of flag words has
     // the first group in its low half: rotate by 16
-    uint64_t acc = ((uint64_t)__builtin_amdgcn_alignbit(ia, ia, 16) << 32) | __builtin_amdgcn_alignbit(ib, ib, 16);
+    // (32-bit halves: funnel shift + or for the upper, shift-or for the lower word -- no 64-bit shifts; the lower word's last step is
+    // not needed)
+    uint32_t hi = __builtin_amdgcn_alignbit(ia, ia, 16), lo = __builtin_amdgcn_alignbit(ib, ib, 16);
 #pragma unroll
     for (int have = 1; have < K;) {
         const int step = (have <= K - have) ? have : K - have;
-        acc |= acc << step;
+        hi |= __builtin_amdgcn_alignbit(hi, lo, 32 - step);
         have += step;
+        if (have < K) lo |= lo << step;
     }
-    bad = (uint32_t)(acc >> 32);
+    bad = hi;
 }
 template <bool WORDS>
 __device__ __forceinline__ void store_word(uint16_t *__restrict__ hit16, int64_t w, uint32_t hit, int64_t n) {
@@ -1067,7 +1075,7 @@ int kmap_pack_planes_dev(const uint32_t *codes_dev, int64_t n, uint32_t *planes_
     KMAP_REQUIRE(n >= 0, "pack_planes: negative size");
     const int64_t ng = kmap_packed_groups(n);
     KMAP_REQUIRE(codes_dev && planes_dev, "pack_planes: null pointer");
-    planes_kernel<<<grid_of(ng, BS_TPB), BS_TPB, 0, as_stream(stream)>>>(codes_dev, ng, planes_dev);
+    planes_kernel<<<grid_of(ng / 2, BS_TPB), BS_TPB, 0, as_stream(stream)>>>(codes_dev, ng / 2, planes_dev);   // ng is even
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;
 }
