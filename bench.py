@@ -138,8 +138,8 @@ STAGE_KERNELS = {
                                      ("compact_count_kernel", 1), ("compact_write_kernel<unsigned int>", 1)]),
     "count_pass_k14": ("count14", [("fine_count_kernel", 1), ("fine_offsets_kernel", 1), ("fine_scatter_kernel", 1), ("fine_zero_heavy_kernel", 1),
                                    ("fine_hist_kernel", 1), ("fine_spill_kernel", 1), ("rc_merge_tiles_kernel", 1), ("compact_write_kernel<unsigned int>", 1)]),
-    "mask_k8": ("e2e", [("hits_planes_kernel<8, false>", 1), ("mask_cover_packed_kernel", 1)]),
-    "scan_k8_r2": ("e2e", [("hits_planes_kernel<8, true>", 1), ("scan_hits_reads_fused_kernel", 1), ("scan_reorder_kernel", 1)]),
+    "mask_k8": ("e2e", [("hits_planes_idx_kernel<8, false>", 1), ("mask_cover_packed_kernel", 1)]),
+    "scan_k8_r2": ("e2e", [("hits_planes_idx_kernel<8, true>", 1), ("scan_hits_reads_fused_kernel", 1), ("scan_reorder_kernel", 1)]),
     "knn_select": ("e2e", [("knn_select_kernel", 1)]),
     "knn_sums": ("e2e", [("knn_profile_kernel", 1), ("knn_sums_mfma_kernel", 1)]),
     "embed_iter_fast": ("e2e", [("forces_sym2_kernel", 1), ("sym_apply_kernel", 1), ("reduce_loss_kernel", 1)]),

@@ -144,9 +144,11 @@ __device__ __forceinline__ uint32_t strand_gt(const uint32_t (&hs)[K], const uin
 // HAZARD (measured, not in the ISA manual's table): a vector instruction issued right behind the s_set_gpr_idx_* that changes
 // M0 can still see the OLD index -- without a wait state ~1 wave in 10^4 produced hit words of the wrong planes at C5 size, a
 // different set of waves every run; with `s_nop 0` (one wait state, what the manual asks between an M0 write and s_movrel /
-// LDS-add-TID / interp) none in repeated full-size runs.  KMAP_IDX_WAIT is two wait states; tests/test_gpu_fullsize.py holds the
+// LDS-add-TID / interp) none in repeated full-size runs.  KMAP_IDX_WAIT is two wait states (behind every index change and
+// behind s_set_gpr_idx_off, whose successor is whatever the compiler schedules next); tests/test_gpu_fullsize.py holds the
 // full-size comparison against the formulation without the index mode.
 #define KMAP_IDX_WAIT "s_nop 1\n\t"
+#define KMAP_IDX_WAIT_END "s_nop 1"      // the same distance between switching the mode off and the compiler's next vector instruction
 typedef uint32_t EPlanes __attribute__((ext_vector_type(8)));   // {A, C, G, T} of word 0 (positions P .. P + 31), of word 1 (the next 32)
 #define KMAP_E_INS "{v[40:47]}"(ea), "{v[48:55]}"(eb)
 __device__ __forceinline__ EPlanes make_eplanes(uint32_t H, uint32_t L, uint32_t H2, uint32_t L2) {
@@ -162,7 +164,7 @@ __device__ __forceinline__ void idx_plane0(const EPlanes &ea, const EPlanes &eb,
     asm("s_set_gpr_idx_on %[c0], gpr_idx(SRC0)\n\t" KMAP_IDX_WAIT
         "v_mov_b32 %[a0], v40\n\t"
         "v_mov_b32 %[b0], v48\n\t"
-        "s_set_gpr_idx_off"
+        "s_set_gpr_idx_off\n\t" KMAP_IDX_WAIT_END
         : [a0] "=&v"(ma), [b0] "=&v"(mb)
         : [c0] "s"(c0), KMAP_E_INS);
 }
@@ -172,7 +174,7 @@ __device__ __forceinline__ void idx_planes1(const EPlanes &ea, const EPlanes &eb
     asm("s_set_gpr_idx_on %[c0], gpr_idx(SRC0,SRC1)\n\t" KMAP_IDX_WAIT
         "v_alignbit_b32 %[a0], v40, v44, %[s]\n\t"
         "v_alignbit_b32 %[b0], v48, v52, %[s]\n\t"
-        "s_set_gpr_idx_off"
+        "s_set_gpr_idx_off\n\t" KMAP_IDX_WAIT_END
         : [a0] "=&v"(ma[J0 + 0]), [b0] "=&v"(mb[J0 + 0])
         : [c0] "s"(c[J0 + 0]), [s] "n"(32 - J0), KMAP_E_INS);
 }
@@ -184,7 +186,7 @@ __device__ __forceinline__ void idx_planes2(const EPlanes &ea, const EPlanes &eb
         "s_set_gpr_idx_idx %[c1]\n\t" KMAP_IDX_WAIT
         "v_alignbit_b32 %[a1], v40, v44, %[s]-1\n\t"
         "v_alignbit_b32 %[b1], v48, v52, %[s]-1\n\t"
-        "s_set_gpr_idx_off"
+        "s_set_gpr_idx_off\n\t" KMAP_IDX_WAIT_END
         : [a0] "=&v"(ma[J0 + 0]), [b0] "=&v"(mb[J0 + 0]), [a1] "=&v"(ma[J0 + 1]), [b1] "=&v"(mb[J0 + 1])
         : [c0] "s"(c[J0 + 0]), [c1] "s"(c[J0 + 1]), [s] "n"(32 - J0), KMAP_E_INS);
 }
@@ -202,7 +204,7 @@ __device__ __forceinline__ void idx_planes4(const EPlanes &ea, const EPlanes &eb
         "s_set_gpr_idx_idx %[c3]\n\t" KMAP_IDX_WAIT
         "v_alignbit_b32 %[a3], v40, v44, %[s]-3\n\t"
         "v_alignbit_b32 %[b3], v48, v52, %[s]-3\n\t"
-        "s_set_gpr_idx_off"
+        "s_set_gpr_idx_off\n\t" KMAP_IDX_WAIT_END
         : [a0] "=&v"(ma[J0 + 0]), [b0] "=&v"(mb[J0 + 0]), [a1] "=&v"(ma[J0 + 1]), [b1] "=&v"(mb[J0 + 1]), [a2] "=&v"(ma[J0 + 2]), [b2] "=&v"(mb[J0 + 2]), [a3] "=&v"(ma[J0 + 3]), [b3] "=&v"(mb[J0 + 3])
         : [c0] "s"(c[J0 + 0]), [c1] "s"(c[J0 + 1]), [c2] "s"(c[J0 + 2]), [c3] "s"(c[J0 + 3]), [s] "n"(32 - J0), KMAP_E_INS);
 }
@@ -232,7 +234,7 @@ __device__ __forceinline__ void idx_planes8(const EPlanes &ea, const EPlanes &eb
         "s_set_gpr_idx_idx %[c7]\n\t" KMAP_IDX_WAIT
         "v_alignbit_b32 %[a7], v40, v44, %[s]-7\n\t"
         "v_alignbit_b32 %[b7], v48, v52, %[s]-7\n\t"
-        "s_set_gpr_idx_off"
+        "s_set_gpr_idx_off\n\t" KMAP_IDX_WAIT_END
         : [a0] "=&v"(ma[J0 + 0]), [b0] "=&v"(mb[J0 + 0]), [a1] "=&v"(ma[J0 + 1]), [b1] "=&v"(mb[J0 + 1]), [a2] "=&v"(ma[J0 + 2]), [b2] "=&v"(mb[J0 + 2]), [a3] "=&v"(ma[J0 + 3]), [b3] "=&v"(mb[J0 + 3]), [a4] "=&v"(ma[J0 + 4]), [b4] "=&v"(mb[J0 + 4]), [a5] "=&v"(ma[J0 + 5]), [b5] "=&v"(mb[J0 + 5]), [a6] "=&v"(ma[J0 + 6]), [b6] "=&v"(mb[J0 + 6]), [a7] "=&v"(ma[J0 + 7]), [b7] "=&v"(mb[J0 + 7])
         : [c0] "s"(c[J0 + 0]), [c1] "s"(c[J0 + 1]), [c2] "s"(c[J0 + 2]), [c3] "s"(c[J0 + 3]), [c4] "s"(c[J0 + 4]), [c5] "s"(c[J0 + 5]), [c6] "s"(c[J0 + 6]), [c7] "s"(c[J0 + 7]), [s] "n"(32 - J0), KMAP_E_INS);
 }
