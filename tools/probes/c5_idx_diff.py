@@ -20,7 +20,7 @@ _ffi.check(lib.kmap_scan_create(C.byref(h)))
 ds.declare_layout(h.value)
 cons = int(kmer2hash(motif))
 res = {}
-for rep in range(2):
+for rep in range(int(sys.argv[2]) if len(sys.argv) > 2 else 2):
     for mode in ("plain", "idx"):
         os.environ["KMAP_SCAN_PLANES"] = mode
         tot = _ffi.i64(0)
