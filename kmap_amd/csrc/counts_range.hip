@@ -28,6 +28,13 @@ __device__ __forceinline__ uint32_t rev_pairs(uint32_t w) {      // the sixteen 
     return ((t >> 1) & 0x55555555u) | ((t & 0x55555555u) << 1);
 }
 
+// ALIGNED: the range is a block of keys with a common prefix of `t` bits (len a power of two, lo a multiple of it: what an equal split
+// over 2 / 4 / 8 ... ranks gives).  "x in range" is then "the first t bits of the window are the prefix" and "rc(x) in range" is "the
+// complements of its last bits, read backwards, are" -- both as masks over the group's 16 windows from two 64-bit shifts and two
+// v_bitop3 per prefix bit, instead of a subtraction and a compare per window and strand.  Only the kept windows (2 / G of them) are
+// hashed: a lane walks the set bits of its mask (the wave as long as its busiest lane: ~8.5 of 16 at G = 8), the slot of a key is
+// again "kept so far + kept lanes below".
+template <bool ALIGNED>
 __global__ __launch_bounds__(RS_TPB) void range_stage_kernel(const uint32_t *__restrict__ codes, const uint16_t *__restrict__ inval,
                                                              const uint32_t *__restrict__ skip, int64_t n, int k, kmap_key_range kr,
                                                              int64_t groups_per_block, uint32_t *__restrict__ out,
@@ -62,27 +69,68 @@ __global__ __launch_bounds__(RS_TPB) void range_stage_kernel(const uint32_t *__r
         // reverse complement of the 32 bases (hi : lo) as (rhi : rlo): window i's reverse complement is its bits [2 i, 2 i + 2 k)
         const uint32_t rlo = rev_pairs(~hi), rhi = rev_pairs(~lo);
         // Every wave fills its own quarter of the step buffer (no reservation: a wave's slot base is fixed), a lane's slot comes from the
-        // ballot of "window i kept" (run so far + kept lanes below), and EVERY lane stores every window -- a window that is not kept goes to
-        // the lane's own trash word behind the buffer -- so the stores need no per-key branch (16 LDS stores per thread and step are ~2 % of
-        // the LDS pipe).  The predicates are combined with & and | on purpose: && / || made the compiler materialise every boolean as
+        // ballot of "this window is kept" (run so far + kept lanes below), and every lane stores every time -- a window that is not kept goes
+        // to the lane's own trash word behind the buffer -- so the stores need no per-key branch (16 LDS stores per thread and step are ~2 %
+        // of the LDS pipe).  The predicates are combined with & and | on purpose: && / || made the compiler materialise every boolean as
         // 0 / 1 in a vector register and compare it again (40 vector instructions per window instead of ~16).
         const bool merge = kr.half != 0u;
         char *const sb = reinterpret_cast<char *>(s_buf);
         const unsigned int trash4 = 4u * (16u * RS_TPB + threadIdx.x);
         const unsigned int run0 = (unsigned int)__builtin_amdgcn_readfirstlane(wave) * (16u * 64u * 4u);
         unsigned int run4 = run0;                                          // byte offset of the wave's next free slot (scalar)
+        if constexpr (ALIGNED) {
+            // masks with window i at bit 31 - 2 i: bit b of the window's key is stream bit 2 i + b, bit b of its reverse complement
+            // the complement of stream bit 2 i + 2 (k - 1 - b / 2) + (b & 1)
+            const int p = 31 - __builtin_clz(kr.len), t = 2 * k - p;
+            const uint32_t pfx = kr.lo >> p;
+            const uint64_t stream = ((uint64_t)hi << 32) | lo;
+            uint32_t own_m = 0xAAAAAAAAu, par_m = merge ? 0xAAAAAAAAu : 0u;
+            for (int b = 0; b < t; ++b) {                                  // t <= 8, uniform
+                const uint32_t cm = 0u - ((pfx >> (t - 1 - b)) & 1u);      // scalar: all ones when the prefix bit is set
+                const uint32_t tb = (uint32_t)((stream << b) >> 32);
+                const uint32_t ub = (uint32_t)((stream << (2 * (k - 1 - (b >> 1)) + (b & 1))) >> 32);
+                own_m &= ~(tb ^ cm);
+                par_m &= ub ^ cm;
+            }
+            uint32_t dead = drop16;                                        // window i: bit 15 - i -> bit 31 - 2 i
+            dead = (dead | (dead << 8)) & 0x00FF00FFu;
+            dead = (dead | (dead << 4)) & 0x0F0F0F0Fu;
+            dead = (dead | (dead << 2)) & 0x33333333u;
+            dead = ((dead | (dead << 1)) & 0x55555555u) << 1;
+            uint32_t cand = (own_m | par_m) & ~dead;
+            // two kept windows per trip, every lane stores both (a lane that has none left: to its trash word) -- no branch inside
+            const uint32_t kmask_v = kmask;
+            while (__builtin_amdgcn_ballot_w64(cand != 0u)) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const uint32_t x = ((i == 0) ? hi : __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * i)) >> sh;
-            const uint32_t rx = ((i == 0) ? rlo : __builtin_amdgcn_alignbit(rhi, rlo, 2 * i)) & kmask;
-            const uint32_t own = x - kr.lo, par = rx - kr.lo;
-            const bool is_own = own < kr.len, is_par = par < kr.len;
-            const bool live = (drop16 & (0x8000u >> i)) == 0u;
-            const bool kp = live & (is_own | (merge & is_par));
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(kp);
-            const unsigned int below = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-            *reinterpret_cast<uint32_t *>(sb + (kp ? (below << 2) + run4 : trash4)) = is_own ? own : kr.half + par;
-            run4 += 4u * (unsigned int)__builtin_popcountll(m);
+                for (int u = 0; u < 2; ++u) {
+                    const uint32_t live = cand;
+                    const int z = __builtin_clz(cand | 1u);                // 2 i of the lane's next kept window (31: none, bit 0 is never a window)
+                    cand &= ~(0x80000000u >> z);
+                    const uint32_t x = (uint32_t)((stream << z) >> 32) >> sh;
+                    const uint32_t rx = __builtin_amdgcn_alignbit(rhi, rlo, z) & kmask_v;
+                    const uint32_t own = x - kr.lo, par = rx - kr.lo;
+                    const bool is_own = own < kr.len;
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(live != 0u);   // the masks are exact: a candidate is kept
+                    const unsigned int below = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+                    const unsigned int at = (below << 2) + run4;
+                    *reinterpret_cast<uint32_t *>(sb + (live != 0u ? at : trash4)) = is_own ? own : kr.half + par;
+                    run4 += 4u * (unsigned int)__builtin_popcountll(m);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t x = ((i == 0) ? hi : __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * i)) >> sh;
+                const uint32_t rx = ((i == 0) ? rlo : __builtin_amdgcn_alignbit(rhi, rlo, 2 * i)) & kmask;
+                const uint32_t own = x - kr.lo, par = rx - kr.lo;
+                const bool is_own = own < kr.len, is_par = par < kr.len;
+                const bool live = (drop16 & (0x8000u >> i)) == 0u;
+                const bool kp = live & (is_own | (merge & is_par));
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(kp);
+                const unsigned int below = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+                *reinterpret_cast<uint32_t *>(sb + (kp ? (below << 2) + run4 : trash4)) = is_own ? own : kr.half + par;
+                run4 += 4u * (unsigned int)__builtin_popcountll(m);
+            }
         }
         if (lane == 0) s_cnt[wave] = (run4 - run0) >> 2;
         __syncthreads();
@@ -141,7 +189,14 @@ int kmap_counts_range_stage(const uint32_t *codes_dev, const uint16_t *inval_dev
     unsigned int *counter = nullptr;
     KMAP_TRY(kmap_scratch((void **)&counter, 64, st, KMAP_SLOT_D));
     KMAP_CHECK_HIP(hipMemsetAsync(counter, 0, 4, st));
-    range_stage_kernel<<<(unsigned)blocks, RS_TPB, 0, st>>>(codes_dev, inval_dev, skip_dev, n, k, kr, gpb, keys, counter);
+    // a range that is a block of keys with a common prefix of 1 .. 8 bits (equal splits over 2, 4, 8 ... ranks): the masked form
+    const bool pow2 = kr.len != 0u && (kr.len & (kr.len - 1u)) == 0u && (kr.lo & (kr.len - 1u)) == 0u;
+    const int tbits = pow2 ? 2 * k - (31 - __builtin_clz(kr.len)) : 0;
+    const char *form = getenv("KMAP_RANGE_STAGE");                          // "plain": the per-window form for every range (tests compare the two)
+    if (tbits >= 1 && tbits <= 8 && !(form && !strcmp(form, "plain")))
+        range_stage_kernel<true><<<(unsigned)blocks, RS_TPB, 0, st>>>(codes_dev, inval_dev, skip_dev, n, k, kr, gpb, keys, counter);
+    else
+        range_stage_kernel<false><<<(unsigned)blocks, RS_TPB, 0, st>>>(codes_dev, inval_dev, skip_dev, n, k, kr, gpb, keys, counter);
     KMAP_CHECK_HIP(hipGetLastError());
     unsigned int used = 0;
     KMAP_CHECK_HIP(hipMemcpyAsync(&used, counter, 4, hipMemcpyDeviceToHost, st));

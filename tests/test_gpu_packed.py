@@ -837,3 +837,47 @@ def test_hit_planes_index_mode_equals_plain_at_block_edges(env, k, monkeypatch):
             assert out["idx"][0][i] == m
             np.testing.assert_array_equal(out["idx"][1][off:off + m], buf[:m])
             off += m
+
+
+@pytest.mark.parametrize("k", [11, 14, 16])
+def test_key_range_stage_masked_form_equals_plain_form(env, k, monkeypatch):
+    """Ranges that are a block of keys with a common prefix of 1 .. 8 bits (equal splits over 2, 4 ... 256 ranks) take the staging pass's
+    masked form: "in range" for the 16 windows of a group at once from the first bits of the window / the complemented last bits of
+    its reverse complement, only the kept windows hashed.  KMAP_RANGE_STAGE=plain runs the per-window form on the same range: the two
+    shards are the same, for first / middle / last ranks, with and without merge and dedupe, on masked reads too; a range that is a
+    power of two long but not aligned, and a prefix of 9 bits, take the per-window form in both runs."""
+    _ffi, DeviceCounts, DeviceSeq, O = env
+    rng = np.random.default_rng(7700 + k)
+    seq, borders = _key_range_reads(rng)
+    ds, dc = DeviceSeq(seq, borders), DeviceCounts()
+    n_bins = 4 ** k
+    try:
+        for round_ in range(2):
+            for G in (2, 4, 16, 256, 512):
+                ln = n_bins // G
+                for r in sorted({0, G // 2 - 1, G // 3, G - 1}):
+                    for merge, dedupe in ((True, False), (False, False), (True, True)):
+                        got = {}
+                        for form in ("masked", "plain"):
+                            if form == "plain":
+                                monkeypatch.setenv("KMAP_RANGE_STAGE", "plain")
+                            else:
+                                monkeypatch.delenv("KMAP_RANGE_STAGE", raising=False)
+                            ds.count_range(dc, k, dedupe, merge, r * ln, ln)
+                            got[form] = dc.fetch()
+                        np.testing.assert_array_equal(got["masked"][0], got["plain"][0], err_msg=f"k={k} G={G} r={r} merge={merge} dedupe={dedupe}")
+                        np.testing.assert_array_equal(got["masked"][1], got["plain"][1], err_msg=f"k={k} G={G} r={r} merge={merge} dedupe={dedupe}")
+            ln = n_bins // 8                                                 # a power of two long, not aligned
+            monkeypatch.delenv("KMAP_RANGE_STAGE", raising=False)
+            ds.count_range(dc, k, False, True, ln // 2, ln)
+            a = dc.fetch()
+            monkeypatch.setenv("KMAP_RANGE_STAGE", "plain")
+            ds.count_range(dc, k, False, True, ln // 2, ln)
+            b = dc.fetch()
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1], b[1])
+            if round_ == 0:                                                  # second round: on the working mask
+                ds.mask(k, np.array([int(O.kmer2hash("AGGACCTACGTACAGG"[:k]))], np.uint64), np.array([2], np.int32))
+    finally:
+        dc.close()
+        ds.close()
