@@ -99,7 +99,6 @@ __global__ __launch_bounds__(RS_TPB) void range_stage_kernel(const uint32_t *__r
             dead = ((dead | (dead << 1)) & 0x55555555u) << 1;
             uint32_t cand = (own_m | par_m) & ~dead;
             // two kept windows per trip, every lane stores both (a lane that has none left: to its trash word) -- no branch inside
-            const uint32_t kmask_v = kmask;
             while (__builtin_amdgcn_ballot_w64(cand != 0u)) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -107,7 +106,7 @@ __global__ __launch_bounds__(RS_TPB) void range_stage_kernel(const uint32_t *__r
                     const int z = __builtin_clz(cand | 1u);                // 2 i of the lane's next kept window (31: none, bit 0 is never a window)
                     cand &= ~(0x80000000u >> z);
                     const uint32_t x = (uint32_t)((stream << z) >> 32) >> sh;
-                    const uint32_t rx = __builtin_amdgcn_alignbit(rhi, rlo, z) & kmask_v;
+                    const uint32_t rx = __builtin_amdgcn_alignbit(rhi, rlo, z) & kmask;
                     const uint32_t own = x - kr.lo, par = rx - kr.lo;
                     const bool is_own = own < kr.len;
                     const unsigned long long m = __builtin_amdgcn_ballot_w64(live != 0u);   // the masks are exact: a candidate is kept
