@@ -203,7 +203,7 @@ int kmap_mask_hamball_packed_dev(const uint32_t *codes_dev, uint16_t *inval_dev,
 int kmap_inval_set_prefix_dev(uint16_t *inval_dev, int64_t m, void *stream);  /* cons/radius: host */
 /* bit planes of the packed reads, built once per upload: planes[2w] / planes[2w + 1] = the high / low bits of the 32 base
  * codes of groups 2w, 2w + 1, first position most significant (an opaque input of the two calls above -- the layout may change
- * between library versions); planes_dev: uint32[kmap_packed_groups(n)] (always an even number of groups) */
+ * between library versions); planes_dev: uint32[kmap_packed_groups(n)] (always an even number of groups); both arrays 8-byte aligned */
 int kmap_pack_planes_dev(const uint32_t *codes_dev, int64_t n, uint32_t *planes_dev, void *stream);
 
 /* ---- motif occurrence scan: get_motif_occurence motif_discovery.py:1422-1477.

@@ -1077,6 +1077,7 @@ int kmap_pack_planes_dev(const uint32_t *codes_dev, int64_t n, uint32_t *planes_
     KMAP_REQUIRE(n >= 0, "pack_planes: negative size");
     const int64_t ng = kmap_packed_groups(n);
     KMAP_REQUIRE(codes_dev && planes_dev, "pack_planes: null pointer");
+    KMAP_REQUIRE((((uintptr_t)codes_dev | (uintptr_t)planes_dev) & 7u) == 0u, "pack_planes: codes / planes must be 8-byte aligned (whole arrays, not offsets into them)");
     planes_kernel<<<grid_of(ng / 2, BS_TPB), BS_TPB, 0, as_stream(stream)>>>(codes_dev, ng / 2, planes_dev);   // ng is even
     KMAP_CHECK_HIP(hipGetLastError());
     return KMAP_OK;

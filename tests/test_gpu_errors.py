@@ -48,6 +48,8 @@ def test_status_codes_and_last_error():
     L.kmap_counts_create(C.byref(c))
     assert L.kmap_counts_fetch(c.value, None, None) == -1                                            # nothing counted
     L.kmap_counts_destroy(c.value)
+    assert L.kmap_pack_planes_dev(buf.ptr + 4, 64, buf.ptr + 512, None) == -1                        # an offset into the code array
+    assert b"aligned" in L.kmap_last_error()
     with pytest.raises(ValueError):
         _ffi.check(-1)
 
